@@ -1,0 +1,193 @@
+"""ctypes binding of libhypel_hip.so (include/hypel.h) -- the only compute backend of the product.
+
+There is deliberately NO CPU fallback here: if the HIP library is missing or there is no GPU,
+`HipBackend()` raises.  (tests/ inject a numpy emulation of this same interface to exercise the
+host-side planner without a GPU; that emulation lives under tests/, not in the package.)
+
+A backend exposes one method per C-ABI entry point.  Pointer arguments are `Ref`s
+(flat torch tensor + element offset); `bind(name, args)` resolves them once and returns a
+zero-argument callable, so a planned step is replayed as a flat list of pre-bound C calls.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhypel_hip.so")
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+GEMM_BM = 128
+
+SEG_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("k", "<i4"), ("reserved", "<i4")])
+GROUP_DTYPE = np.dtype([("c_off", "<i8"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("rows", "<i4"),
+                        ("reserved", "<i4")])
+TILE_DTYPE = np.dtype([("group", "<i4"), ("m0", "<i4")])
+
+
+class Ref:
+    """A device (or, for the test emulation, host) address: flat tensor + element offset."""
+    __slots__ = ("t", "off")
+
+    def __init__(self, t, off=0):
+        self.t = t
+        self.off = int(off)
+
+    def ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+    def __add__(self, elems):
+        return Ref(self.t, self.off + int(elems))
+
+
+def build_library(verbose=False):
+    """Compile libhypel_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "libhypel_hip.so"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_P, _I64, _I32, _F, _U64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_uint64
+
+# name -> argument ctypes (stream appended automatically); mirrors include/hypel.h one to one
+SIGNATURES = {
+    "nhwc_to_pnc": [_P, _P, _I64, _I32, _I32, _I64],
+    "pnc_to_nhwc": [_P, _I64, _P, _I64, _I32, _I32],
+    "fill_f32": [_P, _I64, _F],
+    "seg_gemm_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32],
+    "reduce_splits_f32": [_P, _I64, _I32, _P, _I64, _I32],
+    "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
+    "bn_finalize": [_P, _I32, _I32, _I64, _I32, _F, _P, _P, _P, _P, _F],
+    "rstd_from_var": [_P, _I32, _F, _P],
+    "bn_act_fwd": [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64],
+    "bn_act_bwd_reduce": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P],
+    "bwd_reduce_finalize": [_P, _I32, _I32, _P, _P, _I32],
+    "bn_act_bwd_apply": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _P, _I64],
+    "chanmap_bwd": [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _I32],
+    "softmax_xent": [_P, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _F],
+    "mse": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I64, _F, _P],
+    "sum_f32": [_P, _I64, _F, _P, _P],
+    "adam_tf1": [_P, _P, _P, _P, _I64, _F, _F, _F, _F],
+    "momentum_tf1": [_P, _P, _P, _I64, _F, _F],
+    "dropout_mask": [_P, _I64, _F, _U64, _P],
+    "step_inc": [_P],
+    "argmax_confusion": [_P, _I64, _I64, _I32, _P, _P, _P],
+    "lrn_fwd": [_P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64],
+    "lrn_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64, _I32],
+    "gan_generator_fwd": [_P, _I64, _I32, _P, _I32, _P, _P],
+    "gan_generator_bwd": [_P, _P, _I64, _I32, _P, _I32, _P, _P, _I32, _P, _I32],
+}
+NO_STREAM = {"version", "last_error", "device_info"}
+
+
+class HypelError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise HypelError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    lib.hypel_last_error.restype = ctypes.c_char_p
+    lib.hypel_version.restype = ctypes.c_int
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, "hypel_" + name, None)
+        if fn is None:
+            continue  # optional entry points (checked by tests/test_abi.py against the header)
+        fn.argtypes = list(sig) + [_P]
+        fn.restype = ctypes.c_int
+    lib.hypel_graph_begin_capture.argtypes = [_P]
+    lib.hypel_graph_end_capture.argtypes = [_P, ctypes.POINTER(_P)]
+    lib.hypel_graph_launch.argtypes = [_P, _P]
+    lib.hypel_graph_destroy.argtypes = [_P]
+    lib.hypel_device_info.argtypes = [ctypes.POINTER(_I32), ctypes.POINTER(_I32)]
+    return lib
+
+
+class HipBackend:
+    """Launches hand-written gfx950 kernels through the C-ABI on a torch CUDA(HIP) stream."""
+    name = "hip"
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise HypelError("no HIP device visible: the hypelcnn_amd compute path needs an MI355X "
+                             "(there is no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.lib = load_library()
+        if self.lib.hypel_version() != 1:
+            raise HypelError("libhypel_hip.so ABI version mismatch")
+
+    # -- memory (PyTorch is the allocator: plumbing only) --
+    def empty(self, n, dtype=torch.float32):
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def zeros(self, n, dtype=torch.float32):
+        return torch.zeros(int(n), dtype=dtype, device=self.device)
+
+    def upload(self, array):
+        """numpy array (any dtype, incl. structured tables) -> flat device tensor."""
+        a = np.ascontiguousarray(array)
+        if a.dtype.fields is not None:
+            t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
+        else:
+            t = torch.from_numpy(a.reshape(-1).copy())
+        return t.to(self.device)
+
+    def stream_handle(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # -- launches --
+    def bind(self, name, args, stream=None):
+        fn = getattr(self.lib, "hypel_" + name)
+        st = self.stream_handle() if stream is None else stream
+        cargs = []
+        for a in args:
+            if isinstance(a, Ref):
+                cargs.append(a.ptr())
+            elif a is None:
+                cargs.append(None)
+            else:
+                cargs.append(a)
+        cargs.append(st)
+        cargs = tuple(cargs)
+        lib = self.lib
+
+        def call():
+            rc = fn(*cargs)
+            if rc != 0:
+                raise HypelError(f"hypel_{name} failed ({rc}): {lib.hypel_last_error().decode()}")
+
+        return call
+
+    def call(self, name, *args):
+        self.bind(name, args)()
+
+    # -- HIP graph capture --
+    def capture(self, launches):
+        """Capture a list of bound launches into a hipGraphExec; returns a replay callable."""
+        st = self.stream_handle()
+        lib = self.lib
+        if lib.hypel_graph_begin_capture(st) != 0:
+            raise HypelError(lib.hypel_last_error().decode())
+        try:
+            for f in launches:
+                f()
+        finally:
+            exec_ = _P()
+            rc = lib.hypel_graph_end_capture(st, ctypes.byref(exec_))
+        if rc != 0:
+            raise HypelError(lib.hypel_last_error().decode())
+        handle = exec_.value
+
+        def replay():
+            if lib.hypel_graph_launch(handle, st) != 0:
+                raise HypelError(lib.hypel_last_error().decode())
+
+        replay.handle = handle
+        return replay

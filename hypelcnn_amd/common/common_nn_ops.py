@@ -1,0 +1,611 @@
+"""Graph assembly, optimiser wiring, metrics, iterators, patch extraction -- the build's mirror of
+the reference's common/common_nn_ops.py (same public names; file:line cited per function).
+
+What changes underneath: "tensors" are symbolic nodes of hypelcnn_amd.graph, a training step is a
+pre-planned list of HIP launches (hypelcnn_amd.plan / runtime) and datasets stay resident in HBM.
+"""
+import numpy
+import torch
+
+from hypelcnn_amd import graph as G
+from hypelcnn_amd.common.common_ops import get_class, is_integer_num
+
+INVALID_TARGET_VALUE = 255
+
+
+# ----------------------------------------------------------------------------- data sets
+class DataSet:
+    """reference :23-42"""
+
+    def get_data_shape(self):
+        raise NotImplementedError
+
+    def get_casi_band_count(self):
+        raise NotImplementedError
+
+    def get_scene_shape(self):
+        raise NotImplementedError
+
+    def get_unnormalized_casi_dtype(self):
+        raise NotImplementedError
+
+    def get_data_point(self, point_x, point_y):
+        raise NotImplementedError
+
+
+def get_data_point_func(casi, lidar, neighborhood, point_x, point_y):
+    """reference :169-176 -- the padded scene makes the window start at (x, y)."""
+    side = 2 * neighborhood + 1
+    win = (slice(point_y, point_y + side), slice(point_x, point_x + side))
+    return numpy.concatenate((casi[win], lidar[win]), axis=2)
+
+
+def get_data_point_func_hsi(casi, lidar, neighborhood, point_x, point_y):
+    """reference :180-185"""
+    side = 2 * neighborhood + 1
+    return casi[point_y:point_y + side, point_x:point_x + side, :]
+
+
+class BasicDataSet(DataSet):
+    """Symmetric padding + min/max normalisation + patch slicing (reference :45-106)."""
+
+    def __init__(self, shadow_creator_dict, casi, lidar, neighborhood, normalize, casi_min=None, casi_max=None,
+                 lidar_min=None, lidar_max=None):
+        self.neighborhood = neighborhood
+        self.shadow_creator_dict = shadow_creator_dict
+        self.casi_unnormalized_dtype = casi.dtype
+        pad = ((neighborhood, neighborhood), (neighborhood, neighborhood), (0, 0))
+        self.lidar = None if lidar is None else numpy.pad(lidar, pad, mode="symmetric")
+        self.casi = None if casi is None else numpy.pad(casi, pad, mode="symmetric")
+        self.casi_min, self.casi_max, self.lidar_min, self.lidar_max = 0, 1, 0, 1
+        if normalize:
+            if self.lidar is not None:
+                self.lidar_min = numpy.min(self.lidar) if lidar_min is None else lidar_min
+                self.lidar = self.lidar - self.lidar_min
+                self.lidar_max = numpy.max(self.lidar) if lidar_max is None else lidar_max
+                self.lidar = self.lidar / self.lidar_max
+            if self.casi is not None:
+                self.casi_min = numpy.min(self.casi, axis=(0, 1)) if casi_min is None else casi_min
+                self.casi = self.casi - self.casi_min
+                self.casi_max = numpy.max(self.casi, axis=(0, 1)) if casi_max is None else casi_max
+                self.casi = self.casi / self.casi_max.astype(numpy.float32)
+        self._get_data_point_func = get_data_point_func if self.lidar is not None else get_data_point_func_hsi
+
+    def get_data_shape(self):
+        side = self.neighborhood * 2 + 1
+        return [side, side, self.casi.shape[2] + (1 if self.lidar is not None else 0)]
+
+    def get_casi_band_count(self):
+        return self.casi.shape[2]
+
+    def get_scene_shape(self):
+        ref = self.lidar if self.lidar is not None else self.casi
+        return [ref.shape[0] - 2 * self.neighborhood, ref.shape[1] - 2 * self.neighborhood]
+
+    def get_unnormalized_casi_dtype(self):
+        return self.casi_unnormalized_dtype
+
+    def get_data_point(self, point_x, point_y):
+        return self._get_data_point_func(self.casi, self.lidar, self.neighborhood, point_x, point_y)
+
+
+# ----------------------------------------------------------------------------- value objects (reference :109-165)
+class NNParams:
+    def __init__(self, input_iterator, data_with_labels, metrics, predict_tensor):
+        self.predict_tensor = predict_tensor
+        self.metrics = metrics
+        self.data_with_labels = data_with_labels
+        self.input_iterator = input_iterator
+
+
+class ModelInputParams:
+    def __init__(self, x, y, device_id, is_training):
+        self.is_training = is_training
+        self.device_id = device_id
+        self.y = y
+        self.x = x
+
+
+class HistogramTensorPair:
+    def __init__(self, tensor, name):
+        self.name = name
+        self.tensor = tensor
+
+
+class ModelOutputTensors:
+    def __init__(self, y_conv, image_output, image_original, histogram_tensors):
+        self.image_original = image_original
+        self.image_output = image_output
+        self.y_conv = y_conv
+        self.histogram_tensors = histogram_tensors
+
+
+class TrainingResult:
+    def __init__(self, validation_accuracy, test_accuracy, loss):
+        self.loss = loss
+        self.test_accuracy = test_accuracy
+        self.validation_accuracy = validation_accuracy
+
+
+class AugmentationInfo:
+    def __init__(self, shadow_struct, perform_shadow_augmentation, perform_rotation_augmentation,
+                 perform_spectral_augmentation, perform_reflection_augmentation, augmentation_random_threshold):
+        self.perform_reflection_augmentation = perform_reflection_augmentation
+        self.perform_rotation_augmentation = perform_rotation_augmentation
+        self.perform_shadow_augmentation = perform_shadow_augmentation
+        self.perform_spectral_augmentation = perform_spectral_augmentation
+        self.shadow_struct = shadow_struct
+        self.augmentation_random_threshold = augmentation_random_threshold
+
+
+NO_AUGMENTATION = AugmentationInfo(None, False, False, False, False, 0.0)
+
+
+# ----------------------------------------------------------------------------- residual channel map
+def scale_in_to_out(input_data, output_data, axis_no):
+    """Weight-free residual shortcut with channel-count matching (reference :546-564): identity,
+    integer repeat, or gather with min(round(o*Cin/Cout), Cin-1) (Python round = half to even).
+    Returns a ChanMap; `tensor + chan_map` fuses the gather into the producer's epilogue."""
+    cin, cout = input_data.c, output_data.c
+    scale_ratio = cin / cout
+    inv_scale_ratio = 1 / scale_ratio
+    if is_integer_num(inv_scale_ratio):
+        rep = int(inv_scale_ratio)
+        idx = None if rep == 1 else numpy.arange(cout, dtype=numpy.int32) // rep
+    else:
+        idx = numpy.asarray([min(round(o * scale_ratio), cin - 1) for o in range(cout)], dtype=numpy.int32)
+    return G.ChanMap(input_data, idx)
+
+
+# ----------------------------------------------------------------------------- template / placeholders
+class Placeholder:
+    """A batch-shaped input fed by an iterator: [None, H, W, C] images or [None, classes] labels."""
+
+    def __init__(self, name, hw, c):
+        self.name, self.hw, self.c = name, hw, c
+        self._bound = {}
+
+    def bind(self, tower):
+        t = self._bound.get(id(tower))
+        if t is None:
+            t = tower.placeholder(self.name, self.hw, self.c)
+            self._bound[id(tower)] = t
+        return t
+
+    def get_shape(self):
+        return [None, self.c] if self.hw is None else [None, self.hw[0], self.hw[1], self.c]
+
+
+class Template:
+    """tf.compat.v1.make_template("nn_core", model.create_tensor_graph, class_count=...) (reference :333):
+    every call records a new tower that shares the variables of the first one."""
+
+    def __init__(self, name, fn, **bound):
+        self.store = G.VariableStore(name)
+        self.fn = fn
+        self.bound = bound
+        self.towers = []
+
+    def __call__(self, model_input_params, algorithm_params):
+        tower = G.Tower(self.store, model_input_params.is_training, name=f"tower{len(self.towers)}")
+        self.towers.append(tower)
+        x = model_input_params.x
+        if isinstance(x, Placeholder):
+            x = x.bind(tower)
+        mip = ModelInputParams(x=x, y=model_input_params.y, device_id=model_input_params.device_id,
+                               is_training=model_input_params.is_training)
+        out = self.fn(mip, algorithm_params=algorithm_params, **self.bound)
+        out.tower = tower
+        return out
+
+
+def _bind_labels(labels, tower, classes):
+    if isinstance(labels, Placeholder):
+        return labels.bind(tower)
+    return labels
+
+
+# ----------------------------------------------------------------------------- iterators (reference :188-205)
+class DeviceArrays:
+    """A dataset resident on the compute device: float32 [N,P,P,C] patches + uint8 [N] labels."""
+
+    def __init__(self):
+        self.data = None
+        self.labels = None
+
+    def feed(self, data, labels, device):
+        self.data = torch.as_tensor(numpy.ascontiguousarray(data), dtype=torch.float32).to(device)
+        self.labels = torch.as_tensor(numpy.ascontiguousarray(labels)).to(torch.int64).to(device)
+
+    def __len__(self):
+        return 0 if self.data is None else self.data.shape[0]
+
+
+class BatchIterator:
+    """make_initializable_iterator over shuffle_and_repeat / map / batch (training) or batch (eval).
+
+    Deviation (documented in DESIGN.md): TF's 10 000-element shuffle buffer and op-level RNG streams
+    are not reproducible; each epoch is a fresh permutation drawn from a generator seeded 1234
+    (monitored_session_runner.set_run_seed), batches are cut from the concatenated epochs and the
+    final short batch is kept, as tf.data.batch(drop_remainder=False) does."""
+
+    def __init__(self, element_shape, class_count, batch_size, shuffle, num_epochs, augmentation_info=None, seed=1234):
+        self.element_shape = tuple(element_shape)
+        self.class_count = class_count
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.num_epochs = num_epochs
+        self.augmentation_info = augmentation_info
+        self.arrays = DeviceArrays()
+        self.seed = seed
+        self.images = Placeholder("x", (element_shape[0], element_shape[1]), element_shape[2])
+        self.labels = Placeholder("labels", None, class_count)
+        self._order = None
+        self._pos = 0
+        self._epoch = 0
+        self._gen = None
+
+    def get_next(self):
+        return self.images, self.labels
+
+    # -- session side --
+    def initializer(self, data, labels, device):
+        self.arrays.feed(data, labels, device)
+        self._gen = torch.Generator(device="cpu")
+        self._gen.manual_seed(self.seed)
+        self._epoch = 0
+        self._pos = 0
+        self._order = self._new_epoch()
+
+    def _new_epoch(self):
+        n = len(self.arrays)
+        if self.shuffle:
+            return torch.randperm(n, generator=self._gen).to(self.arrays.data.device)
+        return torch.arange(n, device=self.arrays.data.device)
+
+    def next_batch(self):
+        """Returns (x [b,P,P,C] float32, onehot [b,classes] float32, labels int64) or None when exhausted."""
+        n = len(self.arrays)
+        if n == 0:
+            return None
+        idx_parts = []
+        need = self.batch_size
+        while need > 0:
+            if self._pos >= n:
+                self._epoch += 1
+                if self.num_epochs is not None and self._epoch >= self.num_epochs:
+                    break
+                if not self.shuffle and self.num_epochs is not None:
+                    break
+                self._order = self._new_epoch()
+                self._pos = 0
+            take = min(need, n - self._pos)
+            idx_parts.append(self._order[self._pos:self._pos + take])
+            self._pos += take
+            need -= take
+        if not idx_parts:
+            return None
+        idx = torch.cat(idx_parts) if len(idx_parts) > 1 else idx_parts[0]
+        x = self.arrays.data.index_select(0, idx)
+        lab = self.arrays.labels.index_select(0, idx)
+        if self.augmentation_info is not None:
+            x = apply_augmentations(x, self.augmentation_info, self._gen)
+        onehot = torch.nn.functional.one_hot(lab, self.class_count).to(torch.float32)
+        return x, onehot, lab
+
+
+def training_nn_iterator(data_set, augmentation_info, batch_size, num_epochs, device, prefetch_size):
+    """reference :188-201"""
+    return BatchIterator(data_set.element_shape, data_set.class_count, batch_size, True, num_epochs, augmentation_info)
+
+
+def simple_nn_iterator(data_set, batch_size):
+    """reference :204-205"""
+    return BatchIterator(data_set.element_shape, data_set.class_count, batch_size, False, 1, None)
+
+
+def apply_augmentations(x, info, gen):
+    """Per-sample augmentation (reference :376-440): rot90 by k in {0,1,2} (never 270 degrees, :402),
+    shadow op with probability `augmentation_random_threshold`, left-right / up-down flips with p=0.5,
+    per-channel uniform shift in [-s, 0).  Host-side torch ops on the resident batch (SURVEY §8f "next":
+    a fused device kernel)."""
+    b = x.shape[0]
+    dev = x.device
+    if info.perform_rotation_augmentation:
+        k = torch.randint(0, 3, (b,), generator=gen).to(dev)
+        r1 = torch.rot90(x, 1, dims=(1, 2))
+        r2 = torch.rot90(x, 2, dims=(1, 2))
+        kk = k.view(b, 1, 1, 1)
+        x = torch.where(kk == 1, r1, torch.where(kk == 2, r2, x))
+    if info.perform_shadow_augmentation and info.shadow_struct is not None:
+        pick = (torch.rand(b, generator=gen) < info.augmentation_random_threshold).to(dev).view(b, 1, 1, 1)
+        x = torch.where(pick, info.shadow_struct.shadow_op(x), x)
+    if info.perform_reflection_augmentation:
+        lr = (torch.rand(b, generator=gen) < 0.5).to(dev).view(b, 1, 1, 1)
+        x = torch.where(lr, torch.flip(x, dims=(2,)), x)
+        ud = (torch.rand(b, generator=gen) < 0.5).to(dev).view(b, 1, 1, 1)
+        x = torch.where(ud, torch.flip(x, dims=(1,)), x)
+    if info.perform_spectral_augmentation:
+        s = float(info.perform_spectral_augmentation)
+        delta = (torch.rand(b, x.shape[3], generator=gen) * s - s).to(dev)
+        x = x + delta.view(b, 1, 1, -1)
+    return x.contiguous()
+
+
+# ----------------------------------------------------------------------------- optimiser wiring (reference :208-240)
+class LearningRate:
+    """exponential_decay(staircase=True): lr0 * rate ** (step // decay_steps) (reference :217-221)."""
+
+    def __init__(self, base, decay_step, decay_factor):
+        self.base, self.decay_step, self.decay_factor = base, decay_step, decay_factor
+
+    def eval(self, step):
+        return self.base * self.decay_factor ** (step // self.decay_step)
+
+
+class GraphContext:
+    """What tf.Graph + MonitoredTrainingSession hold in the reference: the variable store, the
+    recorded towers and -- once `session()` is called -- the device session."""
+
+    def __init__(self, template, backend=None):
+        self.template = template
+        self.backend = backend
+        self._session = None
+        self.external_masks = False
+        self.seed = 1234
+        self.capture_graphs = True
+
+    def session(self):
+        if self._session is None:
+            from hypelcnn_amd.runtime import Session
+            if self.backend is None:
+                from hypelcnn_amd.backend import HipBackend
+                self.backend = HipBackend()  # raises without a GPU / library: no CPU fallback
+            self._session = Session(self.template.store, self.backend, seed=self.seed)
+            self._session.finalize_variables()
+            self._session.init_data_parallel()
+        return self._session
+
+
+class LossFetch:
+    """The `cross_entropy` tensor of the reference: value of the last executed training step."""
+
+    def __init__(self):
+        self._compiled = None
+
+    def eval(self):
+        return float("nan") if self._compiled is None else self._compiled.loss_value()
+
+
+class TrainOp:
+    """tf_slim.learning.create_train_op(cross_entropy, optimizer, global_step) (reference :232):
+    one call = next batch -> forward -> backward -> (DP all-reduce) -> optimiser -> global_step += 1."""
+
+    def __init__(self, ctx, tower, loss, iterator, algorithm_params, learning_rate, loss_fetch):
+        self.ctx = ctx
+        self.tower = tower
+        self.loss = loss
+        self.iterator = iterator
+        self.algorithm_params = algorithm_params
+        self.learning_rate = learning_rate
+        self.loss_fetch = loss_fetch
+        opt = algorithm_params["optimizer"]
+        self.momentum = opt[1] if isinstance(opt, (tuple, list)) and opt[0] == "MomentumOptimizer" else None
+        if self.momentum is None and opt != "AdamOptimizer":
+            raise ValueError(f"unknown optimizer {opt!r}")
+
+    def compiled(self, nb):
+        sess = self.ctx.session()
+        ct = sess.compile(self.tower, nb, loss=self.loss, external_masks=self.ctx.external_masks)
+        if self.ctx.capture_graphs and getattr(sess.backend, "name", "") == "hip" and ct._graph_all is None:
+            ct.capture()
+        return ct
+
+    def run(self, batch=None):
+        sess = self.ctx.session()
+        if batch is None:
+            batch = self.iterator.next_batch()
+            if batch is None:
+                raise StopIteration
+        x, onehot, _ = batch
+        ct = self.compiled(x.shape[0])
+        ct.set_input("x", x)
+        ct.set_input("labels", onehot)
+        ct.forward_backward()
+        sess.allreduce_gradients()
+        lr = self.learning_rate.eval(sess.global_step)
+        if self.momentum is None:
+            sess.adam_step(lr)
+        else:
+            sess.momentum_step(lr, self.momentum)
+        self.loss_fetch._compiled = ct
+        return ct
+
+
+def optimize_nn(deep_nn_template, images, labels, device_id, name_prefix, algorithm_params, loss_func, ctx=None,
+                iterator=None):
+    """reference :208-240.  Gradients are those of the mean loss only -- the L2 regulariser declared on
+    the HYPELCNN convolutions never reaches create_train_op in the reference."""
+    tensor_outputs = deep_nn_template(
+        model_input_params=ModelInputParams(x=images, y=labels, device_id=device_id, is_training=True),
+        algorithm_params=algorithm_params)
+    tower = tensor_outputs.tower
+    bound_labels = _bind_labels(labels, tower, None)
+    cross_entropy_expr = G.reduce_mean(loss_func(tensor_outputs, bound_labels))
+    learning_rate = LearningRate(algorithm_params["learning_rate"], algorithm_params["learning_rate_decay_step"],
+                                 algorithm_params["learning_rate_decay_factor"])
+    cross_entropy = LossFetch()
+    ctx = ctx or GraphContext(deep_nn_template)
+    train_step = TrainOp(ctx, tower, cross_entropy_expr, iterator, algorithm_params, learning_rate, cross_entropy)
+    return tensor_outputs.y_conv, cross_entropy, learning_rate, train_step
+
+
+# ----------------------------------------------------------------------------- metrics (reference :243-310)
+class MetricOpsHolder:
+    """Streaming OA / mean-per-class accuracy / Cohen kappa / confusion matrix.  The confusion matrix is
+    accumulated on the device by hypel_argmax_confusion; the scalar metrics are its host-side functions
+    (tf.metrics.accuracy, mean_per_class_accuracy (mean over ALL classes, div_no_nan), tf_slim cohen_kappa)."""
+
+    def __init__(self, ctx, tower, y_conv, class_range, name_prefix):
+        self.ctx = ctx
+        self.tower = tower
+        self.y_conv = y_conv
+        self.num_classes = class_range.stop
+        self.name_prefix = name_prefix
+        self._confusion_dev = None
+        self._labels_dev = {}
+
+    def metric_variables_reset_op(self):
+        be = self.ctx.session().backend
+        if self._confusion_dev is None:
+            self._confusion_dev = be.zeros(self.num_classes * self.num_classes, torch.int32)
+        self._confusion_dev.zero_()
+
+    def combined_metric_update_op(self, batch):
+        from hypelcnn_amd.backend import Ref
+        sess = self.ctx.session()
+        x, _, lab = batch
+        nb = x.shape[0]
+        ct = sess.compile(self.tower, nb)
+        ct.set_input("x", x)
+        ct.forward()
+        st = ct.plan.storage_of(self.y_conv)
+        lab32 = lab.to(torch.int32).contiguous()
+        sess.backend.call("argmax_confusion", Ref(ct.plan.buffers[st.buf], st.ch_off), st.ld, nb, self.y_conv.c,
+                          Ref(lab32), None, Ref(self._confusion_dev))
+        self._keep = lab32
+        return ct
+
+    @property
+    def confusion(self):
+        k = self.num_classes
+        return self._confusion_dev.detach().cpu().numpy().reshape(k, k).astype(numpy.int32)
+
+    @property
+    def accuracy(self):
+        return confusion_metrics(self.confusion)[0]
+
+    @property
+    def mean_per_class_accuracy(self):
+        return confusion_metrics(self.confusion)[1]
+
+    @property
+    def kappa(self):
+        return confusion_metrics(self.confusion)[2]
+
+
+def confusion_metrics(conf):
+    conf = conf.astype(numpy.float64)
+    total = conf.sum()
+    if total == 0:
+        return 0.0, 0.0, 0.0
+    oa = numpy.trace(conf) / total
+    rows = conf.sum(1)
+    per_class = numpy.divide(numpy.diag(conf), rows, out=numpy.zeros_like(rows), where=rows > 0)
+    aa = per_class.mean()
+    pe = float((rows * conf.sum(0)).sum()) / (total * total)
+    kappa = (oa - pe) / (1 - pe) if pe != 1 else 0.0
+    return float(oa), float(aa), float(kappa)
+
+
+def create_metric_tensors(labels, y_conv, class_range, name_prefix, ctx=None, tower=None):
+    return MetricOpsHolder(ctx, tower if tower is not None else y_conv.tower, y_conv, class_range, name_prefix)
+
+
+def calculate_class_accuracies_using_confusion(confusion_matrix, class_range):
+    """reference :280-292: per-class recall and precision."""
+    k = class_range.stop
+    class_precisions, class_recall = numpy.zeros(k), numpy.zeros(k)
+    for index in class_range:
+        truths = numpy.sum(confusion_matrix[index, :])
+        if truths != 0:
+            class_recall[index] = confusion_matrix[index, index] / truths
+        predictions = numpy.sum(confusion_matrix[:, index])
+        if predictions != 0:
+            class_precisions[index] = confusion_matrix[index, index] / predictions
+    return class_recall[class_range], class_precisions[class_range]
+
+
+def calculate_accuracy(sess, nn_params, class_range):
+    """reference :295-310: reset the streaming metrics, drain the iterator, read the metrics."""
+    m = nn_params.metrics
+    m.metric_variables_reset_op()
+    while True:
+        batch = nn_params.input_iterator.next_batch()
+        if batch is None:
+            break
+        m.combined_metric_update_op(batch)
+    confusion_matrix = m.confusion
+    overall_accuracy, mean_per_class_accuracy, kappa = confusion_metrics(confusion_matrix)
+    class_recall, class_precisions = calculate_class_accuracies_using_confusion(confusion_matrix, class_range)
+    return overall_accuracy, class_recall, class_precisions, kappa, mean_per_class_accuracy
+
+
+# ----------------------------------------------------------------------------- graph assembly (reference :330-373)
+def create_graph(training_data_set, testing_data_set, validation_data_set, class_range, batch_size, prefetch_size,
+                 device_id, num_epochs, algorithm_params, model, augmentation_info, create_separate_validation_branch,
+                 backend=None):
+    deep_nn_template = Template("nn_core", model.create_tensor_graph, class_count=class_range.stop)
+    ctx = GraphContext(deep_nn_template, backend)
+
+    training_input_iter = training_nn_iterator(training_data_set, augmentation_info, batch_size, num_epochs,
+                                               device_id, prefetch_size)
+    images, labels = training_input_iter.get_next()
+    training_y_conv, cross_entropy, learning_rate, train_step = optimize_nn(
+        deep_nn_template, images, labels, device_id=device_id, name_prefix="training",
+        algorithm_params=algorithm_params, loss_func=model.get_loss_func, ctx=ctx, iterator=training_input_iter)
+    train_nn_params = NNParams(input_iterator=training_input_iter, data_with_labels=None, metrics=None,
+                               predict_tensor=None)
+
+    def eval_branch(data_set, prefix):
+        it = simple_nn_iterator(data_set, batch_size)
+        imgs, labs = it.get_next()
+        outs = deep_nn_template(ModelInputParams(x=imgs, y=None, device_id=device_id, is_training=False),
+                                algorithm_params=algorithm_params)
+        holder = create_metric_tensors(labs, outs.y_conv, class_range, prefix, ctx=ctx, tower=outs.tower)
+        return NNParams(input_iterator=it, data_with_labels=None, metrics=holder, predict_tensor=outs.y_conv)
+
+    testing_nn_params = eval_branch(testing_data_set, "testing")
+    validation_nn_params = testing_nn_params
+    if create_separate_validation_branch:
+        validation_nn_params = eval_branch(validation_data_set, "validation")
+    return cross_entropy, learning_rate, testing_nn_params, train_nn_params, validation_nn_params, train_step
+
+
+# ----------------------------------------------------------------------------- plugin lookup (reference :443-452)
+def get_model_from_name(model_name):
+    return get_class("nnmodel." + model_name + "." + model_name)()
+
+
+def get_importer_from_name(importer_name):
+    return get_class("importer." + importer_name + "." + importer_name)()
+
+
+def get_loader_from_name(loader_name, path):
+    return get_class("loader." + loader_name + "." + loader_name)(path)
+
+
+# ----------------------------------------------------------------------------- target helpers (reference :465-494)
+def create_target_image_via_samples(sample_set, scene_shape):
+    image = numpy.full([scene_shape[0], scene_shape[1]], INVALID_TARGET_VALUE, dtype=numpy.uint8)
+    targets = numpy.vstack([sample_set.training_targets, sample_set.test_targets, sample_set.validation_targets])
+    for point in targets.astype(int):
+        image[point[1], point[0]] = point[2]
+    return image
+
+
+def read_targets_from_image(targets, class_range):
+    result = numpy.zeros((0, 3), dtype=int)
+    for target_index in class_range:
+        ys, xs = numpy.where(targets == target_index)
+        rows = numpy.stack([xs.astype(int), ys.astype(int), numpy.full(len(xs), target_index, dtype=int)], axis=1)
+        result = numpy.vstack([result, rows])
+    return result
+
+
+def calculate_shadow_ratio(casi, shadow_map, shadow_map_inverse):
+    """reference :473-483: per-band mean(non-shadow) / mean(shadow)."""
+    in_shadow = numpy.ma.array(casi, mask=numpy.repeat((shadow_map == 0)[:, :, None], casi.shape[2], axis=2))
+    in_light = numpy.ma.array(casi, mask=numpy.repeat((shadow_map_inverse == 0)[:, :, None], casi.shape[2], axis=2))
+    ratio = in_light.mean(axis=(0, 1)) / in_shadow.mean(axis=(0, 1))
+    return ratio.filled().astype(numpy.float32)

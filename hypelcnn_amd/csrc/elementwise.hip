@@ -1,0 +1,664 @@
+// HBM-bound kernels of the classifier path: layout conversion, batch-norm statistics, the fused
+// normalise/activate/dropout/residual post-op and its two-pass backward, channel-map gradient,
+// losses, optimisers, dropout masks, metrics, LRN.  Every reduction is two-stage with a fixed
+// combination order (no float atomics) so that results are run-to-run deterministic -- the
+// "per-pixel class labels bit-exact" requirement of BASELINE.json needs that.
+#include "common.h"
+
+namespace {
+
+constexpr int STAT_TX = 64;  // threads along channels
+constexpr int STAT_TY = 4;   // row lanes
+
+// ------------------------------------------------------------------------------------- layout
+__global__ void nhwc_to_pnc_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int p, int c,
+                                   int64_t ld) {
+    const int64_t total = (int64_t)p * n * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % ld);
+        const int64_t rn = i / ld;
+        const int64_t nn = rn % n;
+        const int pp = (int)(rn / n);
+        out[i] = cc < c ? x[(nn * p + pp) * c + cc] : 0.0f;
+    }
+}
+
+__global__ void pnc_to_nhwc_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ x, int64_t n, int p,
+                                   int c) {
+    const int64_t total = n * p * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c);
+        const int64_t np_ = i / c;
+        const int pp = (int)(np_ % p);
+        const int64_t nn = np_ / p;
+        x[i] = in[((int64_t)pp * n + nn) * ld + cc];
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ dst, int64_t count, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = v;
+}
+
+__global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
+                                     float* __restrict__ out, int64_t count, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? out[i] : 0.0f;
+        for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * stride + i];
+        out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------- BN statistics
+// grid = (n_chunks, ceil(c/64)); block = 64 x 4.  Shifted sums (shift = first row of the chunk) keep the
+// fp32 accumulation well conditioned; the chunk's (mean, M2) pair is then exact enough to Chan-merge in fp64.
+__global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t rows,
+                                                                 int c, int chunk_rows, float* __restrict__ partial) {
+    __shared__ float sh[2][STAT_TY][STAT_TX];
+    const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
+    const int col = blockIdx.y * STAT_TX + tx;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = min(rows, r0 + (int64_t)chunk_rows);
+    float s = 0.0f, ss = 0.0f, shift = 0.0f;
+    if (col < c) {
+        shift = x[r0 * ld + col];
+        for (int64_t r = r0 + ty; r < r1; r += STAT_TY) {
+            const float d = x[r * ld + col] - shift;
+            s += d;
+            ss += d * d;
+        }
+    }
+    sh[0][ty][tx] = s;
+    sh[1][ty][tx] = ss;
+    __syncthreads();
+    if (ty == 0 && col < c) {
+        float ts = 0.0f, tss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < STAT_TY; ++k) {
+            ts += sh[0][k][tx];
+            tss += sh[1][k][tx];
+        }
+        const float cnt = (float)(r1 - r0);
+        const float mean_d = ts / cnt;
+        float m2 = tss - ts * mean_d;
+        if (m2 < 0.0f) m2 = 0.0f;
+        float* po = partial + (int64_t)blockIdx.x * 2 * c;
+        po[col] = shift + mean_d;
+        po[c + col] = m2;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int n_chunks, int chunk_rows, int64_t rows,
+                                   int c, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double n_a = 0.0, mean_a = 0.0, m2_a = 0.0;
+    for (int k = 0; k < n_chunks; ++k) {
+        const int64_t r0 = (int64_t)k * chunk_rows;
+        const double n_b = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
+        const double mean_b = partial[(int64_t)k * 2 * c + col];
+        const double m2_b = partial[(int64_t)k * 2 * c + c + col];
+        const double n_ab = n_a + n_b;
+        const double delta = mean_b - mean_a;
+        mean_a += delta * (n_b / n_ab);
+        m2_a += m2_b + delta * delta * (n_a * n_b / n_ab);
+        n_a = n_ab;
+    }
+    const double var = m2_a / n_a;  // biased: what the fused batch norm normalises with
+    mean[col] = (float)mean_a;
+    rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
+    if (moving_mean) {
+        const double unbiased = n_a > 1.0 ? m2_a / (n_a - 1.0) : var;  // Bessel-corrected for the moving average
+        moving_mean[col] = (float)((double)moving_mean[col] * decay + mean_a * (1.0 - (double)decay));
+        moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
+    }
+}
+
+__global__ void rstd_from_var_kernel(const float* __restrict__ var, int c, float eps, float* __restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) rstd[i] = (float)(1.0 / sqrt((double)var[i] + (double)eps));
+}
+
+// ------------------------------------------------------------------------------------- fused post-op
+__global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
+                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                  const float* __restrict__ beta, int act, float alpha, const float* __restrict__ mask,
+                                  int64_t ldm, const float* __restrict__ res1, int64_t ld1,
+                                  const int32_t* __restrict__ idx1, const float* __restrict__ res2, int64_t ld2,
+                                  const int32_t* __restrict__ idx2, float* __restrict__ z, int64_t ldz) {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / c;
+        const int col = (int)(i - row * c);
+        float v = y[row * ldy + col];
+        if (mean) v = (v - mean[col]) * rstd[col] + beta[col];
+        v = hypel_act(v, act, alpha);
+        if (mask) v *= mask[row * ldm + col];
+        if (res1) v += res1[row * ld1 + (idx1 ? idx1[col] : col)];
+        if (res2) v += res2[row * ld2 + (idx2 ? idx2[col] : col)];
+        z[row * ldz + col] = v;
+    }
+}
+
+__device__ __forceinline__ void bwd_elem(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y,
+                                         int64_t ldy, int64_t row, int col, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ beta, int act,
+                                         float alpha, const float* __restrict__ mask, int64_t ldm, float& dyh,
+                                         float& xhat) {
+    float v = y[row * ldy + col];
+    float pre = v;
+    if (mean) {
+        xhat = (v - mean[col]) * rstd[col];
+        pre = xhat + beta[col];
+    } else {
+        xhat = v;
+    }
+    float g = dz[row * lddz + col];
+    if (mask) g *= mask[row * ldm + col];
+    dyh = g * hypel_act_grad(pre, act, alpha);
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
+    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial) {
+    __shared__ float sh[2][STAT_TY][STAT_TX];
+    const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
+    const int col = blockIdx.y * STAT_TX + tx;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = min(rows, r0 + (int64_t)chunk_rows);
+    float s0 = 0.0f, s1 = 0.0f;
+    if (col < c) {
+        for (int64_t r = r0 + ty; r < r1; r += STAT_TY) {
+            float dyh, xhat;
+            bwd_elem(dz, lddz, y, ldy, r, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
+            s0 += dyh;
+            s1 += dyh * xhat;
+        }
+    }
+    sh[0][ty][tx] = s0;
+    sh[1][ty][tx] = s1;
+    __syncthreads();
+    if (ty == 0 && col < c) {
+        float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < STAT_TY; ++k) {
+            t0 += sh[0][k][tx];
+            t1 += sh[1][k][tx];
+        }
+        float* po = partial + (int64_t)blockIdx.x * 2 * c;
+        po[col] = t0;
+        po[c + col] = t1;
+    }
+}
+
+__global__ void bwd_reduce_finalize_kernel(const float* __restrict__ partial, int n_chunks, int c,
+                                           float* __restrict__ sums, float* __restrict__ dparam, int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < n_chunks; ++k) {
+        a += (double)partial[(int64_t)k * 2 * c + col];
+        b += (double)partial[(int64_t)k * 2 * c + c + col];
+    }
+    sums[col] = (float)a;
+    sums[c + col] = (float)b;
+    if (dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + (float)a;
+}
+
+__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y,
+                                        int64_t ldy, int64_t rows, int c, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, const float* __restrict__ beta, int act,
+                                        float alpha, const float* __restrict__ mask, int64_t ldm,
+                                        const float* __restrict__ sums, float* __restrict__ dy, int64_t lddy) {
+    const int64_t total = rows * c;
+    const float inv_m = 1.0f / (float)rows;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / c;
+        const int col = (int)(i - row * c);
+        float dyh, xhat;
+        bwd_elem(dz, lddz, y, ldy, row, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
+        float g = dyh;
+        if (mean) g = rstd[col] * (dyh - sums[col] * inv_m - xhat * (sums[c + col] * inv_m));
+        dy[row * lddy + col] = g;
+    }
+}
+
+__global__ void chanmap_bwd_kernel(const float* __restrict__ dz, int64_t lddz, int64_t rows, int c,
+                                   float* __restrict__ dr, int64_t lddr, int cin, const int32_t* __restrict__ start,
+                                   int accumulate) {
+    const int64_t total = rows * cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cin;
+        const int ci = (int)(i - row * cin);
+        float s = 0.0f;
+        if (start) {
+            const int a = start[ci], b = start[ci + 1];
+            for (int k = a; k < b; ++k) s += dz[row * lddz + k];
+        } else {
+            s = dz[row * lddz + ci];
+        }
+        float* p = dr + row * lddr + ci;
+        *p = accumulate ? *p + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------- losses
+__global__ void softmax_xent_kernel(const float* __restrict__ logits, int64_t ld, int64_t n, int c,
+                                    const float* __restrict__ labels, int64_t ldl, float* __restrict__ loss,
+                                    float* __restrict__ dlogits, int64_t lddl, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* z = logits + i * ld;
+    const float* lab = labels + i * ldl;
+    float zmax = z[0];
+    for (int j = 1; j < c; ++j) zmax = fmaxf(zmax, z[j]);
+    float se = 0.0f;
+    for (int j = 0; j < c; ++j) se += expf(z[j] - zmax);
+    const float lse = logf(se);
+    float l = 0.0f, lsum = 0.0f;
+    for (int j = 0; j < c; ++j) {
+        l -= lab[j] * (z[j] - zmax - lse);
+        lsum += lab[j];
+    }
+    if (loss) loss[i] = l;
+    if (dlogits) {
+        float* d = dlogits + i * lddl;
+        const float inv = 1.0f / se;
+        for (int j = 0; j < c; ++j) d[j] = gscale * (expf(z[j] - zmax) * inv * lsum - lab[j]);
+    }
+}
+
+constexpr int RED_BLOCKS = 1024;
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    // wave64 shuffle reduce, then 4 waves through LDS
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.0f;
+    if (threadIdx.x == 0) t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, int64_t lda,
+                                                           const float* __restrict__ b, int64_t ldb, int64_t rows,
+                                                           int c, float* __restrict__ da, int64_t ldda, float gcoef,
+                                                           float* __restrict__ ws) {
+    __shared__ float sh[4];
+    const int64_t total = rows * c;
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / c;
+        const int col = (int)(i - row * c);
+        const float d = a[row * lda + col] - b[row * ldb + col];
+        s += d * d;
+        if (da) da[row * ldda + col] = gcoef * d;
+    }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x, int64_t count,
+                                                           float* __restrict__ ws) {
+    __shared__ float sh[4];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        s += x[i];
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
+__global__ void sum_finalize_kernel(const float* __restrict__ ws, int n, double scale, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)ws[i];
+        out[0] = (float)(s * scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------- optimisers
+__global__ void adam_tf1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, int64_t count, float lr_t, float b1, float b2, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ void momentum_tf1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ a,
+                                    int64_t count, float lr, float mu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float ai = mu * a[i] + g[i];
+        a[i] = ai;
+        p[i] -= lr * ai;
+    }
+}
+
+// ------------------------------------------------------------------------------------- dropout mask
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void step_inc_kernel(uint64_t* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;
+}
+
+__global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t count, float keep, uint64_t seed,
+                                    const uint64_t* __restrict__ step_dev) {
+    const float scale = 1.0f / keep;
+    const uint64_t step = step_dev[0];
+    const int64_t groups = (count + 3) / 4;
+    for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < groups;
+         gi += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = (uint64_t)gi;
+        uint32_t rnd[4];
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                      (uint32_t)(seed >> 32), rnd);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = gi * 4 + k;
+            if (i < count) {
+                const float u = (float)(rnd[k] >> 8) * (1.0f / 16777216.0f);  // [0,1)
+                mask[i] = u < keep ? scale : 0.0f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- metrics
+__global__ void argmax_confusion_kernel(const float* __restrict__ logits, int64_t ld, int64_t n, int c,
+                                        const int32_t* __restrict__ labels, int32_t* __restrict__ pred,
+                                        int32_t* __restrict__ confusion) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* z = logits + i * ld;
+    int best = 0;
+    float bv = z[0];
+    for (int j = 1; j < c; ++j)
+        if (z[j] > bv) {  // strict: first maximum wins, as tf.argmax
+            bv = z[j];
+            best = j;
+        }
+    if (pred) pred[i] = best;
+    if (confusion && labels) {
+        const int lab = labels[i];
+        if (lab >= 0 && lab < c) atomicAdd(&confusion[lab * c + best], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------- LRN
+__global__ void lrn_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int c, int radius, float bias,
+                               float alpha, float beta, float* __restrict__ y, int64_t ldy) {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / c;
+        const int col = (int)(i - row * c);
+        const float* xr = x + row * ldx;
+        const int lo = max(0, col - radius), hi = min(c - 1, col + radius);
+        float s = 0.0f;
+        for (int j = lo; j <= hi; ++j) s += xr[j] * xr[j];
+        y[row * ldy + col] = xr[col] * powf(bias + alpha * s, -beta);
+    }
+}
+
+// dx_j = dy_j * s_j^-beta - 2 alpha beta x_j * sum_{|i-j|<=r} dy_i x_i s_i^(-beta-1)
+__global__ void lrn_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                               int64_t rows, int c, int radius, float bias, float alpha, float beta,
+                               float* __restrict__ dx, int64_t lddx, int accumulate) {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / c;
+        const int col = (int)(i - row * c);
+        const float* xr = x + row * ldx;
+        const float* gr = dy + row * lddy;
+        const int lo = max(0, col - radius), hi = min(c - 1, col + radius);
+        float win = 0.0f, s_self = 0.0f;
+        for (int k = lo; k <= hi; ++k) {
+            const int l2 = max(0, k - radius), h2 = min(c - 1, k + radius);
+            float s = 0.0f;
+            for (int j = l2; j <= h2; ++j) s += xr[j] * xr[j];
+            s = bias + alpha * s;
+            if (k == col) s_self = s;
+            win += gr[k] * xr[k] * powf(s, -beta - 1.0f);
+        }
+        const float g = gr[col] * powf(s_self, -beta) - 2.0f * alpha * beta * xr[col] * win;
+        float* p = dx + row * lddx + col;
+        *p = accumulate ? *p + g : g;
+    }
+}
+
+}  // namespace
+
+// ======================================================================================= C-ABI
+#define ST ((hipStream_t)stream)
+
+extern "C" int hypel_nhwc_to_pnc(const float* x, float* out, int64_t n, int32_t p, int32_t c, int64_t ld,
+                                 hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && out && n > 0 && p > 0 && c > 0 && ld >= c, "hypel_nhwc_to_pnc");
+    hipLaunchKernelGGL(nhwc_to_pnc_kernel, dim3(hypel_grid_1d((int64_t)p * n * ld, 256)), dim3(256), 0, ST, x, out, n,
+                       p, c, ld);
+    HYPEL_CHECK_LAUNCH("hypel_nhwc_to_pnc");
+    return 0;
+}
+
+extern "C" int hypel_pnc_to_nhwc(const float* in, int64_t ld, float* x, int64_t n, int32_t p, int32_t c,
+                                 hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && in && n > 0 && p > 0 && c > 0 && ld >= c, "hypel_pnc_to_nhwc");
+    hipLaunchKernelGGL(pnc_to_nhwc_kernel, dim3(hypel_grid_1d(n * p * c, 256)), dim3(256), 0, ST, in, ld, x, n, p, c);
+    HYPEL_CHECK_LAUNCH("hypel_pnc_to_nhwc");
+    return 0;
+}
+
+extern "C" int hypel_fill_f32(float* dst, int64_t count, float value, hypel_stream_t stream) {
+    HYPEL_REQUIRE(dst && count >= 0, "hypel_fill_f32");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, dst, count, value);
+    HYPEL_CHECK_LAUNCH("hypel_fill_f32");
+    return 0;
+}
+
+extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_splits, float* out,
+                                       int64_t count, int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(partial && out && n_splits >= 1 && count >= 0, "hypel_reduce_splits_f32");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
+                       n_splits, out, count, accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
+    return 0;
+}
+
+extern "C" int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows,
+                                       float* partial, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_col_stats_partial");
+    const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
+    hipLaunchKernelGGL(col_stats_partial_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, x, ld,
+                       rows, c, chunk_rows, partial);
+    HYPEL_CHECK_LAUNCH("hypel_col_stats_partial");
+    return 0;
+}
+
+extern "C" int hypel_bn_finalize(const float* partial, int32_t n_chunks, int32_t chunk_rows, int64_t rows, int32_t c,
+                                 float eps, float* mean, float* rstd, float* moving_mean, float* moving_var,
+                                 float decay, hypel_stream_t stream) {
+    HYPEL_REQUIRE(partial && mean && rstd && n_chunks > 0 && c > 0, "hypel_bn_finalize");
+    HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_finalize");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, ST, partial, n_chunks, chunk_rows, rows,
+                       c, eps, mean, rstd, moving_mean, moving_var, decay);
+    HYPEL_CHECK_LAUNCH("hypel_bn_finalize");
+    return 0;
+}
+
+extern "C" int hypel_rstd_from_var(const float* var, int32_t c, float eps, float* rstd, hypel_stream_t stream) {
+    HYPEL_REQUIRE(var && rstd && c > 0, "hypel_rstd_from_var");
+    hipLaunchKernelGGL(rstd_from_var_kernel, dim3((c + 63) / 64), dim3(64), 0, ST, var, c, eps, rstd);
+    HYPEL_CHECK_LAUNCH("hypel_rstd_from_var");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, const float* mean,
+                                const float* rstd, const float* beta, int32_t act, float alpha, const float* mask,
+                                int64_t ldm, const float* res1, int64_t ld1, const int32_t* idx1, const float* res2,
+                                int64_t ld2, const int32_t* idx2, float* z, int64_t ldz, hypel_stream_t stream) {
+    HYPEL_REQUIRE(y && z && rows > 0 && c > 0, "hypel_bn_act_fwd");
+    HYPEL_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr) == (beta == nullptr), "hypel_bn_act_fwd");
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(hypel_grid_1d(rows * c, 256)), dim3(256), 0, ST, y, ldy, rows, c, mean,
+                       rstd, beta, act, alpha, mask, ldm, res1, ld1, idx1, res2, ld2, idx2, z, ldz);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_fwd");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                       int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
+                                       float alpha, const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && y && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_bn_act_bwd_reduce");
+    const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, dz,
+                       lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_reduce");
+    return 0;
+}
+
+extern "C" int hypel_bwd_reduce_finalize(const float* partial, int32_t n_chunks, int32_t c, float* sums, float* dparam,
+                                         int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(partial && sums && n_chunks > 0 && c > 0, "hypel_bwd_reduce_finalize");
+    hipLaunchKernelGGL(bwd_reduce_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, ST, partial, n_chunks, c, sums,
+                       dparam, accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_bwd_reduce_finalize");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                      int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
+                                      float alpha, const float* mask, int64_t ldm, const float* sums, float* dy,
+                                      int64_t lddy, hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && y && dy && rows > 0 && c > 0, "hypel_bn_act_bwd_apply");
+    HYPEL_REQUIRE(mean == nullptr || sums != nullptr, "hypel_bn_act_bwd_apply");
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(hypel_grid_1d(rows * c, 256)), dim3(256), 0, ST, dz, lddz, y, ldy,
+                       rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, dy, lddy);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_apply");
+    return 0;
+}
+
+extern "C" int hypel_chanmap_bwd(const float* dz, int64_t lddz, int64_t rows, int32_t c, float* dr, int64_t lddr,
+                                 int32_t cin, const int32_t* start, int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && dr && rows > 0 && c > 0 && cin > 0, "hypel_chanmap_bwd");
+    HYPEL_REQUIRE(start != nullptr || cin == c, "hypel_chanmap_bwd");
+    hipLaunchKernelGGL(chanmap_bwd_kernel, dim3(hypel_grid_1d(rows * cin, 256)), dim3(256), 0, ST, dz, lddz, rows, c,
+                       dr, lddr, cin, start, accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_chanmap_bwd");
+    return 0;
+}
+
+extern "C" int hypel_softmax_xent(const float* logits, int64_t ld, int64_t n, int32_t c, const float* labels,
+                                  int64_t ldl, float* loss, float* dlogits, int64_t lddl, float gscale,
+                                  hypel_stream_t stream) {
+    HYPEL_REQUIRE(logits && labels && n > 0 && c > 0, "hypel_softmax_xent");
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ST, logits, ld, n, c,
+                       labels, ldl, loss, dlogits, lddl, gscale);
+    HYPEL_CHECK_LAUNCH("hypel_softmax_xent");
+    return 0;
+}
+
+extern "C" int hypel_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c, float* out,
+                         float* da, int64_t ldda, float gscale, float* ws, hypel_stream_t stream) {
+    HYPEL_REQUIRE(a && b && out && ws && rows > 0 && c > 0, "hypel_mse");
+    const int64_t total = rows * c;
+    const int grid = hypel_grid_1d(total, 256, RED_BLOCKS);
+    const float gcoef = gscale * 2.0f / (float)total;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(grid), dim3(256), 0, ST, a, lda, b, ldb, rows, c, da, ldda, gcoef, ws);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, ST, ws, grid, 1.0 / (double)total, out);
+    HYPEL_CHECK_LAUNCH("hypel_mse");
+    return 0;
+}
+
+extern "C" int hypel_sum_f32(const float* x, int64_t count, float scale, float* out, float* ws,
+                             hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && out && ws && count > 0, "hypel_sum_f32");
+    const int grid = hypel_grid_1d(count, 256, RED_BLOCKS);
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(grid), dim3(256), 0, ST, x, count, ws);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, ST, ws, grid, (double)scale, out);
+    HYPEL_CHECK_LAUNCH("hypel_sum_f32");
+    return 0;
+}
+
+extern "C" int hypel_adam_tf1(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1,
+                              float beta2, float eps, hypel_stream_t stream) {
+    HYPEL_REQUIRE(p && g && m && v && count >= 0, "hypel_adam_tf1");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(adam_tf1_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, p, g, m, v, count, lr_t,
+                       beta1, beta2, eps);
+    HYPEL_CHECK_LAUNCH("hypel_adam_tf1");
+    return 0;
+}
+
+extern "C" int hypel_momentum_tf1(float* p, const float* g, float* a, int64_t count, float lr, float mu,
+                                  hypel_stream_t stream) {
+    HYPEL_REQUIRE(p && g && a && count >= 0, "hypel_momentum_tf1");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(momentum_tf1_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, p, g, a, count, lr, mu);
+    HYPEL_CHECK_LAUNCH("hypel_momentum_tf1");
+    return 0;
+}
+
+extern "C" int hypel_step_inc(uint64_t* step_dev, hypel_stream_t stream) {
+    HYPEL_REQUIRE(step_dev, "hypel_step_inc");
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, ST, step_dev);
+    HYPEL_CHECK_LAUNCH("hypel_step_inc");
+    return 0;
+}
+
+extern "C" int hypel_dropout_mask(float* mask, int64_t count, float keep_prob, uint64_t seed, const uint64_t* step_dev,
+                                  hypel_stream_t stream) {
+    HYPEL_REQUIRE(mask && step_dev && count > 0 && keep_prob > 0.0f && keep_prob <= 1.0f, "hypel_dropout_mask");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(hypel_grid_1d((count + 3) / 4, 256)), dim3(256), 0, ST, mask, count,
+                       keep_prob, seed, step_dev);
+    HYPEL_CHECK_LAUNCH("hypel_dropout_mask");
+    return 0;
+}
+
+extern "C" int hypel_argmax_confusion(const float* logits, int64_t ld, int64_t n, int32_t c, const int32_t* labels,
+                                      int32_t* pred, int32_t* confusion, hypel_stream_t stream) {
+    HYPEL_REQUIRE(logits && n > 0 && c > 0, "hypel_argmax_confusion");
+    hipLaunchKernelGGL(argmax_confusion_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ST, logits, ld, n, c,
+                       labels, pred, confusion);
+    HYPEL_CHECK_LAUNCH("hypel_argmax_confusion");
+    return 0;
+}
+
+extern "C" int hypel_lrn_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t radius, float bias,
+                             float alpha, float beta, float* y, int64_t ldy, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && y && rows > 0 && c > 0 && radius >= 0, "hypel_lrn_fwd");
+    hipLaunchKernelGGL(lrn_fwd_kernel, dim3(hypel_grid_1d(rows * c, 256)), dim3(256), 0, ST, x, ldx, rows, c, radius,
+                       bias, alpha, beta, y, ldy);
+    HYPEL_CHECK_LAUNCH("hypel_lrn_fwd");
+    return 0;
+}
+
+extern "C" int hypel_lrn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,
+                             int32_t radius, float bias, float alpha, float beta, float* dx, int64_t lddx,
+                             int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && dy && dx && rows > 0 && c > 0 && radius >= 0, "hypel_lrn_bwd");
+    hipLaunchKernelGGL(lrn_bwd_kernel, dim3(hypel_grid_1d(rows * c, 256)), dim3(256), 0, ST, x, ldx, dy, lddy, rows, c,
+                       radius, bias, alpha, beta, dx, lddx, accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_lrn_bwd");
+    return 0;
+}

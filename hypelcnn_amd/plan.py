@@ -1,0 +1,719 @@
+"""Lower a recorded `Tower` (hypelcnn_amd.graph) to a flat list of HIP kernel launches.
+
+Layout decisions:
+  * every patch tensor lives PIXEL-MAJOR in HBM: buffer[p][n][c], p = y*W + x.  A SAME
+    convolution is then, per output pixel, a sum over its VALID taps of dense
+    [N x Cin] x [Cin x Cout] products on contiguous row blocks: exact-tap work (2 620 instead of
+    4 116 (pixel, tap) pairs for the four kernels of a 7x7 level), no im2col buffer, no masks.
+  * flatten + fully_connected is the same sum over pixel blocks; the FC weight rows
+    [p*C, (p+1)*C) are the "tap" of pixel p, so the reference's (h, w, c) flatten order is kept.
+  * channel concat / split / crop are views: producers write at channel offsets, consumers read
+    with (pixel map, channel offset).
+  * the backward pass is derived here per node (no autograd engine): residual-map gradient,
+    two-pass batch-norm/activation backward, data gradient (same GEMM, transposed weights),
+    filter gradient (same GEMM, transposed activations, split over batch rows with a
+    deterministic second-stage reduction).
+"""
+import numpy as np
+
+from . import graph as G
+from .backend import GEMM_BM, GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
+
+STAT_CHUNK_ROWS = 256
+WGRAD_ROW_CHUNK = 512
+TARGET_BLOCKS = 1024
+
+
+class Launch:
+    __slots__ = ("name", "args", "flops", "bytes", "tag")
+
+    def __init__(self, name, args, flops=0, nbytes=0, tag=""):
+        self.name = name
+        self.args = args
+        self.flops = flops
+        self.bytes = nbytes
+        self.tag = tag
+
+
+class Storage:
+    """Where a SymTensor lives for a given batch size."""
+
+    def __init__(self, buf, nb, ld, pixmap, ch_off, c, npix):
+        self.buf = buf
+        self.nb = nb
+        self.ld = ld
+        self.pixmap = pixmap
+        self.ch_off = ch_off
+        self.c = c
+        self.npix = npix
+
+    def pix_off(self, p):
+        q = p if self.pixmap is None else self.pixmap[p]
+        return q * self.nb * self.ld + self.ch_off
+
+    @property
+    def contiguous(self):
+        return self.pixmap is None
+
+    @property
+    def rows(self):
+        return self.npix * self.nb
+
+
+def valid_taps(h, w, k, oy, ox):
+    """Taps (i, j) of a kxk SAME kernel that read a real pixel for output (oy, ox); pad_before=(k-1)//2."""
+    pb = (k - 1) // 2
+    out = []
+    for i in range(k):
+        iy = oy + i - pb
+        if iy < 0 or iy >= h:
+            continue
+        for j in range(k):
+            ix = ox + j - pb
+            if 0 <= ix < w:
+                out.append((i, j, iy * w + ix))
+    return out
+
+
+class GemmTables:
+    """Host-side builder of the (groups, segments, tiles) tables of one hypel_seg_gemm_f32 launch."""
+
+    def __init__(self):
+        self.groups = []  # (c_off, [segs], rows)
+
+    def add_group(self, c_off, segs, rows):
+        self.groups.append((int(c_off), segs, int(rows)))
+
+    def finalize(self, n):
+        segs = []
+        garr = np.zeros(len(self.groups), GROUP_DTYPE)
+        tiles = []
+        macs = 0
+        for gi, (c_off, gs, rows) in enumerate(self.groups):
+            garr[gi] = (c_off, len(segs), len(gs), rows, 0)
+            ksum = 0
+            for (a_off, b_off, k) in gs:
+                segs.append((int(a_off), int(b_off), int(k), 0))
+                ksum += k
+            macs += rows * ksum * n
+            for m0 in range(0, rows, GEMM_BM):
+                tiles.append((ksum * min(GEMM_BM, rows - m0), gi, m0))
+        tiles.sort(key=lambda t: -t[0])  # heavy tiles first: the tail of the grid is the cheap work
+        sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
+        tarr = np.array([(g, m0) for _, g, m0 in tiles], TILE_DTYPE) if tiles else np.zeros(0, TILE_DTYPE)
+        return garr, sarr, tarr, macs
+
+
+class TowerPlan:
+    """Buffers + launch lists of one tower at one batch size."""
+
+    def __init__(self, tower, nb, session, loss=None, labels_c=None, external_masks=False, seed=1234):
+        self.tower = tower
+        self.nb = int(nb)
+        self.sess = session
+        self.be = session.backend
+        self.training = tower.is_training
+        self.loss = loss
+        self.external_masks = external_masks
+        self.seed = seed
+        self.buffers = {}  # name -> flat tensor
+        self.tables = []  # keep uploaded tables alive
+        self.storage = {}  # id(owner SymTensor) -> Storage (for owners)
+        self.grad_written = {}  # id(owner) -> bool
+        self.fwd = []
+        self.bwd = []
+        self.node_aux = {}
+        self.mask_bufs = {}
+        self.scratch_sizes = {"scratch_partial": 1, "scratch_wgrad": 1, "scratch_red": 2048, "sums": 2}
+        self._pending_scratch = []
+        self._build()
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, name, n, dtype=None):
+        import torch
+        t = self.be.zeros(max(int(n), 1), dtype or torch.float32)
+        self.buffers[name] = t
+        return t
+
+    def _ref(self, name, off=0):
+        return Ref(self.buffers[name], off)
+
+    def storage_of(self, t):
+        own = t.owner
+        st = self.storage[id(own)]
+        if t.root is None:
+            return st
+        return Storage(st.buf, st.nb, st.ld, t.pixmap, t.ch_off, t.c, t.npix)
+
+    def grad_storage_of(self, t):
+        st = self.storage_of(t)
+        return Storage("g:" + st.buf, st.nb, st.ld, st.pixmap, st.ch_off, st.c, st.npix)
+
+    def _new_value(self, t, name):
+        buf = self._alloc(name, t.npix * self.nb * t.c)
+        st = Storage(name, self.nb, t.c, None, 0, t.c, t.npix)
+        self.storage[id(t)] = st
+        return st
+
+    def _ensure_grad(self, owner):
+        st = self.storage[id(owner)]
+        gname = "g:" + st.buf
+        if gname not in self.buffers:
+            self._alloc(gname, owner.npix * self.nb * owner.c)
+            self.grad_written[id(owner)] = False
+        return gname
+
+    def _grad_target(self, t):
+        """Returns (Storage of the gradient view, accumulate flag) and marks it written; emits a
+        zero fill first when the first contribution only covers a view of the buffer."""
+        own = t.owner
+        self._ensure_grad(own)
+        gst = self.grad_storage_of(t)
+        written = self.grad_written[id(own)]
+        if not written and t.root is not None:
+            full = self.storage[id(own)]
+            self.bwd.append(Launch("fill_f32", (self._ref(gst.buf), full.rows * full.ld, 0.0), tag="zero-grad-view"))
+            written = True
+        self.grad_written[id(own)] = True
+        return gst, 1 if written else 0
+
+    # ------------------------------------------------------------------ parameters
+    def _p(self, var):
+        return Ref(self.sess.params, var.offset)
+
+    def _g(self, var):
+        return Ref(self.sess.grads, var.offset)
+
+    def _s(self, var):
+        return Ref(self.sess.state, var.offset)
+
+    @staticmethod
+    def _assert_contiguous(vars_):
+        for a, b in zip(vars_[:-1], vars_[1:]):
+            if b.offset != a.offset + a.size:
+                raise RuntimeError(f"variables {a.name} / {b.name} of a merged level are not contiguous")
+
+    # ------------------------------------------------------------------ gemm emission
+    def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag):
+        garr, sarr, tarr, macs = tables.finalize(n)
+        if len(tarr) == 0:
+            return
+        g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
+        self.tables += [g_t, s_t, t_t]
+        lst.append(Launch("seg_gemm_f32", (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n),
+                                           Ref(g_t), Ref(s_t), Ref(t_t), int(len(tarr)), bias_ref, int(accumulate)),
+                          flops=2 * macs, tag=tag))
+
+    # ------------------------------------------------------------------ build
+    def _build(self):
+        tw = self.tower
+        nb = self.nb
+        # inputs: the loader hands over NHWC batches; keep a persistent staging tensor and convert
+        for name, t in tw.inputs.items():
+            if t.hw is None:
+                self._alloc("in:" + name, nb * t.c)
+                self.storage[id(t)] = Storage("in:" + name, nb, t.c, None, 0, t.c, 1)
+            else:
+                self._alloc("in:" + name, nb * t.npix * t.c)  # NHWC as delivered
+                st = self._new_value(t, "pnc:" + name)
+                self.fwd.append(Launch("nhwc_to_pnc", (self._ref("in:" + name), self._ref(st.buf), nb, t.npix, t.c,
+                                                       st.ld), nbytes=8 * nb * t.npix * t.c, tag="layout"))
+        if self.training:
+            import torch
+            self._alloc("step_ctr", 1, torch.int64)
+        for idx, node in enumerate(tw.nodes):
+            if isinstance(node, G.LinearNode):
+                self._fwd_linear(idx, node)
+            elif isinstance(node, G.PostNode):
+                self._fwd_post(idx, node)
+            elif isinstance(node, G.LRNNode):
+                self._fwd_lrn(idx, node)
+            else:
+                raise TypeError(node)
+        if self.loss is not None:
+            self._emit_loss()
+        if self.training and self.loss is not None:
+            for idx in range(len(tw.nodes) - 1, -1, -1):
+                node = tw.nodes[idx]
+                if isinstance(node, G.LinearNode):
+                    self._bwd_linear(idx, node)
+                elif isinstance(node, G.PostNode):
+                    self._bwd_post(idx, node)
+                elif isinstance(node, G.LRNNode):
+                    self._bwd_lrn(idx, node)
+            if tw.n_dropout and not self.external_masks:
+                self.bwd.append(Launch("step_inc", (self._ref("step_ctr"),), tag="rng"))
+        # shared scratch (stream order makes reuse safe)
+        for name, size in self.scratch_sizes.items():
+            self._alloc(name, size)
+        for launch, pos, name in self._pending_scratch:
+            args = list(launch.args)
+            args[pos] = self._ref(name)
+            launch.args = tuple(args)
+
+    def _scratch(self, launch, pos, name, size=0):
+        self.scratch_sizes[name] = max(self.scratch_sizes.get(name, 1), int(size))
+        self._pending_scratch.append((launch, pos, name))
+
+    # ------------------------------------------------------------------ LinearNode forward
+    def _vec_params(self, node):
+        """Concatenated per-channel vectors of a (possibly merged) node."""
+        brs = node.branches
+        aux = {}
+        if node.has_bn:
+            for i, key in enumerate(("beta", "mm", "mv")):
+                vs = [b.bn[i] for b in brs]
+                self._assert_contiguous(vs)
+                aux[key] = vs[0]
+        if node.has_bias:
+            vs = [b.bias for b in brs]
+            self._assert_contiguous(vs)
+            aux["bias"] = vs[0]
+        ws = [b.w for b in brs]
+        self._assert_contiguous(ws)
+        aux["w0"] = ws[0]
+        aux["wsize"] = sum(w.size for w in ws)
+        return aux
+
+    def _fwd_linear(self, idx, node):
+        nb = self.nb
+        out = node.out
+        c = node.cout
+        aux = self._vec_params(node)
+        self.node_aux[idx] = aux
+        ybuf = f"y:{idx}"
+        self._alloc(ybuf, out.npix * nb * c)
+        y_st = Storage(ybuf, nb, c, None, 0, c, out.npix)
+        aux["y"] = y_st
+        bias_ref = self._p(aux["bias"]) if node.has_bias else None
+        w_base = aux["w0"].offset
+
+        if node.kind == "conv":
+            src = node.sources[0]
+            s_st = self.storage_of(src)
+            h, w = src.hw
+            choff = 0
+            by_cout = {}
+            for b in node.branches:
+                by_cout.setdefault(b.cout, []).append((b, choff))
+                choff += b.cout
+            for cout, items in by_cout.items():
+                tb = GemmTables()
+                for b, off in items:
+                    if b.k == 1 and s_st.contiguous:
+                        tb.add_group(off, [(s_st.pix_off(0), b.w.offset, src.c)], out.npix * nb)
+                        continue
+                    for p in range(h * w):
+                        segs = [(s_st.pix_off(pin), b.w.offset + (i * b.k + j) * src.c * cout, src.c)
+                                for (i, j, pin) in valid_taps(h, w, b.k, p // w, p % w)]
+                        tb.add_group(p * nb * c + off, segs, nb)
+                # the kernel indexes bias by (c_off % ldc) + column, so merged branches share one launch
+                self._emit_gemm(self.fwd, tb, cout, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), cout, 0,
+                                self._ref(ybuf), c, bias_ref, 0, f"fwd:{items[0][0].scope}")
+        else:  # dense
+            b = node.branches[0]
+            rowbase = 0
+            for si, src in enumerate(node.sources):
+                s_st = self.storage_of(src)
+                tb = GemmTables()
+                segs = [(s_st.pix_off(p), b.w.offset + (rowbase + p * src.c) * c, src.c) for p in range(src.npix)]
+                tb.add_group(0, segs, nb)
+                self._emit_gemm(self.fwd, tb, c, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), c, 0,
+                                self._ref(ybuf), c, bias_ref if si == 0 else None, 1 if si > 0 else 0,
+                                f"fwd:{b.scope}")
+                rowbase += src.npix * src.c
+
+        rows = out.npix * nb
+        # ---- batch-norm statistics ----
+        if node.has_bn:
+            self._alloc(f"mean:{idx}", c)
+            self._alloc(f"rstd:{idx}", c)
+            if node.training:
+                n_chunks = (rows + STAT_CHUNK_ROWS - 1) // STAT_CHUNK_ROWS
+                l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, STAT_CHUNK_ROWS, None),
+                            nbytes=4 * rows * c, tag="bn-stats")
+                self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
+                l2 = Launch("bn_finalize", (None, n_chunks, STAT_CHUNK_ROWS, rows, c, float(node.bn_eps),
+                                            self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"), self._s(aux["mm"]),
+                                            self._s(aux["mv"]), float(node.bn_decay)), tag="bn-finalize")
+                self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+                self.fwd += [l1, l2]
+                aux["mean"] = self._ref(f"mean:{idx}")
+            else:
+                self.fwd.append(Launch("rstd_from_var", (self._s(aux["mv"]), c, float(node.bn_eps),
+                                                         self._ref(f"rstd:{idx}")), tag="bn-infer"))
+                aux["mean"] = self._s(aux["mm"])
+            aux["rstd"] = self._ref(f"rstd:{idx}")
+            aux["beta_ref"] = self._p(aux["beta"])
+        # ---- fused post-op ----
+        if node.has_post:
+            zbuf = f"z:{idx}"
+            self._alloc(zbuf, rows * c)
+            self.storage[id(out)] = Storage(zbuf, nb, c, None, 0, c, out.npix)
+            self._emit_post_fwd(idx, node, self._ref(ybuf), c, rows, c, aux, self._ref(zbuf))
+        else:
+            self.storage[id(out)] = y_st
+
+    def _mask_ref(self, idx, node, rows, c):
+        if node.dropout_keep is None:
+            return None
+        name = f"mask:{idx}"
+        self._alloc(name, rows * c)
+        self.mask_bufs[node.dropout_index] = name
+        if not self.external_masks:
+            self.fwd.append(Launch("dropout_mask", (self._ref(name), rows * c, float(node.dropout_keep),
+                                                    int(self.seed * 1000003 + idx), self._ref("step_ctr")), tag="rng"))
+        else:
+            self.buffers[name].fill_(1.0)
+        return self._ref(name)
+
+    def _res_args(self, node):
+        out = []
+        for (src, ridx) in node.residuals:
+            st = self.storage_of(src)
+            if not st.contiguous:
+                raise NotImplementedError("residual source must cover the same pixels")
+            iref = None
+            if ridx is not None:
+                t = self.be.upload(np.asarray(ridx, np.int32))
+                self.tables.append(t)
+                iref = Ref(t)
+            out.append((self._ref(st.buf, st.ch_off), st.ld, iref))
+        while len(out) < 2:
+            out.append((None, 0, None))
+        return out
+
+    def _emit_post_fwd(self, idx, node, y_ref, ldy, rows, c, aux, z_ref):
+        has_bn = isinstance(node, G.LinearNode) and node.has_bn
+        mask = self._mask_ref(idx, node, rows, c)
+        aux["mask"] = mask
+        (r1, ld1, i1), (r2, ld2, i2) = self._res_args(node)
+        act = node.act
+        self.fwd.append(Launch("bn_act_fwd", (
+            y_ref, ldy, rows, c, aux.get("mean") if has_bn else None, aux.get("rstd") if has_bn else None,
+            aux.get("beta_ref") if has_bn else None, act.code if act else 0, act.alpha if act else 0.0, mask, c,
+            r1, ld1, i1, r2, ld2, i2, z_ref, c), nbytes=4 * rows * c * (2 + len(node.residuals)), tag="post-fwd"))
+
+    def _fwd_post(self, idx, node):
+        src, out = node.src, node.out
+        s_st = self.storage_of(src)
+        if not s_st.contiguous:
+            raise NotImplementedError
+        rows, c = out.npix * self.nb, out.c
+        st = self._new_value(out, f"z:{idx}")
+        aux = {}
+        self.node_aux[idx] = aux
+        self._emit_post_fwd(idx, node, self._ref(s_st.buf, s_st.ch_off), s_st.ld, rows, c, aux, self._ref(st.buf))
+
+    def _fwd_lrn(self, idx, node):
+        src, out = node.src, node.out
+        s_st = self.storage_of(src)
+        rows, c = out.npix * self.nb, out.c
+        st = self._new_value(out, f"z:{idx}")
+        self.fwd.append(Launch("lrn_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, rows, c, node.radius,
+                                           float(node.bias), float(node.alpha), float(node.beta), self._ref(st.buf), c),
+                               nbytes=8 * rows * c, tag="lrn"))
+
+    # ------------------------------------------------------------------ loss
+    def _emit_loss(self):
+        loss = self.loss
+        ps = loss.per_sample
+        nb = self.nb
+        logits = ps.logits
+        l_st = self.storage_of(logits)
+        lab = ps.labels
+        lab_st = self.storage_of(lab)
+        self._alloc("loss_ps", nb)
+        self._alloc("loss_ce", 1)
+        self._alloc("loss_mse", 1)
+        dl = None
+        lddl = 0
+        if self.training:
+            gst, acc = self._grad_target(logits)
+            assert acc == 0
+            dl, lddl = self._ref(gst.buf, gst.ch_off), gst.ld
+        self.fwd.append(Launch("softmax_xent", (self._ref(l_st.buf, l_st.ch_off), l_st.ld, nb, logits.c,
+                                                self._ref(lab_st.buf), lab_st.ld, self._ref("loss_ps"), dl, lddl,
+                                                1.0 / nb), tag="loss"))
+        l2 = Launch("sum_f32", (self._ref("loss_ps"), nb, 1.0 / nb, self._ref("loss_ce"), None), tag="loss")
+        self._scratch(l2, 4, "scratch_red")
+        self.fwd.append(l2)
+        if ps.extra_mse is not None:
+            m = ps.extra_mse
+            a_st = self.storage_of(m.a)
+            src = m.b.sources[0]  # flatten(image_original): the NHWC staging tensor already has (h, w, c) order
+            assert src.node is None and src.root is None, "reconstruction target must be the network input"
+            feat = src.npix * src.c
+            assert feat == m.a.c
+            da, ldda = None, 0
+            if self.training:
+                gst, acc = self._grad_target(m.a)
+                assert acc == 0
+                da, ldda = self._ref(gst.buf), gst.ld
+            l3 = Launch("mse", (self._ref(a_st.buf), a_st.ld, self._ref("in:" + src.name), feat, nb, feat,
+                                self._ref("loss_mse"), da, ldda, 1.0, None), nbytes=12 * nb * feat, tag="loss")
+            self._scratch(l3, 10, "scratch_red")
+            self.fwd.append(l3)
+
+    # ------------------------------------------------------------------ backward
+    def _bwd_residuals(self, node, dz_ref, lddz, rows, c):
+        for (src, ridx) in node.residuals:
+            if not src.owner.needs_grad:
+                continue
+            gst, acc = self._grad_target(src)
+            sref = None
+            if ridx is not None:
+                cin = src.c
+                ridx = np.asarray(ridx)
+                assert (np.diff(ridx) >= 0).all(), "channel maps are monotone"
+                start = np.searchsorted(ridx, np.arange(cin + 1), side="left").astype(np.int32)
+                t = self.be.upload(start)
+                self.tables.append(t)
+                sref = Ref(t)
+            self.bwd.append(Launch("chanmap_bwd", (dz_ref, lddz, rows, c, self._ref(gst.buf, gst.ch_off), gst.ld,
+                                                   src.c, sref, acc), nbytes=4 * rows * (c + 2 * src.c),
+                                   tag="res-bwd"))
+
+    def _bwd_linear(self, idx, node):
+        nb = self.nb
+        out = node.out
+        c = node.cout
+        rows = out.npix * nb
+        aux = self.node_aux[idx]
+        own = out.owner
+        if not self.grad_written.get(id(own), False):
+            raise RuntimeError(f"node {idx} ({node.branches[0].scope}) receives no gradient")
+        z_st = self.storage[id(out)]
+        dz = self._ref("g:" + z_st.buf)
+        y_ref = self._ref(aux["y"].buf)
+        dy = dz  # backward post-op runs in place
+        if node.has_post:
+            self._bwd_residuals(node, dz, c, rows, c)
+            self._emit_post_bwd(node, aux, dz, y_ref, rows, c, dy, want_param=True)
+        elif node.has_bias:
+            self._emit_post_bwd(node, aux, dz, y_ref, rows, c, None, want_param=True)
+
+        # ---- data gradient ----
+        if node.kind == "conv":
+            src = node.sources[0]
+            s_st = self.storage_of(src)
+            h, w = src.hw
+            if src.owner.needs_grad:
+                gst, acc = self._grad_target(src)
+                choff = 0
+                by_cout = {}
+                for b in node.branches:
+                    by_cout.setdefault(b.cout, []).append((b, choff))
+                    choff += b.cout
+                for cout, items in by_cout.items():
+                    tb = GemmTables()
+                    if len(items) == 1 and items[0][0].k == 1 and gst.contiguous:
+                        b, off = items[0]
+                        tb.add_group(gst.pix_off(0), [(off, b.w.offset, cout)], src.npix * nb)
+                    else:
+                        for pin in range(h * w):
+                            iy, ix = pin // w, pin % w
+                            segs = []
+                            for b, off in items:
+                                pb = (b.k - 1) // 2
+                                for i in range(b.k):
+                                    oy = iy - (i - pb)
+                                    if oy < 0 or oy >= h:
+                                        continue
+                                    for j in range(b.k):
+                                        ox = ix - (j - pb)
+                                        if 0 <= ox < w:
+                                            segs.append(((oy * w + ox) * nb * c + off,
+                                                         b.w.offset + (i * b.k + j) * src.c * cout, cout))
+                            tb.add_group(gst.pix_off(pin), segs, nb)
+                    self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
+                                    self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}")
+                    acc = 1
+            # ---- filter gradient ----
+            self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w)
+        else:
+            b = node.branches[0]
+            rowbase = 0
+            for src in node.sources:
+                s_st = self.storage_of(src)
+                if src.owner.needs_grad:
+                    gst, acc = self._grad_target(src)
+                    tb = GemmTables()
+                    for p in range(src.npix):
+                        tb.add_group(gst.pix_off(p), [(0, b.w.offset + (rowbase + p * src.c) * c, c)], nb)
+                    self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), c, 1, self._ref(gst.buf),
+                                    gst.ld, None, acc, f"dgrad:{b.scope}")
+                rowbase += src.npix * src.c
+            self._wgrad_dense(idx, node, aux, dy, c)
+
+    def _emit_post_bwd(self, node, aux, dz, y_ref, rows, c, dy, want_param):
+        has_bn = isinstance(node, G.LinearNode) and node.has_bn
+        act = node.act
+        code, alpha = (act.code, act.alpha) if act else (0, 0.0)
+        mean = aux.get("mean") if has_bn else None
+        rstd = aux.get("rstd") if has_bn else None
+        beta = aux.get("beta_ref") if has_bn else None
+        mask = aux.get("mask")
+        dparam = None
+        if want_param and isinstance(node, G.LinearNode):
+            if has_bn:
+                dparam = self._g(aux["beta"])
+            elif node.has_bias:
+                dparam = self._g(aux["bias"])
+        sums = None
+        if has_bn or dparam is not None:
+            n_chunks = (rows + STAT_CHUNK_ROWS - 1) // STAT_CHUNK_ROWS
+            l1 = Launch("bn_act_bwd_reduce", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
+                                              STAT_CHUNK_ROWS, None), nbytes=8 * rows * c, tag="post-bwd-reduce")
+            self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
+            l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, 0), tag="post-bwd-finalize")
+            self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+            self._scratch(l2, 3, "sums", 2 * c)
+            self.bwd += [l1, l2]
+            sums = "pending"
+        if dy is not None and (has_bn or code != 0 or mask is not None):
+            l3 = Launch("bn_act_bwd_apply", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c, None, dy,
+                                             c), nbytes=12 * rows * c, tag="post-bwd-apply")
+            if sums is not None:
+                self._scratch(l3, 13, "sums", 2 * c)
+            self.bwd.append(l3)
+
+    def _wgrad_splits(self, base_blocks, max_segs):
+        s = max(1, min(max_segs, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
+        return min(s, 64)
+
+    def _emit_wgrad(self, tables_by_split_builder, n_groups_blocks, max_segs, slab, w0_offset, n, a_ref, lda, b_ref, ldb,
+                    tag):
+        """tables_by_split_builder(S) -> GemmTables whose groups write to c_off = split*slab + local."""
+        S = self._wgrad_splits(n_groups_blocks, max_segs)
+        tb = tables_by_split_builder(S)
+        if S == 1:
+            self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None, 0,
+                            tag)
+            return
+        launch_pos = len(self.bwd)
+        self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads), n, None, 0, tag)
+        l = self.bwd[launch_pos]
+        self._scratch(l, 6, "scratch_wgrad", S * slab)
+        l2 = Launch("reduce_splits_f32", (None, slab, S, Ref(self.sess.grads, w0_offset), slab, 0),
+                    nbytes=4 * slab * (S + 1), tag="wgrad-reduce")
+        self._scratch(l2, 0, "scratch_wgrad", S * slab)
+        self.bwd.append(l2)
+
+    @staticmethod
+    def _split_even(segs, S):
+        """Partition a list into S contiguous chunks (some possibly empty)."""
+        n = len(segs)
+        return [segs[(n * s) // S:(n * (s + 1)) // S] for s in range(S)]
+
+    def _wgrad_conv(self, idx, node, aux, s_st, src, dy, c, h, w):
+        nb = self.nb
+        choff = 0
+        w_base = aux["w0"].offset
+        by_cout = {}
+        for b in node.branches:
+            by_cout.setdefault(b.cout, []).append((b, choff))
+            choff += b.cout
+        for cout, items in by_cout.items():
+            # the slab of one launch = the contiguous weights of its branches
+            lo = min(b.w.offset for b, _ in items)
+            hi = max(b.w.offset + b.w.size for b, _ in items)
+            slab = hi - lo
+            group_list = []  # (local c_off, segs)
+            for b, off in items:
+                pb = (b.k - 1) // 2
+                for i in range(b.k):
+                    for j in range(b.k):
+                        segs = []
+                        for oy in range(h):
+                            iy = oy + i - pb
+                            if iy < 0 or iy >= h:
+                                continue
+                            for ox in range(w):
+                                ix = ox + j - pb
+                                if ix < 0 or ix >= w:
+                                    continue
+                                pin, pout = iy * w + ix, oy * w + ox
+                                for r0 in range(0, nb, WGRAD_ROW_CHUNK):
+                                    kc = min(WGRAD_ROW_CHUNK, nb - r0)
+                                    segs.append((s_st.pix_off(pin) + r0 * s_st.ld, (pout * nb + r0) * c + off, kc))
+                        group_list.append((b.w.offset - lo + (i * b.k + j) * src.c * cout, segs))
+            blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((cout + 127) // 128)
+            max_segs = max(len(s) for _, s in group_list)
+
+            def build(S, group_list=group_list, slab=slab, rows=src.c):
+                tb = GemmTables()
+                for (loc, segs) in group_list:
+                    for s, chunk in enumerate(self._split_even(segs, S)):
+                        tb.add_group(s * slab + loc, chunk, rows)
+                return tb
+
+            self._emit_wgrad(build, blocks, max_segs, slab, lo, cout, self._ref(s_st.buf), s_st.ld, dy, c,
+                             f"wgrad:{items[0][0].scope}")
+
+    def _wgrad_dense(self, idx, node, aux, dy, c):
+        nb = self.nb
+        b = node.branches[0]
+        rowbase = 0
+        for src in node.sources:
+            s_st = self.storage_of(src)
+            slab = src.npix * src.c * c
+            lo = b.w.offset + rowbase * c
+            group_list = []
+            for p in range(src.npix):
+                segs = []
+                for r0 in range(0, nb, WGRAD_ROW_CHUNK):
+                    kc = min(WGRAD_ROW_CHUNK, nb - r0)
+                    segs.append((s_st.pix_off(p) + r0 * s_st.ld, r0 * c, kc))
+                group_list.append((p * src.c * c, segs))
+            blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((c + 127) // 128)
+            max_segs = max(len(s) for _, s in group_list)
+
+            def build(S, group_list=group_list, slab=slab, rows=src.c):
+                tb = GemmTables()
+                for (loc, segs) in group_list:
+                    for s, chunk in enumerate(self._split_even(segs, S)):
+                        tb.add_group(s * slab + loc, chunk, rows)
+                return tb
+
+            self._emit_wgrad(build, blocks, max_segs, slab, lo, c, self._ref(s_st.buf), s_st.ld, dy, c,
+                             f"wgrad:{b.scope}")
+            rowbase += src.npix * src.c
+
+    def _bwd_post(self, idx, node):
+        out, src = node.out, node.src
+        rows, c = out.npix * self.nb, out.c
+        aux = self.node_aux[idx]
+        z_st = self.storage[id(out)]
+        if not self.grad_written.get(id(out.owner), False):
+            raise RuntimeError(f"post node {idx} receives no gradient")
+        dz = self._ref("g:" + z_st.buf)
+        self._bwd_residuals(node, dz, c, rows, c)
+        if not src.owner.needs_grad:
+            return
+        s_st = self.storage_of(src)
+        act = node.act
+        code, alpha = (act.code, act.alpha) if act else (0, 0.0)
+        mask = aux.get("mask")
+        if code != 0 or mask is not None:
+            self.bwd.append(Launch("bn_act_bwd_apply", (dz, c, self._ref(s_st.buf, s_st.ch_off), s_st.ld, rows, c, None,
+                                                        None, None, code, alpha, mask, c, None, dz, c),
+                                   nbytes=12 * rows * c, tag="post-bwd-apply"))
+        gst, acc = self._grad_target(src)
+        self.bwd.append(Launch("chanmap_bwd", (dz, c, rows, c, self._ref(gst.buf, gst.ch_off), gst.ld, c, None, acc),
+                               nbytes=12 * rows * c, tag="post-bwd-pass"))
+
+    def _bwd_lrn(self, idx, node):
+        out, src = node.out, node.src
+        rows, c = out.npix * self.nb, out.c
+        z_st = self.storage[id(out)]
+        if not self.grad_written.get(id(out.owner), False):
+            raise RuntimeError(f"lrn node {idx} receives no gradient")
+        if not src.owner.needs_grad:
+            return
+        s_st = self.storage_of(src)
+        gst, acc = self._grad_target(src)
+        self.bwd.append(Launch("lrn_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf), c,
+                                           rows, c, node.radius, float(node.bias), float(node.alpha), float(node.beta),
+                                           self._ref(gst.buf, gst.ch_off), gst.ld, acc), nbytes=16 * rows * c,
+                               tag="lrn-bwd"))

@@ -1,0 +1,245 @@
+"""Session: parameter storage, compiled towers, optimiser step, data-parallel gradient exchange.
+
+The TF1 reference runs `session.run(train_step)` in a loop (classify/monitored_session_runner.py:
+182-184).  Here a "session" owns
+  * one flat fp32 buffer per kind (parameters, gradients, optimiser slots, BN moving statistics) so
+    that the optimiser is ONE launch and the data-parallel exchange is ONE RCCL all-reduce;
+  * per (tower, batch size) a `CompiledTower`: pre-bound C-ABI launches, optionally captured in a
+    HIP graph and replayed.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import graph as G
+from .backend import Ref
+from .plan import TowerPlan
+
+
+class CompiledTower:
+    def __init__(self, plan, backend):
+        self.plan = plan
+        self.be = backend
+        self.fwd = [backend.bind(l.name, l.args) for l in plan.fwd]
+        self.bwd = [backend.bind(l.name, l.args) for l in plan.bwd]
+        self._graph_fwd = None
+        self._graph_all = None
+
+    # ---- inputs / outputs ----
+    def input(self, name):
+        return self.plan.buffers["in:" + name]
+
+    def set_input(self, name, tensor):
+        dst = self.plan.buffers["in:" + name]
+        dst.copy_(tensor.reshape(-1).to(dst.dtype), non_blocking=True)
+
+    def value(self, sym, nhwc=True):
+        """Fetch a tensor of the tower as [N, H, W, C] / [N, C] (host-side check helper)."""
+        st = self.plan.storage_of(sym)
+        buf = self.plan.buffers[st.buf]
+        nb = self.plan.nb
+        own = self.plan.storage[id(sym.owner)]
+        full = buf[: sym.owner.npix * nb * own.ld].reshape(sym.owner.npix, nb, own.ld)
+        pm = list(range(sym.npix)) if st.pixmap is None else st.pixmap
+        v = full[pm][:, :, st.ch_off:st.ch_off + st.c]
+        v = v.permute(1, 0, 2)
+        if sym.hw is None:
+            return v.reshape(nb, st.c)
+        return v.reshape(nb, sym.hw[0], sym.hw[1], st.c)
+
+    def grad_value(self, sym):
+        st = self.plan.grad_storage_of(sym)
+        buf = self.plan.buffers[st.buf]
+        nb = self.plan.nb
+        own = self.plan.storage[id(sym.owner)]
+        full = buf[: sym.owner.npix * nb * own.ld].reshape(sym.owner.npix, nb, own.ld)
+        pm = list(range(sym.npix)) if st.pixmap is None else st.pixmap
+        v = full[pm][:, :, st.ch_off:st.ch_off + st.c].permute(1, 0, 2)
+        return v.reshape(nb, st.c) if sym.hw is None else v.reshape(nb, sym.hw[0], sym.hw[1], st.c)
+
+    def dropout_mask(self, index):
+        return self.plan.buffers[self.plan.mask_bufs[index]]
+
+    # ---- execution ----
+    def forward(self):
+        if self._graph_fwd is not None:
+            self._graph_fwd()
+        else:
+            for f in self.fwd:
+                f()
+
+    def forward_backward(self):
+        if self._graph_all is not None:
+            self._graph_all()
+        else:
+            for f in self.fwd:
+                f()
+            for f in self.bwd:
+                f()
+
+    def capture(self):
+        """Capture forward (+ backward) into HIP graphs: one host call per step instead of ~300."""
+        self.forward_backward() if self.bwd else self.forward()  # warm: first-use allocations / lazy module loads
+        self.be.synchronize()
+        if self.bwd:
+            self._graph_all = self.be.capture(self.fwd + self.bwd)
+        else:
+            self._graph_fwd = self.be.capture(self.fwd)
+
+    def loss_value(self):
+        b = self.plan.buffers
+        v = float(b["loss_ce"][0])
+        if self.plan.loss is not None and self.plan.loss.per_sample.extra_mse is not None:
+            v += float(b["loss_mse"][0])
+        return v
+
+    def flops(self):
+        return sum(l.flops for l in self.plan.fwd), sum(l.flops for l in self.plan.bwd)
+
+
+class Session:
+    def __init__(self, store, backend, seed=1234):
+        self.store = store
+        self.backend = backend
+        self.seed = seed
+        self.params = self.grads = self.state = None
+        self.slot_m = self.slot_v = None
+        self.trainable = []
+        self.stateful = []
+        self.global_step = 0
+        self._compiled = {}
+        self.dist = None  # (world_size, rank) once init_data_parallel() ran
+
+    # ---- variables ----
+    def finalize_variables(self, rng=None):
+        """Lay variables out in the flat buffers (weights first, then per-channel vectors, each in
+        creation order so that the vectors of a merged level are contiguous) and initialise them."""
+        order = self.store.order
+        weights = [v for v in order if v.trainable and len(v.shape) > 1]
+        vectors = [v for v in order if v.trainable and len(v.shape) == 1]
+        self.trainable = weights + vectors
+        off = 0
+        for v in self.trainable:
+            v.offset = off
+            off += v.size
+        n_train = off
+        mm = [v for v in order if not v.trainable and v.name.endswith("moving_mean")]
+        mv = [v for v in order if not v.trainable and v.name.endswith("moving_variance")]
+        other = [v for v in order if not v.trainable and v not in mm and v not in mv]
+        self.stateful = mm + mv + other
+        off = 0
+        for v in self.stateful:
+            v.offset = off
+            off += v.size
+        be = self.backend
+        self.params = be.zeros(n_train)
+        self.grads = be.zeros(n_train)
+        self.slot_m = be.zeros(n_train)
+        self.slot_v = be.zeros(n_train)
+        self.state = be.zeros(max(off, 1))
+        rng = rng or np.random.default_rng(self.seed)
+        host_p = np.zeros(n_train, np.float32)
+        for v in self.trainable:
+            host_p[v.offset:v.offset + v.size] = v.init(rng, v.shape).reshape(-1)
+        host_s = np.zeros(max(off, 1), np.float32)
+        for v in self.stateful:
+            host_s[v.offset:v.offset + v.size] = v.init(rng, v.shape).reshape(-1)
+        self.params.copy_(torch.from_numpy(host_p))
+        self.state.copy_(torch.from_numpy(host_s))
+        return n_train
+
+    def _lookup(self, name):
+        v = self.store.vars.get(name) or self.store.vars.get(f"{self.store.prefix}/{name}")
+        if v is None:
+            raise KeyError(name)
+        return v
+
+    def _buf_of(self, v):
+        return self.params if v.trainable else self.state
+
+    def get_variable(self, name):
+        v = self._lookup(name)
+        return self._buf_of(v)[v.offset:v.offset + v.size].detach().cpu().numpy().reshape(v.shape).copy()
+
+    def set_variable(self, name, value):
+        v = self._lookup(name)
+        arr = np.ascontiguousarray(value, np.float32).reshape(-1)
+        assert arr.size == v.size, (name, arr.size, v.size)
+        self._buf_of(v)[v.offset:v.offset + v.size].copy_(torch.from_numpy(arr))
+
+    def get_gradient(self, name):
+        v = self._lookup(name)
+        return self.grads[v.offset:v.offset + v.size].detach().cpu().numpy().reshape(v.shape).copy()
+
+    def variable_names(self):
+        return [v.name for v in self.store.order]
+
+    def state_dict(self):
+        """Checkpoint payload keyed by the TF variable names (monitored_session_runner.py:164-168)."""
+        d = {v.name: self.get_variable(v.name) for v in self.store.order}
+        d["global_step"] = np.asarray(self.global_step, np.int64)
+        d["training_optimizer/m"] = self.slot_m.detach().cpu().numpy()
+        d["training_optimizer/v"] = self.slot_v.detach().cpu().numpy()
+        return d
+
+    def load_state_dict(self, d):
+        for v in self.store.order:
+            if v.name in d:
+                self.set_variable(v.name, d[v.name])
+        if "global_step" in d:
+            self.global_step = int(d["global_step"])
+        if "training_optimizer/m" in d and d["training_optimizer/m"].size == self.slot_m.numel():
+            self.slot_m.copy_(torch.from_numpy(np.asarray(d["training_optimizer/m"], np.float32)))
+            self.slot_v.copy_(torch.from_numpy(np.asarray(d["training_optimizer/v"], np.float32)))
+
+    # ---- towers ----
+    def compile(self, tower, nb, loss=None, external_masks=False):
+        key = (id(tower), int(nb), id(loss), external_masks)
+        ct = self._compiled.get(key)
+        if ct is None:
+            plan = TowerPlan(tower, nb, self, loss=loss, external_masks=external_masks, seed=self.seed)
+            ct = CompiledTower(plan, self.backend)
+            self._compiled[key] = ct
+        return ct
+
+    # ---- optimiser (common_nn_ops.py:223-230) ----
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        t = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        self.backend.call("adam_tf1", Ref(self.params), Ref(self.grads), Ref(self.slot_m), Ref(self.slot_v),
+                          self.params.numel(), float(lr_t), float(beta1), float(beta2), float(eps))
+        self.global_step += 1
+
+    def momentum_step(self, lr, mu):
+        self.backend.call("momentum_tf1", Ref(self.params), Ref(self.grads), Ref(self.slot_m), self.params.numel(),
+                          float(lr), float(mu))
+        self.global_step += 1
+
+    # ---- data parallel (new vs the reference: SURVEY §2.3 / §8e) ----
+    def init_data_parallel(self, broadcast=True):
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            self.dist = None
+            return
+        self.dist = (dist.get_world_size(), dist.get_rank())
+        if broadcast:
+            dist.broadcast(self.params, src=0)
+            dist.broadcast(self.state, src=0)
+
+    def allreduce_gradients(self):
+        """One flat all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests), then average."""
+        if self.dist is None:
+            return
+        import torch.distributed as dist
+        dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+        self.grads.mul_(1.0 / self.dist[0])
+
+    def average_state(self):
+        """BN moving statistics are per-rank (local batch statistics); average them before
+        a checkpoint / evaluation so every rank holds the same model."""
+        if self.dist is None:
+            return
+        import torch.distributed as dist
+        dist.all_reduce(self.state, op=dist.ReduceOp.SUM)
+        self.state.mul_(1.0 / self.dist[0])

@@ -1,0 +1,169 @@
+/* hypel.h -- C-ABI of libhypel_hip.so: the MI355X (gfx950) compute path behind the
+ * NNModel / GAN-wrapper plugin API of aligokalppeker/hypelcnn.
+ *
+ * The reference has NO native layer: every entry point below replaces a call the reference
+ * makes into TensorFlow / tf_slim kernels (reference file:line cited per function).  The
+ * binding a maintainer would add on the reference side is a ctypes stub.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer unless it says "host".
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t); no implicit syncs,
+ *    no allocation; the caller (PyTorch caching allocator on the Python side) owns every
+ *    buffer including workspaces.
+ *  - return 0 on success, negative on error; message via hypel_last_error() (thread-local).
+ *  - activations are row-major matrices [rows, C] with a leading dimension `ld` (floats).
+ *    Internally the host keeps patch tensors PIXEL-MAJOR: [P = H*W][N][C], i.e. the rows
+ *    of pixel p for the whole minibatch are contiguous.  That turns a SAME convolution
+ *    into a sum over VALID taps of plain GEMMs on contiguous row blocks (no im2col, no
+ *    padding taps): see hypel_seg_gemm_f32.  hypel_nhwc_to_pnc converts the loader's
+ *    NHWC batches (importer/InMemoryImporter.py:27-38).
+ *  - weights keep the TF variable layouts: conv HWIO [kh][kw][Cin][Cout], FC [in][out],
+ *    BN vectors [C] -- checkpoints keyed by TF names map 1:1.
+ */
+#ifndef HYPEL_H
+#define HYPEL_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hypel_stream_t; /* hipStream_t */
+
+#define HYPEL_ABI_VERSION 1
+
+/* activation codes (leaky_relu: HYPELCNNModel.py:39, DUALCNNModel.py:18, shadow_data_models.py:53;
+ * relu: tf_slim default, CONCNNModel.py; sigmoid: HYPELCNNModel.py:93; tanh: shadow_data_models.py:86) */
+enum { HYPEL_ACT_NONE = 0, HYPEL_ACT_LRELU = 1, HYPEL_ACT_RELU = 2, HYPEL_ACT_SIGMOID = 3, HYPEL_ACT_TANH = 4 };
+
+int hypel_version(void);
+const char* hypel_last_error(void);
+/* number of compute units / XCDs of the current device (host query, for table building) */
+int hypel_device_info(int32_t* n_cu, int32_t* n_xcd);
+
+/* ---- layout ------------------------------------------------------------------------------- */
+/* x[N][P][C] (NHWC with P=H*W) -> out[P][N][ld] (pad columns zeroed).  Replaces the
+ * feed_dict/prefetch_to_device hand-over (InMemoryImporter.py:80-83, common_nn_ops.py:200). */
+int hypel_nhwc_to_pnc(const float* x, float* out, int64_t n, int32_t p, int32_t c, int64_t ld,
+                      hypel_stream_t stream);
+int hypel_pnc_to_nhwc(const float* in, int64_t ld, float* x, int64_t n, int32_t p, int32_t c,
+                      hypel_stream_t stream);
+int hypel_fill_f32(float* dst, int64_t count, float value, hypel_stream_t stream);
+
+/* ---- grouped multi-segment GEMM (fp32 MFMA, 32x32x2) ------------------------------------------
+ * For every group g:  C_g[rows_g x n] (+)= sum_{s in segs(g)} op(A_s)[rows_g x k_s] * op(B_s)[k_s x n] (+ bias)
+ *   trans_a = 0: op(A_s)[i][kk] = A[a_off + i*lda + kk]      trans_a = 1: A[a_off + kk*lda + i]
+ *   trans_b = 0: op(B_s)[kk][j] = B[b_off + kk*ldb + j]      trans_b = 1: B[b_off + j*ldb + kk]
+ *   C_g[i][j] = C[c_off + i*ldc + j]
+ * One kernel covers: tf_slim.conv2d 1x1 and kxk SAME as exact-tap sums (HYPELCNNModel.py:136,
+ * 157,177; DUALCNNModel.py:99; CONCNNModel.py:33-60), tf_slim.fully_connected incl. the
+ * flatten that precedes it (HYPELCNNModel.py:74-94,121; DUALCNNModel.py:31,48-54), and their
+ * data-gradient (trans_b=1) and filter-gradient (trans_a=1, split over rows) passes that
+ * tf.gradients derives inside create_train_op (common_nn_ops.py:232).
+ * bias (optional) is indexed by the ABSOLUTE output column, (c_off mod ldc) + j, so the branches of a
+ * merged multi-kernel level (groups starting at different channel offsets) share one launch.
+ * `tiles` lists the (group, first row) of every 128-row output tile; tables live on the device. */
+typedef struct { int64_t a_off; int64_t b_off; int32_t k; int32_t reserved; } hypel_seg_t;
+typedef struct { int64_t c_off; int32_t seg_begin; int32_t seg_count; int32_t rows; int32_t reserved; } hypel_group_t;
+typedef struct { int32_t group; int32_t m0; } hypel_tile_t;
+#define HYPEL_GEMM_BM 128
+
+int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb, int32_t trans_b,
+                       float* c, int64_t ldc, int32_t n, const hypel_group_t* groups, const hypel_seg_t* segs,
+                       const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
+                       hypel_stream_t stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*stride + i], s ascending (deterministic split-K). */
+int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_splits, float* out, int64_t count,
+                            int32_t accumulate, hypel_stream_t stream);
+
+/* ---- batch norm statistics (tf_slim.batch_norm fused, HYPELCNNModel.py:37,43-44) ------------------
+ * partial[chunk][0][c] = mean of the chunk's rows, partial[chunk][1][c] = sum of squared deviations.
+ * chunk = `chunk_rows` consecutive rows (last may be short). */
+int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows, float* partial,
+                            hypel_stream_t stream);
+/* Chan-merge the chunk partials in chunk order (fp64) -> mean[c], rstd[c] = 1/sqrt(var_biased+eps);
+ * optional moving-average update m <- m*decay + batch*(1-decay) with the Bessel-corrected variance. */
+int hypel_bn_finalize(const float* partial, int32_t n_chunks, int32_t chunk_rows, int64_t rows, int32_t c, float eps,
+                      float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
+                      hypel_stream_t stream);
+/* inference: rstd[c] = 1/sqrt(moving_var[c] + eps) */
+int hypel_rstd_from_var(const float* var, int32_t c, float eps, float* rstd, hypel_stream_t stream);
+
+/* ---- fused post-op: z = act((y - mean) * rstd + beta) * mask + res1[:, idx1] + res2[:, idx2] ---------
+ * mean/rstd/beta NULL -> no normalisation (bias was added by the GEMM).  mask NULL -> no dropout
+ * (tf_slim.dropout, HYPELCNNModel.py:123).  idx NULL -> identity channel map; otherwise the
+ * scale_in_to_out gather/repeat index vector (common_nn_ops.py:546-564). */
+int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, const float* mean, const float* rstd,
+                     const float* beta, int32_t act, float alpha, const float* mask, int64_t ldm, const float* res1,
+                     int64_t ld1, const int32_t* idx1, const float* res2, int64_t ld2, const int32_t* idx2, float* z,
+                     int64_t ldz, hypel_stream_t stream);
+/* backward pass 1: partial[chunk][0][c] = sum dyh, partial[chunk][1][c] = sum dyh*xhat over the chunk rows,
+ * dyh = dz*mask*act'(yh).  (xhat := y when there is no normalisation.) */
+int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                            const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                            const float* mask, int64_t ldm, int32_t chunk_rows, float* partial, hypel_stream_t stream);
+/* sums[0][c] = sum over chunks (fp64, chunk order) of partial[.][0][c]; sums[1][c] likewise;
+ * dparam (beta or bias gradient) = sums[0] (+= when accumulate). */
+int hypel_bwd_reduce_finalize(const float* partial, int32_t n_chunks, int32_t c, float* sums, float* dparam,
+                              int32_t accumulate, hypel_stream_t stream);
+/* backward pass 2: dy = rstd*(dyh - sums0/M - xhat*sums1/M)   (or dy = dyh without normalisation).
+ * dy may alias dz. */
+int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                           const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                           const float* mask, int64_t ldm, const float* sums, float* dy, int64_t lddy,
+                           hypel_stream_t stream);
+/* gradient of the channel map: dr[row][ci] (+)= sum_{c in [start[ci], start[ci+1])} dz[row][c];
+ * start NULL -> identity (cin == c). */
+int hypel_chanmap_bwd(const float* dz, int64_t lddz, int64_t rows, int32_t c, float* dr, int64_t lddr, int32_t cin,
+                      const int32_t* start, int32_t accumulate, hypel_stream_t stream);
+
+/* ---- losses ------------------------------------------------------------------------------------------ */
+/* tf.nn.softmax_cross_entropy_with_logits (HYPELCNNModel.py:102, DUALCNNModel.py:88, cut_wrapper.py:382,413):
+ * loss[i] = -sum_j labels[i][j]*log_softmax(logits[i])[j];
+ * dlogits[i][j] = gscale*(softmax[i][j]*sum_j labels[i][j] - labels[i][j])  (dlogits NULL -> skipped). */
+int hypel_softmax_xent(const float* logits, int64_t ld, int64_t n, int32_t c, const float* labels, int64_t ldl,
+                       float* loss, float* dlogits, int64_t lddl, float gscale, hypel_stream_t stream);
+/* reconstruction MSE (HYPELCNNModel.py:106-109): out[0] = mean((a-b)^2) over rows x c;
+ * da = gscale*2*(a-b)/(rows*c) (da NULL -> skipped).  ws: >= 1024 floats. */
+int hypel_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c, float* out, float* da,
+              int64_t ldda, float gscale, float* ws, hypel_stream_t stream);
+/* out[0] = sum(x[0..count)) * scale, deterministic two-stage.  ws >= 1024 floats. */
+int hypel_sum_f32(const float* x, int64_t count, float scale, float* out, float* ws, hypel_stream_t stream);
+
+/* ---- optimisers (common_nn_ops.py:223-230; gan_common.py:264-265) ---------------------------------------- */
+/* TF1 Adam: m=b1*m+(1-b1)g; v=b2*v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps), lr_t precomputed on the host. */
+int hypel_adam_tf1(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1, float beta2,
+                   float eps, hypel_stream_t stream);
+/* TF1 Momentum: a = mu*a + g; p -= lr*a. */
+int hypel_momentum_tf1(float* p, const float* g, float* a, int64_t count, float lr, float mu, hypel_stream_t stream);
+
+/* ---- dropout mask (tf_slim.dropout): mask in {0, 1/keep}, Philox4x32-10 counter RNG ----------------------
+ * counter = (element group, *step_dev), key = seed: the step lives on the device so that a captured
+ * HIP graph draws fresh masks on every replay; hypel_step_inc bumps it once per training step. */
+int hypel_dropout_mask(float* mask, int64_t count, float keep_prob, uint64_t seed, const uint64_t* step_dev,
+                       hypel_stream_t stream);
+int hypel_step_inc(uint64_t* step_dev, hypel_stream_t stream);
+
+/* ---- evaluation (common_nn_ops.py:243-277): pred[i] = argmax logits[i] (first max, as tf.argmax);
+ * confusion[label][pred] += 1 (int32 atomics). labels: int32 class ids. pred may be NULL. */
+int hypel_argmax_confusion(const float* logits, int64_t ld, int64_t n, int32_t c, const int32_t* labels,
+                           int32_t* pred, int32_t* confusion, hypel_stream_t stream);
+
+/* ---- LRN (tf.nn.local_response_normalization, CONCNNModel.py:37,41) -------------------------------------- */
+int hypel_lrn_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t radius, float bias, float alpha,
+                  float beta, float* y, int64_t ldy, hypel_stream_t stream);
+int hypel_lrn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c, int32_t radius,
+                  float bias, float alpha, float beta, float* dx, int64_t lddx, int32_t accumulate,
+                  hypel_stream_t stream);
+
+/* ---- graph capture helpers (HIP graphs instead of a tracing compiler) ---------------------------------------- */
+int hypel_graph_begin_capture(hypel_stream_t stream);
+int hypel_graph_end_capture(hypel_stream_t stream, void** graph_exec_out);
+int hypel_graph_launch(void* graph_exec, hypel_stream_t stream);
+int hypel_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPEL_H */

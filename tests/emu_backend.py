@@ -1,0 +1,333 @@
+"""TEST INFRASTRUCTURE: a numpy emulation of the libhypel_hip.so entry points (include/hypel.h).
+
+There is no GPU in the build container, so the host-side logic of the product (graph recording,
+planning, table building, the hand-derived backward pass, optimiser wiring) is exercised here
+against this executable specification of every kernel's contract; the `-m gpu` tests then check the
+real HIP kernels against the oracle.  Never imported by the hypelcnn_amd package.
+"""
+import numpy as np
+import torch
+
+from hypelcnn_amd.backend import GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
+
+
+def _arr(ref, dtype=np.float32):
+    """numpy view of the tensor behind a Ref starting at its offset."""
+    if ref is None:
+        return None
+    a = ref.t.numpy()
+    if a.dtype != dtype:
+        a = a.view(dtype) if a.dtype.itemsize == np.dtype(dtype).itemsize else a
+    return a[ref.off:]
+
+
+def _mat(ref, ld, rows, cols, dtype=np.float32):
+    a = _arr(ref, dtype)
+    return np.lib.stride_tricks.as_strided(a, shape=(rows, cols), strides=(ld * a.itemsize, a.itemsize))
+
+
+def _act(v, code, alpha):
+    if code == 1:
+        return np.where(v > 0, v, v * alpha)
+    if code == 2:
+        return np.where(v > 0, v, 0)
+    if code == 3:
+        return 1.0 / (1.0 + np.exp(-v))
+    if code == 4:
+        return np.tanh(v)
+    return v
+
+
+def _act_grad(v, code, alpha):
+    if code == 1:
+        return np.where(v > 0, 1.0, alpha)
+    if code == 2:
+        return np.where(v > 0, 1.0, 0.0)
+    if code == 3:
+        s = 1.0 / (1.0 + np.exp(-v))
+        return s * (1 - s)
+    if code == 4:
+        t = np.tanh(v)
+        return 1 - t * t
+    return np.ones_like(v)
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.launch_log = []
+
+    def empty(self, n, dtype=torch.float32):
+        return torch.zeros(int(n), dtype=dtype)
+
+    def zeros(self, n, dtype=torch.float32):
+        return torch.zeros(int(n), dtype=dtype)
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        if a.dtype.fields is not None:
+            return torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
+        return torch.from_numpy(a.reshape(-1).copy())
+
+    def synchronize(self):
+        pass
+
+    def bind(self, name, args, stream=None):
+        fn = getattr(self, "k_" + name)
+        return lambda: fn(*args)
+
+    def call(self, name, *args):
+        getattr(self, "k_" + name)(*args)
+
+    def capture(self, launches):
+        def replay():
+            for f in launches:
+                f()
+        return replay
+
+    # ------------------------------------------------------------------ kernels
+    def k_nhwc_to_pnc(self, x, out, n, p, c, ld):
+        xv = _arr(x)[: n * p * c].reshape(n, p, c)
+        o = _arr(out)[: p * n * ld].reshape(p, n, ld)
+        o[:, :, :c] = xv.transpose(1, 0, 2)
+        o[:, :, c:] = 0
+
+    def k_pnc_to_nhwc(self, inp, ld, x, n, p, c):
+        i = _arr(inp)[: p * n * ld].reshape(p, n, ld)
+        _arr(x)[: n * p * c].reshape(n, p, c)[...] = i[:, :, :c].transpose(1, 0, 2)
+
+    def k_fill_f32(self, dst, count, value):
+        _arr(dst)[:count] = value
+
+    def k_seg_gemm_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate):
+        A, B, C = _arr(a), _arr(b), _arr(c)
+        g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
+        s = segs.t.numpy()[segs.off:].view(SEG_DTYPE)
+        t = tiles.t.numpy()[tiles.off:].view(TILE_DTYPE)[:n_tiles]
+        # tiles must cover every group's rows exactly once
+        seen = {}
+        for tt in t:
+            seen.setdefault(int(tt["group"]), []).append(int(tt["m0"]))
+        for gi, m0s in seen.items():
+            rows = int(g[gi]["rows"])
+            assert sorted(m0s) == list(range(0, rows, 128)), (gi, m0s, rows)
+        bv = _arr(bias)
+        for gi in seen:
+            grp = g[gi]
+            rows = int(grp["rows"])
+            acc = np.zeros((rows, n), np.float64)
+            for si in range(int(grp["seg_begin"]), int(grp["seg_begin"]) + int(grp["seg_count"])):
+                sg = s[si]
+                k = int(sg["k"])
+                if k == 0:
+                    continue
+                ao, bo = int(sg["a_off"]), int(sg["b_off"])
+                if ta:
+                    am = np.lib.stride_tricks.as_strided(A[ao:], (k, rows), (lda * 4, 4)).T
+                else:
+                    am = np.lib.stride_tricks.as_strided(A[ao:], (rows, k), (lda * 4, 4))
+                if tb:
+                    bm = np.lib.stride_tricks.as_strided(B[bo:], (n, k), (ldb * 4, 4)).T
+                else:
+                    bm = np.lib.stride_tricks.as_strided(B[bo:], (k, n), (ldb * 4, 4))
+                acc += am.astype(np.float64) @ bm.astype(np.float64)
+            co = int(grp["c_off"])
+            cm = np.lib.stride_tricks.as_strided(C[co:], (rows, n), (ldc * 4, 4))
+            if bv is not None:
+                col0 = co % ldc
+                acc += bv[col0:col0 + n]
+            if accumulate:
+                cm += acc.astype(np.float32)
+            else:
+                cm[...] = acc.astype(np.float32)
+
+    def k_reduce_splits_f32(self, partial, stride, n_splits, out, count, accumulate):
+        p = _arr(partial)
+        o = _arr(out)[:count]
+        tot = np.zeros(count, np.float64)
+        for k in range(n_splits):
+            tot += p[k * stride:k * stride + count]
+        if accumulate:
+            o += tot.astype(np.float32)
+        else:
+            o[...] = tot.astype(np.float32)
+
+    def k_col_stats_partial(self, x, ld, rows, c, chunk_rows, partial):
+        xm = _mat(x, ld, rows, c)
+        n_chunks = (rows + chunk_rows - 1) // chunk_rows
+        po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c)
+        for k in range(n_chunks):
+            blk = xm[k * chunk_rows:(k + 1) * chunk_rows].astype(np.float64)
+            m = blk.mean(0)
+            po[k, 0] = m
+            po[k, 1] = ((blk - m) ** 2).sum(0)
+
+    def k_bn_finalize(self, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, mm, mv, decay):
+        po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c).astype(np.float64)
+        n_a, mean_a, m2_a = 0.0, np.zeros(c), np.zeros(c)
+        for k in range(n_chunks):
+            n_b = min(rows, (k + 1) * chunk_rows) - k * chunk_rows
+            d = po[k, 0] - mean_a
+            n_ab = n_a + n_b
+            mean_a = mean_a + d * n_b / n_ab
+            m2_a = m2_a + po[k, 1] + d * d * n_a * n_b / n_ab
+            n_a = n_ab
+        var = m2_a / n_a
+        _arr(mean)[:c] = mean_a
+        _arr(rstd)[:c] = 1.0 / np.sqrt(var + eps)
+        if mm is not None:
+            unb = m2_a / (n_a - 1) if n_a > 1 else var
+            mmv, mvv = _arr(mm)[:c], _arr(mv)[:c]
+            mmv[...] = mmv * np.float64(decay) + mean_a * (1 - np.float64(decay))
+            mvv[...] = mvv * np.float64(decay) + unb * (1 - np.float64(decay))
+
+    def k_rstd_from_var(self, var, c, eps, rstd):
+        _arr(rstd)[:c] = 1.0 / np.sqrt(_arr(var)[:c].astype(np.float64) + eps)
+
+    def _pre(self, y, ldy, rows, c, mean, rstd, beta):
+        v = _mat(y, ldy, rows, c).astype(np.float64)
+        if mean is not None:
+            xhat = (v - _arr(mean)[:c]) * _arr(rstd)[:c]
+            return xhat, xhat + _arr(beta)[:c]
+        return v, v
+
+    def k_bn_act_fwd(self, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, r1, ld1, i1, r2, ld2, i2, z, ldz):
+        _, pre = self._pre(y, ldy, rows, c, mean, rstd, beta)
+        v = _act(pre, act, alpha)
+        if mask is not None:
+            v = v * _mat(mask, ldm, rows, c)
+        for (r, ld, idx) in ((r1, ld1, i1), (r2, ld2, i2)):
+            if r is None:
+                continue
+            if idx is None:
+                v = v + _mat(r, ld, rows, c)
+            else:
+                ii = _arr(idx, np.int32)[:c]
+                src = _mat(r, ld, rows, int(ii.max()) + 1)
+                v = v + src[:, ii]
+        _mat(z, ldz, rows, c)[...] = v.astype(np.float32)
+
+    def _dyh(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm):
+        xhat, pre = self._pre(y, ldy, rows, c, mean, rstd, beta)
+        g = _mat(dz, lddz, rows, c).astype(np.float64)
+        if mask is not None:
+            g = g * _mat(mask, ldm, rows, c)
+        return g * _act_grad(pre, act, alpha), xhat
+
+    def k_bn_act_bwd_reduce(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows,
+                            partial):
+        dyh, xhat = self._dyh(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm)
+        n_chunks = (rows + chunk_rows - 1) // chunk_rows
+        po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c)
+        for k in range(n_chunks):
+            sl = slice(k * chunk_rows, (k + 1) * chunk_rows)
+            po[k, 0] = dyh[sl].sum(0)
+            po[k, 1] = (dyh[sl] * xhat[sl]).sum(0)
+
+    def k_bwd_reduce_finalize(self, partial, n_chunks, c, sums, dparam, accumulate):
+        po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c).astype(np.float64)
+        s = po.sum(0)
+        _arr(sums)[: 2 * c] = s.reshape(-1)
+        if dparam is not None:
+            d = _arr(dparam)[:c]
+            d[...] = (d if accumulate else 0) + s[0]
+
+    def k_bn_act_bwd_apply(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, dy, lddy):
+        dyh, xhat = self._dyh(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm)
+        g = dyh
+        if mean is not None:
+            s = _arr(sums)[: 2 * c].astype(np.float64).reshape(2, c)
+            g = _arr(rstd)[:c] * (dyh - s[0] / rows - xhat * s[1] / rows)
+        _mat(dy, lddy, rows, c)[...] = g.astype(np.float32)
+
+    def k_chanmap_bwd(self, dz, lddz, rows, c, dr, lddr, cin, start, accumulate):
+        g = _mat(dz, lddz, rows, c).astype(np.float64)
+        if start is None:
+            assert cin == c
+            s = g
+        else:
+            st = _arr(start, np.int32)[: cin + 1]
+            cs = np.concatenate([np.zeros((rows, 1)), np.cumsum(g, 1)], 1)
+            s = cs[:, st[1:]] - cs[:, st[:-1]]
+        d = _mat(dr, lddr, rows, cin)
+        if accumulate:
+            d += s.astype(np.float32)
+        else:
+            d[...] = s.astype(np.float32)
+
+    def k_softmax_xent(self, logits, ld, n, c, labels, ldl, loss, dlogits, lddl, gscale):
+        z = _mat(logits, ld, n, c).astype(np.float64)
+        lab = _mat(labels, ldl, n, c).astype(np.float64)
+        zm = z.max(1, keepdims=True)
+        e = np.exp(z - zm)
+        se = e.sum(1, keepdims=True)
+        if loss is not None:
+            _arr(loss)[:n] = -(lab * (z - zm - np.log(se))).sum(1)
+        if dlogits is not None:
+            _mat(dlogits, lddl, n, c)[...] = gscale * (e / se * lab.sum(1, keepdims=True) - lab)
+
+    def k_mse(self, a, lda, b, ldb, rows, c, out, da, ldda, gscale, ws):
+        d = _mat(a, lda, rows, c).astype(np.float64) - _mat(b, ldb, rows, c)
+        _arr(out)[0] = (d * d).mean()
+        if da is not None:
+            _mat(da, ldda, rows, c)[...] = gscale * 2.0 * d / (rows * c)
+
+    def k_sum_f32(self, x, count, scale, out, ws):
+        _arr(out)[0] = _arr(x)[:count].astype(np.float64).sum() * scale
+
+    def k_adam_tf1(self, p, g, m, v, count, lr_t, b1, b2, eps):
+        pv, gv, mv, vv = (_arr(t)[:count] for t in (p, g, m, v))
+        mv[...] = np.float32(b1) * mv + np.float32(1 - b1) * gv
+        vv[...] = np.float32(b2) * vv + np.float32(1 - b2) * gv * gv
+        pv -= np.float32(lr_t) * mv / (np.sqrt(vv) + np.float32(eps))
+
+    def k_momentum_tf1(self, p, g, a, count, lr, mu):
+        pv, gv, av = (_arr(t)[:count] for t in (p, g, a))
+        av[...] = np.float32(mu) * av + gv
+        pv -= np.float32(lr) * av
+
+    def k_dropout_mask(self, mask, count, keep, seed, step_dev):
+        step = int(step_dev.t.numpy()[step_dev.off])
+        rng = np.random.default_rng([int(seed) & 0xFFFFFFFF, step])
+        _arr(mask)[:count] = (rng.random(count) < keep) / keep
+
+    def k_step_inc(self, step_dev):
+        step_dev.t[step_dev.off] += 1
+
+    def k_argmax_confusion(self, logits, ld, n, c, labels, pred, confusion):
+        z = _mat(logits, ld, n, c)
+        best = z.argmax(1)
+        if pred is not None:
+            _arr(pred, np.int32)[:n] = best
+        if confusion is not None and labels is not None:
+            lab = _arr(labels, np.int32)[:n]
+            conf = _arr(confusion, np.int32)[: c * c].reshape(c, c)
+            np.add.at(conf, (lab, best), 1)
+
+    def _lrn_s(self, xm, radius, bias, alpha):
+        c = xm.shape[1]
+        sq = xm * xm
+        cs = np.concatenate([np.zeros((xm.shape[0], 1)), np.cumsum(sq, 1)], 1)
+        lo = np.maximum(np.arange(c) - radius, 0)
+        hi = np.minimum(np.arange(c) + radius + 1, c)
+        return bias + alpha * (cs[:, hi] - cs[:, lo]), lo, hi
+
+    def k_lrn_fwd(self, x, ldx, rows, c, radius, bias, alpha, beta, y, ldy):
+        xm = _mat(x, ldx, rows, c).astype(np.float64)
+        s, _, _ = self._lrn_s(xm, radius, bias, alpha)
+        _mat(y, ldy, rows, c)[...] = (xm * s ** (-beta)).astype(np.float32)
+
+    def k_lrn_bwd(self, x, ldx, dy, lddy, rows, c, radius, bias, alpha, beta, dx, lddx, accumulate):
+        xm = _mat(x, ldx, rows, c).astype(np.float64)
+        g = _mat(dy, lddy, rows, c).astype(np.float64)
+        s, lo, hi = self._lrn_s(xm, radius, bias, alpha)
+        t = g * xm * s ** (-beta - 1)
+        ct = np.concatenate([np.zeros((rows, 1)), np.cumsum(t, 1)], 1)
+        res = g * s ** (-beta) - 2 * alpha * beta * xm * (ct[:, hi] - ct[:, lo])
+        d = _mat(dx, lddx, rows, c)
+        if accumulate:
+            d += res.astype(np.float32)
+        else:
+            d[...] = res.astype(np.float32)
