@@ -119,6 +119,11 @@ class HipBackend:
         self.lib = load_library()
         if self.lib.hypel_version() != 1:
             raise HypelError("libhypel_hip.so ABI version mismatch")
+        # All hypel launches (and the torch plumbing ops around them) run on ONE dedicated non-default
+        # stream: HIP cannot capture the legacy null stream into a graph, and a private stream keeps the
+        # step ordered without device-wide syncs.
+        self.stream = torch.cuda.Stream(self.device)
+        torch.cuda.set_stream(self.stream)
 
     # -- memory (PyTorch is the allocator: plumbing only) --
     def empty(self, n, dtype=torch.float32):
@@ -137,7 +142,7 @@ class HipBackend:
         return t.to(self.device)
 
     def stream_handle(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return self.stream.cuda_stream
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)

@@ -16,6 +16,8 @@
 //    beyond the segment's K, so ragged shapes (n = 60, 120, K = 145) cost only LDS zero fill.
 //  * 1-D grid with the bijective XCD remap: the blocks that share an A row-tile (different
 //    column tiles) run on the same XCD and hit its L2.
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,7 +27,7 @@ namespace {
 constexpr int BK = 32;
 
 template <int WM, int WN, int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, 3) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
                                                         const hypel_group_t* __restrict__ groups,
@@ -69,7 +71,9 @@ __global__ __launch_bounds__(256) void seg_gemm_kernel(const float* __restrict__
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // wave index as a SCALAR: every predicate derived from it is wave-uniform and compiles to s_cbranch,
+    // not to exec-masked regions around the MFMAs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -87,10 +91,25 @@ __global__ __launch_bounds__(256) void seg_gemm_kernel(const float* __restrict__
 
     // wave-uniform activity of each 32x32 accumulator tile
     bool row_act[TM], col_act[TN];
+    bool any_row = false, any_col = false;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) row_act[i] = (wm * TM + i) * 32 < rows_left;
+    for (int i = 0; i < TM; ++i) {
+        row_act[i] = (wm * TM + i) * 32 < rows_left;
+        any_row = any_row || row_act[i];
+    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) col_act[j] = (wn * TN + j) * 32 < cols_left;
+    for (int j = 0; j < TN; ++j) {
+        col_act[j] = (wn * TN + j) * 32 < cols_left;
+        any_col = any_col || col_act[j];
+    }
+    const bool any_act = any_row && any_col;
+    // per-lane LDS read bases (k advances by immediate offsets in the unrolled loop)
+    const int a_rd = TA ? (lhi * A_PITCH + wm * TM * 32 + l31) : ((wm * TM * 32 + l31) * A_PITCH + lhi);
+    const int b_rd = TB ? ((wn * TN * 32 + l31) * B_PITCH + lhi) : (lhi * B_PITCH + wn * TN * 32 + l31);
+    constexpr int A_KSTEP = TA ? 2 * A_PITCH : 2;      // LDS distance of one k2 step
+    constexpr int A_TILE = TA ? 32 : 32 * A_PITCH;     // LDS distance between the wave's 32-row tiles
+    constexpr int B_KSTEP = TB ? 2 : 2 * B_PITCH;
+    constexpr int B_TILE = TB ? 32 * B_PITCH : 32;
 
     float ra[A_PER_THREAD], rb[B_PER_THREAD];
 
@@ -102,48 +121,48 @@ __global__ __launch_bounds__(256) void seg_gemm_kernel(const float* __restrict__
     bool have = ls < s_end;
     if (have) seg = segs[ls];
 
+    // Staging loads are raw buffer loads: the tile base lives in a scalar descriptor, each thread keeps ONE
+    // 32-bit offset per operand and the per-load row step is a scalar soffset.  An invalid element is fetched
+    // at an out-of-range voffset, which the hardware returns as 0 (no masks, no 64-bit address registers).
+    auto stage = [&](const float* base, int64_t ld, int row0, int col, int rows_valid, int cols_valid,
+                     auto& regs, auto rstep_c, auto count_c) {
+        constexpr int RSTEP = decltype(rstep_c)::value;
+        constexpr int COUNT = decltype(count_c)::value;
+        const int ld4 = (int)ld * 4;
+        // bytes up to the end of the last valid row
+        const int span = rows_valid > 0 && cols_valid > 0 ? ((rows_valid - 1) * (int)ld + cols_valid) * 4 : 0;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
+        const int kOOB = 0x7fffffff;
+        const int voff = col < cols_valid ? (row0 * (int)ld + col) * 4 : kOOB;
+        if (rows_valid >= COUNT * RSTEP) {  // uniform: every staged row exists
+#pragma unroll
+            for (int i = 0; i < COUNT; ++i)
+                regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, i * RSTEP * ld4, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < COUNT; ++i) {
+                const int v = (row0 + i * RSTEP) < rows_valid ? voff : kOOB;
+                regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, i * RSTEP * ld4, 0));
+            }
+        }
+    };
+
     auto load_tiles = [&](const hypel_seg_t& sg, int k0) {
-        const int k_left = sg.k - k0;
-        // ---- A ----
-        if (!TA) {
-            // rows = output rows (m), cols = k
-            const float* base = A + sg.a_off + (int64_t)m0 * lda + k0;
-            const bool cok = a_col < k_left;
-#pragma unroll
-            for (int i = 0; i < A_PER_THREAD; ++i) {
-                const int row = a_row0 + i * A_RSTEP;
-                ra[i] = (cok && row < rows_left) ? base[(int64_t)row * lda + a_col] : 0.0f;
-            }
-        } else {
-            // rows = k (reduction rows), cols = output rows (m)
-            const float* base = A + sg.a_off + (int64_t)k0 * lda + m0;
-            const bool cok = a_col < rows_left;
-#pragma unroll
-            for (int i = 0; i < A_PER_THREAD; ++i) {
-                const int row = a_row0 + i * A_RSTEP;
-                ra[i] = (cok && row < k_left) ? base[(int64_t)row * lda + a_col] : 0.0f;
-            }
-        }
-        // ---- B ----
-        if (!TB) {
-            // rows = k, cols = n
-            const float* base = B + sg.b_off + (int64_t)k0 * ldb + n0;
-            const bool cok = b_col < cols_left;
-#pragma unroll
-            for (int i = 0; i < B_PER_THREAD; ++i) {
-                const int row = b_row0 + i * B_RSTEP;
-                rb[i] = (cok && row < k_left) ? base[(int64_t)row * ldb + b_col] : 0.0f;
-            }
-        } else {
-            // rows = n, cols = k
-            const float* base = B + sg.b_off + (int64_t)n0 * ldb + k0;
-            const bool cok = b_col < k_left;
-#pragma unroll
-            for (int i = 0; i < B_PER_THREAD; ++i) {
-                const int row = b_row0 + i * B_RSTEP;
-                rb[i] = (cok && row < cols_left) ? base[(int64_t)row * ldb + b_col] : 0.0f;
-            }
-        }
+        const int k_left = min(BK, sg.k - k0);
+        const int m_left = min(BM, rows_left);
+        const int n_left = min(BN, cols_left);
+        if (!TA)  // rows = output rows (m), cols = k
+            stage(A + sg.a_off + (int64_t)m0 * lda + k0, lda, a_row0, a_col, m_left, k_left, ra,
+                  std::integral_constant<int, A_RSTEP>{}, std::integral_constant<int, A_PER_THREAD>{});
+        else  // rows = k (reduction rows), cols = output rows (m)
+            stage(A + sg.a_off + (int64_t)k0 * lda + m0, lda, a_row0, a_col, k_left, m_left, ra,
+                  std::integral_constant<int, A_RSTEP>{}, std::integral_constant<int, A_PER_THREAD>{});
+        if (!TB)  // rows = k, cols = n
+            stage(B + sg.b_off + (int64_t)k0 * ldb + n0, ldb, b_row0, b_col, k_left, n_left, rb,
+                  std::integral_constant<int, B_RSTEP>{}, std::integral_constant<int, B_PER_THREAD>{});
+        else  // rows = n, cols = k
+            stage(B + sg.b_off + (int64_t)n0 * ldb + k0, ldb, b_row0, b_col, n_left, k_left, rb,
+                  std::integral_constant<int, B_RSTEP>{}, std::integral_constant<int, B_PER_THREAD>{});
     };
 
     if (have) load_tiles(seg, lk);
@@ -167,26 +186,38 @@ __global__ __launch_bounds__(256) void seg_gemm_kernel(const float* __restrict__
         have = ls < s_end;
         if (have) load_tiles(seg, lk);
 
-        const int ksteps = (kvalid + 1) >> 1;
-        for (int k2 = 0; k2 < ksteps; ++k2) {
-            const int kk = 2 * k2 + lhi;
-            float a[TM], b[TN];
+        // One straight-line path (no per-tile branches, so the accumulators stay put and the compiler
+        // pipelines the ds_reads under the MFMAs).  Ragged shapes rely on the zero-filled LDS image; the
+        // only skips are wave-uniform: a wave with no active tile, and the second half of a short k-tile.
+        if (any_act) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mrow = (wm * TM + i) * 32 + l31;
-                a[i] = TA ? As[kk * A_PITCH + mrow] : As[mrow * A_PITCH + kk];
-            }
+            for (int k2 = 0; k2 < BK / 4; ++k2) {
+                float a[TM], b[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int ncol = (wn * TN + j) * 32 + l31;
-                b[j] = TB ? Bs[ncol * B_PITCH + kk] : Bs[kk * B_PITCH + ncol];
-            }
+                for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) b[j] = Bs[b_rd + j * B_TILE + k2 * B_KSTEP];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (row_act[i] && col_act[j])
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (kvalid > BK / 2) {
+#pragma unroll
+                for (int k2 = BK / 4; k2 < BK / 2; ++k2) {
+                    float a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = Bs[b_rd + j * B_TILE + k2 * B_KSTEP];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
         }
     }
 

@@ -26,6 +26,7 @@ class Ctx:
         self.new_moving = {}  # name -> updated moving stat (training only)
         self.trace = {}  # scope -> forward value (for layer-wise parity)
         self.drop_idx = 0
+        self.kink_force = {}  # scope -> {flat index: bool} (see ops.leaky_relu)
 
     def p(self, name):
         return self.vars[name]
@@ -54,15 +55,24 @@ def _conv_bn_act(ctx, x, scope, act):
     BN before the activation (Appendix A.1; nnmodel/HYPELCNNModel.py:40-45)."""
     y = O.conv2d_same(x, ctx.p(scope + "/weights"))
     y = _bn(ctx, y, scope)
-    y = act(y) if act is not None else y
+    y = _apply_act(act, y, scope)
     ctx.trace[scope] = y.v
     return y
+
+
+def _apply_act(act, y, scope):
+    if act is None:
+        return y
+    try:
+        return act(y, scope=scope)
+    except TypeError:
+        return act(y)
 
 
 def _fc_bn_act(ctx, x, scope, act):
     y = O.dense(x, ctx.p(scope + "/weights"))
     y = _bn(ctx, y, scope)
-    y = act(y) if act is not None else y
+    y = _apply_act(act, y, scope)
     ctx.trace[scope] = y.v
     return y
 
@@ -140,7 +150,12 @@ def hypelcnn_forward(ctx, x, class_count, alg):
     ctx.bn_decay = alg["bn_decay"]
     alpha = alg["lrelu_alpha"]
     use_res = alg["use_residual"]
-    lrelu = lambda t: O.leaky_relu(t, alpha)
+
+    class _LRelu:  # scope-aware so that tests can pin individual kink decisions
+        def __call__(self, t, scope=None):
+            return O.leaky_relu(t, alpha, ctx.kink_force.get(scope))
+
+    lrelu = _LRelu()
     f = alg["filter_count"]
     n_spec = alg["spectral_hierarchy_level"]
 

@@ -221,9 +221,15 @@ def moving_average_update(moving, batch_value, decay):
 
 
 # --------------------------------------------------------------------------- elementwise
-def leaky_relu(x, alpha):
-    """gen_nn_ops.leaky_relu: x>0 ? x : alpha*x; gradient uses the same x>0 test."""
+def leaky_relu(x, alpha, force=None):
+    """gen_nn_ops.leaky_relu: x>0 ? x : alpha*x; gradient uses the same x>0 test.
+    `force` ({flat index: bool}) pins the branch of individual elements: parity tests use it to enumerate the
+    admissible branch assignments of elements whose pre-activation is within fp32 rounding of the kink."""
     pos = x.v > 0
+    if force:
+        pos = pos.copy()
+        for i, b in force.items():
+            pos.reshape(-1)[i] = b
     out = np.where(pos, x.v, x.v * alpha).astype(x.v.dtype)
     return Var(out, (x,), lambda g: _acc(x, np.where(pos, g, g * alpha)))
 

@@ -1,4 +1,4 @@
-"""Independent torch-CPU (float64 autograd) composition of the same graphs, used ONLY to
+"""ORACLE (test infrastructure). Independent torch-CPU autograd composition of the same graphs, used to
 cross-check oracle/ (a second implementation written against torch.nn.functional, NCHW
 convolutions with explicit asymmetric padding).  Not an oracle for the product by itself."""
 import math

@@ -37,11 +37,12 @@ MODEL_FWD = {
 
 
 def forward_backward(model_name, params, x, labels_onehot, class_count, alg, is_training=True,
-                     dropout_masks=None):
+                     dropout_masks=None, kink_force=None):
     """One forward (+ backward when training) pass.  Returns dict(loss, per_sample, logits,
     grads{name}, new_moving{name}, trace{scope})."""
     fwd, loss_fn = MODEL_FWD[model_name]
     ctx = M.Ctx(params, is_training, dropout_masks)
+    ctx.kink_force = kink_force or {}
     xin = O.Var(x)
     out = fwd(ctx, xin, class_count, alg)
     res = {"logits": out["y_conv"].v, "trace": ctx.trace, "outputs": out}

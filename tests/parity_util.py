@@ -53,14 +53,14 @@ def make_params(model_name, patch, channels, classes, alg, rng):
                 p[k] = rng.standard_normal(p[k].shape) * 0.1
             if k.endswith("moving_variance"):
                 p[k] = rng.random(p[k].shape) + 0.5
-        return p
+        return {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}  # fp32-representable
     table = (OM.dualcnn_layer_table if model_name == "DUALCNNModel" else OM.concnn_layer_table)(patch, channels,
                                                                                                 classes, alg)
     p = OM.xavier_init_params(table, rng, np.float64)
     for k in p:
         if k.endswith("biases"):
             p[k] = rng.standard_normal(p[k].shape) * 0.05
-    return p
+    return {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}  # fp32-representable
 
 
 def make_masks(built, nb, rng):
@@ -73,7 +73,8 @@ def make_masks(built, nb, rng):
             continue
         out = node.out
         shape = (nb, out.c) if out.hw is None else (nb, out.hw[0], out.hw[1], out.c)
-        masks[f"dropout_{node.dropout_index}"] = (rng.random(shape) < keep) / keep
+        m = ((rng.random(shape) < keep) / keep).astype(np.float32)  # fp32-representable, like the device mask
+        masks[f"dropout_{node.dropout_index}"] = m.astype(np.float64)
     return masks
 
 
@@ -102,18 +103,72 @@ def compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg, 
     err = np.abs(logits - ref["logits"]).max()
     assert err < tol_logit, f"logits max abs err {err}"
     assert abs(ct.loss_value() - ref["loss"]) < tol_logit * max(1.0, abs(ref["loss"])), (ct.loss_value(), ref["loss"])
-    worst = ("", 0.0)
-    for k, g in ref["grads"].items():
-        got = sess.get_gradient("nn_core/" + k)
-        scale = max(np.abs(g).max(), 1e-6)
-        e = np.abs(got - g).max() / scale
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < tol_grad, f"gradient {worst[0]} rel err {worst[1]}"
+    def grad_errors(r):
+        out = {}
+        for k, g in r["grads"].items():
+            got = sess.get_gradient("nn_core/" + k)
+            out[k] = np.abs(got - g).max() / max(np.abs(g).max(), 1e-6)
+        return out
+
+    errs = grad_errors(ref)
+    worst = max(((k, e) for k, e in errs.items()), key=lambda t: t[1])
+    if worst[1] >= tol_grad:
+        # Piecewise-linear activations: an fp32 pre-activation within rounding of a leaky-ReLU kink may take the
+        # other branch than the fp64 oracle (observed: 1-2 of ~2.5e6 elements at the full GRSS2013 size), which
+        # changes the gradient by a discrete amount.  For elements the ORACLE itself flags as ambiguous
+        # (|pre-activation| < 1e-4) the product's own branch decision is read back from its device buffers and
+        # pinned in the oracle; everywhere else the decisions must already agree.  Then gradients must match.
+        force, n_amb, n_flip = product_kink_decisions(built, ct, ref, alg)
+        assert n_flip > 0, f"gradient {worst[0]} rel err {worst[1]} vs fp64 oracle and no kink flip explains it"
+        alt = OT.forward_backward(model_name, {k: v.copy() for k, v in params.items()}, x.astype(np.float64),
+                                  onehot.astype(np.float64), classes, alg, True, masks, kink_force=force)
+        errs2 = grad_errors(alt)
+        best = max(((k, e) for k, e in errs2.items()), key=lambda t: t[1])
+        assert best[1] < tol_grad, (f"gradient {worst[0]} rel err {worst[1]} vs fp64 oracle; after pinning {n_flip} "
+                                    f"kink flips (of {n_amb} ambiguous): {best}")
+        worst = best
     for k, v in ref["new_moving"].items():
         got = sess.get_variable("nn_core/" + k)
         assert np.abs(got - v).max() < 1e-4 * max(1.0, np.abs(v).max()), k
     return ref, err, worst
+
+
+def product_kink_decisions(built, ct, ref, alg):
+    """For every leaky-ReLU layer: recompute the product's pre-activation yh = (Y - mean) * rstd + beta from ITS
+    buffers (fp32, same expression as the kernel), compare branch decisions with the oracle's forward, and return
+    {scope: {flat NHWC index: bool}} for the oracle-ambiguous elements that differ."""
+    from hypelcnn_amd import graph as G
+    plan = ct.plan
+    sess = built.ctx.session()
+    nb = plan.nb
+    alpha = alg.get("lrelu_alpha", 0.0)
+    force, n_amb, n_flip = {}, 0, 0
+    for idx, node in enumerate(built.train_tower.nodes):
+        if not isinstance(node, G.LinearNode) or node.act is None or node.act.kind != "lrelu" or not node.has_bn:
+            continue
+        aux = plan.node_aux[idx]
+        c = node.cout
+        out = node.out
+        y = plan.buffers[aux["y"].buf][: out.npix * nb * c].reshape(out.npix, nb, c)
+        mean = plan.buffers[f"mean:{idx}"][:c]
+        rstd = plan.buffers[f"rstd:{idx}"][:c]
+        beta = sess.params[aux["beta"].offset:aux["beta"].offset + c]
+        yh = ((y - mean) * rstd + beta).permute(1, 0, 2).cpu().numpy()  # [nb, P, C]
+        off = 0
+        for b in node.branches:
+            got = yh[:, :, off:off + b.cout].reshape(-1)
+            act64 = ref["trace"][b.scope].reshape(-1)
+            pre64 = np.where(act64 > 0, act64, act64 / alpha)
+            amb = np.abs(pre64) < 1e-4
+            differ = (got > 0) != (pre64 > 0)
+            assert not (differ & ~amb).any(), f"{b.scope}: branch decision differs outside the ambiguous zone"
+            n_amb += int(amb.sum())
+            idxs = np.flatnonzero(differ)
+            if len(idxs):
+                n_flip += len(idxs)
+                force[b.scope] = {int(i): bool(got[i] > 0) for i in idxs}
+            off += b.cout
+    return force, n_amb, n_flip
 
 
 def run_eval(built, x):

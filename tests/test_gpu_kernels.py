@@ -1,0 +1,308 @@
+"""-m gpu: every HIP kernel, called through the C-ABI, against the executable spec (tests/emu_backend.py,
+itself validated against the oracle by tests/test_host_plan_emu.py) on identical random inputs, at the
+ragged shapes the models actually produce (K = 145, n = 15/60/120, rows % 128 != 0, channel offsets)."""
+import numpy as np
+import pytest
+import torch
+
+from hypelcnn_amd.backend import GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
+from hypelcnn_amd.plan import GemmTables
+from tests.emu_backend import EmuBackend
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from hypelcnn_amd.backend import HipBackend
+    return HipBackend()
+
+
+class Both:
+    """Mirror host arrays onto both backends; run the same launch; compare named outputs."""
+
+    def __init__(self, hip):
+        self.hip, self.emu = hip, EmuBackend()
+        self.h, self.e = {}, {}
+
+    def arr(self, name, a):
+        a = np.ascontiguousarray(a)
+        self.e[name] = self.emu.upload(a)
+        self.h[name] = self.hip.upload(a)
+        return name
+
+    def run(self, kernel, *args):
+        def conv(store):
+            out = []
+            for a in args:
+                if isinstance(a, tuple) and len(a) == 2 and isinstance(a[0], str):
+                    out.append(Ref(store[a[0]], a[1]))
+                elif isinstance(a, str) and a in store:
+                    out.append(Ref(store[a]))
+                else:
+                    out.append(a)
+            return out
+        self.emu.call(kernel, *conv(self.e))
+        self.hip.call(kernel, *conv(self.h))
+        self.hip.synchronize()
+
+    def check(self, name, rtol=1e-4, atol=1e-5, dtype=np.float32):
+        got = self.h[name].cpu().numpy().view(dtype) if dtype != np.float32 else self.h[name].cpu().numpy()
+        ref = self.e[name].numpy().view(dtype) if dtype != np.float32 else self.e[name].numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol * scale, err_msg=name)
+
+
+def _tables(b, groups):
+    tb = GemmTables()
+    for g in groups:
+        tb.add_group(*g)
+    return tb
+
+
+@pytest.mark.parametrize("rows,k,n,ta,tb_,acc,bias", [
+    (300, 145, 120, 0, 0, 0, False),   # conv_enc_0 shape, ragged rows
+    (128, 32, 32, 0, 0, 0, False),
+    (1, 1, 1, 0, 0, 0, True),
+    (257, 60, 15, 0, 0, 1, True),      # level-2 branch, n=15, accumulate + bias
+    (200, 480, 480, 0, 0, 0, False),
+    (131, 120, 145, 0, 1, 1, False),   # dgrad: B transposed
+    (64, 980, 60, 0, 1, 0, False),
+    (145, 333, 120, 1, 0, 0, False),   # wgrad: A transposed, M = Cin = 145
+    (60, 1000, 60, 1, 0, 0, False),
+    (15, 77, 45, 1, 0, 1, False),
+    (130, 33, 70, 1, 1, 0, False),
+])
+def test_seg_gemm_single_segment(hip, rows, k, n, ta, tb_, acc, bias):
+    rng = np.random.default_rng(rows * 7 + k)
+    b = Both(hip)
+    lda = (rows if ta else k) + 3
+    ldb = (k if tb_ else n) + 5
+    ldc = n + 2
+    a = rng.standard_normal(((k if ta else rows), lda)).astype(np.float32)
+    bm = rng.standard_normal(((n if tb_ else k), ldb)).astype(np.float32)
+    c0 = rng.standard_normal((rows, ldc)).astype(np.float32)
+    bv = rng.standard_normal(ldc).astype(np.float32)
+    tabs = _tables(b, [(0, [(0, 0, k)], rows)])
+    garr, sarr, tarr, _ = tabs.finalize(n)
+    for nm, arr in (("a", a), ("b", bm), ("c", c0), ("bias", bv), ("g", garr), ("s", sarr), ("t", tarr)):
+        b.arr(nm, arr)
+    b.run("seg_gemm_f32", "a", lda, ta, "b", ldb, tb_, "c", ldc, n, "g", "s", "t", len(tarr), "bias" if bias else None,
+          acc)
+    b.check("c", rtol=2e-4, atol=2e-5)
+
+
+def test_seg_gemm_multi_group_multi_segment(hip):
+    """Conv-like: 9 groups (pixels) x up to 9 segments (taps) with channel offsets, two cout branches merged."""
+    rng = np.random.default_rng(3)
+    nb, cin, cout, c_total, P = 70, 37, 20, 45, 9
+    x = rng.standard_normal(P * nb * cin).astype(np.float32)
+    w = rng.standard_normal(9 * cin * cout + 11).astype(np.float32)
+    y = np.zeros(P * nb * c_total, np.float32)
+    groups = []
+    for p in range(P):
+        oy, ox = divmod(p, 3)
+        segs = []
+        for i in range(3):
+            for j in range(3):
+                iy, ix = oy + i - 1, ox + j - 1
+                if 0 <= iy < 3 and 0 <= ix < 3:
+                    segs.append(((iy * 3 + ix) * nb * cin, 11 + (i * 3 + j) * cin * cout, cin))
+        groups.append((p * nb * c_total + 25, segs, nb))
+    b = Both(hip)
+    garr, sarr, tarr, macs = _tables(b, groups).finalize(cout)
+    bias = rng.standard_normal(c_total).astype(np.float32)
+    for nm, arr in (("x", x), ("w", w), ("y", y), ("bias", bias), ("g", garr), ("s", sarr), ("t", tarr)):
+        b.arr(nm, arr)
+    b.run("seg_gemm_f32", "x", cin, 0, "w", cout, 0, "y", c_total, cout, "g", "s", "t", len(tarr), "bias", 0)
+    b.check("y", rtol=2e-4, atol=2e-5)
+    got = b.h["y"].cpu().numpy().reshape(P * nb, c_total)
+    assert (got[:, :25] == 0).all(), "columns outside the branch must stay untouched"
+
+
+def test_seg_gemm_empty_group_writes_zero(hip):
+    b = Both(hip)
+    garr, sarr, tarr, _ = _tables(b, [(0, [], 50)]).finalize(40)
+    for nm, arr in (("a", np.ones(10, np.float32)), ("c", np.full(50 * 40, 7.0, np.float32)), ("g", garr), ("s", sarr),
+                    ("t", tarr)):
+        b.arr(nm, arr)
+    b.run("seg_gemm_f32", "a", 1, 1, "a", 1, 0, "c", 40, 40, "g", "s", "t", len(tarr), None, 0)
+    assert (b.h["c"].cpu().numpy() == 0).all()
+
+
+def test_layout_roundtrip(hip):
+    rng = np.random.default_rng(0)
+    n, p, c = 37, 49, 145
+    b = Both(hip)
+    b.arr("x", rng.standard_normal(n * p * c).astype(np.float32))
+    b.arr("o", np.zeros(p * n * c, np.float32))
+    b.arr("x2", np.zeros(n * p * c, np.float32))
+    b.run("nhwc_to_pnc", "x", "o", n, p, c, c)
+    b.check("o", rtol=0, atol=0)
+    b.run("pnc_to_nhwc", "o", c, "x2", n, p, c)
+    assert torch.equal(b.h["x2"], b.h["x"])
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 145), (50176 // 8, 480), (257, 15), (5, 7), (256, 64)])
+def test_bn_stats_and_finalize(hip, rows, c):
+    rng = np.random.default_rng(rows)
+    b = Both(hip)
+    x = (rng.standard_normal((rows, c)) * rng.random(c) * 3 + rng.standard_normal(c) * 10).astype(np.float32)
+    chunk = 256
+    nch = (rows + chunk - 1) // chunk
+    b.arr("x", x)
+    b.arr("part", np.zeros(nch * 2 * c, np.float32))
+    for nm in ("mean", "rstd"):
+        b.arr(nm, np.zeros(c, np.float32))
+    b.arr("mm", rng.standard_normal(c).astype(np.float32))
+    b.arr("mv", (rng.random(c) + 0.5).astype(np.float32))
+    b.run("col_stats_partial", "x", c, rows, c, chunk, "part")
+    b.check("part", rtol=1e-4, atol=1e-4)
+    b.run("bn_finalize", "part", nch, chunk, rows, c, 1e-3, "mean", "rstd", "mm", "mv", 0.95)
+    for nm in ("mean", "rstd", "mm", "mv"):
+        b.check(nm, rtol=1e-5, atol=1e-6)
+    # against the definition
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(b.h["mean"].cpu().numpy(), x64.mean(0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b.h["rstd"].cpu().numpy(), 1 / np.sqrt(x64.var(0) + 1e-3), rtol=1e-5)
+
+
+@pytest.mark.parametrize("act,use_bn,use_mask,nres", [(1, True, False, 2), (3, True, False, 0), (0, True, False, 0),
+                                                     (1, False, True, 1), (2, False, False, 1), (4, False, False, 0),
+                                                     (1, True, True, 0)])
+def test_post_op_forward_backward(hip, act, use_bn, use_mask, nres):
+    rng = np.random.default_rng(act * 10 + nres)
+    rows, c, cin = 777, 60, 145
+    b = Both(hip)
+    b.arr("y", rng.standard_normal((rows, c)).astype(np.float32))
+    b.arr("dz", rng.standard_normal((rows, c)).astype(np.float32))
+    b.arr("mean", rng.standard_normal(c).astype(np.float32) * 0.1)
+    b.arr("rstd", (rng.random(c) + 0.5).astype(np.float32))
+    b.arr("beta", rng.standard_normal(c).astype(np.float32) * 0.1)
+    b.arr("mask", ((rng.random((rows, c)) < 0.3) / 0.3).astype(np.float32))
+    b.arr("r1", rng.standard_normal((rows, cin)).astype(np.float32))
+    b.arr("r2", rng.standard_normal((rows, c)).astype(np.float32))
+    idx = np.minimum(np.round(np.arange(c) * cin / c), cin - 1).astype(np.int32)
+    b.arr("idx", idx)
+    b.arr("z", np.zeros(rows * c, np.float32))
+    bn = ("mean", "rstd", "beta") if use_bn else (None, None, None)
+    mask = "mask" if use_mask else None
+    r1 = ("r1", cin, "idx") if nres >= 1 else (None, 0, None)
+    r2 = ("r2", c, None) if nres >= 2 else (None, 0, None)
+    b.run("bn_act_fwd", "y", c, rows, c, *bn, act, 0.18, mask, c, *r1, *r2, "z", c)
+    b.check("z", rtol=1e-5, atol=1e-6)
+    chunk = 256
+    nch = (rows + chunk - 1) // chunk
+    b.arr("part", np.zeros(nch * 2 * c, np.float32))
+    b.arr("sums", np.zeros(2 * c, np.float32))
+    b.arr("dparam", np.zeros(c, np.float32))
+    b.arr("dy", np.zeros(rows * c, np.float32))
+    b.run("bn_act_bwd_reduce", "dz", c, "y", c, rows, c, *bn, act, 0.18, mask, c, chunk, "part")
+    b.check("part", rtol=1e-4, atol=1e-5)
+    b.run("bwd_reduce_finalize", "part", nch, c, "sums", "dparam", 0)
+    b.check("sums", rtol=1e-5, atol=1e-6)
+    b.check("dparam", rtol=1e-5, atol=1e-6)
+    b.run("bn_act_bwd_apply", "dz", c, "y", c, rows, c, *bn, act, 0.18, mask, c, "sums", "dy", c)
+    b.check("dy", rtol=1e-4, atol=1e-5)
+    # channel-map gradient
+    start = np.searchsorted(idx, np.arange(cin + 1), side="left").astype(np.int32)
+    b.arr("start", start)
+    b.arr("dr", rng.standard_normal((rows, cin)).astype(np.float32))
+    b.run("chanmap_bwd", "dz", c, rows, c, "dr", cin, cin, "start", 1)
+    b.check("dr", rtol=1e-5, atol=1e-6)
+    b.run("chanmap_bwd", "dz", c, rows, c, "dy", c, c, None, 0)
+    b.check("dy", rtol=0, atol=0)
+
+
+def test_losses(hip):
+    rng = np.random.default_rng(1)
+    n, c = 1000, 15
+    b = Both(hip)
+    b.arr("logits", (rng.standard_normal((n, c)) * 5).astype(np.float32))
+    b.arr("lab", np.eye(c, dtype=np.float32)[rng.integers(0, c, n)])
+    b.arr("loss", np.zeros(n, np.float32))
+    b.arr("dl", np.zeros(n * c, np.float32))
+    b.run("softmax_xent", "logits", c, n, c, "lab", c, "loss", "dl", c, 1.0 / n)
+    b.check("loss", rtol=1e-5, atol=1e-6)
+    b.check("dl", rtol=1e-4, atol=1e-7)
+    # K6: zero logits -> log(classes)
+    b.arr("z0", np.zeros((4, c), np.float32))
+    b.run("softmax_xent", "z0", c, 4, c, "lab", c, "loss", None, 0, 1.0)
+    np.testing.assert_allclose(b.h["loss"].cpu().numpy()[:4], np.log(c), rtol=1e-6)
+    rows, f = 64, 7105
+    b.arr("a", rng.random((rows, f)).astype(np.float32))
+    b.arr("bb", rng.random((rows, f)).astype(np.float32))
+    b.arr("out", np.zeros(1, np.float32))
+    b.arr("da", np.zeros(rows * f, np.float32))
+    b.arr("ws", np.zeros(2048, np.float32))
+    b.run("mse", "a", f, "bb", f, rows, f, "out", "da", f, 1.0, "ws")
+    b.check("out", rtol=1e-5)
+    b.check("da", rtol=1e-5, atol=1e-9)
+    b.run("sum_f32", "loss", n, 1.0 / n, "out", "ws")
+    b.check("out", rtol=1e-5)
+
+
+def test_optimizers_and_reduce(hip):
+    rng = np.random.default_rng(2)
+    n = 100003
+    b = Both(hip)
+    for nm in ("p", "g", "m"):
+        b.arr(nm, rng.standard_normal(n).astype(np.float32))
+    b.arr("v", rng.random(n).astype(np.float32))
+    b.run("adam_tf1", "p", "g", "m", "v", n, 3e-4, 0.9, 0.999, 1e-8)
+    for nm in ("p", "m", "v"):
+        b.check(nm, rtol=2e-5, atol=1e-6)
+    b.run("momentum_tf1", "p", "g", "m", n, 1e-3, 0.9)
+    b.check("p", rtol=2e-5, atol=1e-6)
+    b.arr("part", rng.standard_normal(5 * 1000).astype(np.float32))
+    b.arr("out", rng.standard_normal(900).astype(np.float32))
+    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 1)
+    b.check("out", rtol=1e-5, atol=1e-6)
+    # K4: first Adam step from zero slots ~ -lr*sign(g)
+    b.arr("p0", np.zeros(3, np.float32)); b.arr("g0", np.array([0.3, -2.0, 1e-3], np.float32))
+    b.arr("m0", np.zeros(3, np.float32)); b.arr("v0", np.zeros(3, np.float32))
+    lr_t = 3e-4 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    b.run("adam_tf1", "p0", "g0", "m0", "v0", 3, float(lr_t), 0.9, 0.999, 1e-8)
+    g = np.array([0.3, -2.0, 1e-3])
+    np.testing.assert_allclose(b.h["p0"].cpu().numpy(), -3e-4 * g / (np.abs(g) + 1e-8 / np.sqrt(1 - 0.999)), rtol=1e-4)
+
+
+def test_dropout_mask_statistics_and_replay(hip):
+    n = 1 << 20
+    mask = hip.zeros(n)
+    step = hip.zeros(1, torch.int64)
+    hip.call("dropout_mask", Ref(mask), n, 0.3, 1234, Ref(step))
+    m1 = mask.clone()
+    hip.call("dropout_mask", Ref(mask), n, 0.3, 1234, Ref(step))
+    assert torch.equal(m1, mask), "same (seed, step) -> same mask"
+    vals = torch.unique(mask).cpu().numpy()
+    np.testing.assert_allclose(vals, [0.0, 1 / 0.3], rtol=1e-6)
+    frac = float((mask > 0).float().mean())
+    assert abs(frac - 0.3) < 5e-3
+    hip.call("step_inc", Ref(step))
+    hip.call("dropout_mask", Ref(mask), n, 0.3, 1234, Ref(step))
+    assert not torch.equal(m1, mask) and int(step[0]) == 1
+
+
+def test_argmax_confusion_and_lrn(hip):
+    rng = np.random.default_rng(4)
+    n, c = 5000, 15
+    b = Both(hip)
+    logits = rng.standard_normal((n, c)).astype(np.float32)
+    logits[::7, 3] = logits[::7, 9] = 50.0  # ties: first maximum wins
+    b.arr("logits", logits)
+    b.arr("lab", rng.integers(0, c, n).astype(np.int32))
+    b.arr("pred", np.zeros(n, np.int32))
+    b.arr("conf", np.zeros(c * c, np.int32))
+    b.run("argmax_confusion", "logits", c, n, c, "lab", "pred", "conf")
+    assert torch.equal(b.h["pred"].cpu(), b.e["pred"])
+    assert torch.equal(b.h["conf"].cpu(), b.e["conf"])
+    rows, cc = 300, 384
+    b.arr("x", rng.standard_normal((rows, cc)).astype(np.float32))
+    b.arr("dy", rng.standard_normal((rows, cc)).astype(np.float32))
+    b.arr("y", np.zeros(rows * cc, np.float32))
+    b.arr("dx", np.zeros(rows * cc, np.float32))
+    b.run("lrn_fwd", "x", cc, rows, cc, 5, 1.0, 1.0, 0.5, "y", cc)
+    b.check("y", rtol=1e-5, atol=1e-6)
+    b.run("lrn_bwd", "x", cc, "dy", cc, rows, cc, 5, 1.0, 1.0, 0.5, "dx", cc, 0)
+    b.check("dx", rtol=1e-4, atol=1e-5)

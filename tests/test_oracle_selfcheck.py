@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import cref, host, models as M, ops as O, train as T
-from tests import ref_torch as R
+from oracle import torch_ref as R
 
 ALG_SMALL = {"drop_out_ratio": 0.7, "filter_count": 48, "learning_rate": 3e-4, "learning_rate_decay_factor": 0.96,
              "learning_rate_decay_step": 350, "lrelu_alpha": 0.18, "optimizer": "AdamOptimizer", "bn_decay": 0.95,
