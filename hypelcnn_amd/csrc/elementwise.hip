@@ -10,6 +10,25 @@ namespace {
 constexpr int STAT_TX = 64;  // threads along channels
 constexpr int STAT_TY = 4;   // row lanes
 
+// Elementwise kernels walk [rows x c] matrices in blocks of EW_ROWS rows: the (row, col) split of a flat
+// index then needs only 32-bit arithmetic (a 64-bit i / c per element costs more than the memory access).
+constexpr int EW_ROWS = 64;
+static inline int ew_grid(int64_t rows) {
+    int64_t g = (rows + EW_ROWS - 1) / EW_ROWS;
+    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+#define EW_FOREACH(rows, c, BODY)                                                                      \
+    for (int64_t rb = (int64_t)blockIdx.x * EW_ROWS; rb < (rows); rb += (int64_t)gridDim.x * EW_ROWS) { \
+        const uint32_t nrow = (uint32_t)min((int64_t)EW_ROWS, (rows) - rb);                            \
+        const uint32_t nel = nrow * (uint32_t)(c);                                                      \
+        for (uint32_t e = threadIdx.x; e < nel; e += blockDim.x) {                                      \
+            const uint32_t rr = e / (uint32_t)(c);                                                      \
+            const int col = (int)(e - rr * (uint32_t)(c));                                              \
+            const int64_t row = rb + rr;                                                                \
+            BODY                                                                                        \
+        }                                                                                               \
+    }
+
 // ------------------------------------------------------------------------------------- layout
 __global__ void nhwc_to_pnc_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int p, int c,
                                    int64_t ld) {
@@ -41,9 +60,11 @@ __global__ void fill_kernel(float* __restrict__ dst, int64_t count, float v) {
 }
 
 __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
-                                     float* __restrict__ out, int64_t count, int accumulate) {
+                                     float* __restrict__ out, int64_t count, int accumulate,
+                                     const float* __restrict__ bias, int n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         float s = accumulate ? out[i] : 0.0f;
+        if (bias) s += bias[(int)(i % n)];
         for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * stride + i];
         out[i] = s;
     }
@@ -154,10 +175,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t ldy, int6
                                   int64_t ldm, const float* __restrict__ res1, int64_t ld1,
                                   const int32_t* __restrict__ idx1, const float* __restrict__ res2, int64_t ld2,
                                   const int32_t* __restrict__ idx2, float* __restrict__ z, int64_t ldz) {
-    const int64_t total = rows * c;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / c;
-        const int col = (int)(i - row * c);
+    EW_FOREACH(rows, c, {
         float v = y[row * ldy + col];
         if (mean) v = (v - mean[col]) * rstd[col] + beta[col];
         v = hypel_act(v, act, alpha);
@@ -165,7 +183,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t ldy, int6
         if (res1) v += res1[row * ld1 + (idx1 ? idx1[col] : col)];
         if (res2) v += res2[row * ld2 + (idx2 ? idx2[col] : col)];
         z[row * ldz + col] = v;
-    }
+    })
 }
 
 __device__ __forceinline__ void bwd_elem(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y,
@@ -248,36 +266,33 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dz, int64_t ld
                                         const float* __restrict__ rstd, const float* __restrict__ beta, int act,
                                         float alpha, const float* __restrict__ mask, int64_t ldm,
                                         const float* __restrict__ sums, float* __restrict__ dy, int64_t lddy) {
-    const int64_t total = rows * c;
     const float inv_m = 1.0f / (float)rows;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / c;
-        const int col = (int)(i - row * c);
-        float dyh, xhat;
+    EW_FOREACH(rows, c, {
+        float dyh;
+        float xhat;
         bwd_elem(dz, lddz, y, ldy, row, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
         float g = dyh;
         if (mean) g = rstd[col] * (dyh - sums[col] * inv_m - xhat * (sums[c + col] * inv_m));
         dy[row * lddy + col] = g;
-    }
+    })
 }
 
 __global__ void chanmap_bwd_kernel(const float* __restrict__ dz, int64_t lddz, int64_t rows, int c,
                                    float* __restrict__ dr, int64_t lddr, int cin, const int32_t* __restrict__ start,
                                    int accumulate) {
-    const int64_t total = rows * cin;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / cin;
-        const int ci = (int)(i - row * cin);
+    EW_FOREACH(rows, cin, {
+        const int ci = col;
         float s = 0.0f;
         if (start) {
-            const int a = start[ci], b = start[ci + 1];
+            const int a = start[ci];
+            const int b = start[ci + 1];
             for (int k = a; k < b; ++k) s += dz[row * lddz + k];
         } else {
             s = dz[row * lddz + ci];
         }
         float* p = dr + row * lddr + ci;
         *p = accumulate ? *p + s : s;
-    }
+    })
 }
 
 // ------------------------------------------------------------------------------------- losses
@@ -518,11 +533,13 @@ extern "C" int hypel_fill_f32(float* dst, int64_t count, float value, hypel_stre
 }
 
 extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_splits, float* out,
-                                       int64_t count, int32_t accumulate, hypel_stream_t stream) {
+                                       int64_t count, int32_t accumulate, const float* bias, int32_t n,
+                                       hypel_stream_t stream) {
     HYPEL_REQUIRE(partial && out && n_splits >= 1 && count >= 0, "hypel_reduce_splits_f32");
+    HYPEL_REQUIRE(bias == nullptr || n > 0, "hypel_reduce_splits_f32");
     if (count == 0) return 0;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
-                       n_splits, out, count, accumulate);
+                       n_splits, out, count, accumulate, bias, n);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
     return 0;
 }
@@ -561,7 +578,7 @@ extern "C" int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32
                                 int64_t ld2, const int32_t* idx2, float* z, int64_t ldz, hypel_stream_t stream) {
     HYPEL_REQUIRE(y && z && rows > 0 && c > 0, "hypel_bn_act_fwd");
     HYPEL_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr) == (beta == nullptr), "hypel_bn_act_fwd");
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(hypel_grid_1d(rows * c, 256)), dim3(256), 0, ST, y, ldy, rows, c, mean,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(rows)), dim3(256), 0, ST, y, ldy, rows, c, mean,
                        rstd, beta, act, alpha, mask, ldm, res1, ld1, idx1, res2, ld2, idx2, z, ldz);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_fwd");
     return 0;
@@ -594,7 +611,7 @@ extern "C" int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float
                                       int64_t lddy, hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && y && dy && rows > 0 && c > 0, "hypel_bn_act_bwd_apply");
     HYPEL_REQUIRE(mean == nullptr || sums != nullptr, "hypel_bn_act_bwd_apply");
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(hypel_grid_1d(rows * c, 256)), dim3(256), 0, ST, dz, lddz, y, ldy,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(rows)), dim3(256), 0, ST, dz, lddz, y, ldy,
                        rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, dy, lddy);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_apply");
     return 0;
@@ -604,7 +621,7 @@ extern "C" int hypel_chanmap_bwd(const float* dz, int64_t lddz, int64_t rows, in
                                  int32_t cin, const int32_t* start, int32_t accumulate, hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && dr && rows > 0 && c > 0 && cin > 0, "hypel_chanmap_bwd");
     HYPEL_REQUIRE(start != nullptr || cin == c, "hypel_chanmap_bwd");
-    hipLaunchKernelGGL(chanmap_bwd_kernel, dim3(hypel_grid_1d(rows * cin, 256)), dim3(256), 0, ST, dz, lddz, rows, c,
+    hipLaunchKernelGGL(chanmap_bwd_kernel, dim3(ew_grid(rows)), dim3(256), 0, ST, dz, lddz, rows, c,
                        dr, lddr, cin, start, accumulate);
     HYPEL_CHECK_LAUNCH("hypel_chanmap_bwd");
     return 0;

@@ -98,7 +98,10 @@ class GemmTables:
             macs += rows * ksum * n
             for m0 in range(0, rows, GEMM_BM):
                 tiles.append((ksum * min(GEMM_BM, rows - m0), gi, m0))
-        tiles.sort(key=lambda t: -t[0])  # heavy tiles first: the tail of the grid is the cheap work
+        # Row-chunk major, heavy tiles first inside a chunk.  With the kernel's XCD remap each XCD works through a
+        # contiguous range of this list, i.e. through whole row chunks: the ~49 pixel blocks of activations that
+        # all the (pixel, branch) tiles of one chunk keep re-reading stay resident in that XCD's 4 MB L2.
+        tiles.sort(key=lambda t: (t[2] // GEMM_BM, -t[0]))
         sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
         tarr = np.array([(g, m0) for _, g, m0 in tiles], TILE_DTYPE) if tiles else np.zeros(0, TILE_DTYPE)
         return garr, sarr, tarr, macs
@@ -194,7 +197,64 @@ class TowerPlan:
                 raise RuntimeError(f"variables {a.name} / {b.name} of a merged level are not contiguous")
 
     # ------------------------------------------------------------------ gemm emission
-    def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag):
+    def _split_k(self, tables, n, lda, ta, ldb, tb, ldc):
+        """FC-shaped products have too few 128x128 output tiles to fill 256 CUs (fc_0 forward: 64 blocks;
+        image_gen_net_4 data gradient: 32).  When the output is one dense range, cut every group's K into S
+        slices that write partial slabs; hypel_reduce_splits_f32 sums them in a fixed order."""
+        groups = tables.groups
+        if ldc != n or not groups:
+            return None
+        n_nt = (n + 127) // 128 if n > 64 else 1
+        blocks = sum((rows + GEMM_BM - 1) // GEMM_BM for _, _, rows in groups) * n_nt
+        kmax = max(sum(k for _, _, k in gs) for _, gs, _ in groups)
+        if blocks >= 192 or kmax < 512:
+            return None
+        S = min((384 + blocks - 1) // blocks, kmax // 128, 32)
+        if S < 2:
+            return None
+        order = sorted(groups, key=lambda g: g[0])
+        c_min = order[0][0]
+        pos = c_min
+        for c_off, _, rows in order:  # dense, gap-free cover
+            if c_off != pos:
+                return None
+            pos += rows * n
+        count = pos - c_min
+        if c_min % n:
+            return None
+        a_ks = lda if ta else 1
+        b_ks = 1 if tb else ldb
+        out = GemmTables()
+        for c_off, gs, rows in groups:
+            ktot = sum(k for _, _, k in gs)
+            cuts = [((ktot * s // S) + 31) // 32 * 32 for s in range(S)] + [ktot]
+            cuts = [min(c, ktot) for c in cuts]
+            parts = [[] for _ in range(S)]
+            base = 0
+            for (a_off, b_off, k) in gs:
+                for s in range(S):
+                    lo, hi = max(cuts[s], base), min(cuts[s + 1], base + k)
+                    if hi > lo:
+                        parts[s].append((a_off + (lo - base) * a_ks, b_off + (lo - base) * b_ks, hi - lo))
+                base += k
+            for s in range(S):
+                out.add_group(s * count + (c_off - c_min), parts[s], rows)
+        return out, S, c_min, count
+
+    def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
+                   allow_split=True):
+        split = self._split_k(tables, n, lda, ta, ldb, tb, ldc) if allow_split else None
+        if split is not None:
+            stab, S, c_min, count = split
+            pos = len(lst)
+            self._emit_gemm(lst, stab, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, None, 0, tag + "/splitk",
+                            allow_split=False)
+            self._scratch(lst[pos], 6, "scratch_wgrad", S * count)
+            l2 = Launch("reduce_splits_f32", (None, count, S, c_ref + c_min, count, int(accumulate), bias_ref, int(n)),
+                        nbytes=4 * count * (S + 1), tag="splitk-reduce")
+            self._scratch(l2, 0, "scratch_wgrad", S * count)
+            lst.append(l2)
+            return
         garr, sarr, tarr, macs = tables.finalize(n)
         if len(tarr) == 0:
             return
@@ -589,13 +649,14 @@ class TowerPlan:
         tb = tables_by_split_builder(S)
         if S == 1:
             self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None, 0,
-                            tag)
+                            tag, allow_split=False)
             return
         launch_pos = len(self.bwd)
-        self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads), n, None, 0, tag)
+        self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads), n, None, 0, tag,
+                        allow_split=False)
         l = self.bwd[launch_pos]
         self._scratch(l, 6, "scratch_wgrad", S * slab)
-        l2 = Launch("reduce_splits_f32", (None, slab, S, Ref(self.sess.grads, w0_offset), slab, 0),
+        l2 = Launch("reduce_splits_f32", (None, slab, S, Ref(self.sess.grads, w0_offset), slab, 0, None, 0),
                     nbytes=4 * slab * (S + 1), tag="wgrad-reduce")
         self._scratch(l2, 0, "scratch_wgrad", S * slab)
         self.bwd.append(l2)

@@ -143,10 +143,12 @@ class EmuBackend:
             else:
                 cm[...] = acc.astype(np.float32)
 
-    def k_reduce_splits_f32(self, partial, stride, n_splits, out, count, accumulate):
+    def k_reduce_splits_f32(self, partial, stride, n_splits, out, count, accumulate, bias=None, n=0):
         p = _arr(partial)
         o = _arr(out)[:count]
         tot = np.zeros(count, np.float64)
+        if bias is not None:
+            tot += np.resize(_arr(bias)[:n], count)
         for k in range(n_splits):
             tot += p[k * stride:k * stride + count]
         if accumulate:

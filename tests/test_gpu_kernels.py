@@ -256,7 +256,10 @@ def test_optimizers_and_reduce(hip):
     b.check("p", rtol=2e-5, atol=1e-6)
     b.arr("part", rng.standard_normal(5 * 1000).astype(np.float32))
     b.arr("out", rng.standard_normal(900).astype(np.float32))
-    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 1)
+    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 1, None, 0)
+    b.check("out", rtol=1e-5, atol=1e-6)
+    b.arr("rb", rng.standard_normal(90).astype(np.float32))
+    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 0, "rb", 90)
     b.check("out", rtol=1e-5, atol=1e-6)
     # K4: first Adam step from zero slots ~ -lr*sign(g)
     b.arr("p0", np.zeros(3, np.float32)); b.arr("g0", np.array([0.3, -2.0, 1e-3], np.float32))

@@ -47,6 +47,7 @@ SMALL_H = {"drop_out_ratio": 0.7, "filter_count": 48, "learning_rate": 3e-4, "le
 
 @pytest.mark.parametrize("model_name,patch,ch,classes,alg,nb", [
     ("HYPELCNNModel", 5, 11, 4, SMALL_H, 6),                      # tiny, ragged everything
+    ("HYPELCNNModel", 7, 9, 4, dict(SMALL_H, filter_count=96), 37),  # fc_0 K=588 -> split-K forward
     ("HYPELCNNModel", 7, 21, 5, SMALL_H, 150),                    # rows per pixel > one 128-row tile
     ("HYPELCNNModel", 3, 7, 3, dict(SMALL_H, use_residual=False, spectral_hierarchy_level=2), 1),  # batch of one
     ("DUALCNNModel", 5, 7, 3, {"drop_out_ratio": 0.7, "lrelu_alpha": 0.18, "filter_count": 32, "hs_lidar_diff": 1,

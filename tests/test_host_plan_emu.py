@@ -32,6 +32,7 @@ def _case(model_name, patch, ch, classes, alg, nb, seed):
 
 @pytest.mark.parametrize("model_name,patch,ch,classes,alg,nb", [
     ("HYPELCNNModel", 5, 11, 4, ALG_H, 6),
+    ("HYPELCNNModel", 7, 9, 4, dict(ALG_H, filter_count=96), 5),  # fc_0 has K=588: exercises the split-K path
     ("HYPELCNNModel", 3, 7, 3, dict(ALG_H, use_residual=False, spectral_hierarchy_level=2), 5),
     ("DUALCNNModel", 5, 7, 3, ALG_D, 4),
     ("CONCNNModel", 5, 9, 3, ALG_C, 4),
