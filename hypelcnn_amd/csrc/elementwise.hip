@@ -10,24 +10,54 @@ namespace {
 constexpr int STAT_TX = 64;  // threads along channels
 constexpr int STAT_TY = 4;   // row lanes
 
-// Elementwise kernels walk [rows x c] matrices in blocks of EW_ROWS rows: the (row, col) split of a flat
-// index then needs only 32-bit arithmetic (a 64-bit i / c per element costs more than the memory access).
-constexpr int EW_ROWS = 64;
-static inline int ew_grid(int64_t rows) {
-    int64_t g = (rows + EW_ROWS - 1) / EW_ROWS;
-    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+// Elementwise kernels map a 256-thread block onto [TY rows x TX column-vectors] (TX = power of two >= the
+// number of column vectors, capped at 256), so (row, col) needs no division, consecutive lanes touch
+// consecutive 16-byte vectors of a row, and the grid (up to 8192 blocks) keeps every CU's queues full.
+struct EwShape {
+    int tx_log2;  // log2(TX)
+    int grid;
+};
+static inline EwShape ew_shape(int64_t rows, int cvec) {
+    int l = 0;
+    while ((1 << l) < cvec && l < 8) ++l;
+    const int ty = 256 >> l;
+    int64_t g = (rows + ty - 1) / ty;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return EwShape{l, (int)g};
 }
-#define EW_FOREACH(rows, c, BODY)                                                                      \
-    for (int64_t rb = (int64_t)blockIdx.x * EW_ROWS; rb < (rows); rb += (int64_t)gridDim.x * EW_ROWS) { \
-        const uint32_t nrow = (uint32_t)min((int64_t)EW_ROWS, (rows) - rb);                            \
-        const uint32_t nel = nrow * (uint32_t)(c);                                                      \
-        for (uint32_t e = threadIdx.x; e < nel; e += blockDim.x) {                                      \
-            const uint32_t rr = e / (uint32_t)(c);                                                      \
-            const int col = (int)(e - rr * (uint32_t)(c));                                              \
-            const int64_t row = rb + rr;                                                                \
-            BODY                                                                                        \
-        }                                                                                               \
+static inline bool aligned16(const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+    float v[1];
+    __device__ __forceinline__ void load(const float* p) { v[0] = p[0]; }
+    __device__ __forceinline__ void store(float* p) const { p[0] = v[0]; }
+};
+template <>
+struct Vec<4> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
+template <int VEC, class F>
+__device__ __forceinline__ void ew_loop(int64_t rows, int c, int tx_log2, F body) {
+    const int TX = 1 << tx_log2;
+    const int TY = 256 >> tx_log2;
+    const int tx = threadIdx.x & (TX - 1);
+    const int ty = threadIdx.x >> tx_log2;
+    const int cv = c / VEC;
+    for (int64_t row = (int64_t)blockIdx.x * TY + ty; row < rows; row += (int64_t)gridDim.x * TY)
+        for (int cvi = tx; cvi < cv; cvi += TX) body(row, cvi * VEC);
+}
 
 // ------------------------------------------------------------------------------------- layout
 __global__ void nhwc_to_pnc_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int p, int c,
@@ -83,6 +113,7 @@ __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __r
     float s = 0.0f, ss = 0.0f, shift = 0.0f;
     if (col < c) {
         shift = x[r0 * ld + col];
+#pragma unroll 4
         for (int64_t r = r0 + ty; r < r1; r += STAT_TY) {
             const float d = x[r * ld + col] - shift;
             s += d;
@@ -169,21 +200,54 @@ __global__ void rstd_from_var_kernel(const float* __restrict__ var, int c, float
 }
 
 // ------------------------------------------------------------------------------------- fused post-op
-__global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
-                                  const float* __restrict__ mean, const float* __restrict__ rstd,
-                                  const float* __restrict__ beta, int act, float alpha, const float* __restrict__ mask,
-                                  int64_t ldm, const float* __restrict__ res1, int64_t ld1,
-                                  const int32_t* __restrict__ idx1, const float* __restrict__ res2, int64_t ld2,
-                                  const int32_t* __restrict__ idx2, float* __restrict__ z, int64_t ldz) {
-    EW_FOREACH(rows, c, {
-        float v = y[row * ldy + col];
-        if (mean) v = (v - mean[col]) * rstd[col] + beta[col];
-        v = hypel_act(v, act, alpha);
-        if (mask) v *= mask[row * ldm + col];
-        if (res1) v += res1[row * ld1 + (idx1 ? idx1[col] : col)];
-        if (res2) v += res2[row * ld2 + (idx2 ? idx2[col] : col)];
-        z[row * ldz + col] = v;
-    })
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(
+    const float* __restrict__ y, int64_t ldy, int64_t rows, int c, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ beta, int act, float alpha,
+    const float* __restrict__ mask, int64_t ldm, const float* __restrict__ res1, int64_t ld1,
+    const int32_t* __restrict__ idx1, const float* __restrict__ res2, int64_t ld2, const int32_t* __restrict__ idx2,
+    float* __restrict__ z, int64_t ldz, int tx_log2) {
+    ew_loop<VEC>(rows, c, tx_log2, [&](int64_t row, int col) {
+        Vec<VEC> v;
+        v.load(y + row * ldy + col);
+        if (mean) {
+            Vec<VEC> m, r, b;
+            m.load(mean + col); r.load(rstd + col); b.load(beta + col);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v.v[k] = (v.v[k] - m.v[k]) * r.v[k] + b.v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v.v[k] = hypel_act(v.v[k], act, alpha);
+        if (mask) {
+            Vec<VEC> mk;
+            mk.load(mask + row * ldm + col);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v.v[k] *= mk.v[k];
+        }
+        if (res1) {
+            if (idx1) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v.v[k] += res1[row * ld1 + idx1[col + k]];
+            } else {
+                Vec<VEC> t;
+                t.load(res1 + row * ld1 + col);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v.v[k] += t.v[k];
+            }
+        }
+        if (res2) {
+            if (idx2) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v.v[k] += res2[row * ld2 + idx2[col + k]];
+            } else {
+                Vec<VEC> t;
+                t.load(res2 + row * ld2 + col);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v.v[k] += t.v[k];
+            }
+        }
+        v.store(z + row * ldz + col);
+    });
 }
 
 __device__ __forceinline__ void bwd_elem(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y,
@@ -215,6 +279,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const int64_t r1 = min(rows, r0 + (int64_t)chunk_rows);
     float s0 = 0.0f, s1 = 0.0f;
     if (col < c) {
+#pragma unroll 4
         for (int64_t r = r0 + ty; r < r1; r += STAT_TY) {
             float dyh, xhat;
             bwd_elem(dz, lddz, y, ldy, r, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
@@ -261,38 +326,69 @@ __global__ __launch_bounds__(256) void bwd_reduce_finalize_kernel(const float* _
     }
 }
 
-__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y,
-                                        int64_t ldy, int64_t rows, int c, const float* __restrict__ mean,
-                                        const float* __restrict__ rstd, const float* __restrict__ beta, int act,
-                                        float alpha, const float* __restrict__ mask, int64_t ldm,
-                                        const float* __restrict__ sums, float* __restrict__ dy, int64_t lddy) {
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int64_t ldm, const float* __restrict__ sums, float* __restrict__ dy,
+    int64_t lddy, int tx_log2) {
     const float inv_m = 1.0f / (float)rows;
-    EW_FOREACH(rows, c, {
-        float dyh;
-        float xhat;
-        bwd_elem(dz, lddz, y, ldy, row, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
-        float g = dyh;
-        if (mean) g = rstd[col] * (dyh - sums[col] * inv_m - xhat * (sums[c + col] * inv_m));
-        dy[row * lddy + col] = g;
-    })
+    ew_loop<VEC>(rows, c, tx_log2, [&](int64_t row, int col) {
+        Vec<VEC> yv, g;
+        yv.load(y + row * ldy + col);
+        g.load(dz + row * lddz + col);
+        if (mask) {
+            Vec<VEC> mk;
+            mk.load(mask + row * ldm + col);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g.v[k] *= mk.v[k];
+        }
+        if (mean) {
+            Vec<VEC> m, r, b, s0, s1;
+            m.load(mean + col); r.load(rstd + col); b.load(beta + col);
+            s0.load(sums + col); s1.load(sums + c + col);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float xhat = (yv.v[k] - m.v[k]) * r.v[k];
+                const float dyh = g.v[k] * hypel_act_grad(xhat + b.v[k], act, alpha);
+                g.v[k] = r.v[k] * (dyh - s0.v[k] * inv_m - xhat * (s1.v[k] * inv_m));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g.v[k] *= hypel_act_grad(yv.v[k], act, alpha);
+        }
+        g.store(dy + row * lddy + col);
+    });
 }
 
-__global__ void chanmap_bwd_kernel(const float* __restrict__ dz, int64_t lddz, int64_t rows, int c,
-                                   float* __restrict__ dr, int64_t lddr, int cin, const int32_t* __restrict__ start,
-                                   int accumulate) {
-    EW_FOREACH(rows, cin, {
-        const int ci = col;
-        float s = 0.0f;
+template <int VEC>
+__global__ __launch_bounds__(256) void chanmap_bwd_kernel(const float* __restrict__ dz, int64_t lddz, int64_t rows,
+                                                           int c, float* __restrict__ dr, int64_t lddr, int cin,
+                                                           const int32_t* __restrict__ start, int accumulate,
+                                                           int tx_log2) {
+    ew_loop<VEC>(rows, cin, tx_log2, [&](int64_t row, int col) {
+        Vec<VEC> s;
         if (start) {
-            const int a = start[ci];
-            const int b = start[ci + 1];
-            for (int k = a; k < b; ++k) s += dz[row * lddz + k];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int a = start[col + k];
+                const int b = start[col + k + 1];
+                float t = 0.0f;
+                for (int q = a; q < b; ++q) t += dz[row * lddz + q];
+                s.v[k] = t;
+            }
         } else {
-            s = dz[row * lddz + ci];
+            s.load(dz + row * lddz + col);
         }
-        float* p = dr + row * lddr + ci;
-        *p = accumulate ? *p + s : s;
-    })
+        float* p = dr + row * lddr + col;
+        if (accumulate) {
+            Vec<VEC> o;
+            o.load(p);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s.v[k] += o.v[k];
+        }
+        s.store(p);
+    });
 }
 
 // ------------------------------------------------------------------------------------- losses
@@ -578,8 +674,17 @@ extern "C" int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32
                                 int64_t ld2, const int32_t* idx2, float* z, int64_t ldz, hypel_stream_t stream) {
     HYPEL_REQUIRE(y && z && rows > 0 && c > 0, "hypel_bn_act_fwd");
     HYPEL_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr) == (beta == nullptr), "hypel_bn_act_fwd");
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(rows)), dim3(256), 0, ST, y, ldy, rows, c, mean,
-                       rstd, beta, act, alpha, mask, ldm, res1, ld1, idx1, res2, ld2, idx2, z, ldz);
+    const bool v4 = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(mask) && aligned16(mean) &&
+                    aligned16(rstd) && aligned16(beta) && ldy % 4 == 0 && ldz % 4 == 0 && (!mask || ldm % 4 == 0) &&
+                    (!res1 || idx1 || (aligned16(res1) && ld1 % 4 == 0)) &&
+                    (!res2 || idx2 || (aligned16(res2) && ld2 % 4 == 0));
+    const EwShape sh = ew_shape(rows, v4 ? c / 4 : c);
+    if (v4)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<4>, dim3(sh.grid), dim3(256), 0, ST, y, ldy, rows, c, mean, rstd, beta,
+                           act, alpha, mask, ldm, res1, ld1, idx1, res2, ld2, idx2, z, ldz, sh.tx_log2);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(sh.grid), dim3(256), 0, ST, y, ldy, rows, c, mean, rstd, beta,
+                           act, alpha, mask, ldm, res1, ld1, idx1, res2, ld2, idx2, z, ldz, sh.tx_log2);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_fwd");
     return 0;
 }
@@ -611,8 +716,16 @@ extern "C" int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float
                                       int64_t lddy, hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && y && dy && rows > 0 && c > 0, "hypel_bn_act_bwd_apply");
     HYPEL_REQUIRE(mean == nullptr || sums != nullptr, "hypel_bn_act_bwd_apply");
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(rows)), dim3(256), 0, ST, dz, lddz, y, ldy,
-                       rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, dy, lddy);
+    const bool v4 = (c % 4 == 0) && aligned16(y) && aligned16(dz) && aligned16(dy) && aligned16(mask) &&
+                    aligned16(mean) && aligned16(rstd) && aligned16(beta) && aligned16(sums) && ldy % 4 == 0 &&
+                    lddz % 4 == 0 && lddy % 4 == 0 && (!mask || ldm % 4 == 0);
+    const EwShape sh = ew_shape(rows, v4 ? c / 4 : c);
+    if (v4)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(sh.grid), dim3(256), 0, ST, dz, lddz, y, ldy, rows, c, mean,
+                           rstd, beta, act, alpha, mask, ldm, sums, dy, lddy, sh.tx_log2);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<1>, dim3(sh.grid), dim3(256), 0, ST, dz, lddz, y, ldy, rows, c, mean,
+                           rstd, beta, act, alpha, mask, ldm, sums, dy, lddy, sh.tx_log2);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_apply");
     return 0;
 }
@@ -621,8 +734,14 @@ extern "C" int hypel_chanmap_bwd(const float* dz, int64_t lddz, int64_t rows, in
                                  int32_t cin, const int32_t* start, int32_t accumulate, hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && dr && rows > 0 && c > 0 && cin > 0, "hypel_chanmap_bwd");
     HYPEL_REQUIRE(start != nullptr || cin == c, "hypel_chanmap_bwd");
-    hipLaunchKernelGGL(chanmap_bwd_kernel, dim3(ew_grid(rows)), dim3(256), 0, ST, dz, lddz, rows, c,
-                       dr, lddr, cin, start, accumulate);
+    const bool v4 = (cin % 4 == 0) && aligned16(dr) && lddr % 4 == 0 && (start || (aligned16(dz) && lddz % 4 == 0));
+    const EwShape sh = ew_shape(rows, v4 ? cin / 4 : cin);
+    if (v4)
+        hipLaunchKernelGGL(chanmap_bwd_kernel<4>, dim3(sh.grid), dim3(256), 0, ST, dz, lddz, rows, c, dr, lddr, cin,
+                           start, accumulate, sh.tx_log2);
+    else
+        hipLaunchKernelGGL(chanmap_bwd_kernel<1>, dim3(sh.grid), dim3(256), 0, ST, dz, lddz, rows, c, dr, lddr, cin,
+                           start, accumulate, sh.tx_log2);
     HYPEL_CHECK_LAUNCH("hypel_chanmap_bwd");
     return 0;
 }

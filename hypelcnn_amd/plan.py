@@ -19,7 +19,15 @@ import numpy as np
 from . import graph as G
 from .backend import GEMM_BM, GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
 
-STAT_CHUNK_ROWS = 256
+STAT_CHUNK_ROWS = 256  # upper bound; see stat_chunk_rows()
+
+
+def stat_chunk_rows(rows):
+    """Rows per partial-reduction block: ~256 blocks per 64-column stripe, between 16 and 256 rows each
+    (a thread walks chunk/4 rows serially, so short matrices get short chunks)."""
+    c = (rows + 255) // 256
+    c = max(16, min(STAT_CHUNK_ROWS, c))
+    return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
 TARGET_BLOCKS = 1024
 
@@ -389,11 +397,12 @@ class TowerPlan:
             self._alloc(f"mean:{idx}", c)
             self._alloc(f"rstd:{idx}", c)
             if node.training:
-                n_chunks = (rows + STAT_CHUNK_ROWS - 1) // STAT_CHUNK_ROWS
-                l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, STAT_CHUNK_ROWS, None),
+                chunk = stat_chunk_rows(rows)
+                n_chunks = (rows + chunk - 1) // chunk
+                l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, chunk, None),
                             nbytes=4 * rows * c, tag="bn-stats")
                 self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                l2 = Launch("bn_finalize", (None, n_chunks, STAT_CHUNK_ROWS, rows, c, float(node.bn_eps),
+                l2 = Launch("bn_finalize", (None, n_chunks, chunk, rows, c, float(node.bn_eps),
                                             self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"), self._s(aux["mm"]),
                                             self._s(aux["mv"]), float(node.bn_decay)), tag="bn-finalize")
                 self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
@@ -622,9 +631,10 @@ class TowerPlan:
                 dparam = self._g(aux["bias"])
         sums = None
         if has_bn or dparam is not None:
-            n_chunks = (rows + STAT_CHUNK_ROWS - 1) // STAT_CHUNK_ROWS
+            chunk = stat_chunk_rows(rows)
+            n_chunks = (rows + chunk - 1) // chunk
             l1 = Launch("bn_act_bwd_reduce", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
-                                              STAT_CHUNK_ROWS, None), nbytes=8 * rows * c, tag="post-bwd-reduce")
+                                              chunk, None), nbytes=8 * rows * c, tag="post-bwd-reduce")
             self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
             l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, 0), tag="post-bwd-finalize")
             self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)

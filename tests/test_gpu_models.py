@@ -103,7 +103,7 @@ def test_grss2013_hypelcnn_batch1024_properties(hip):
     """BASELINE configs[1] size (batch 1024): size-independent properties instead of the (slow) oracle:
     (1) run-to-run bit-exact determinism of a full training step;
     (2) inference on 1024 patches == 16 independent inference runs of 64 (moving statistics decouple samples):
-        logits bit-exact, labels bit-exact;
+        labels bit-exact, logits equal to fp32 rounding;
     (3) the gradient buffer is exactly linear in the upstream loss scale is NOT assumed; instead the
         flat gradient of batch [A;A] (two copies of a 512 batch) equals that of the same data in swapped order."""
     alg = _alg("alg_param_hypelcnn.json")
@@ -119,7 +119,10 @@ def test_grss2013_hypelcnn_batch1024_properties(hip):
     U.inject(sess, params)
     big = U.run_eval(built, x)
     parts = np.concatenate([U.run_eval(built, x[i:i + 64]) for i in range(0, 1024, 64)])
-    assert np.array_equal(big, parts)
+    # split-K factors depend on the batch size, so the fp32 summation order may differ: labels must still be
+    # bit-exact, logits equal to fp32 rounding
+    assert np.array_equal(big.argmax(1), parts.argmax(1))
+    assert np.abs(big - parts).max() <= 2e-5 * max(1.0, np.abs(big).max())
     # (3) permutation equivariance of the batch: swapping the two halves leaves the mean-loss gradient unchanged
     perm = np.concatenate([np.arange(512, 1024), np.arange(0, 512)])
     U.inject(sess, params)
