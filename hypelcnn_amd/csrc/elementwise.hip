@@ -35,6 +35,7 @@ struct Vec<1> {
     float v[1];
     __device__ __forceinline__ void load(const float* p) { v[0] = p[0]; }
     __device__ __forceinline__ void store(float* p) const { p[0] = v[0]; }
+    __device__ __forceinline__ void load_param(const float* p) { v[0] = p[0]; }
 };
 template <>
 struct Vec<4> {
@@ -45,6 +46,10 @@ struct Vec<4> {
     }
     __device__ __forceinline__ void store(float* p) const {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    // per-channel parameter vectors live at arbitrary offsets of the flat parameter buffer: dword loads
+    __device__ __forceinline__ void load_param(const float* p) {
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
     }
 };
 
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
         v.load(y + row * ldy + col);
         if (mean) {
             Vec<VEC> m, r, b;
-            m.load(mean + col); r.load(rstd + col); b.load(beta + col);
+            m.load_param(mean + col); r.load_param(rstd + col); b.load_param(beta + col);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) v.v[k] = (v.v[k] - m.v[k]) * r.v[k] + b.v[k];
         }
@@ -345,8 +350,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         }
         if (mean) {
             Vec<VEC> m, r, b, s0, s1;
-            m.load(mean + col); r.load(rstd + col); b.load(beta + col);
-            s0.load(sums + col); s1.load(sums + c + col);
+            m.load_param(mean + col); r.load_param(rstd + col); b.load_param(beta + col);
+            s0.load_param(sums + col); s1.load_param(sums + c + col);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float xhat = (yv.v[k] - m.v[k]) * r.v[k];
@@ -674,8 +679,8 @@ extern "C" int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32
                                 int64_t ld2, const int32_t* idx2, float* z, int64_t ldz, hypel_stream_t stream) {
     HYPEL_REQUIRE(y && z && rows > 0 && c > 0, "hypel_bn_act_fwd");
     HYPEL_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr) == (beta == nullptr), "hypel_bn_act_fwd");
-    const bool v4 = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(mask) && aligned16(mean) &&
-                    aligned16(rstd) && aligned16(beta) && ldy % 4 == 0 && ldz % 4 == 0 && (!mask || ldm % 4 == 0) &&
+    const bool v4 = (c % 4 == 0) && aligned16(y) && aligned16(z) && aligned16(mask) && ldy % 4 == 0 &&
+                    ldz % 4 == 0 && (!mask || ldm % 4 == 0) &&
                     (!res1 || idx1 || (aligned16(res1) && ld1 % 4 == 0)) &&
                     (!res2 || idx2 || (aligned16(res2) && ld2 % 4 == 0));
     const EwShape sh = ew_shape(rows, v4 ? c / 4 : c);
@@ -717,8 +722,7 @@ extern "C" int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float
     HYPEL_REQUIRE(dz && y && dy && rows > 0 && c > 0, "hypel_bn_act_bwd_apply");
     HYPEL_REQUIRE(mean == nullptr || sums != nullptr, "hypel_bn_act_bwd_apply");
     const bool v4 = (c % 4 == 0) && aligned16(y) && aligned16(dz) && aligned16(dy) && aligned16(mask) &&
-                    aligned16(mean) && aligned16(rstd) && aligned16(beta) && aligned16(sums) && ldy % 4 == 0 &&
-                    lddz % 4 == 0 && lddy % 4 == 0 && (!mask || ldm % 4 == 0);
+                    ldy % 4 == 0 && lddz % 4 == 0 && lddy % 4 == 0 && (!mask || ldm % 4 == 0);
     const EwShape sh = ew_shape(rows, v4 ? c / 4 : c);
     if (v4)
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(sh.grid), dim3(256), 0, ST, dz, lddz, y, ldy, rows, c, mean,

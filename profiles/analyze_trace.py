@@ -1,0 +1,48 @@
+import csv, json, sys, os
+sys.path.insert(0, "/root/repo")
+import numpy as np
+trace = sys.argv[1]
+rows = list(csv.DictReader(open(trace)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+# plan
+from tests.emu_backend import EmuBackend
+import bench
+ctx, train_step, lr, alg = bench.build_model(1024, EmuBackend())
+ctx.capture_graphs = False
+ct = train_step.compiled(1024)
+plan = ct.plan
+launches = plan.fwd + plan.bwd
+names = []
+for l in launches:
+    names.append(l.name)
+    if l.name in ("mse", "sum_f32"): names.append(l.name + "_fin")
+# find the last full step in the trace: locate sequences starting with nhwc_to_pnc
+kn = [r['Kernel_Name'] for r in rows]
+starts = [i for i, k in enumerate(kn) if 'nhwc_to_pnc' in k]
+i0 = starts[-1]
+seq = rows[i0:]
+# walk: match only hypel kernels (skip torch/copy)
+def is_h(k): return 'anonymous namespace' in k
+seq = [r for r in seq if is_h(r['Kernel_Name'])]
+out = []
+j = 0
+for l in launches:
+    n_k = 2 if l.name in ("mse", "sum_f32") else 1
+    dur = 0
+    for _ in range(n_k):
+        r = seq[j]; j += 1
+        dur += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    out.append((l.name, l.tag, l.flops, dur, r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size')))
+tot = sum(o[3] for o in out)
+print("total kernel ns per step", tot, " gemm ns", sum(o[3] for o in out if o[0]=='seg_gemm_f32'))
+print(f"{'name':18s} {'tag':34s} {'GFLOP':>8s} {'us':>8s} {'TF/s':>7s} grid")
+for o in out:
+    if o[3] > 20000:
+        tf = o[2]/o[3]/1e3 if o[2] else 0
+        print(f"{o[0]:18s} {o[1]:34s} {o[2]/1e9:8.2f} {o[3]/1e3:8.1f} {tf:7.1f} {o[4]}")
+bytag = {}
+for o in out:
+    key = o[0] if o[0] != 'seg_gemm_f32' else 'gemm:' + o[1].split(':')[0]
+    bytag.setdefault(key, [0, 0, 0]); bytag[key][0] += o[3]; bytag[key][1] += o[2]; bytag[key][2] += 1
+for k, v in sorted(bytag.items(), key=lambda t: -t[1][0]):
+    print(f"{k:28s} {v[0]/1e3:9.1f} us  n={v[2]:3d}  {v[1]/max(v[0],1)/1e3:6.1f} TF/s")

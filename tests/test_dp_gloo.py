@@ -1,0 +1,70 @@
+"""CPU, world_size 2, gloo: the data-parallel path -- identical weights after broadcast, one flat
+gradient all-reduce, identical parameters on both ranks after the optimiser step, and the exchanged gradient
+equals the mean of the two shards' gradients computed without DP."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ALG = {"drop_out_ratio": 0.7, "filter_count": 48, "learning_rate": 3e-4, "learning_rate_decay_factor": 0.96,
+       "learning_rate_decay_step": 350, "lrelu_alpha": 0.18, "optimizer": "AdamOptimizer", "bn_decay": 0.95,
+       "l2regularizer_scale": 1e-5, "spectral_hierarchy_level": 2, "spatial_hierarchy_level": 2,
+       "degradation_coeff": 3, "use_residual": True}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data(rank):
+    rng = np.random.default_rng(77)
+    x = rng.random((8, 5, 5, 9)).astype(np.float32)
+    onehot = np.eye(4, dtype=np.float32)[rng.integers(0, 4, 8)]
+    return x[rank::2], onehot[rank::2]
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import parity_util as U
+    from tests.emu_backend import EmuBackend
+    built = U.build("HYPELCNNModel", 5, 9, 4, ALG, EmuBackend(), with_eval=False)
+    built.ctx.seed = 100 + rank          # different init per rank: the broadcast must make them equal
+    sess = built.ctx.session()
+    p0 = sess.params.clone()
+    x, onehot = _data(rank)
+    U.run_train_step(built, x, onehot, {})
+    local = sess.grads.clone()
+    sess.allreduce_gradients()
+    sess.adam_step(3e-4)
+    torch.save({"p0": p0, "local": local, "avg": sess.grads.clone(), "p1": sess.params.clone(),
+                "state": sess.state.clone()}, os.path.join(outdir, f"r{rank}.pt"))
+    sess.average_state()
+    torch.save(sess.state.clone(), os.path.join(outdir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_exchange(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["p0"], r1["p0"]), "rank-0 weights must be broadcast"
+    assert not torch.equal(r0["local"], r1["local"]), "shards differ, so local gradients differ"
+    assert torch.equal(r0["avg"], r1["avg"])
+    torch.testing.assert_close(r0["avg"], (r0["local"] + r1["local"]) / 2, rtol=1e-6, atol=1e-9)
+    assert torch.equal(r0["p1"], r1["p1"]), "parameters stay in lock-step"
+    assert not torch.equal(r0["state"], r1["state"]), "BN moving statistics are per-rank until averaged"
+    assert torch.equal(torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt"))
