@@ -1,0 +1,66 @@
+"""Whole data set resident in HBM (reference importer/InMemoryImporter.py:14-86).
+
+The reference feeds the full float32 [N,P,P,C] array through a placeholder once per iterator
+initialisation (:80-83); here `init_tensors` uploads it once and the iterator gathers batches on the
+device, so a training step never touches host memory."""
+import time
+from collections import namedtuple
+
+import numpy
+
+from hypelcnn_amd.common.common_nn_ops import get_loader_from_name
+from hypelcnn_amd.importer.DataImporter import DataImporter
+
+Target = namedtuple("Target", ["data", "labels"])
+InMemoryDataTensor = namedtuple("InMemoryDataTensor", ["dataset", "x", "y_"])
+
+
+class DataSetSpec:
+    """Stands where the reference has a tf.data.Dataset: the static element shape and class count."""
+
+    def __init__(self, element_shape, class_count):
+        self.element_shape = tuple(int(v) for v in element_shape)
+        self.class_count = int(class_count)
+
+
+class InMemoryImporter(DataImporter):
+
+    @staticmethod
+    def _get_data_with_labels(targets, loader, data_set):
+        """reference :27-38 -- one patch per target row [x, y, class]."""
+        shape = [targets.shape[0]] + list(data_set.get_data_shape())
+        data = numpy.zeros(shape, dtype=numpy.float32)
+        labels = numpy.zeros(targets.shape[0], dtype=numpy.uint8)
+        for i, point in enumerate(targets):
+            data[i] = data_set.get_data_point(int(point[0]), int(point[1]))
+            labels[i] = point[2]
+        return Target(data=data, labels=labels)
+
+    def read_data_set(self, loader_name, path, train_data_ratio, test_data_ratio, neighborhood, normalize):
+        start = time.time()
+        loader = get_loader_from_name(loader_name, path)
+        data_set = loader.load_data(neighborhood, normalize)
+        sample_set = loader.load_samples(train_data_ratio, test_data_ratio)
+        train = self._get_data_with_labels(sample_set.training_targets, loader, data_set)
+        val = self._get_data_with_labels(sample_set.validation_targets, loader, data_set)
+        test = self._get_data_with_labels(sample_set.test_targets, loader, data_set)
+        print(f"Loaded dataset({time.time() - start:.3f} sec)")
+        return train, test, val, data_set.shadow_creator_dict, loader.get_class_count(), \
+            data_set.get_scene_shape(), loader.get_samples_color_list()
+
+    def convert_data_to_tensor(self, test_data_with_labels, training_data_with_labels, validation_data_with_labels,
+                               class_range):
+        def spec(t):
+            return DataSetSpec(t.data.shape[1:], class_range.stop)
+
+        training = InMemoryDataTensor(dataset=spec(training_data_with_labels), x="training_x", y_="training_y_")
+        testing = InMemoryDataTensor(dataset=spec(test_data_with_labels), x="testing_x", y_="testing_y_")
+        # the reference reuses the testing placeholders for validation (:76-78)
+        return testing, training, testing
+
+    def init_tensors(self, session, tensor, nn_params):
+        d = nn_params.data_with_labels
+        nn_params.input_iterator.initializer(d.data, d.labels, session.backend.device)
+
+    def requires_separate_validation_branch(self):
+        return True

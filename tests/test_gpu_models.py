@@ -147,3 +147,16 @@ def test_hip_graph_replay_equals_eager(hip):
     ct.forward_backward()  # a second replay keeps updating the moving statistics
     torch.cuda.synchronize()
     assert not torch.equal(mm, sess.state)
+
+
+def test_end_to_end_training_on_gpu(tmp_path):
+    """flags -> SyntheticDataLoader -> InMemoryImporter -> create_graph -> run_monitored_session on the real
+    backend (HIP-graph replay of the step, device-side metrics): the classifier learns the synthetic scene."""
+    from hypelcnn_amd.classify import train_for_classification as T
+    from tests.test_training_loop_emu import ALG, _flags
+    flags = _flags(tmp_path, 151)
+    model = T.get_model_from_name(flags.model_name)
+    log_dir = os.path.join(flags.base_log_path, T.get_log_suffix(flags))
+    res = T.perform_an_episode(flags, dict(ALG), model, log_dir)
+    assert np.isfinite(res.loss) and res.test_accuracy > 0.85 and res.validation_accuracy > 0.85
+    assert "model.ckpt-150.npz" in os.listdir(log_dir)
