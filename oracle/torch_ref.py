@@ -143,3 +143,51 @@ def concnn(P, x, class_count, alg, training, masks=None):
         n32 = n32 * masks["dropout_1"]
     n33 = cb(n32, "conv33")
     return n33.reshape(n33.shape[0], -1) @ P["fc/weights"] + P["fc/biases"]
+
+
+# ----------------------------------------------------------------------------- GAN stacks (cross-check of oracle/gan.py)
+def gen_t(P, x, pre, only_encoder=False):
+    n, b = x.shape[0], x.shape[-1]
+    a = [x.reshape(n, 1, b)]
+
+    def c1d(inp, i):
+        w = P[f"{pre}net{i}/weights"]
+        k = w.shape[0]
+        pl = (k - 1) // 2
+        return F.conv1d(F.pad(inp, (pl, k - 1 - pl)), w.reshape(1, 1, k)) + P[f"{pre}net{i}/biases"]
+
+    last = 4 if only_encoder else 6
+    for i in range(1, last + 1):
+        h = F.leaky_relu(c1d(a[-1], i), 0.1)
+        a.append(h + a[-1] + (a[-2] if i >= 2 else 0))
+    out = a[-1] if only_encoder else torch.tanh(c1d(a[-1], 7))
+    return out.reshape(n, 1, 1, b)
+
+
+def dis_t(P, x, pre):
+    h = x.reshape(x.shape[0], -1)
+    h = F.leaky_relu(h @ P[pre + "fully_connected/weights"] + P[pre + "fully_connected/biases"], 0.1)
+    h = F.leaky_relu(h @ P[pre + "fully_connected_1/weights"] + P[pre + "fully_connected_1/biases"], 0.1)
+    return h @ P[pre + "fully_connected_2/weights"] + P[pre + "fully_connected_2/biases"]
+
+
+def feat_t(P, x, pre, patches, embed):
+    n, b = x.shape[0], x.shape[-1]
+    flat = x.reshape(n, b)
+    ps = b // patches
+    outs, idx = [], 0
+    for s in range(0, b, ps):
+        cur = flat[:, s:s + ps]
+        for _ in range(4):
+            sc = pre + "fully_connected" + ("" if idx == 0 else f"_{idx}")
+            cur = F.leaky_relu(cur @ P[sc + "/weights"] + P[sc + "/biases"], 0.1)
+            idx += 1
+        outs.append((cur / torch.sqrt(torch.clamp((cur * cur).sum(), min=1e-12))).unsqueeze(1))
+    return torch.cat(outs, 1)
+
+
+def nce_t(fg, fr, tau):
+    logits = torch.matmul(fg, fr.transpose(1, 2)) / tau
+    n, p, _ = logits.shape
+    lab = torch.eye(p, dtype=logits.dtype).reshape(1, -1).repeat(n, 1)
+    return (-(lab * F.log_softmax(logits.reshape(n, -1), -1)).sum(-1)).mean()
