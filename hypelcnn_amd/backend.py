@@ -76,8 +76,13 @@ SIGNATURES = {
     "argmax_confusion": [_P, _I64, _I64, _I32, _P, _P, _P],
     "lrn_fwd": [_P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64],
     "lrn_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64, _I32],
-    "gan_generator_fwd": [_P, _I64, _I32, _P, _I32, _P, _P],
-    "gan_generator_bwd": [_P, _P, _I64, _I32, _P, _I32, _P, _P, _I32, _P, _I32],
+    "gan_generator_fwd": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64],
+    "gan_generator_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P],
+    "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
+    "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
+    "l2norm_fwd": [_P, _I64, _I64, _I32, _P, _I64, _P],
+    "l2norm_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I64, _I32],
+    "nce_loss": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
 }
 NO_STREAM = {"version", "last_error", "device_info"}
 
@@ -104,6 +109,8 @@ def load_library(path=LIB_PATH):
     lib.hypel_graph_launch.argtypes = [_P, _P]
     lib.hypel_graph_destroy.argtypes = [_P]
     lib.hypel_device_info.argtypes = [ctypes.POINTER(_I32), ctypes.POINTER(_I32)]
+    lib.hypel_gan_generator_blocks.argtypes = [_I64]
+    lib.hypel_gan_generator_blocks.restype = ctypes.c_int
     return lib
 
 
@@ -146,6 +153,9 @@ class HipBackend:
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
+
+    def gan_generator_blocks(self, n):
+        return int(self.lib.hypel_gan_generator_blocks(int(n)))
 
     # -- launches --
     def bind(self, name, args, stream=None):

@@ -1,0 +1,501 @@
+// Shadow-GAN kernels (gan/shadow_data_models.py, gan/wrappers/*).  The stacks are 1-channel 1-D convolutions
+// over <= 360 bands and tiny MLPs: <= 0.4 MFLOP per sample, i.e. launch/latency and HBM bound, not MFMA work
+// (SURVEY F8.iii).  The reference executes ~30 TensorFlow ops per generator application; here ONE wavefront
+// runs the whole 7-layer generator of a sample out of LDS (activations, skip sums and weights never leave the
+// CU), and the backward kernel recomputes that forward instead of storing 13 intermediate tensors.
+#include "common.h"
+
+namespace {
+
+constexpr float GEN_ALPHA = 0.1f;  // leaky_relu(alpha=0.1), shadow_data_models.py:53
+constexpr int GEN_WAVES = 4;
+
+struct GenLayout {
+    int k[7], pl[7], woff[7], wtotal, layers;
+};
+
+__host__ __device__ inline GenLayout gen_layout(int bands, int only_encoder) {
+    GenLayout g;
+    const int ks[7] = {bands, bands / 2, bands / 4, bands / 8, bands / 4, bands / 2, bands};
+    int off = 0;
+    for (int i = 0; i < 7; ++i) {
+        g.k[i] = ks[i];
+        g.pl[i] = (ks[i] - 1) / 2;  // SAME: pad_left = floor((k-1)/2), the rest on the right
+        g.woff[i] = off;
+        off += ks[i];
+    }
+    g.wtotal = off;
+    g.layers = only_encoder ? 4 : 7;
+    return g;
+}
+
+// out[p] = bias + sum_j w[j] * in[p + j - pl]   (zero outside [0, B))
+__device__ __forceinline__ float conv_at(const float* __restrict__ in, const float* __restrict__ w, int k, int pl,
+                                         int bands, int p, float bias) {
+    const int j0 = max(0, pl - p), j1 = min(k, bands + pl - p);
+    float acc = bias;
+    for (int j = j0; j < j1; ++j) acc += w[j] * in[p + j - pl];
+    return acc;
+}
+
+// One wave: forward of one sample.  a: [7][bands] activations (a[0] = input), slope: [6][bands] (may be null).
+// Returns through `last`: for the full generator the pre-tanh c7 in tmp[bands]; for the encoder a[4].
+__device__ __forceinline__ void gen_forward_wave(const GenLayout& g, int bands, int lane, const float* __restrict__ ws,
+                                                 const float* __restrict__ bs, float* __restrict__ a,
+                                                 float* __restrict__ slope, float* __restrict__ tmp) {
+    const int hidden = g.layers == 7 ? 6 : 4;
+    for (int i = 1; i <= hidden; ++i) {
+        const float* in = a + (i - 1) * bands;
+        float* out = a + i * bands;
+        for (int p = lane; p < bands; p += 64) {
+            const float c = conv_at(in, ws + g.woff[i - 1], g.k[i - 1], g.pl[i - 1], bands, p, bs[i - 1]);
+            const float s = c > 0.0f ? 1.0f : GEN_ALPHA;
+            if (slope) slope[(i - 1) * bands + p] = s;
+            float v = c * s + in[p];
+            if (i >= 2) v += a[(i - 2) * bands + p];
+            out[p] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (g.layers == 7) {
+        const float* in = a + 6 * bands;
+        for (int p = lane; p < bands; p += 64) tmp[p] = conv_at(in, ws + g.woff[6], g.k[6], g.pl[6], bands, p, bs[6]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64 * GEN_WAVES) void gan_generator_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                            int64_t n, int bands,
+                                                                            const float* __restrict__ w,
+                                                                            const float* __restrict__ b,
+                                                                            int only_encoder, float* __restrict__ out,
+                                                                            int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GenLayout g = gen_layout(bands, only_encoder);
+    float* ws = smem;                 // [wtotal]
+    float* bs = ws + g.wtotal;        // [8]
+    float* wave_base = bs + 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < g.wtotal; i += blockDim.x) ws[i] = w[i];
+    if (threadIdx.x < 7) bs[threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    float* a = wave_base + (size_t)wave * 8 * bands;  // 7 activation rows + 1 tmp row
+    float* tmp = a + 7 * bands;
+    for (int64_t s = (int64_t)blockIdx.x * GEN_WAVES + wave; s < n; s += (int64_t)gridDim.x * GEN_WAVES) {
+        for (int p = lane; p < bands; p += 64) a[p] = x[s * ldx + p];
+        __builtin_amdgcn_wave_barrier();
+        gen_forward_wave(g, bands, lane, ws, bs, a, nullptr, tmp);
+        for (int p = lane; p < bands; p += 64)
+            out[s * ldo + p] = only_encoder ? a[4 * bands + p] : tanhf(tmp[p]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Backward: per sample recompute the forward, then walk the layers in reverse.
+//   a_i = h_i + a_{i-1} + a_{i-2}  =>  da_{i-1} += da_i, da_{i-2} += da_i, dc_i = da_i * slope_i
+//   dW_i[j] += sum_p dc_i[p] * a_{i-1}[p + j - pl],  db_i += sum_p dc_i[p],  da_{i-1}[q] += sum_j w_i[j] dc_i[q - j + pl]
+// Weight gradients are accumulated per wave in LDS (lane l owns taps l, l+64, ...), combined per block, and
+// written to pw[block][wtotal] / pb[block][8]; hypel_reduce_splits_f32 sums the blocks in fixed order.
+__global__ __launch_bounds__(64 * GEN_WAVES) void gan_generator_bwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
+    const float* __restrict__ w, const float* __restrict__ b, int only_encoder, float* __restrict__ dx, int64_t lddx,
+    int accumulate_dx, float* __restrict__ pw, float* __restrict__ pb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GenLayout g = gen_layout(bands, only_encoder);
+    float* ws = smem;
+    float* bs = ws + g.wtotal;
+    float* wave_base = bs + 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < g.wtotal; i += blockDim.x) ws[i] = w[i];
+    if (threadIdx.x < 7) bs[threadIdx.x] = b[threadIdx.x];
+    // per-wave regions: a[7][B], tmp[B], slope[6][B], da[7][B], dc[B], dw[wtotal], db[8]
+    const size_t per_wave = (size_t)(7 + 1 + 6 + 7 + 1) * bands + g.wtotal + 8;
+    float* a = wave_base + wave * per_wave;
+    float* tmp = a + 7 * bands;
+    float* slope = tmp + bands;
+    float* da = slope + 6 * bands;
+    float* dc = da + 7 * bands;
+    float* dw = dc + bands;
+    float* db = dw + g.wtotal;
+    for (int i = lane; i < g.wtotal; i += 64) dw[i] = 0.0f;
+    if (lane < 8) db[lane] = 0.0f;
+    __syncthreads();
+    const int hidden = g.layers == 7 ? 6 : 4;
+
+    for (int64_t s = (int64_t)blockIdx.x * GEN_WAVES + wave; s < n; s += (int64_t)gridDim.x * GEN_WAVES) {
+        for (int p = lane; p < bands; p += 64) a[p] = x[s * ldx + p];
+        for (int i = lane; i < 7 * bands; i += 64) da[i] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        gen_forward_wave(g, bands, lane, ws, bs, a, slope, tmp);
+
+        auto layer_bwd = [&](int li /*0-based layer*/, const float* in /*a_{i-1}*/, float* din /*da_{i-1}*/) {
+            const int k = g.k[li], pl = g.pl[li];
+            const float* wl = ws + g.woff[li];
+            // bias gradient: wave sum of dc
+            float sb = 0.0f;
+            for (int p = lane; p < bands; p += 64) sb += dc[p];
+            for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
+            if (lane == 0) db[li] += sb;
+            // weight gradient: lane owns taps j = lane, lane+64, ...
+            for (int j = lane; j < k; j += 64) {
+                const int p0 = max(0, pl - j), p1 = min(bands, bands + pl - j);
+                float acc = 0.0f;
+                for (int p = p0; p < p1; ++p) acc += dc[p] * in[p + j - pl];
+                dw[g.woff[li] + j] += acc;
+            }
+            // input gradient: din[q] += sum_j w[j] * dc[q - j + pl]
+            for (int q = lane; q < bands; q += 64) {
+                const int j0 = max(0, q + pl - (bands - 1)), j1 = min(k, q + pl + 1);
+                float acc = 0.0f;
+                for (int j = j0; j < j1; ++j) acc += wl[j] * dc[q - j + pl];
+                din[q] += acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        if (g.layers == 7) {
+            for (int p = lane; p < bands; p += 64) {
+                const float t = tanhf(tmp[p]);
+                dc[p] = dout[s * lddo + p] * (1.0f - t * t);
+            }
+            __builtin_amdgcn_wave_barrier();
+            layer_bwd(6, a + 6 * bands, da + 6 * bands);
+        } else {
+            for (int p = lane; p < bands; p += 64) da[4 * bands + p] = dout[s * lddo + p];
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int i = hidden; i >= 1; --i) {
+            for (int p = lane; p < bands; p += 64) {
+                const float gi = da[i * bands + p];
+                da[(i - 1) * bands + p] += gi;
+                if (i >= 2) da[(i - 2) * bands + p] += gi;
+                dc[p] = gi * slope[(i - 1) * bands + p];
+            }
+            __builtin_amdgcn_wave_barrier();
+            layer_bwd(i - 1, a + (i - 1) * bands, da + (i - 1) * bands);
+        }
+        if (dx) {
+            for (int p = lane; p < bands; p += 64) {
+                float* d = dx + s * lddx + p;
+                *d = accumulate_dx ? *d + da[p] : da[p];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // combine the waves of this block (fixed order) and publish the block's partial sums
+    float* pwb = pw + (size_t)blockIdx.x * g.wtotal;
+    for (int i = threadIdx.x; i < g.wtotal; i += blockDim.x) {
+        float t = 0.0f;
+        for (int wv = 0; wv < GEN_WAVES; ++wv) t += (wave_base + wv * per_wave + (7 + 1 + 6 + 7 + 1) * bands)[i];
+        pwb[i] = t;
+    }
+    if (threadIdx.x < 8) {
+        float t = 0.0f;
+        for (int wv = 0; wv < GEN_WAVES; ++wv)
+            t += (wave_base + wv * per_wave + (7 + 1 + 6 + 7 + 1) * bands + g.wtotal)[threadIdx.x];
+        pb[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------- losses
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.0f;
+    if (threadIdx.x == 0) t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+
+// mode 0: weight*mean((a-target)^2)   mode 1: weight*mean(|a-b|)   mode 2: weight*mean(a)
+__global__ __launch_bounds__(256) void gan_loss_partial_kernel(int mode, const float* __restrict__ a, int64_t lda,
+                                                                const float* __restrict__ b, int64_t ldb,
+                                                                int64_t rows, int c, float target, float gcoef,
+                                                                float* __restrict__ da, int64_t ldda, int acc_da,
+                                                                float* __restrict__ db, int64_t lddb, int acc_db,
+                                                                float* __restrict__ ws) {
+    __shared__ float sh[4];
+    float s = 0.0f;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x)
+        for (int col = threadIdx.x; col < c; col += 256) {
+            const float av = a[row * lda + col];
+            float val, ga, gb = 0.0f;
+            if (mode == 0) {
+                const float d = av - target;
+                val = d * d;
+                ga = 2.0f * d;
+            } else if (mode == 1) {
+                const float d = av - b[row * ldb + col];
+                val = fabsf(d);
+                ga = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+                gb = -ga;
+            } else {
+                val = av;
+                ga = 1.0f;
+            }
+            s += val;
+            if (da) {
+                float* p = da + row * ldda + col;
+                *p = (acc_da ? *p : 0.0f) + gcoef * ga;
+            }
+            if (db) {
+                float* p = db + row * lddb + col;
+                *p = (acc_db ? *p : 0.0f) + gcoef * gb;
+            }
+        }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ ws, int n, double scale,
+                                                             float* __restrict__ loss, int accumulate) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)ws[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.0f) + (float)(sh[0] * scale);
+}
+
+// l2 regulariser: loss += scale/2 * sum w^2, dw += scale * w
+__global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w, int64_t count, float scale,
+                                                      float* __restrict__ dw, float* __restrict__ ws) {
+    __shared__ float sh[4];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float v = w[i];
+        s += v * v;
+        if (dw) dw[i] += scale * v;
+    }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
+// tf.math.l2_normalize(x) with axis=None: the norm of the WHOLE [rows x c] tensor (shadow_data_models.py:147).
+// One block; stat[0] = sum x^2, stat[1] = rsqrt(max(sum, 1e-12)).
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int c,
+                                                          float* __restrict__ y, int64_t ldy,
+                                                          float* __restrict__ stat) {
+    __shared__ double sh[256];
+    __shared__ float inv_s;
+    const int64_t total = rows * c;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const float v = x[(i / c) * ldx + (i % c)];
+        s += (double)v * v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double ss = sh[0];
+        const float inv = (float)(1.0 / sqrt(ss > 1e-12 ? ss : 1e-12));
+        stat[0] = (float)ss;
+        stat[1] = inv;
+        inv_s = inv;
+    }
+    __syncthreads();
+    const float inv = inv_s;
+    for (int64_t i = threadIdx.x; i < total; i += 256) y[(i / c) * ldy + (i % c)] = x[(i / c) * ldx + (i % c)] * inv;
+}
+
+// dx = g*inv - x * (sum g.x) * inv^3   (dx = g*inv when the clamp is active)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ dy, int64_t lddy, int64_t rows,
+                                                          int c, const float* __restrict__ stat,
+                                                          float* __restrict__ dx, int64_t lddx, int accumulate) {
+    __shared__ double sh[256];
+    __shared__ float dot_s;
+    const int64_t total = rows * c;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < total; i += 256)
+        s += (double)x[(i / c) * ldx + (i % c)] * (double)dy[(i / c) * lddy + (i % c)];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dot_s = (float)sh[0];
+    __syncthreads();
+    const float inv = stat[1];
+    const float coef = stat[0] > 1e-12f ? dot_s * inv * inv * inv : 0.0f;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const float g = dy[(i / c) * lddy + (i % c)] * inv - x[(i / c) * ldx + (i % c)] * coef;
+        float* p = dx + (i / c) * lddx + (i % c);
+        *p = accumulate ? *p + g : g;
+    }
+}
+
+// patch-NCE (cut_wrapper.py:360-420): per sample logits[p][q] = <g_p, r_q>/tau over e, labels = eye(P) flattened:
+//   loss_n = P * logsumexp(all P^2 logits) - sum_p logits[p][p];  d logits = P*softmax - eye.
+__global__ void nce_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ r, int64_t ldr,
+                           int64_t n, int p, int e, float inv_tau, float gcoef, float* __restrict__ loss_ps,
+                           float* __restrict__ dg, int64_t lddg, int acc_dg, float* __restrict__ dr, int64_t lddr,
+                           int acc_dr) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float* gs = g + s * ldg;
+    const float* rs = r + s * ldr;
+    auto logit = [&](int a, int b) {
+        float d = 0.0f;
+        for (int k = 0; k < e; ++k) d += gs[a * e + k] * rs[b * e + k];
+        return d * inv_tau;
+    };
+    float mx = -3.4e38f;
+    for (int a = 0; a < p; ++a)
+        for (int b = 0; b < p; ++b) mx = fmaxf(mx, logit(a, b));
+    float se = 0.0f, diag = 0.0f;
+    for (int a = 0; a < p; ++a)
+        for (int b = 0; b < p; ++b) {
+            const float l = logit(a, b);
+            se += expf(l - mx);
+            if (a == b) diag += l;
+        }
+    const float lse = mx + logf(se);
+    loss_ps[s] = (float)p * lse - diag;
+    if (!dg && !dr) return;
+    const float inv_se = 1.0f / se;
+    if (dg)
+        for (int a = 0; a < p; ++a)
+            for (int k = 0; k < e; ++k) {
+                float acc = 0.0f;
+                for (int b = 0; b < p; ++b) {
+                    const float dl = (float)p * expf(logit(a, b) - mx) * inv_se - (a == b ? 1.0f : 0.0f);
+                    acc += dl * rs[b * e + k];
+                }
+                float* q = dg + s * lddg + a * e + k;
+                *q = (acc_dg ? *q : 0.0f) + gcoef * inv_tau * acc;
+            }
+    if (dr)
+        for (int b = 0; b < p; ++b)
+            for (int k = 0; k < e; ++k) {
+                float acc = 0.0f;
+                for (int a = 0; a < p; ++a) {
+                    const float dl = (float)p * expf(logit(a, b) - mx) * inv_se - (a == b ? 1.0f : 0.0f);
+                    acc += dl * gs[a * e + k];
+                }
+                float* q = dr + s * lddr + b * e + k;
+                *q = (acc_dr ? *q : 0.0f) + gcoef * inv_tau * acc;
+            }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+static size_t gen_fwd_lds(int bands, int only_encoder) {
+    const GenLayout g = gen_layout(bands, only_encoder);
+    return sizeof(float) * ((size_t)g.wtotal + 8 + (size_t)GEN_WAVES * 8 * bands);
+}
+static size_t gen_bwd_lds(int bands, int only_encoder) {
+    const GenLayout g = gen_layout(bands, only_encoder);
+    return sizeof(float) * ((size_t)g.wtotal + 8 + (size_t)GEN_WAVES * ((size_t)22 * bands + g.wtotal + 8));
+}
+
+extern "C" int hypel_gan_generator_blocks(int64_t n) {
+    int64_t b = (n + GEN_WAVES - 1) / GEN_WAVES;
+    if (b < 1) b = 1;
+    if (b > 512) b = 512;
+    return (int)b;
+}
+
+extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w,
+                                       const float* b, int32_t only_encoder, float* out, int64_t ldo,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && w && b && out && n > 0 && bands >= 8, "hypel_gan_generator_fwd");
+    const size_t lds = gen_fwd_lds(bands, only_encoder);
+    HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_gan_generator_fwd");
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)gan_generator_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(gan_generator_fwd_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * GEN_WAVES), lds, ST, x,
+                       ldx, n, bands, w, b, only_encoder, out, ldo);
+    HYPEL_CHECK_LAUNCH("hypel_gan_generator_fwd");
+    return 0;
+}
+
+extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n,
+                                       int32_t bands, const float* w, const float* b, int32_t only_encoder, float* dx,
+                                       int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && bands >= 8, "hypel_gan_generator_bwd");
+    const size_t lds = gen_bwd_lds(bands, only_encoder);
+    HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_gan_generator_bwd");
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)gan_generator_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(gan_generator_bwd_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * GEN_WAVES), lds, ST, x,
+                       ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb);
+    HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd");
+    return 0;
+}
+
+extern "C" int hypel_gan_loss(int32_t mode, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,
+                              int32_t c, float target, float weight, float* loss, int32_t accumulate_loss, float* da,
+                              int64_t ldda, int32_t acc_da, float* db, int64_t lddb, int32_t acc_db, float* ws,
+                              hypel_stream_t stream) {
+    HYPEL_REQUIRE(a && loss && ws && rows > 0 && c > 0 && mode >= 0 && mode <= 2, "hypel_gan_loss");
+    HYPEL_REQUIRE(mode != 1 || b != nullptr, "hypel_gan_loss");
+    const int grid = (int)(rows < 1024 ? rows : 1024);
+    const double count = (double)rows * c;
+    hipLaunchKernelGGL(gan_loss_partial_kernel, dim3(grid), dim3(256), 0, ST, mode, a, lda, b, ldb, rows, c, target,
+                       (float)(weight / count), da, ldda, acc_da, db, lddb, acc_db, ws);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, grid, (double)weight / count, loss,
+                       accumulate_loss);
+    HYPEL_CHECK_LAUNCH("hypel_gan_loss");
+    return 0;
+}
+
+extern "C" int hypel_l2_reg(const float* w, int64_t count, float scale, float* loss, int32_t accumulate_loss, float* dw,
+                            float* ws, hypel_stream_t stream) {
+    HYPEL_REQUIRE(w && loss && ws && count > 0, "hypel_l2_reg");
+    const int grid = hypel_grid_1d(count, 256, 1024);
+    hipLaunchKernelGGL(l2_reg_kernel, dim3(grid), dim3(256), 0, ST, w, count, scale, dw, ws);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, grid, 0.5 * (double)scale, loss,
+                       accumulate_loss);
+    HYPEL_CHECK_LAUNCH("hypel_l2_reg");
+    return 0;
+}
+
+extern "C" int hypel_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, float* y, int64_t ldy,
+                                float* stat, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && y && stat && rows > 0 && c > 0, "hypel_l2norm_fwd");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(1), dim3(256), 0, ST, x, ldx, rows, c, y, ldy, stat);
+    HYPEL_CHECK_LAUNCH("hypel_l2norm_fwd");
+    return 0;
+}
+
+extern "C" int hypel_l2norm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,
+                                const float* stat, float* dx, int64_t lddx, int32_t accumulate,
+                                hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && dy && dx && stat && rows > 0 && c > 0, "hypel_l2norm_bwd");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(1), dim3(256), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
+                       accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_l2norm_bwd");
+    return 0;
+}
+
+extern "C" int hypel_nce_loss(const float* g, int64_t ldg, const float* r, int64_t ldr, int64_t n, int32_t p,
+                              int32_t e, float tau, float weight, float* loss, int32_t accumulate_loss, float* dg,
+                              int64_t lddg, int32_t acc_dg, float* dr, int64_t lddr, int32_t acc_dr, float* ws,
+                              hypel_stream_t stream) {
+    HYPEL_REQUIRE(g && r && loss && ws && n > 0 && p > 0 && e > 0 && tau > 0.0f, "hypel_nce_loss");
+    // ws: [n] per-sample losses followed by 1024 floats of reduction scratch
+    hipLaunchKernelGGL(nce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ST, g, ldg, r, ldr, n, p, e,
+                       1.0f / tau, (float)(weight / (double)n), ws, dg, lddg, acc_dg, dr, lddr, acc_dr);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, (int)n, (double)weight / (double)n, loss,
+                       accumulate_loss);
+    HYPEL_CHECK_LAUNCH("hypel_nce_loss");
+    return 0;
+}

@@ -1,0 +1,90 @@
+"""CycleGAN wrapper (reference gan/wrappers/cycle_gan_wrapper.py:48-333): two GAN models in ModelX2Y / ModelY2X,
+reconstructions F(G(x)), G(F(y)), LS-GAN losses + cycle consistency (+ the reference's "identity" loss
+|x - G_x2y(x)|, |y - G_y2x(y)|, :303-333), tensor pools, sequential G-then-D phases."""
+from hypelcnn_amd import graph as G
+from hypelcnn_amd.gan.wrappers import gan_common as C
+from hypelcnn_amd.gan.wrappers.wrapper import InferenceWrapper, Wrapper
+
+model_forward_generator_name = "ModelX2Y"
+model_backward_generator_name = "ModelY2X"
+
+
+class CycleGANWrapper(Wrapper):
+    def __init__(self, cycle_consistency_loss_weight, identity_loss_weight, use_identity_loss, generator_fn,
+                 discriminator_fn):
+        self._cycle_consistency_loss_weight = cycle_consistency_loss_weight
+        self._identity_loss_weight = identity_loss_weight
+        self._use_identity_loss = use_identity_loss
+        self._generator_fn, self._discriminator_fn = generator_fn, discriminator_fn
+        self.backend = None
+
+    def define_model(self, images_x, images_y):
+        tower = images_x.tower
+        with G.variable_scope(C.model_base_name):
+            with G.variable_scope(model_forward_generator_name):
+                m_x2y = C.build_gan_model(tower, self._generator_fn, self._discriminator_fn, images_x, images_y,
+                                          "pool_fake_y")
+            with G.variable_scope(model_backward_generator_name):
+                m_y2x = C.build_gan_model(tower, self._generator_fn, self._discriminator_fn, images_y, images_x,
+                                          "pool_fake_x")
+            with G.variable_scope(model_backward_generator_name), G.variable_scope("Generator"):
+                rec_x = self._generator_fn(m_x2y.generated_data)
+            with G.variable_scope(model_forward_generator_name), G.variable_scope("Generator"):
+                rec_y = self._generator_fn(m_y2x.generated_data)
+        # identity_x = generator_x2y(data_x) is the SAME tensor as model_x2y.generated_data (reference :303-306)
+        return C.CycleGANModel(m_x2y, m_y2x, rec_x, rec_y, m_x2y.generated_data, m_y2x.generated_data)
+
+    def define_loss(self, model):
+        x, y = model.model_x2y.generator_inputs, model.model_y2x.generator_inputs
+        cw = self._cycle_consistency_loss_weight
+        terms = C.ls_terms_generator(model.model_x2y.discriminator_gen_outputs) + \
+            C.ls_terms_generator(model.model_y2x.discriminator_gen_outputs) + \
+            [G.LossTerm("mean_abs", x, model.reconstructed_x, weight=cw / 2.0),
+             G.LossTerm("mean_abs", y, model.reconstructed_y, weight=cw / 2.0)]
+        if self._use_identity_loss:
+            terms += [G.LossTerm("mean_abs", x, model.identity_x, weight=self._identity_loss_weight),
+                      G.LossTerm("mean_abs", y, model.identity_y, weight=self._identity_loss_weight)]
+        # each generator is trained on its own adversarial term + the full auxiliary loss; the two adversarial terms
+        # have disjoint variable support, so ONE backward pass of the sum yields both gradient sets
+        gen = C.Phase("gen", terms, [model.model_x2y.generator_scope, model.model_y2x.generator_scope], "gen", None)
+        dis = C.Phase("dis",
+                      C.ls_terms_discriminator(model.model_x2y.discriminator_real_outputs,
+                                               model.model_x2y.discriminator_pool_outputs) +
+                      C.ls_terms_discriminator(model.model_y2x.discriminator_real_outputs,
+                                               model.model_y2x.discriminator_pool_outputs),
+                      [model.model_x2y.discriminator_scope, model.model_y2x.discriminator_scope], "dis",
+                      [("pool_fake_y", model.model_x2y.generated_data), ("pool_fake_x", model.model_y2x.generated_data)])
+        return C.GANLoss([gen, dis], model.model_x2y.tower,
+                         [model.model_x2y.generated_data, model.model_y2x.generated_data])
+
+    def define_train_ops(self, model, loss, max_number_of_steps, **kwargs):
+        return C.define_standard_train_ops(model, loss, max_number_of_steps, kwargs["generator_lr"],
+                                           kwargs["discriminator_lr"], backend=self.backend)
+
+    def get_train_hooks_fn(self):
+        return lambda train_ops: [train_ops.run_step]
+
+
+class CycleGANInferenceWrapper(InferenceWrapper):
+    """Generator-only graph for shadow (x2y) / de-shadow (y2x) conversion (reference :118-186)."""
+
+    def __init__(self, shadow_generator_fn):
+        self._shadow_generator_fn = shadow_generator_fn
+
+    def scope_of(self, is_shadow_graph):
+        name = model_forward_generator_name if is_shadow_graph else model_backward_generator_name
+        return f"{C.model_base_name}/{name}/{C.model_generator_name}"
+
+    def construct_inference_graph(self, input_tensor, is_shadow_graph, clip_invalid_values):
+        name = model_forward_generator_name if is_shadow_graph else model_backward_generator_name
+        with G.variable_scope(C.model_base_name), G.variable_scope(name), G.variable_scope(C.model_generator_name):
+            return self._shadow_generator_fn(input_tensor)
+
+    def make_inference_graph(self, data_set, is_shadow_graph, clip_invalid_values):
+        tower, x, _ = C.new_gan_tower(data_set.get_casi_band_count())
+        return x, self.construct_inference_graph(x, is_shadow_graph, clip_invalid_values)
+
+    def create_generator_restorer(self):
+        prefixes = (f"{C.model_base_name}/{model_forward_generator_name}",
+                    f"{C.model_base_name}/{model_backward_generator_name}")
+        return lambda names: [n for n in names if n.startswith(prefixes)]

@@ -92,6 +92,56 @@ class Variable:
         self.trainable = trainable
         self.size = int(np.prod(self.shape))
         self.offset = None  # element offset in the flat parameter / state buffer (set by the session)
+        self.group = "default"  # optimiser group: variables of one group are contiguous in the flat buffers
+        self.l2_scale = 0.0  # tf_slim.l2_regularizer scale attached to this variable (0 = none)
+
+
+# tf.compat.v1.variable_scope: name prefixes + default-name uniquification.  Re-entering a scope restarts the
+# default-name counters, which is how AUTO_REUSE shares un-named tf_slim layers (fully_connected, _1, ...).
+_VSCOPE = [""]
+_DEFAULT_NAME_COUNTS = {}
+
+
+class variable_scope:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        full = (_VSCOPE[-1] + "/" + self.name) if _VSCOPE[-1] else self.name
+        _VSCOPE.append(full)
+        for k in [k for k in _DEFAULT_NAME_COUNTS if k[0].startswith(full)]:
+            del _DEFAULT_NAME_COUNTS[k]
+        return full
+
+    def __exit__(self, *exc):
+        _VSCOPE.pop()
+        return False
+
+
+def current_scope():
+    return _VSCOPE[-1]
+
+
+def unique_default_name(base):
+    key = (_VSCOPE[-1], base)
+    n = _DEFAULT_NAME_COUNTS.get(key, 0)
+    _DEFAULT_NAME_COUNTS[key] = n + 1
+    return base if n == 0 else f"{base}_{n}"
+
+
+def _scoped(name):
+    return (_VSCOPE[-1] + "/" + name) if _VSCOPE[-1] else name
+
+
+GROUP_MARKERS = ("Generator", "Discriminator", "FeatDiscriminator")
+
+
+def group_of(full_name):
+    parts = full_name.split("/")
+    for i, p in enumerate(parts):
+        if p in GROUP_MARKERS:
+            return "/".join(parts[:i + 1])
+    return "default"
 
 
 class VariableStore:
@@ -104,10 +154,12 @@ class VariableStore:
         self.order = []
 
     def get(self, name, shape, init, trainable=True):
+        name = _scoped(name)
         full = f"{self.prefix}/{name}" if self.prefix else name
         v = self.vars.get(full)
         if v is None:
             v = Variable(full, shape, init, trainable)
+            v.group = group_of(full)
             self.vars[full] = v
             self.order.append(v)
         elif v.shape != tuple(shape):
@@ -253,6 +305,26 @@ class LRNNode:
         self.out = None
 
 
+class GeneratorNode:
+    """Whole shadowdata_generator_model as ONE fused op (gan/shadow_data_models.py:43-90): [N,B] -> [N,B]."""
+
+    def __init__(self, src, weights, biases, only_encoder):
+        self.src = src
+        self.weights = weights  # 7 Variables [k,1,1]
+        self.biases = biases  # 7 Variables [1]
+        self.only_encoder = only_encoder
+        self.out = None
+
+
+class FeatStackNode:
+    """tf.math.l2_normalize (whole-tensor norm) of each slice embedding [N,E], stacked to [N, P*E]
+    (gan/shadow_data_models.py:147-149)."""
+
+    def __init__(self, srcs):
+        self.srcs = srcs
+        self.out = None
+
+
 class Tower:
     """One instantiation of the model template (train / test / validation towers share variables)."""
 
@@ -307,6 +379,9 @@ def _make_branch(tower, scope, k, cin, cout, is_conv, opts):
     w_init = opts.get("weights_initializer") or xavier_init()
     shape = (k, k, cin, cout) if is_conv else (cin, cout)
     w = st.get(f"{scope}/weights", shape, w_init, True)
+    reg = opts.get("weights_regularizer")
+    if reg:
+        w.l2_scale = float(reg)
     bias = bn = None
     if opts.get("normalizer_fn") == batch_norm:
         # a normaliser suppresses the bias (tf_slim layers.convolution / fully_connected)
@@ -328,7 +403,8 @@ def conv2d(inputs, num_outputs, kernel_size, scope, activation_fn=_UNSET, normal
            data_format=None):
     """tf_slim.conv2d: NHWC, stride 1, SAME, square kernel (HYPELCNNModel.py:136,157,177)."""
     opts = _defaults(dict(activation_fn=activation_fn, normalizer_fn=normalizer_fn, normalizer_params=normalizer_params,
-                          weights_initializer=weights_initializer, biases_initializer=biases_initializer))
+                          weights_initializer=weights_initializer, biases_initializer=biases_initializer,
+                          weights_regularizer=weights_regularizer))
     k = kernel_size[0] if isinstance(kernel_size, (list, tuple)) else int(kernel_size)
     if isinstance(kernel_size, (list, tuple)) and kernel_size[0] != kernel_size[1]:
         raise NotImplementedError("only square kernels are on the hot path (HYPELCNNModel.py:174)")
@@ -342,11 +418,21 @@ def conv2d(inputs, num_outputs, kernel_size, scope, activation_fn=_UNSET, normal
     return node.out
 
 
-def fully_connected(inputs, num_outputs, scope, activation_fn=_UNSET, normalizer_fn=_UNSET, normalizer_params=_UNSET,
-                    weights_initializer=_UNSET, biases_initializer=_UNSET, weights_regularizer=_UNSET):
+def l2_regularizer(scale):
+    """tf_slim.l2_regularizer(scale): scale * sum(w^2) / 2; recorded on the variable, applied by GAN phases
+    (tfgan.gan_loss adds the scope's regularisation losses; the classifier path never does, Appendix A.7)."""
+    return float(scale)
+
+
+def fully_connected(inputs, num_outputs, scope=None, activation_fn=_UNSET, normalizer_fn=_UNSET,
+                    normalizer_params=_UNSET, weights_initializer=_UNSET, biases_initializer=_UNSET,
+                    weights_regularizer=_UNSET):
     """tf_slim.fully_connected on [N, F]; F may be a flatten / axis-1 concat of patch tensors."""
     opts = _defaults(dict(activation_fn=activation_fn, normalizer_fn=normalizer_fn, normalizer_params=normalizer_params,
-                          weights_initializer=weights_initializer, biases_initializer=biases_initializer))
+                          weights_initializer=weights_initializer, biases_initializer=biases_initializer,
+                          weights_regularizer=weights_regularizer))
+    if scope is None:
+        scope = unique_default_name("fully_connected")
     if isinstance(inputs, FlatTensor):
         sources, feats, tower = inputs.sources, inputs.features, inputs.tower
     else:
@@ -455,6 +541,46 @@ def local_response_normalization(inputs, depth_radius=5, bias=1.0, alpha=1.0, be
     node.out = SymTensor(inputs.tower, inputs.hw, inputs.c, node=node)
     inputs.tower.nodes.append(node)
     return node.out
+
+
+def he_truncated_init():
+    """tf.compat.v1.initializers.variance_scaling(scale=2.0): fan_in, truncated normal (shadow_data_models.py:95)."""
+    return variance_scaling_init(2.0)
+
+
+def shadow_generator(netinput, create_only_encoder, is_training=True):
+    """Records the fused generator; variables net1..net7/{weights [k,1,1], biases [1]} are zero-initialised
+    (shadow_data_models.py:47).  The full generator and its encoder-only prefix share net1..net4."""
+    tower = netinput.tower
+    st = tower.store
+    b = netinput.c
+    ks = [b, b // 2, b // 4, b // 8, b // 4, b // 2, b]
+    ws, bs = [], []
+    for i, k in enumerate(ks, start=1):  # all seven exist in TF as soon as the full generator was built once
+        ws.append(st.get(f"net{i}/weights", (k, 1, 1), zeros_init(), True))
+    for i in range(1, 8):
+        bs.append(st.get(f"net{i}/biases", (1,), zeros_init(), True))
+    node = GeneratorNode(netinput.use(), ws, bs, bool(create_only_encoder))
+    node.out = SymTensor(tower, None, b, node=node)
+    tower.nodes.append(node)
+    return node.out
+
+
+def feature_stack(embeddings):
+    tower = embeddings[0].tower
+    node = FeatStackNode([e.use() for e in embeddings])
+    node.out = SymTensor(tower, None, sum(e.c for e in embeddings), node=node)
+    node.out.parts = len(embeddings)
+    tower.nodes.append(node)
+    return node.out
+
+
+# GAN loss terms: (kind, tensors..., weight).  A phase minimises the sum of its terms w.r.t. its variable groups.
+class LossTerm:
+    def __init__(self, kind, a, b=None, target=0.0, weight=1.0, tau=None, parts=None, embed=None):
+        self.kind = kind  # "mean_sq" | "mean_abs" | "mean" | "nce"
+        self.a, self.b = a, b
+        self.target, self.weight, self.tau, self.parts, self.embed = target, weight, tau, parts, embed
 
 
 # ------------------------------------------------------------------------------- loss expressions

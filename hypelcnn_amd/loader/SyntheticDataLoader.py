@@ -44,6 +44,12 @@ class SyntheticDataLoader(DataLoader):
         t = numpy.linspace(0, 1, b)
         spectra = numpy.stack([0.5 + 0.4 * numpy.sin(2 * numpy.pi * (t * (1 + 0.35 * i) + rng.rand())) for i in range(k)])
         casi = (spectra[labels] * 2000 + rng.randn(h, w, b) * 60 + 2200).astype(numpy.float32)
+        # a blobby shadow region whose pixels are attenuated band by band (what the GAN has to learn to map)
+        sseed = rng.rand(3, 2) * [h, w]
+        sd = ((yy[..., None] - sseed[:, 0]) ** 2 + (xx[..., None] - sseed[:, 1]) ** 2).min(-1)
+        self._shadow_map = (sd < (min(h, w) / 4.5) ** 2).astype(numpy.uint8)
+        atten = 0.35 + 0.3 * numpy.linspace(0, 1, b)
+        casi = numpy.where(self._shadow_map[..., None] == 1, casi * atten, casi).astype(numpy.float32)
         lidar = None
         if c["lidar"]:
             heights = rng.rand(k) * 30
@@ -57,7 +63,14 @@ class SyntheticDataLoader(DataLoader):
                             normalize=normalize)
 
     def load_shadow_map(self, neighborhood, data_set):
-        return None, None
+        """load_shadow_map_common (reference common_nn_ops.py:567-571): padded map + per-band lit/shadow ratio."""
+        from hypelcnn_amd.common.common_nn_ops import calculate_shadow_ratio
+        if getattr(self, "_shadow_map", None) is None:
+            self._scene()
+        shadow_map = numpy.pad(self._shadow_map, neighborhood, mode="symmetric")
+        ratio = None if data_set is None else calculate_shadow_ratio(
+            data_set.casi, shadow_map, numpy.logical_not(shadow_map).astype(int))
+        return shadow_map, ratio
 
     def load_samples(self, train_data_ratio, test_data_ratio):
         if getattr(self, "_labels", None) is None:

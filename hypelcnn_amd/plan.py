@@ -137,7 +137,20 @@ class TowerPlan:
         self.mask_bufs = {}
         self.scratch_sizes = {"scratch_partial": 1, "scratch_wgrad": 1, "scratch_red": 2048, "sums": 2}
         self._pending_scratch = []
+        self.param_written = set()  # variables whose gradient was already written in this plan (shared weights)
         self._build()
+
+    # ---- which variables does this plan train / which tensors need a gradient (overridden by PhasePlan) ----
+    def _trains(self, variables):
+        return True
+
+    def _needs_grad(self, t):
+        return t.owner.needs_grad
+
+    def _param_acc(self, var):
+        acc = 1 if var.name in self.param_written else 0
+        self.param_written.add(var.name)
+        return acc
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, name, n, dtype=None):
@@ -527,7 +540,7 @@ class TowerPlan:
     # ------------------------------------------------------------------ backward
     def _bwd_residuals(self, node, dz_ref, lddz, rows, c):
         for (src, ridx) in node.residuals:
-            if not src.owner.needs_grad:
+            if not self._needs_grad(src):
                 continue
             gst, acc = self._grad_target(src)
             sref = None
@@ -556,10 +569,11 @@ class TowerPlan:
         dz = self._ref("g:" + z_st.buf)
         y_ref = self._ref(aux["y"].buf)
         dy = dz  # backward post-op runs in place
+        trains = self._trains([b.w for b in node.branches])
         if node.has_post:
             self._bwd_residuals(node, dz, c, rows, c)
-            self._emit_post_bwd(node, aux, dz, y_ref, rows, c, dy, want_param=True)
-        elif node.has_bias:
+            self._emit_post_bwd(node, aux, dz, y_ref, rows, c, dy, want_param=trains)
+        elif node.has_bias and trains:
             self._emit_post_bwd(node, aux, dz, y_ref, rows, c, None, want_param=True)
 
         # ---- data gradient ----
@@ -567,7 +581,7 @@ class TowerPlan:
             src = node.sources[0]
             s_st = self.storage_of(src)
             h, w = src.hw
-            if src.owner.needs_grad:
+            if self._needs_grad(src):
                 gst, acc = self._grad_target(src)
                 choff = 0
                 by_cout = {}
@@ -599,13 +613,14 @@ class TowerPlan:
                                     self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}")
                     acc = 1
             # ---- filter gradient ----
-            self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w)
+            if trains:
+                self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w)
         else:
             b = node.branches[0]
             rowbase = 0
             for src in node.sources:
                 s_st = self.storage_of(src)
-                if src.owner.needs_grad:
+                if self._needs_grad(src):
                     gst, acc = self._grad_target(src)
                     tb = GemmTables()
                     for p in range(src.npix):
@@ -613,7 +628,8 @@ class TowerPlan:
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), c, 1, self._ref(gst.buf),
                                     gst.ld, None, acc, f"dgrad:{b.scope}")
                 rowbase += src.npix * src.c
-            self._wgrad_dense(idx, node, aux, dy, c)
+            if trains:
+                self._wgrad_dense(idx, node, aux, dy, c)
 
     def _emit_post_bwd(self, node, aux, dz, y_ref, rows, c, dy, want_param):
         has_bn = isinstance(node, G.LinearNode) and node.has_bn
@@ -636,7 +652,10 @@ class TowerPlan:
             l1 = Launch("bn_act_bwd_reduce", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
                                               chunk, None), nbytes=8 * rows * c, tag="post-bwd-reduce")
             self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
-            l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, 0), tag="post-bwd-finalize")
+            pacc = 0
+            if dparam is not None:
+                pacc = self._param_acc(aux["beta"] if has_bn else aux["bias"])
+            l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, pacc), tag="post-bwd-finalize")
             self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
             self._scratch(l2, 3, "sums", 2 * c)
             self.bwd += [l1, l2]
@@ -653,20 +672,20 @@ class TowerPlan:
         return min(s, 64)
 
     def _emit_wgrad(self, tables_by_split_builder, n_groups_blocks, max_segs, slab, w0_offset, n, a_ref, lda, b_ref, ldb,
-                    tag):
+                    tag, acc=0):
         """tables_by_split_builder(S) -> GemmTables whose groups write to c_off = split*slab + local."""
         S = self._wgrad_splits(n_groups_blocks, max_segs)
         tb = tables_by_split_builder(S)
         if S == 1:
-            self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None, 0,
-                            tag, allow_split=False)
+            self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None,
+                            acc, tag, allow_split=False)
             return
         launch_pos = len(self.bwd)
         self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads), n, None, 0, tag,
                         allow_split=False)
         l = self.bwd[launch_pos]
         self._scratch(l, 6, "scratch_wgrad", S * slab)
-        l2 = Launch("reduce_splits_f32", (None, slab, S, Ref(self.sess.grads, w0_offset), slab, 0, None, 0),
+        l2 = Launch("reduce_splits_f32", (None, slab, S, Ref(self.sess.grads, w0_offset), slab, acc, None, 0),
                     nbytes=4 * slab * (S + 1), tag="wgrad-reduce")
         self._scratch(l2, 0, "scratch_wgrad", S * slab)
         self.bwd.append(l2)
@@ -719,8 +738,9 @@ class TowerPlan:
                         tb.add_group(s * slab + loc, chunk, rows)
                 return tb
 
+            acc = max(self._param_acc(b.w) for b, _ in items)
             self._emit_wgrad(build, blocks, max_segs, slab, lo, cout, self._ref(s_st.buf), s_st.ld, dy, c,
-                             f"wgrad:{items[0][0].scope}")
+                             f"wgrad:{items[0][0].scope}", acc=acc)
 
     def _wgrad_dense(self, idx, node, aux, dy, c):
         nb = self.nb
@@ -747,8 +767,10 @@ class TowerPlan:
                         tb.add_group(s * slab + loc, chunk, rows)
                 return tb
 
+            acc = self._param_acc(b.w) if rowbase == 0 else (1 if b.w.name + f"#{rowbase}" in self.param_written else 0)
+            self.param_written.add(b.w.name + f"#{rowbase}")
             self._emit_wgrad(build, blocks, max_segs, slab, lo, c, self._ref(s_st.buf), s_st.ld, dy, c,
-                             f"wgrad:{b.scope}")
+                             f"wgrad:{b.scope}", acc=acc)
             rowbase += src.npix * src.c
 
     def _bwd_post(self, idx, node):
@@ -760,7 +782,7 @@ class TowerPlan:
             raise RuntimeError(f"post node {idx} receives no gradient")
         dz = self._ref("g:" + z_st.buf)
         self._bwd_residuals(node, dz, c, rows, c)
-        if not src.owner.needs_grad:
+        if not self._needs_grad(src):
             return
         s_st = self.storage_of(src)
         act = node.act
@@ -780,7 +802,7 @@ class TowerPlan:
         z_st = self.storage[id(out)]
         if not self.grad_written.get(id(out.owner), False):
             raise RuntimeError(f"lrn node {idx} receives no gradient")
-        if not src.owner.needs_grad:
+        if not self._needs_grad(src):
             return
         s_st = self.storage_of(src)
         gst, acc = self._grad_target(src)
@@ -788,3 +810,240 @@ class TowerPlan:
                                            rows, c, node.radius, float(node.bias), float(node.alpha), float(node.beta),
                                            self._ref(gst.buf, gst.ch_off), gst.ld, acc), nbytes=16 * rows * c,
                                tag="lrn-bwd"))
+
+
+# =========================================================================================== GAN phases
+def gen_kernel_sizes(bands):
+    return [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
+
+
+class PhasePlan(TowerPlan):
+    """One train op of a GAN step (tfgan RunTrainOpsHook = one session.run): the sub-graph that the phase's loss
+    terms depend on, differentiated w.r.t. the variable groups the phase trains.  `outputs` (no loss terms) gives a
+    forward-only plan, e.g. "generate fresh fake data for the tensor pool"."""
+
+    def __init__(self, tower, nb, session, terms=(), train_groups=(), outputs=(), seed=1234):
+        self.terms = list(terms)
+        self.train_groups = set(train_groups)
+        self.outputs = list(outputs)
+        super().__init__(tower, nb, session, loss=None, external_masks=True, seed=seed)
+
+    # ---- analysis ----
+    def _trains(self, variables):
+        return all(v.group in self.train_groups for v in variables)
+
+    def _needs_grad(self, t):
+        return id(t.owner) in self._grad_needed
+
+    def _node_inputs(self, node):
+        if isinstance(node, G.LinearNode):
+            return list(node.sources) + [r for r, _ in node.residuals]
+        if isinstance(node, G.PostNode):
+            return [node.src] + [r for r, _ in node.residuals]
+        if isinstance(node, G.FeatStackNode):
+            return list(node.srcs)
+        return [node.src]
+
+    def _node_vars(self, node):
+        if isinstance(node, G.LinearNode):
+            out = []
+            for b in node.branches:
+                out.append(b.w)
+                if b.bias is not None:
+                    out.append(b.bias)
+            return out
+        if isinstance(node, G.GeneratorNode):
+            return list(node.weights) + list(node.biases)
+        return []
+
+    def _analyse(self):
+        roots = []
+        for t in self.terms:
+            roots += [t.a] + ([t.b] if t.b is not None else [])
+        roots += self.outputs
+        needed = set()
+        stack = [r.owner for r in roots]
+        while stack:
+            t = stack.pop()
+            if t.node is None or id(t.node) in needed:
+                continue
+            needed.add(id(t.node))
+            stack += [i.owner for i in self._node_inputs(t.node)]
+        self.needed = [n for n in self.tower.nodes if id(n) in needed]
+        self._grad_needed = set()
+        for n in self.needed:
+            vs = self._node_vars(n)
+            own = bool(vs) and any(v.group in self.train_groups for v in vs)
+            if own or any(id(i.owner) in self._grad_needed for i in self._node_inputs(n)):
+                self._grad_needed.add(id(n.out))
+
+    # ---- build ----
+    def _build(self):
+        self._analyse()
+        nb = self.nb
+        used_inputs = set()
+        for n in self.needed:
+            for i in self._node_inputs(n):
+                if i.owner.node is None:
+                    used_inputs.add(id(i.owner))
+        for t in self.terms:
+            for x in (t.a, t.b):
+                if x is not None and x.owner.node is None:
+                    used_inputs.add(id(x.owner))
+        for name, t in self.tower.inputs.items():
+            if id(t) not in used_inputs:
+                continue
+            assert t.hw is None, "GAN inputs are [N, B]"
+            self._alloc("in:" + name, nb * t.c)
+            self.storage[id(t)] = Storage("in:" + name, nb, t.c, None, 0, t.c, 1)
+        self._alloc("loss", 1)
+        for idx, node in enumerate(self.tower.nodes):
+            if node not in self.needed:
+                continue
+            if isinstance(node, G.LinearNode):
+                self._fwd_linear(idx, node)
+            elif isinstance(node, G.GeneratorNode):
+                self._fwd_generator(idx, node)
+            elif isinstance(node, G.FeatStackNode):
+                self._fwd_featstack(idx, node)
+            elif isinstance(node, G.PostNode):
+                self._fwd_post(idx, node)
+            else:
+                raise TypeError(node)
+        for ti, term in enumerate(self.terms):
+            self._emit_term(ti, term)
+        if self.terms:
+            for idx in range(len(self.tower.nodes) - 1, -1, -1):
+                node = self.tower.nodes[idx]
+                if node not in self.needed or id(node.out) not in self._grad_needed:
+                    continue
+                if not self.grad_written.get(id(node.out.owner), False):
+                    continue  # this application does not feed the phase's loss
+                if isinstance(node, G.LinearNode):
+                    self._bwd_linear(idx, node)
+                elif isinstance(node, G.GeneratorNode):
+                    self._bwd_generator(idx, node)
+                elif isinstance(node, G.FeatStackNode):
+                    self._bwd_featstack(idx, node)
+                elif isinstance(node, G.PostNode):
+                    self._bwd_post(idx, node)
+            self._emit_regularisers()
+        for name, size in self.scratch_sizes.items():
+            self._alloc(name, size)
+        for launch, pos, name in self._pending_scratch:
+            args = list(launch.args)
+            args[pos] = self._ref(name)
+            launch.args = tuple(args)
+
+    # ---- fused generator ----
+    def _gen_refs(self, node):
+        self._assert_contiguous(node.weights)
+        self._assert_contiguous(node.biases)
+        return node.weights[0], node.biases[0], sum(w.size for w in node.weights)
+
+    def _fwd_generator(self, idx, node):
+        src, out = node.src, node.out
+        s_st = self.storage_of(src)
+        st = self._new_value(out, f"z:{idx}")
+        w0, b0, _ = self._gen_refs(node)
+        self.fwd.append(Launch("gan_generator_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c,
+                                                     self._p(w0), self._p(b0), int(node.only_encoder),
+                                                     self._ref(st.buf), st.ld), nbytes=8 * self.nb * src.c,
+                               tag="gen-fwd"))
+
+    def _bwd_generator(self, idx, node):
+        src, out = node.src, node.out
+        s_st = self.storage_of(src)
+        z_st = self.storage[id(out)]
+        w0, b0, wtotal = self._gen_refs(node)
+        blocks = self.be.gan_generator_blocks(self.nb)
+        dx, lddx, acc = None, 0, 0
+        if self._needs_grad(src):
+            gst, acc = self._grad_target(src)
+            dx, lddx = self._ref(gst.buf, gst.ch_off), gst.ld
+        l1 = Launch("gan_generator_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
+                                          z_st.ld, self.nb, src.c, self._p(w0), self._p(b0), int(node.only_encoder),
+                                          dx, lddx, acc, None, None), nbytes=12 * self.nb * src.c, tag="gen-bwd")
+        self._scratch(l1, 12, "scratch_gen_w", blocks * wtotal)
+        self._scratch(l1, 13, "scratch_gen_b", blocks * 8)
+        self.bwd.append(l1)
+        if self._trains(node.weights):
+            wacc = self._param_acc(w0)
+            l2 = Launch("reduce_splits_f32", (None, wtotal, blocks, self._g(w0), wtotal, wacc, None, 0), tag="gen-dw")
+            self._scratch(l2, 0, "scratch_gen_w", blocks * wtotal)
+            l3 = Launch("reduce_splits_f32", (None, 8, blocks, self._g(b0), 7, wacc, None, 0), tag="gen-db")
+            self._scratch(l3, 0, "scratch_gen_b", blocks * 8)
+            self.bwd += [l2, l3]
+
+    # ---- feature stack (global l2 normalise per slice, stacked) ----
+    def _fwd_featstack(self, idx, node):
+        out = node.out
+        st = self._new_value(out, f"z:{idx}")
+        self._alloc(f"l2stat:{idx}", 2 * len(node.srcs))
+        off = 0
+        for p, src in enumerate(node.srcs):
+            s_st = self.storage_of(src)
+            self.fwd.append(Launch("l2norm_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c,
+                                                  self._ref(st.buf, off), st.ld, self._ref(f"l2stat:{idx}", 2 * p)),
+                                   tag="l2norm"))
+            off += src.c
+
+    def _bwd_featstack(self, idx, node):
+        out = node.out
+        st = self.storage[id(out)]
+        off = 0
+        for p, src in enumerate(node.srcs):
+            if self._needs_grad(src):
+                s_st = self.storage_of(src)
+                gst, acc = self._grad_target(src)
+                self.bwd.append(Launch("l2norm_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld,
+                                                      self._ref("g:" + st.buf, off), st.ld, self.nb, src.c,
+                                                      self._ref(f"l2stat:{idx}", 2 * p),
+                                                      self._ref(gst.buf, gst.ch_off), gst.ld, acc), tag="l2norm-bwd"))
+            off += src.c
+
+    # ---- loss terms ----
+    def _grad_ref(self, t):
+        if t is None or not self._needs_grad(t):
+            return None, 0, 0
+        gst, acc = self._grad_target(t)
+        return self._ref(gst.buf, gst.ch_off), gst.ld, acc
+
+    def _emit_term(self, ti, term):
+        nb = self.nb
+        a_st = self.storage_of(term.a)
+        a_ref = self._ref(a_st.buf, a_st.ch_off)
+        acc_loss = 1 if ti > 0 else 0
+        da, ldda, acc_a = self._grad_ref(term.a)
+        if term.kind == "nce":
+            b_st = self.storage_of(term.b)
+            db, lddb, acc_b = self._grad_ref(term.b)
+            l = Launch("nce_loss", (a_ref, a_st.ld, self._ref(b_st.buf, b_st.ch_off), b_st.ld, nb, int(term.parts),
+                                    int(term.embed), float(term.tau), float(term.weight), self._ref("loss"), acc_loss,
+                                    da, ldda, acc_a, db, lddb, acc_b, None), tag="loss-nce")
+            self._scratch(l, 17, "scratch_nce", nb + 1024)
+            self.fwd.append(l)
+            return
+        mode = {"mean_sq": 0, "mean_abs": 1, "mean": 2}[term.kind]
+        b_ref, ldb, db, lddb, acc_b = None, 0, None, 0, 0
+        if term.b is not None:
+            b_st = self.storage_of(term.b)
+            b_ref, ldb = self._ref(b_st.buf, b_st.ch_off), b_st.ld
+            db, lddb, acc_b = self._grad_ref(term.b)
+        l = Launch("gan_loss", (mode, a_ref, a_st.ld, b_ref, ldb, nb, term.a.c, float(term.target), float(term.weight),
+                                self._ref("loss"), acc_loss, da, ldda, acc_a, db, lddb, acc_b, None),
+                   tag="loss-" + term.kind)
+        self._scratch(l, 17, "scratch_red")
+        self.fwd.append(l)
+
+    def _emit_regularisers(self):
+        """tfgan.gan_loss adds the trained scope's regularisation losses (shadow_data_models.py:96,129)."""
+        seen = set()
+        for node in self.needed:
+            for v in self._node_vars(node):
+                if v.l2_scale and v.group in self.train_groups and v.name not in seen and v.name in self.param_written:
+                    seen.add(v.name)
+                    l = Launch("l2_reg", (self._p(v), v.size, float(v.l2_scale), self._ref("loss"), 1, self._g(v), None),
+                               tag="l2-reg")
+                    self._scratch(l, 6, "scratch_red")
+                    self.bwd.append(l)

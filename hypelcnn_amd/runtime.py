@@ -14,7 +14,7 @@ import torch
 
 from . import graph as G
 from .backend import Ref
-from .plan import TowerPlan
+from .plan import PhasePlan, TowerPlan
 
 
 class CompiledTower:
@@ -89,6 +89,8 @@ class CompiledTower:
 
     def loss_value(self):
         b = self.plan.buffers
+        if "loss" in b and "loss_ce" not in b:
+            return float(b["loss"][0])
         v = float(b["loss_ce"][0])
         if self.plan.loss is not None and self.plan.loss.per_sample.extra_mse is not None:
             v += float(b["loss_mse"][0])
@@ -116,13 +118,21 @@ class Session:
         """Lay variables out in the flat buffers (weights first, then per-channel vectors, each in
         creation order so that the vectors of a merged level are contiguous) and initialise them."""
         order = self.store.order
-        weights = [v for v in order if v.trainable and len(v.shape) > 1]
-        vectors = [v for v in order if v.trainable and len(v.shape) == 1]
-        self.trainable = weights + vectors
+        groups = []
+        for v in order:
+            if v.trainable and v.group not in groups:
+                groups.append(v.group)
+        self.trainable = []
+        self.group_ranges = {}
         off = 0
-        for v in self.trainable:
-            v.offset = off
-            off += v.size
+        for gname in groups:  # one contiguous range per optimiser group (GAN: generator / discriminator / ...)
+            lo = off
+            members = [v for v in order if v.trainable and v.group == gname]
+            for v in [m for m in members if len(m.shape) > 1] + [m for m in members if len(m.shape) == 1]:
+                v.offset = off
+                off += v.size
+                self.trainable.append(v)
+            self.group_ranges[gname] = (lo, off)
         n_train = off
         mm = [v for v in order if not v.trainable and v.name.endswith("moving_mean")]
         mv = [v for v in order if not v.trainable and v.name.endswith("moving_variance")]
@@ -202,6 +212,35 @@ class Session:
             ct = CompiledTower(plan, self.backend)
             self._compiled[key] = ct
         return ct
+
+    def compile_phase(self, tower, nb, terms=(), train_groups=(), outputs=(), key=None):
+        k = ("phase", id(tower), int(nb), key)
+        ct = self._compiled.get(k)
+        if ct is None:
+            plan = PhasePlan(tower, nb, self, terms=terms, train_groups=train_groups, outputs=outputs, seed=self.seed)
+            ct = CompiledTower(plan, self.backend)
+            self._compiled[k] = ct
+        return ct
+
+    def adam_step_groups(self, groups, lr, t, beta1=0.5, beta2=0.999, eps=1e-8):
+        """TF1 Adam on the flat ranges of the given optimiser groups (gan_common.py:264-265: beta1 = 0.5)."""
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        for gname in groups:
+            lo, hi = self.group_ranges[gname]
+            if hi > lo:
+                self.backend.call("adam_tf1", Ref(self.params, lo), Ref(self.grads, lo), Ref(self.slot_m, lo),
+                                  Ref(self.slot_v, lo), hi - lo, float(lr_t), float(beta1), float(beta2), float(eps))
+
+    def allreduce_group_gradients(self, groups):
+        if self.dist is None:
+            return
+        import torch.distributed as dist
+        for gname in groups:
+            lo, hi = self.group_ranges[gname]
+            if hi > lo:
+                view = self.grads[lo:hi]
+                dist.all_reduce(view, op=dist.ReduceOp.SUM)
+                view.mul_(1.0 / self.dist[0])
 
     # ---- optimiser (common_nn_ops.py:223-230) ----
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):

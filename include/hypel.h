@@ -159,6 +159,41 @@ int hypel_lrn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, in
                   float bias, float alpha, float beta, float* dx, int64_t lddx, int32_t accumulate,
                   hypel_stream_t stream);
 
+/* ---- shadow GAN stacks (gan/shadow_data_models.py, gan/wrappers/) -------------------------------------------
+ * Fused generator (shadowdata_generator_model :43-90): x[N][B] -> out[N][B]; seven 1-channel SAME 1-D convolutions
+ * over the band axis with kernel sizes B, B/2, B/4, B/8, B/4, B/2, B, leaky-ReLU(0.1), skip sums
+ * n_i = c_i + n_{i-1} + n_{i-2}, tanh on the last layer; only_encoder != 0 stops after layer 4 and returns n4.
+ * w = the layers' kernels concatenated (TF variables netK/weights [k,1,1]), b = 7 biases.  One wavefront per
+ * sample, everything in LDS.  The backward recomputes the forward per sample; weight / bias gradients are
+ * written as per-block partial sums pw[blocks][sum k], pb[blocks][8] with blocks = hypel_gan_generator_blocks(n)
+ * (reduce with hypel_reduce_splits_f32).  dx may be NULL. */
+int hypel_gan_generator_blocks(int64_t n);
+int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w, const float* b,
+                            int32_t only_encoder, float* out, int64_t ldo, hypel_stream_t stream);
+int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,
+                            const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
+                            int32_t accumulate_dx, float* pw, float* pb, hypel_stream_t stream);
+/* tensorflow_gan losses: mode 0: weight*mean((a-target)^2) (least squares, pass weight/2),
+ * mode 1: weight*mean(|a-b|) (cycle consistency / absolute_difference), mode 2: weight*mean(a) (Wasserstein).
+ * loss[0] (+)= value; da / db (nullable) (+)= gradient.  ws >= 1024 floats. */
+int hypel_gan_loss(int32_t mode, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c,
+                   float target, float weight, float* loss, int32_t accumulate_loss, float* da, int64_t ldda,
+                   int32_t acc_da, float* db, int64_t lddb, int32_t acc_db, float* ws, hypel_stream_t stream);
+/* tf_slim.l2_regularizer: loss[0] (+)= scale/2 * sum w^2 ; dw (nullable) += scale * w.  ws >= 1024 floats. */
+int hypel_l2_reg(const float* w, int64_t count, float scale, float* loss, int32_t accumulate_loss, float* dw,
+                 float* ws, hypel_stream_t stream);
+/* tf.math.l2_normalize(axis=None) over the whole [rows x c] tensor (shadow_data_models.py:147).
+ * stat[0] = sum x^2, stat[1] = rsqrt(max(sum, 1e-12)). */
+int hypel_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, float* y, int64_t ldy, float* stat,
+                     hypel_stream_t stream);
+int hypel_l2norm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,
+                     const float* stat, float* dx, int64_t lddx, int32_t accumulate, hypel_stream_t stream);
+/* patch-NCE (cut_wrapper.py:360-420): g, r are [n][p][e] embeddings; per sample softmax-CE over the p*p logits
+ * <g_a, r_b>/tau against the flattened identity; loss[0] (+)= weight * mean over n.  ws >= n + 1024 floats. */
+int hypel_nce_loss(const float* g, int64_t ldg, const float* r, int64_t ldr, int64_t n, int32_t p, int32_t e,
+                   float tau, float weight, float* loss, int32_t accumulate_loss, float* dg, int64_t lddg,
+                   int32_t acc_dg, float* dr, int64_t lddr, int32_t acc_dr, float* ws, hypel_stream_t stream);
+
 /* ---- graph capture helpers (HIP graphs instead of a tracing compiler) ---------------------------------------- */
 int hypel_graph_begin_capture(hypel_stream_t stream);
 int hypel_graph_end_capture(hypel_stream_t stream, void** graph_exec_out);

@@ -333,3 +333,201 @@ class EmuBackend:
             d += res.astype(np.float32)
         else:
             d[...] = res.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------- GAN kernels
+def _gen_layout(bands):
+    ks = [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
+    offs = np.concatenate([[0], np.cumsum(ks)]).astype(int)
+    return ks, offs
+
+
+def _conv1d_same(a, w):
+    """a [N,B] float64, w [k]; out[p] = sum_j w[j] a[p + j - pl], pl = (k-1)//2."""
+    n, bands = a.shape
+    k = len(w)
+    pl = (k - 1) // 2
+    ap = np.pad(a, ((0, 0), (pl, k - 1 - pl)))
+    out = np.zeros_like(a)
+    for j in range(k):
+        out += w[j] * ap[:, j:j + bands]
+    return out
+
+
+def _conv1d_same_T(g, w):
+    """adjoint of _conv1d_same w.r.t. its input."""
+    n, bands = g.shape
+    k = len(w)
+    pl = (k - 1) // 2
+    gp = np.zeros((n, bands + k - 1))
+    for j in range(k):
+        gp[:, j:j + bands] += w[j] * g
+    return gp[:, pl:pl + bands]
+
+
+def _gen_forward(x, w, b, bands, only_encoder):
+    ks, offs = _gen_layout(bands)
+    a = [x]
+    slopes = []
+    hidden = 4 if only_encoder else 6
+    for i in range(1, hidden + 1):
+        c = _conv1d_same(a[-1], w[offs[i - 1]:offs[i]]) + b[i - 1]
+        s = np.where(c > 0, 1.0, 0.1)
+        slopes.append(s)
+        v = c * s + a[-1]
+        if i >= 2:
+            v = v + a[-2]
+        a.append(v)
+    c7 = None
+    if not only_encoder:
+        c7 = _conv1d_same(a[6], w[offs[6]:offs[7]]) + b[6]
+    return a, slopes, c7
+
+
+def _emu_generator_blocks(n):
+    return int(max(1, min(512, (n + 3) // 4)))
+
+
+def _k_gan_generator_fwd(self, x, ldx, n, bands, w, b, only_encoder, out, ldo):
+    xs = _mat(x, ldx, n, bands).astype(np.float64)
+    ks, offs = _gen_layout(bands)
+    wv, bv = _arr(w)[:offs[7]].astype(np.float64), _arr(b)[:7].astype(np.float64)
+    a, _, c7 = _gen_forward(xs, wv, bv, bands, only_encoder)
+    _mat(out, ldo, n, bands)[...] = (a[4] if only_encoder else np.tanh(c7)).astype(np.float32)
+
+
+def _k_gan_generator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb):
+    xs = _mat(x, ldx, n, bands).astype(np.float64)
+    g = _mat(dout, lddo, n, bands).astype(np.float64)
+    ks, offs = _gen_layout(bands)
+    wv, bv = _arr(w)[:offs[7]].astype(np.float64), _arr(b)[:7].astype(np.float64)
+    a, slopes, c7 = _gen_forward(xs, wv, bv, bands, only_encoder)
+    dw, db = np.zeros(offs[7]), np.zeros(8)
+    hidden = 4 if only_encoder else 6
+    da = [np.zeros_like(xs) for _ in range(7)]
+
+    def layer_bwd(li, dc):
+        k = ks[li]
+        pl = (k - 1) // 2
+        ap = np.pad(a[li], ((0, 0), (pl, k - 1 - pl)))
+        for j in range(k):
+            dw[offs[li] + j] += (dc * ap[:, j:j + bands]).sum()
+        db[li] += dc.sum()
+        da[li] += _conv1d_same_T(dc, wv[offs[li]:offs[li + 1]])
+
+    if only_encoder:
+        da[4] = g.copy()
+    else:
+        t = np.tanh(c7)
+        layer_bwd(6, g * (1 - t * t))
+    for i in range(hidden, 0, -1):
+        gi = da[i]
+        da[i - 1] = da[i - 1] + gi
+        if i >= 2:
+            da[i - 2] = da[i - 2] + gi
+        layer_bwd(i - 1, gi * slopes[i - 1])
+    if dx is not None:
+        d = _mat(dx, lddx, n, bands)
+        if accumulate_dx:
+            d += da[0].astype(np.float32)
+        else:
+            d[...] = da[0].astype(np.float32)
+    blocks = _emu_generator_blocks(n)
+    pwv = _arr(pw)[: blocks * offs[7]].reshape(blocks, offs[7])
+    pbv = _arr(pb)[: blocks * 8].reshape(blocks, 8)
+    pwv[...] = 0
+    pbv[...] = 0
+    pwv[0] = dw
+    pbv[0] = db
+
+
+def _k_gan_loss(self, mode, a, lda, b, ldb, rows, c, target, weight, loss, accumulate_loss, da, ldda, acc_da, db, lddb,
+                acc_db, ws):
+    av = _mat(a, lda, rows, c).astype(np.float64)
+    cnt = rows * c
+    if mode == 0:
+        d = av - target
+        val, ga, gb = (d * d).sum(), 2 * d, None
+    elif mode == 1:
+        d = av - _mat(b, ldb, rows, c)
+        val, ga = np.abs(d).sum(), np.sign(d)
+        gb = -ga
+    else:
+        val, ga, gb = av.sum(), np.ones_like(av), None
+    lv = _arr(loss)
+    lv[0] = (lv[0] if accumulate_loss else 0.0) + weight * val / cnt
+    for ref, ld, acc, gr in ((da, ldda, acc_da, ga), (db, lddb, acc_db, gb)):
+        if ref is not None and gr is not None:
+            m = _mat(ref, ld, rows, c)
+            upd = (weight / cnt * gr).astype(np.float32)
+            if acc:
+                m += upd
+            else:
+                m[...] = upd
+
+
+def _k_l2_reg(self, w, count, scale, loss, accumulate_loss, dw, ws):
+    wv = _arr(w)[:count].astype(np.float64)
+    lv = _arr(loss)
+    lv[0] = (lv[0] if accumulate_loss else 0.0) + 0.5 * scale * (wv * wv).sum()
+    if dw is not None:
+        _arr(dw)[:count] += (scale * wv).astype(np.float32)
+
+
+def _k_l2norm_fwd(self, x, ldx, rows, c, y, ldy, stat):
+    xv = _mat(x, ldx, rows, c).astype(np.float64)
+    ss = (xv * xv).sum()
+    inv = 1.0 / np.sqrt(max(ss, 1e-12))
+    st = _arr(stat)
+    st[0], st[1] = ss, inv
+    _mat(y, ldy, rows, c)[...] = (xv * inv).astype(np.float32)
+
+
+def _k_l2norm_bwd(self, x, ldx, dy, lddy, rows, c, stat, dx, lddx, accumulate):
+    xv = _mat(x, ldx, rows, c).astype(np.float64)
+    g = _mat(dy, lddy, rows, c).astype(np.float64)
+    st = _arr(stat)
+    inv = float(st[1])
+    coef = float((g * xv).sum()) * inv ** 3 if st[0] > 1e-12 else 0.0
+    res = g * inv - xv * coef
+    d = _mat(dx, lddx, rows, c)
+    if accumulate:
+        d += res.astype(np.float32)
+    else:
+        d[...] = res.astype(np.float32)
+
+
+def _k_nce_loss(self, g, ldg, r, ldr, n, p, e, tau, weight, loss, accumulate_loss, dg, lddg, acc_dg, dr, lddr, acc_dr,
+                ws):
+    gv = _mat(g, ldg, n, p * e).astype(np.float64).reshape(n, p, e)
+    rv = _mat(r, ldr, n, p * e).astype(np.float64).reshape(n, p, e)
+    logits = np.einsum("npe,nqe->npq", gv, rv) / tau
+    flat = logits.reshape(n, -1)
+    mx = flat.max(1, keepdims=True)
+    ex = np.exp(flat - mx)
+    se = ex.sum(1, keepdims=True)
+    lse = (mx + np.log(se))[:, 0]
+    per = p * lse - np.trace(logits, axis1=1, axis2=2)
+    lv = _arr(loss)
+    lv[0] = (lv[0] if accumulate_loss else 0.0) + weight * per.mean()
+    dl = (p * ex / se).reshape(n, p, p) - np.eye(p)
+    coef = weight / n / tau
+    for ref, ld, acc, gr in ((dg, lddg, acc_dg, np.einsum("npq,nqe->npe", dl, rv)),
+                             (dr, lddr, acc_dr, np.einsum("npq,npe->nqe", dl, gv))):
+        if ref is not None:
+            m = _mat(ref, ld, n, p * e)
+            upd = (coef * gr).reshape(n, p * e).astype(np.float32)
+            if acc:
+                m += upd
+            else:
+                m[...] = upd
+
+
+EmuBackend.k_gan_generator_fwd = _k_gan_generator_fwd
+EmuBackend.k_gan_generator_bwd = _k_gan_generator_bwd
+EmuBackend.k_gan_loss = _k_gan_loss
+EmuBackend.k_l2_reg = _k_l2_reg
+EmuBackend.k_l2norm_fwd = _k_l2norm_fwd
+EmuBackend.k_l2norm_bwd = _k_l2norm_bwd
+EmuBackend.k_nce_loss = _k_nce_loss
+EmuBackend.gan_generator_blocks = lambda self, n: _emu_generator_blocks(n)

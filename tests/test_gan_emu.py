@@ -1,0 +1,89 @@
+"""CPU (numpy kernel emulation): the GAN wrappers of the product vs oracle/gan.py -- per-phase losses and
+gradients for every wrapper kind, then multi-step training (sequential phases, TF1 Adam beta1=0.5, LR schedule)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan as OG
+from tests import gan_util as U
+from tests.emu_backend import EmuBackend
+
+
+def _data(n, b, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random((n, 1, 1, b)).astype(np.float32).astype(np.float64), \
+        (rng.random((n, 1, 1, b)) * 0.5).astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("kind,bands,patches", [("cycle_gan", 16, 4), ("gan_x2y", 16, 4), ("gan_y2x", 24, 4),
+                                                ("cut_x2y", 24, 6), ("cut_y2x", 64, 6), ("dcl_gan", 16, 4),
+                                                ("dcl_cycle_gan", 16, 4)])
+def test_phase_gradients_match_oracle(kind, bands, patches):
+    n = 6
+    cfg = OG.GanConfig(kind, bands, patches=patches, max_steps=20)
+    params = U.fp32(OG.init_gan_params(kind, bands, np.random.default_rng(2), patches=patches, dtype=np.float64,
+                                       zero_generator=False))
+    x, y = _data(n, bands, 4)
+    wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
+    assert [p.name for p in loss.phases] == OG.phase_list(kind)
+    sess = ops.ctx.session()
+    U.inject(sess, params)
+    U.check_phase_gradients(cfg, ops, params, x, y, tol=5e-5)
+
+
+@pytest.mark.parametrize("kind", ["cycle_gan", "cut_x2y"])
+def test_training_steps_track_oracle_trainer(kind):
+    bands, n, steps = 16, 6, 6
+    cfg = OG.GanConfig(kind, bands, patches=4, max_steps=8)   # LR decays from step 4 on
+    params = U.fp32(OG.init_gan_params(kind, bands, np.random.default_rng(3), patches=4, dtype=np.float64,
+                                       zero_generator=False))
+    wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
+    ops.pool_override = lambda name, fresh: fresh            # pass-through pool (the oracle trainer does the same)
+    sess = ops.ctx.session()
+    U.inject(sess, params)
+    trainer = OG.GanTrainer(cfg, {k: v.copy() for k, v in params.items()})
+    for s in range(steps):
+        x, y = _data(n, bands, 100 + s)
+        ops.run_step(torch.as_tensor(x.reshape(n, -1), dtype=torch.float32),
+                     torch.as_tensor(y.reshape(n, -1), dtype=torch.float32))
+        ref_losses = trainer.step(x, y)
+        got = ops.losses()
+        for ph, v in ref_losses.items():
+            assert abs(got[ph] - v) < 2e-3 * max(1.0, abs(v)), (s, ph, got[ph], v)
+    assert sess.global_step == steps
+    for k, v in trainer.params.items():
+        got = sess.get_variable(k)
+        assert np.abs(got - v).max() < 2e-3 * max(np.abs(v).max(), 1e-3), k
+
+
+def test_zero_init_generator_known_answers():
+    """K1: zero weights -> encoder output 5x, generator output tanh(0) = 0 (reference zero-initialises, :47)."""
+    from hypelcnn_amd.gan.shadow_data_models import shadowdata_generator_model
+    from hypelcnn_amd.gan.wrappers import gan_common as C
+    from hypelcnn_amd import graph as G
+    tower, x, _ = C.new_gan_tower(16)
+    with G.variable_scope("Model"), G.variable_scope("Generator"):
+        enc = shadowdata_generator_model(x, True)
+    with G.variable_scope("Model"), G.variable_scope("Generator"):
+        full = shadowdata_generator_model(x, False)
+    ctx = C.GanContext(tower, EmuBackend())
+    sess = ctx.session()
+    assert len(sess.variable_names()) == 14 and float(sess.params.abs().sum()) == 0.0
+    ct = sess.compile_phase(tower, 3, outputs=[enc, full], key="k1")
+    xv = torch.rand(3, 16)
+    ct.set_input("x", xv)
+    ct.forward()
+    torch.testing.assert_close(ct.value(enc), 5 * xv)
+    assert float(ct.value(full).abs().max()) == 0.0
+
+
+def test_tensor_pool_semantics():
+    from hypelcnn_amd.gan.wrappers.gan_common import TensorPool
+    pool = TensorPool(pool_size=3, pooling_probability=0.5, seed=0)
+    vals = [torch.full((2,), float(i)) for i in range(40)]
+    outs = [pool.query(v) for v in vals]
+    assert all(torch.equal(o, v) for o, v in zip(outs[:3], vals[:3]))           # filling: pass-through
+    later = [float(o[0]) for o in outs[3:]]
+    same = sum(1 for o, v in zip(outs[3:], vals[3:]) if torch.equal(o, v))
+    assert 8 < same < 30 and any(l < i + 3 for i, l in enumerate(later))        # some historical samples returned
+    assert len(pool.items) == 3

@@ -309,3 +309,82 @@ def test_argmax_confusion_and_lrn(hip):
     b.check("y", rtol=1e-5, atol=1e-6)
     b.run("lrn_bwd", "x", cc, "dy", cc, rows, cc, 5, 1.0, 1.0, 0.5, "dx", cc, 0)
     b.check("dx", rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- GAN kernels
+@pytest.mark.parametrize("bands,n,only_enc", [(64, 37, 0), (64, 2048, 0), (144, 130, 0), (360, 70, 0), (64, 50, 1),
+                                              (360, 33, 1), (16, 5, 0)])
+def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
+    rng = np.random.default_rng(bands + n)
+    ks = [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
+    wtot = sum(ks)
+    b = Both(hip)
+    b.arr("x", rng.random((n, bands)).astype(np.float32))
+    b.arr("w", (rng.standard_normal(wtot) * 0.3 / np.sqrt(np.repeat(ks, ks))).astype(np.float32))
+    b.arr("bias", (rng.standard_normal(8) * 0.05).astype(np.float32))
+    b.arr("out", np.zeros(n * bands, np.float32))
+    b.run("gan_generator_fwd", "x", bands, n, bands, "w", "bias", only_enc, "out", bands)
+    b.check("out", rtol=2e-5, atol=2e-6)
+    blocks = hip.gan_generator_blocks(n)
+    assert blocks == b.emu.gan_generator_blocks(n)
+    b.arr("dout", rng.standard_normal((n, bands)).astype(np.float32))
+    b.arr("dx", rng.standard_normal((n, bands)).astype(np.float32))
+    b.arr("pw", np.zeros(blocks * wtot, np.float32))
+    b.arr("pb", np.zeros(blocks * 8, np.float32))
+    b.arr("dw", np.zeros(wtot, np.float32))
+    b.arr("db", np.zeros(8, np.float32))
+    b.run("gan_generator_bwd", "x", bands, "dout", bands, n, bands, "w", "bias", only_enc, "dx", bands, 1, "pw", "pb")
+    b.check("dx", rtol=1e-4, atol=1e-5)
+    b.run("reduce_splits_f32", "pw", wtot, blocks, "dw", wtot, 0, None, 0)
+    b.run("reduce_splits_f32", "pb", 8, blocks, "db", 7, 0, None, 0)
+    b.check("dw", rtol=2e-4, atol=2e-5)
+    b.check("db", rtol=2e-4, atol=2e-5)
+
+
+def test_gan_losses_l2norm_nce(hip):
+    rng = np.random.default_rng(11)
+    rows, c = 2048, 32
+    b = Both(hip)
+    b.arr("a", rng.standard_normal((rows, c)).astype(np.float32))
+    b.arr("bb", rng.standard_normal((rows, c)).astype(np.float32))
+    b.arr("loss", np.zeros(1, np.float32))
+    b.arr("ws", np.zeros(rows + 4096, np.float32))
+    for mode in (0, 1, 2):
+        b.arr("da", rng.standard_normal((rows, c)).astype(np.float32))
+        b.arr("db", np.zeros(rows * c, np.float32))
+        b.run("gan_loss", mode, "a", c, "bb" if mode == 1 else None, c, rows, c, 1.0, 0.5, "loss", 0 if mode == 0 else 1,
+              "da", c, 1, "db" if mode == 1 else None, c, 0, "ws")
+        b.check("da", rtol=1e-5, atol=1e-7)
+        if mode == 1:
+            b.check("db", rtol=1e-5, atol=1e-8)
+    b.check("loss", rtol=1e-5)
+    b.arr("w", rng.standard_normal(10007).astype(np.float32))
+    b.arr("dw", rng.standard_normal(10007).astype(np.float32))
+    b.run("l2_reg", "w", 10007, 1e-4, "loss", 1, "dw", "ws")
+    b.check("loss", rtol=1e-5)
+    b.check("dw", rtol=1e-6, atol=1e-7)
+    # whole-tensor l2 normalise on a strided [N, E] slice of a [N, P*E] stack
+    n, p, e = 777, 7, 2
+    b.arr("x", rng.standard_normal((n, e)).astype(np.float32))
+    b.arr("stack", np.zeros(n * p * e, np.float32))
+    b.arr("stat", np.zeros(2, np.float32))
+    b.run("l2norm_fwd", "x", e, n, e, ("stack", 3 * e), p * e, "stat")
+    b.check("stack", rtol=1e-5, atol=1e-8)
+    b.check("stat", rtol=1e-5)
+    b.arr("dstack", rng.standard_normal((n, p * e)).astype(np.float32))
+    b.arr("dxn", np.zeros(n * e, np.float32))
+    b.run("l2norm_bwd", "x", e, ("dstack", 3 * e), p * e, n, e, "stat", "dxn", e, 0)
+    b.check("dxn", rtol=1e-4, atol=1e-7)
+    # patch-NCE
+    b.arr("g", rng.standard_normal((n, p * e)).astype(np.float32) * 0.3)
+    b.arr("r", rng.standard_normal((n, p * e)).astype(np.float32) * 0.3)
+    b.arr("dg", np.zeros(n * p * e, np.float32))
+    b.arr("dr", rng.standard_normal((n, p * e)).astype(np.float32))
+    b.run("nce_loss", "g", p * e, "r", p * e, n, p, e, 0.07, 10.0, "loss", 0, "dg", p * e, 0, "dr", p * e, 1, "ws")
+    b.check("loss", rtol=1e-4)
+    b.check("dg", rtol=2e-3, atol=1e-5)
+    b.check("dr", rtol=2e-3, atol=1e-5)
+    # K6: all-equal logits -> P * log(P^2) per sample
+    b.arr("g0", np.zeros((n, p * e), np.float32))
+    b.run("nce_loss", "g0", p * e, "r", p * e, n, p, e, 0.07, 1.0, "loss", 0, None, 0, 0, None, 0, 0, "ws")
+    np.testing.assert_allclose(b.h["loss"].cpu().numpy()[0], p * np.log(p * p), rtol=1e-5)
