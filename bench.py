@@ -39,36 +39,27 @@ def build_model(batch, backend):
     return ctx, train_step, lr, alg
 
 
-def gemm_launch_indices(ct):
-    plan = ct.plan
-    n_f = len(plan.fwd)
-    idx = [(i, l.flops) for i, l in enumerate(plan.fwd + plan.bwd) if l.name == "seg_gemm_f32"]
-    return idx, n_f
-
-
 def measure_gemm_events(ct, sess, lr, steps):
-    """Eager replay of the same step with a HIP event pair around every hypel_seg_gemm_f32 launch
-    (events recorded on the stream the kernels are launched on)."""
-    idx, _ = gemm_launch_indices(ct)
-    launches = ct.fwd + ct.bwd
-    is_gemm = {i for i, _ in idx}
+    """Serial replay of the same step (every launch on the main stream, no graph) with a HIP event pair around
+    every hypel_seg_gemm_f32 launch, recorded on the stream the kernels are launched on."""
+    launches = ct.serial_launches()
     total_ms, total_flops, n_launch = 0.0, 0, 0
     for _ in range(steps):
         evs = []
-        for i, f in enumerate(launches):
-            if i in is_gemm:
+        for l, f in launches:
+            if l.name == "seg_gemm_f32":
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 f()
                 b.record()
-                evs.append((a, b))
+                evs.append((a, b, l.flops))
             else:
                 f()
         sess.adam_step(lr.eval(sess.global_step))
         torch.cuda.synchronize()
-        total_ms += sum(a.elapsed_time(b) for a, b in evs)
+        total_ms += sum(a.elapsed_time(b) for a, b, _ in evs)
         n_launch += len(evs)
-        total_flops += sum(fl for _, fl in idx)
+        total_flops += sum(fl for _, _, fl in evs)
     return total_ms, total_flops, n_launch
 
 

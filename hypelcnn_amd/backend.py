@@ -104,6 +104,8 @@ def load_library(path=LIB_PATH):
             continue  # optional entry points (checked by tests/test_abi.py against the header)
         fn.argtypes = list(sig) + [_P]
         fn.restype = ctypes.c_int
+    lib.hypel_stream_fork.argtypes = [_P, _P]
+    lib.hypel_stream_join.argtypes = [_P, _P]
     lib.hypel_graph_begin_capture.argtypes = [_P]
     lib.hypel_graph_end_capture.argtypes = [_P, ctypes.POINTER(_P)]
     lib.hypel_graph_launch.argtypes = [_P, _P]
@@ -131,6 +133,9 @@ class HipBackend:
         # step ordered without device-wide syncs.
         self.stream = torch.cuda.Stream(self.device)
         torch.cuda.set_stream(self.stream)
+        # side stream: independent kernels of the backward pass (filter gradients) run here and fill the grid
+        # tails of the data-gradient kernels on the main stream
+        self.side_stream = torch.cuda.Stream(self.device)
 
     # -- memory (PyTorch is the allocator: plumbing only) --
     def empty(self, n, dtype=torch.float32):
@@ -159,8 +164,20 @@ class HipBackend:
 
     # -- launches --
     def bind(self, name, args, stream=None):
+        if name == "_fork" or name == "_join":
+            fn = self.lib.hypel_stream_fork if name == "_fork" else self.lib.hypel_stream_join
+            main, side, lib = self.stream.cuda_stream, self.side_stream.cuda_stream, self.lib
+
+            def sync_call():
+                if fn(main, side) != 0:
+                    raise HypelError(lib.hypel_last_error().decode())
+
+            return sync_call
         fn = getattr(self.lib, "hypel_" + name)
-        st = self.stream_handle() if stream is None else stream
+        if stream == 1:
+            st = self.side_stream.cuda_stream
+        else:
+            st = self.stream_handle() if stream is None or stream == 0 else stream
         cargs = []
         for a in args:
             if isinstance(a, Ref):

@@ -35,6 +35,27 @@ extern "C" int hypel_device_info(int32_t* n_cu, int32_t* n_xcd) {
     return 0;
 }
 
+static int dep(hipStream_t from, hipStream_t to, const char* what) {
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, from);
+    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+    if (ev) (void)hipEventDestroy(ev);  // destruction is deferred until the event completes
+    if (e != hipSuccess) {
+        hypel_set_error("%s: %s", what, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+extern "C" int hypel_stream_fork(hypel_stream_t main_stream, hypel_stream_t side_stream) {
+    return dep((hipStream_t)main_stream, (hipStream_t)side_stream, "hypel_stream_fork");
+}
+
+extern "C" int hypel_stream_join(hypel_stream_t main_stream, hypel_stream_t side_stream) {
+    return dep((hipStream_t)side_stream, (hipStream_t)main_stream, "hypel_stream_join");
+}
+
 extern "C" int hypel_graph_begin_capture(hypel_stream_t stream) {
     hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) {

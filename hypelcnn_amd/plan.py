@@ -33,14 +33,18 @@ TARGET_BLOCKS = 1024
 
 
 class Launch:
-    __slots__ = ("name", "args", "flops", "bytes", "tag")
+    __slots__ = ("name", "args", "flops", "bytes", "tag", "stream")
 
-    def __init__(self, name, args, flops=0, nbytes=0, tag=""):
+    def __init__(self, name, args, flops=0, nbytes=0, tag="", stream=0):
         self.name = name
         self.args = args
         self.flops = flops
         self.bytes = nbytes
         self.tag = tag
+        self.stream = stream  # 0 = main, 1 = side (concurrent filter gradients)
+
+
+USE_SIDE_STREAM = True
 
 
 class Storage:
@@ -322,6 +326,8 @@ class TowerPlan:
                     self._bwd_post(idx, node)
                 elif isinstance(node, G.LRNNode):
                     self._bwd_lrn(idx, node)
+            if getattr(self, "_side_open", False):
+                self.bwd.append(Launch("_join", (), tag="join"))
             if tw.n_dropout and not self.external_masks:
                 self.bwd.append(Launch("step_inc", (self._ref("step_ctr"),), tag="rng"))
         # shared scratch (stream order makes reuse safe)
@@ -614,7 +620,7 @@ class TowerPlan:
                     acc = 1
             # ---- filter gradient ----
             if trains:
-                self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w)
+                self._on_side(lambda: self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w))
         else:
             b = node.branches[0]
             rowbase = 0
@@ -629,7 +635,7 @@ class TowerPlan:
                                     gst.ld, None, acc, f"dgrad:{b.scope}")
                 rowbase += src.npix * src.c
             if trains:
-                self._wgrad_dense(idx, node, aux, dy, c)
+                self._on_side(lambda: self._wgrad_dense(idx, node, aux, dy, c))
 
     def _emit_post_bwd(self, node, aux, dz, y_ref, rows, c, dy, want_param):
         has_bn = isinstance(node, G.LinearNode) and node.has_bn
@@ -666,6 +672,27 @@ class TowerPlan:
             if sums is not None:
                 self._scratch(l3, 13, "sums", 2 * c)
             self.bwd.append(l3)
+
+    def _on_side(self, emit):
+        """Emit launches that only READ the layer's finished dY / X and WRITE parameter gradients on the side
+        stream: they run concurrently with the data-gradient chain that continues on the main stream.  Scratch
+        used there gets its own buffers (suffix _s1)."""
+        if not USE_SIDE_STREAM:
+            emit()
+            return
+        start = len(self.bwd)
+        emit()
+        new = self.bwd[start:]
+        if not new:
+            return
+        for l in new:
+            l.stream = 1
+        for i, (launch, pos, name) in enumerate(self._pending_scratch):
+            if launch in new and not name.endswith("_s1"):
+                self.scratch_sizes[name + "_s1"] = max(self.scratch_sizes.get(name + "_s1", 1), self.scratch_sizes[name])
+                self._pending_scratch[i] = (launch, pos, name + "_s1")
+        self.bwd[start:start] = [Launch("_fork", (), tag="fork")]
+        self._side_open = True
 
     def _wgrad_splits(self, base_blocks, max_segs):
         s = max(1, min(max_segs, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
@@ -927,6 +954,8 @@ class PhasePlan(TowerPlan):
                     self._bwd_featstack(idx, node)
                 elif isinstance(node, G.PostNode):
                     self._bwd_post(idx, node)
+            if getattr(self, "_side_open", False):
+                self.bwd.append(Launch("_join", (), tag="join"))
             self._emit_regularisers()
         for name, size in self.scratch_sizes.items():
             self._alloc(name, size)

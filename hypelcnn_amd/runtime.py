@@ -21,10 +21,16 @@ class CompiledTower:
     def __init__(self, plan, backend):
         self.plan = plan
         self.be = backend
-        self.fwd = [backend.bind(l.name, l.args) for l in plan.fwd]
-        self.bwd = [backend.bind(l.name, l.args) for l in plan.bwd]
+        self.fwd = [backend.bind(l.name, l.args, l.stream) for l in plan.fwd]
+        self.bwd = [backend.bind(l.name, l.args, l.stream) for l in plan.bwd]
         self._graph_fwd = None
         self._graph_all = None
+
+    def serial_launches(self):
+        """The same step with every launch on the main stream (no fork/join): per-kernel timing needs kernels that
+        do not overlap."""
+        return [(l, self.be.bind(l.name, l.args, 0)) for l in self.plan.fwd + self.plan.bwd
+                if l.name not in ("_fork", "_join")]
 
     # ---- inputs / outputs ----
     def input(self, name):
