@@ -16,6 +16,8 @@
 //    beyond the segment's K, so ragged shapes (n = 60, 120, K = 145) cost only LDS zero fill.
 //  * 1-D grid with the bijective XCD remap: the blocks that share an A row-tile (different
 //    column tiles) run on the same XCD and hit its L2.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -274,10 +276,14 @@ extern "C" int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, 
     HYPEL_REQUIRE(n > 0 && n_tiles >= 0, "hypel_seg_gemm_f32");
     if (n_tiles == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    // Tile choice (measured, profiles/r1_*): 128x64 blocks (4 waves/SIMD -> 1024 resident blocks) beat 128x128
+    // (3 waves/SIMD -> 768) on every layer of the model by 1.1-1.7x: the grids here are only 1-4 "waves" of blocks,
+    // so the finer grain wastes less of the last wave.  HYPEL_GEMM_BN128=1 restores 128x128 for n > 64.
+    static const int bn128 = getenv("HYPEL_GEMM_BN128") ? atoi(getenv("HYPEL_GEMM_BN128")) : 0;
     if (n <= 32)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, st);
-    else if (n <= 64)
+    else if (n <= 64 || !bn128)
         launch_cfg<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, st);
     else

@@ -229,7 +229,7 @@ class TowerPlan:
         groups = tables.groups
         if ldc != n or not groups:
             return None
-        n_nt = (n + 127) // 128 if n > 64 else 1
+        n_nt = (n + 63) // 64 if n > 32 else 1
         blocks = sum((rows + GEMM_BM - 1) // GEMM_BM for _, _, rows in groups) * n_nt
         kmax = max(sum(k for _, _, k in gs) for _, gs, _ in groups)
         if blocks >= 192 or kmax < 512:
@@ -755,7 +755,7 @@ class TowerPlan:
                                     kc = min(WGRAD_ROW_CHUNK, nb - r0)
                                     segs.append((s_st.pix_off(pin) + r0 * s_st.ld, (pout * nb + r0) * c + off, kc))
                         group_list.append((b.w.offset - lo + (i * b.k + j) * src.c * cout, segs))
-            blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((cout + 127) // 128)
+            blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((cout + 63) // 64)
             max_segs = max(len(s) for _, s in group_list)
 
             def build(S, group_list=group_list, slab=slab, rows=src.c):
@@ -784,7 +784,7 @@ class TowerPlan:
                     kc = min(WGRAD_ROW_CHUNK, nb - r0)
                     segs.append((s_st.pix_off(p) + r0 * s_st.ld, r0 * c, kc))
                 group_list.append((p * src.c * c, segs))
-            blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((c + 127) // 128)
+            blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((c + 63) // 64)
             max_segs = max(len(s) for _, s in group_list)
 
             def build(S, group_list=group_list, slab=slab, rows=src.c):
