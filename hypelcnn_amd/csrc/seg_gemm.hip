@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256, 3) void seg_gemm_kernel(const float* __restric
                      auto& regs, auto rstep_c, auto count_c) {
         constexpr int RSTEP = decltype(rstep_c)::value;
         constexpr int COUNT = decltype(count_c)::value;
-        const int ld4 = (int)ld * 4;
+        // wave-uniform by construction; say so, or hipcc wraps every buffer_load in a waterfall loop
+        const int ld4 = __builtin_amdgcn_readfirstlane((int)ld * 4);
         // bytes up to the end of the last valid row
-        const int span = rows_valid > 0 && cols_valid > 0 ? ((rows_valid - 1) * (int)ld + cols_valid) * 4 : 0;
+        const int span = __builtin_amdgcn_readfirstlane(
+            rows_valid > 0 && cols_valid > 0 ? ((rows_valid - 1) * (int)ld + cols_valid) * 4 : 0);
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
         const int kOOB = 0x7fffffff;
         const int voff = col < cols_valid ? (row0 * (int)ld + col) * 4 : kOOB;
