@@ -92,9 +92,11 @@ class GemmTables:
 
     def __init__(self):
         self.groups = []  # (c_off, [segs], rows)
+        self.keys = []  # optional locality key per group (tiles are ordered key-major)
 
-    def add_group(self, c_off, segs, rows):
+    def add_group(self, c_off, segs, rows, key=None):
         self.groups.append((int(c_off), segs, int(rows)))
+        self.keys.append(key)
 
     def finalize(self, n):
         segs = []
@@ -109,13 +111,15 @@ class GemmTables:
                 ksum += k
             macs += rows * ksum * n
             for m0 in range(0, rows, GEMM_BM):
-                tiles.append((ksum * min(GEMM_BM, rows - m0), gi, m0))
+                key = self.keys[gi] if self.keys[gi] is not None else m0 // GEMM_BM
+                tiles.append((ksum * min(GEMM_BM, rows - m0), gi, m0, key))
         # Row-chunk major, heavy tiles first inside a chunk.  With the kernel's XCD remap each XCD works through a
         # contiguous range of this list, i.e. through whole row chunks: the ~49 pixel blocks of activations that
         # all the (pixel, branch) tiles of one chunk keep re-reading stay resident in that XCD's 4 MB L2.
-        tiles.sort(key=lambda t: (t[2] // GEMM_BM, -t[0]))
+        # Filter-gradient launches pass key = split index (= batch-row range), for the same reason.
+        tiles.sort(key=lambda t: (t[3], -t[0]))
         sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
-        tarr = np.array([(g, m0) for _, g, m0 in tiles], TILE_DTYPE) if tiles else np.zeros(0, TILE_DTYPE)
+        tarr = np.array([(g, m0) for _, g, m0, _ in tiles], TILE_DTYPE) if tiles else np.zeros(0, TILE_DTYPE)
         return garr, sarr, tarr, macs
 
 
@@ -695,8 +699,18 @@ class TowerPlan:
         self._side_open = True
 
     def _wgrad_splits(self, base_blocks, max_segs):
-        s = max(1, min(max_segs, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
+        """Number of batch-row ranges the filter-gradient reduction is cut into.  A split is the SAME row range for
+        every (tap, pixel pair), and tiles are ordered split-major, so each XCD streams its own rows of X and dY
+        through its L2 once while all taps consume them (the per-tap formulation re-fetched them ~10-20x)."""
+        s = max(1, min(self.nb // 64 if self.nb >= 64 else 1, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
+        if s >= 8:
+            s = (s + 7) // 8 * 8
         return min(s, 64)
+
+    def _row_ranges(self, S):
+        nb = self.nb
+        cuts = [min(nb, (nb * s // S + 31) // 32 * 32) for s in range(S)] + [nb]
+        return [(cuts[s], cuts[s + 1]) for s in range(S)]
 
     def _emit_wgrad(self, tables_by_split_builder, n_groups_blocks, max_segs, slab, w0_offset, n, a_ref, lda, b_ref, ldb,
                     tag, acc=0):
@@ -736,12 +750,12 @@ class TowerPlan:
             lo = min(b.w.offset for b, _ in items)
             hi = max(b.w.offset + b.w.size for b, _ in items)
             slab = hi - lo
-            group_list = []  # (local c_off, segs)
+            group_list = []  # (local c_off, [(a_off, b_off)] pixel pairs)
             for b, off in items:
                 pb = (b.k - 1) // 2
                 for i in range(b.k):
                     for j in range(b.k):
-                        segs = []
+                        pairs = []
                         for oy in range(h):
                             iy = oy + i - pb
                             if iy < 0 or iy >= h:
@@ -750,19 +764,17 @@ class TowerPlan:
                                 ix = ox + j - pb
                                 if ix < 0 or ix >= w:
                                     continue
-                                pin, pout = iy * w + ix, oy * w + ox
-                                for r0 in range(0, nb, WGRAD_ROW_CHUNK):
-                                    kc = min(WGRAD_ROW_CHUNK, nb - r0)
-                                    segs.append((s_st.pix_off(pin) + r0 * s_st.ld, (pout * nb + r0) * c + off, kc))
-                        group_list.append((b.w.offset - lo + (i * b.k + j) * src.c * cout, segs))
+                                pairs.append((s_st.pix_off(iy * w + ix), (oy * w + ox) * nb * c + off))
+                        group_list.append((b.w.offset - lo + (i * b.k + j) * src.c * cout, pairs))
             blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((cout + 63) // 64)
             max_segs = max(len(s) for _, s in group_list)
 
-            def build(S, group_list=group_list, slab=slab, rows=src.c):
+            def build(S, group_list=group_list, slab=slab, rows=src.c, lda=s_st.ld, ldb=c):
                 tb = GemmTables()
-                for (loc, segs) in group_list:
-                    for s, chunk in enumerate(self._split_even(segs, S)):
-                        tb.add_group(s * slab + loc, chunk, rows)
+                for si, (r0, r1) in enumerate(self._row_ranges(S)):
+                    for (loc, pairs) in group_list:
+                        segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs] if r1 > r0 else []
+                        tb.add_group(si * slab + loc, segs, rows, key=si)
                 return tb
 
             acc = max(self._param_acc(b.w) for b, _ in items)
@@ -777,21 +789,16 @@ class TowerPlan:
             s_st = self.storage_of(src)
             slab = src.npix * src.c * c
             lo = b.w.offset + rowbase * c
-            group_list = []
-            for p in range(src.npix):
-                segs = []
-                for r0 in range(0, nb, WGRAD_ROW_CHUNK):
-                    kc = min(WGRAD_ROW_CHUNK, nb - r0)
-                    segs.append((s_st.pix_off(p) + r0 * s_st.ld, r0 * c, kc))
-                group_list.append((p * src.c * c, segs))
+            group_list = [(p * src.c * c, [(s_st.pix_off(p), 0)]) for p in range(src.npix)]
             blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((c + 63) // 64)
-            max_segs = max(len(s) for _, s in group_list)
+            max_segs = 1
 
-            def build(S, group_list=group_list, slab=slab, rows=src.c):
+            def build(S, group_list=group_list, slab=slab, rows=src.c, lda=s_st.ld, ldb=c):
                 tb = GemmTables()
-                for (loc, segs) in group_list:
-                    for s, chunk in enumerate(self._split_even(segs, S)):
-                        tb.add_group(s * slab + loc, chunk, rows)
+                for si, (r0, r1) in enumerate(self._row_ranges(S)):
+                    for (loc, pairs) in group_list:
+                        segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs] if r1 > r0 else []
+                        tb.add_group(si * slab + loc, segs, rows, key=si)
                 return tb
 
             acc = self._param_acc(b.w) if rowbase == 0 else (1 if b.w.name + f"#{rowbase}" in self.param_written else 0)

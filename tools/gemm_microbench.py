@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""A/B micro-benchmark of hypel_seg_gemm_f32 on the shapes of the GRSS2013 HYPELCNN step (batch 1024).
+Interleaves variants (selected through environment variables read at launch time by the library is not
+possible, so variants are separate processes; within a process rounds are interleaved over shapes).
+
+  python tools/gemm_microbench.py [--rounds 20]
+prints per shape: median / min microseconds and algorithmic TFLOP/s."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--filter", type=str, default="")
+    args = ap.parse_args()
+    from hypelcnn_amd.backend import HipBackend
+    be = HipBackend()
+    ctx, train_step, lr, alg = bench.build_model(1024, be)
+    ctx.capture_graphs = False
+    sess = ctx.session()
+    ct = train_step.compiled(1024)
+    x = torch.rand((1024, 7, 7, 145)).cuda()
+    ct.set_input("x", x)
+    ct.set_input("labels", torch.nn.functional.one_hot(torch.randint(0, 15, (1024,)), 15).float().cuda())
+    ct.forward_backward()  # fill every buffer with realistic data
+    torch.cuda.synchronize()
+    items = [(l, f) for l, f in ct.serial_launches() if l.name == "seg_gemm_f32" and args.filter in l.tag]
+    times = {l.tag: [] for l, _ in items}
+    for r in range(args.rounds):
+        for l, f in items:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            f()
+            b.record()
+            torch.cuda.synchronize()
+            times[l.tag].append(a.elapsed_time(b) * 1e3)
+    tot = 0.0
+    for l, _ in items:
+        t = np.array(times[l.tag][2:])
+        med = float(np.median(t))
+        tot += med
+        if med > 40:
+            print(f"{l.tag:34s} {l.flops / 1e9:7.2f} GF  med {med:8.1f} us  min {t.min():8.1f} us  {l.flops / med / 1e6:6.1f} TF/s")
+    flops = sum(l.flops for l, _ in items)
+    print(f"TOTAL {tot / 1e3:.3f} ms  {flops / tot / 1e6:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
