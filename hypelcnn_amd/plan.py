@@ -698,25 +698,36 @@ class TowerPlan:
         self.bwd[start:start] = [Launch("_fork", (), tag="fork")]
         self._side_open = True
 
-    def _wgrad_splits(self, base_blocks, max_segs):
-        """Number of batch-row ranges the filter-gradient reduction is cut into.  A split is the SAME row range for
-        every (tap, pixel pair), and tiles are ordered split-major, so each XCD streams its own rows of X and dY
-        through its L2 once while all taps consume them (the per-tap formulation re-fetched them ~10-20x)."""
-        s = max(1, min(self.nb // 64 if self.nb >= 64 else 1, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
-        if s >= 8:
-            s = (s + 7) // 8 * 8
-        return min(s, 64)
+    def _wgrad_splits(self, base_blocks, n_pairs):
+        """Filter-gradient reduction = S_pix x S_row splits: the pixel-pair list is cut into S_pix contiguous chunks
+        and the batch rows into S_row ranges (the SAME ranges for every tap).  Tiles are ordered split-major, so each
+        XCD streams its own rows of X and dY through its L2 once while all taps consume them (the per-tap
+        formulation re-fetched them 10-20x).  Multi-tap levels use row ranges only; single-tap layers also cut the
+        pixel list, otherwise the launch would have too few blocks."""
+        want = max(1, min(64, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
+        max_row = max(1, self.nb // 64)
+        s_row = min(want, max_row)
+        if s_row >= 8:
+            s_row = s_row // 8 * 8
+        s_pix = max(1, min(n_pairs, want // s_row))
+        return s_pix, s_row
 
-    def _row_ranges(self, S):
+    def _split_ranges(self, s_pix, s_row, n_pairs):
+        """[(pair_lo, pair_hi, r0, r1)] in split order (row range major: the XCD-locality key)."""
         nb = self.nb
-        cuts = [min(nb, (nb * s // S + 31) // 32 * 32) for s in range(S)] + [nb]
-        return [(cuts[s], cuts[s + 1]) for s in range(S)]
+        rcuts = [min(nb, (nb * s // s_row + 31) // 32 * 32) for s in range(s_row)] + [nb]
+        out = []
+        for sr in range(s_row):
+            for sp in range(s_pix):
+                out.append((n_pairs * sp // s_pix, n_pairs * (sp + 1) // s_pix, rcuts[sr], rcuts[sr + 1]))
+        return out
 
     def _emit_wgrad(self, tables_by_split_builder, n_groups_blocks, max_segs, slab, w0_offset, n, a_ref, lda, b_ref, ldb,
                     tag, acc=0):
         """tables_by_split_builder(S) -> GemmTables whose groups write to c_off = split*slab + local."""
-        S = self._wgrad_splits(n_groups_blocks, max_segs)
-        tb = tables_by_split_builder(S)
+        s_pix, s_row = self._wgrad_splits(n_groups_blocks, max_segs)
+        S = s_pix * s_row
+        tb = tables_by_split_builder((s_pix, s_row))
         if S == 1:
             self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None,
                             acc, tag, allow_split=False)
@@ -769,11 +780,13 @@ class TowerPlan:
             blocks = len(group_list) * ((src.c + GEMM_BM - 1) // GEMM_BM) * ((cout + 63) // 64)
             max_segs = max(len(s) for _, s in group_list)
 
-            def build(S, group_list=group_list, slab=slab, rows=src.c, lda=s_st.ld, ldb=c):
+            def build(S, group_list=group_list, slab=slab, rows=src.c, lda=s_st.ld, ldb=c, npairs=max_segs):
                 tb = GemmTables()
-                for si, (r0, r1) in enumerate(self._row_ranges(S)):
+                for si, (p0, p1, r0, r1) in enumerate(self._split_ranges(S[0], S[1], npairs)):
                     for (loc, pairs) in group_list:
-                        segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs] if r1 > r0 else []
+                        # a tap with fewer valid pixel pairs than the widest one gets proportionally cut chunks
+                        q0, q1 = len(pairs) * p0 // npairs, len(pairs) * p1 // npairs
+                        segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs[q0:q1]] if r1 > r0 else []
                         tb.add_group(si * slab + loc, segs, rows, key=si)
                 return tb
 
@@ -795,7 +808,7 @@ class TowerPlan:
 
             def build(S, group_list=group_list, slab=slab, rows=src.c, lda=s_st.ld, ldb=c):
                 tb = GemmTables()
-                for si, (r0, r1) in enumerate(self._row_ranges(S)):
+                for si, (p0, p1, r0, r1) in enumerate(self._split_ranges(1, S[0] * S[1], 1)):
                     for (loc, pairs) in group_list:
                         segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs] if r1 > r0 else []
                         tb.add_group(si * slab + loc, segs, rows, key=si)
