@@ -707,8 +707,8 @@ class TowerPlan:
         want = max(1, min(64, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
         max_row = max(1, self.nb // 64)
         s_row = min(want, max_row)
-        if s_row >= 8:
-            s_row = s_row // 8 * 8
+        if s_row >= 5:  # a multiple of 8 row ranges maps whole ranges onto the 8 XCDs
+            s_row = min(max(8, max_row // 8 * 8), (s_row + 7) // 8 * 8)
         s_pix = max(1, min(n_pairs, want // s_row))
         return s_pix, s_row
 
