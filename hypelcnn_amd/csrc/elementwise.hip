@@ -96,12 +96,15 @@ __global__ void fill_kernel(float* __restrict__ dst, int64_t count, float v) {
 
 __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
                                      float* __restrict__ out, int64_t count, int accumulate,
-                                     const float* __restrict__ bias, int n) {
+                                     const float* __restrict__ bias, int n, int64_t ldc) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = accumulate ? out[i] : 0.0f;
+        // ldc > 0: element i is (row i / n, column i % n) of an [rows x n] window with leading dimension ldc,
+        // on both the partial slabs and the output
+        const int64_t o = ldc > 0 ? (i / n) * ldc + (i % n) : i;
+        float s = accumulate ? out[o] : 0.0f;
         if (bias) s += bias[(int)(i % n)];
-        for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * stride + i];
-        out[i] = s;
+        for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * stride + o];
+        out[o] = s;
     }
 }
 
@@ -635,12 +638,12 @@ extern "C" int hypel_fill_f32(float* dst, int64_t count, float value, hypel_stre
 
 extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_splits, float* out,
                                        int64_t count, int32_t accumulate, const float* bias, int32_t n,
-                                       hypel_stream_t stream) {
+                                       int64_t ldc, hypel_stream_t stream) {
     HYPEL_REQUIRE(partial && out && n_splits >= 1 && count >= 0, "hypel_reduce_splits_f32");
-    HYPEL_REQUIRE(bias == nullptr || n > 0, "hypel_reduce_splits_f32");
+    HYPEL_REQUIRE((bias == nullptr && ldc <= 0) || n > 0, "hypel_reduce_splits_f32");
     if (count == 0) return 0;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
-                       n_splits, out, count, accumulate, bias, n);
+                       n_splits, out, count, accumulate, bias, n, ldc);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
     return 0;
 }

@@ -257,8 +257,10 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
     constexpr int BN = WN * TN * 32;
     const int n_nt = (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
-#define HYPEL_GO(TA_, TB_)                                                                                   \
-    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_>), dim3(grid), dim3(256), 0, st, a, lda, b, \
+    // diagnostic: unused dynamic LDS lowers the number of resident blocks per CU (occupancy experiments)
+    static const int lds_pad = getenv("HYPEL_GEMM_LDS_PAD") ? atoi(getenv("HYPEL_GEMM_LDS_PAD")) : 0;
+#define HYPEL_GO(TA_, TB_)                                                                                         \
+    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_>), dim3(grid), dim3(256), lds_pad, st, a, lda, b, \
                        ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate)
     if (!ta && !tb) HYPEL_GO(false, false);
     else if (!ta && tb) HYPEL_GO(false, true);

@@ -30,6 +30,8 @@ def stat_chunk_rows(rows):
     return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
 TARGET_BLOCKS = 1024
+MAX_TAPS_PER_TILE = 13
+TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
 
 
 class Launch:
@@ -279,7 +281,7 @@ class TowerPlan:
             self._emit_gemm(lst, stab, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, None, 0, tag + "/splitk",
                             allow_split=False)
             self._scratch(lst[pos], 6, "scratch_wgrad", S * count)
-            l2 = Launch("reduce_splits_f32", (None, count, S, c_ref + c_min, count, int(accumulate), bias_ref, int(n)),
+            l2 = Launch("reduce_splits_f32", (None, count, S, c_ref + c_min, count, int(accumulate), bias_ref, int(n), 0),
                         nbytes=4 * count * (S + 1), tag="splitk-reduce")
             self._scratch(l2, 0, "scratch_wgrad", S * count)
             lst.append(l2)
@@ -383,6 +385,20 @@ class TowerPlan:
             src = node.sources[0]
             s_st = self.storage_of(src)
             h, w = src.hw
+            rows_all = out.npix * nb
+            # Tap splitting: a block that walks all 49 taps of a 7x7 branch runs ~4x longer than the average tile
+            # and finishes alone at ~40 % MFMA utilisation.  Branches with more than MAX_TAPS_PER_TILE taps have
+            # their tap list cut into S chunks; chunk s writes a partial copy Y_s of the output (same layout,
+            # stored behind Y in the same buffer) and a strided reduce adds Y_1.. into Y.
+            splits = {}
+            if bias_ref is None and nb >= TAP_SPLIT_MIN_BATCH:
+                for b in node.branches:
+                    taps = min(b.k, h) * min(b.k, w)
+                    if taps > MAX_TAPS_PER_TILE:
+                        splits[id(b)] = (taps + MAX_TAPS_PER_TILE - 1) // MAX_TAPS_PER_TILE
+            s_max = max(splits.values()) if splits else 1
+            if s_max > 1:
+                self._alloc(ybuf, rows_all * c * s_max)
             choff = 0
             by_cout = {}
             for b in node.branches:
@@ -394,13 +410,23 @@ class TowerPlan:
                     if b.k == 1 and s_st.contiguous:
                         tb.add_group(off, [(s_st.pix_off(0), b.w.offset, src.c)], out.npix * nb)
                         continue
+                    S = splits.get(id(b), 1)
                     for p in range(h * w):
                         segs = [(s_st.pix_off(pin), b.w.offset + (i * b.k + j) * src.c * cout, src.c)
                                 for (i, j, pin) in valid_taps(h, w, b.k, p // w, p % w)]
-                        tb.add_group(p * nb * c + off, segs, nb)
+                        for si in range(S):
+                            chunk = segs[len(segs) * si // S:len(segs) * (si + 1) // S]
+                            tb.add_group(si * rows_all * c + p * nb * c + off, chunk, nb)
                 # the kernel indexes bias by (c_off % ldc) + column, so merged branches share one launch
                 self._emit_gemm(self.fwd, tb, cout, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), cout, 0,
-                                self._ref(ybuf), c, bias_ref, 0, f"fwd:{items[0][0].scope}")
+                                self._ref(ybuf), c, bias_ref, 0, f"fwd:{items[0][0].scope}", allow_split=False)
+                for b, off in items:
+                    S = splits.get(id(b), 1)
+                    if S > 1:
+                        self.fwd.append(Launch("reduce_splits_f32", (self._ref(ybuf, rows_all * c + off), rows_all * c,
+                                                                     S - 1, self._ref(ybuf, off), rows_all * cout, 1,
+                                                                     None, cout, c),
+                                               nbytes=4 * rows_all * cout * (S + 1), tag="tap-split-reduce"))
         else:  # dense
             b = node.branches[0]
             rowbase = 0
@@ -737,7 +763,7 @@ class TowerPlan:
                         allow_split=False)
         l = self.bwd[launch_pos]
         self._scratch(l, 6, "scratch_wgrad", S * slab)
-        l2 = Launch("reduce_splits_f32", (None, slab, S, Ref(self.sess.grads, w0_offset), slab, acc, None, 0),
+        l2 = Launch("reduce_splits_f32", (None, slab, S, Ref(self.sess.grads, w0_offset), slab, acc, None, 0, 0),
                     nbytes=4 * slab * (S + 1), tag="wgrad-reduce")
         self._scratch(l2, 0, "scratch_wgrad", S * slab)
         self.bwd.append(l2)
@@ -1018,9 +1044,9 @@ class PhasePlan(TowerPlan):
         self.bwd.append(l1)
         if self._trains(node.weights):
             wacc = self._param_acc(w0)
-            l2 = Launch("reduce_splits_f32", (None, wtotal, blocks, self._g(w0), wtotal, wacc, None, 0), tag="gen-dw")
+            l2 = Launch("reduce_splits_f32", (None, wtotal, blocks, self._g(w0), wtotal, wacc, None, 0, 0), tag="gen-dw")
             self._scratch(l2, 0, "scratch_gen_w", blocks * wtotal)
-            l3 = Launch("reduce_splits_f32", (None, 8, blocks, self._g(b0), 7, wacc, None, 0), tag="gen-db")
+            l3 = Launch("reduce_splits_f32", (None, 8, blocks, self._g(b0), 7, wacc, None, 0, 0), tag="gen-db")
             self._scratch(l3, 0, "scratch_gen_b", blocks * 8)
             self.bwd += [l2, l3]
 

@@ -73,11 +73,12 @@ int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
                        hypel_stream_t stream);
 
-/* out[i] = (accumulate ? out[i] : 0) + (bias ? bias[i mod n] : 0) + sum_s partial[s*stride + i], s ascending
- * (deterministic second stage of every split-K launch: filter gradients, and FC-shaped products whose
- * output has too few 128x128 tiles to fill 256 CUs). */
+/* out[o(i)] = (accumulate ? out[o(i)] : 0) + (bias ? bias[i mod n] : 0) + sum_s partial[s*stride + o(i)], s ascending
+ * (deterministic second stage of every split launch: filter gradients, FC-shaped products whose output has too
+ * few tiles to fill 256 CUs, and the tap-split heavy branches of a multi-kernel level).
+ * ldc <= 0: o(i) = i (dense).  ldc > 0: o(i) = (i / n) * ldc + i mod n, a [count/n x n] window of a wider matrix. */
 int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_splits, float* out, int64_t count,
-                            int32_t accumulate, const float* bias, int32_t n, hypel_stream_t stream);
+                            int32_t accumulate, const float* bias, int32_t n, int64_t ldc, hypel_stream_t stream);
 
 /* ---- batch norm statistics (tf_slim.batch_norm fused, HYPELCNNModel.py:37,43-44) ------------------
  * partial[chunk][0][c] = mean of the chunk's rows, partial[chunk][1][c] = sum of squared deviations.

@@ -145,18 +145,21 @@ class EmuBackend:
             else:
                 cm[...] = acc.astype(np.float32)
 
-    def k_reduce_splits_f32(self, partial, stride, n_splits, out, count, accumulate, bias=None, n=0):
+    def k_reduce_splits_f32(self, partial, stride, n_splits, out, count, accumulate, bias=None, n=0, ldc=0):
         p = _arr(partial)
-        o = _arr(out)[:count]
+        idx = np.arange(count)
+        if ldc > 0:
+            idx = (idx // n) * ldc + idx % n
+        ov = _arr(out)
         tot = np.zeros(count, np.float64)
         if bias is not None:
             tot += np.resize(_arr(bias)[:n], count)
         for k in range(n_splits):
-            tot += p[k * stride:k * stride + count]
+            tot += p[k * stride + idx]
         if accumulate:
-            o += tot.astype(np.float32)
+            ov[idx] += tot.astype(np.float32)
         else:
-            o[...] = tot.astype(np.float32)
+            ov[idx] = tot.astype(np.float32)
 
     def k_col_stats_partial(self, x, ld, rows, c, chunk_rows, partial):
         xm = _mat(x, ld, rows, c)

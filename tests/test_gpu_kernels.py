@@ -256,11 +256,16 @@ def test_optimizers_and_reduce(hip):
     b.check("p", rtol=2e-5, atol=1e-6)
     b.arr("part", rng.standard_normal(5 * 1000).astype(np.float32))
     b.arr("out", rng.standard_normal(900).astype(np.float32))
-    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 1, None, 0)
+    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 1, None, 0, 0)
     b.check("out", rtol=1e-5, atol=1e-6)
     b.arr("rb", rng.standard_normal(90).astype(np.float32))
-    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 0, "rb", 90)
+    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 0, "rb", 90, 0)
     b.check("out", rtol=1e-5, atol=1e-6)
+    # strided window: 20 rows x 7 columns of a matrix with leading dimension 13, 3 slabs of stride 400
+    b.arr("spart", rng.standard_normal(3 * 400).astype(np.float32))
+    b.arr("sout", rng.standard_normal(400).astype(np.float32))
+    b.run("reduce_splits_f32", ("spart", 5), 400, 3, ("sout", 5), 140, 1, None, 7, 13)
+    b.check("sout", rtol=1e-5, atol=1e-6)
     # K4: first Adam step from zero slots ~ -lr*sign(g)
     b.arr("p0", np.zeros(3, np.float32)); b.arr("g0", np.array([0.3, -2.0, 1e-3], np.float32))
     b.arr("m0", np.zeros(3, np.float32)); b.arr("v0", np.zeros(3, np.float32))
@@ -335,8 +340,8 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.arr("db", np.zeros(8, np.float32))
     b.run("gan_generator_bwd", "x", bands, "dout", bands, n, bands, "w", "bias", only_enc, "dx", bands, 1, "pw", "pb")
     b.check("dx", rtol=1e-4, atol=1e-5)
-    b.run("reduce_splits_f32", "pw", wtot, blocks, "dw", wtot, 0, None, 0)
-    b.run("reduce_splits_f32", "pb", 8, blocks, "db", 7, 0, None, 0)
+    b.run("reduce_splits_f32", "pw", wtot, blocks, "dw", wtot, 0, None, 0, 0)
+    b.run("reduce_splits_f32", "pb", 8, blocks, "db", 7, 0, None, 0, 0)
     b.check("dw", rtol=2e-4, atol=2e-5)
     b.check("db", rtol=2e-4, atol=2e-5)
 

@@ -74,3 +74,15 @@ def test_exact_tap_flop_count_matches_survey():
     assert fwd == 2 * 2 * 78579058
     n_params = built.ctx.session().params.numel()
     assert n_params == 8160297
+
+
+def test_tap_split_forward_matches_oracle(monkeypatch):
+    """Heavy branches (k >= 5) of a level have their tap list split into chunks that write partial outputs, summed
+    by the strided reduce; force the path at a tiny batch."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TAP_SPLIT_MIN_BATCH", 1)
+    monkeypatch.setattr(plan, "MAX_TAPS_PER_TILE", 4)
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 7, 9, 4, ALG_H, 5, 21)
+    ct = U.run_train_step(built, x, onehot, masks)
+    assert any(l.tag == "tap-split-reduce" for l in ct.plan.fwd)
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, ALG_H, tol_logit=2e-5, tol_grad=2e-4)
