@@ -30,7 +30,7 @@ def stat_chunk_rows(rows):
     return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
 TARGET_BLOCKS = 1024
-MAX_TAPS_PER_TILE = 13
+MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
 
 
