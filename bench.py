@@ -25,15 +25,23 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f
 MAC_FWD_PER_PATCH = 78579058  # SURVEY.md Appendix B.1 (exact taps, training graph)
 
 
-def build_model(batch, backend):
+CLASSIFIER_WORKLOADS = {
+    # name: (model, alg json, patch, channels, classes, default batch/GPU, exact fwd MAC per patch)
+    "hypelcnn": ("HYPELCNNModel", "alg_param_hypelcnn.json", 7, 145, 15, 1024, 78579058),
+    "dualcnn": ("DUALCNNModel", "alg_param_dualcnn.json", 11, 49, 20, 512, None),
+}
+
+
+def build_model(batch, backend, workload="hypelcnn"):
     from hypelcnn_amd.common import common_nn_ops as cno
-    alg = json.load(open(os.path.join(ROOT, "hypelcnn_amd", "nnmodel", "modelconfigs", "alg_param_hypelcnn.json")))
+    name, cfg, patch, chans, classes, _, _ = CLASSIFIER_WORKLOADS[workload]
+    alg = json.load(open(os.path.join(ROOT, "hypelcnn_amd", "nnmodel", "modelconfigs", cfg)))
     alg["batch_size"] = batch
-    model = cno.get_model_from_name("HYPELCNNModel")
-    template = cno.Template("nn_core", model.create_tensor_graph, class_count=15)
+    model = cno.get_model_from_name(name)
+    template = cno.Template("nn_core", model.create_tensor_graph, class_count=classes)
     ctx = cno.GraphContext(template, backend)
-    images = cno.Placeholder("x", (7, 7), 145)
-    labels = cno.Placeholder("labels", None, 15)
+    images = cno.Placeholder("x", (patch, patch), chans)
+    labels = cno.Placeholder("labels", None, classes)
     _, cross_entropy, lr, train_step = cno.optimize_nn(template, images, labels, "/gpu:0", "training", alg,
                                                        model.get_loss_func, ctx=ctx)
     return ctx, train_step, lr, alg
@@ -44,6 +52,8 @@ def measure_gemm_events(ct, sess, lr, steps):
     every hypel_seg_gemm_f32 launch, recorded on the stream the kernels are launched on."""
     launches = ct.serial_launches()
     total_ms, total_flops, n_launch = 0.0, 0, 0
+    measure_gemm_events.bytes_per_launch = (sum(l.bytes for l, _ in launches if l.name == "seg_gemm_f32") /
+                                            max(1, sum(1 for l, _ in launches if l.name == "seg_gemm_f32")))
     for _ in range(steps):
         evs = []
         for l, f in launches:
@@ -63,15 +73,11 @@ def measure_gemm_events(ct, sess, lr, steps):
     return total_ms, total_flops, n_launch
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle restatement (numpy, float32, OpenBLAS threads) of the identical train step on a bounded sample:
-    batch 64 (BASELINE configs[0] shape), repeated until ~seconds_budget of CPU work."""
+def _cpu_numpy_oracle(alg, nb, seconds_budget):
     from oracle import models as OM, train as OT
-    alg = json.load(open(os.path.join(ROOT, "hypelcnn_amd", "nnmodel", "modelconfigs", "alg_param_hypelcnn.json")))
     rng = np.random.default_rng(1234)
     params = OM.hypelcnn_init_params(7, 145, 15, alg, rng, np.float32)
     tr = OT.ClassifierTrainer("HYPELCNNModel", params, 15, alg)
-    nb = 64
     x = rng.random((nb, 7, 7, 145), dtype=np.float32)
     onehot = np.eye(15, dtype=np.float32)[rng.integers(0, 15, nb)]
     tr.train_step(x, onehot)  # warm-up
@@ -82,10 +88,117 @@ def cpu_baseline(seconds_budget=20.0):
         n += 1
         if time.perf_counter() - t0 > seconds_budget or n >= 50:
             break
-    dt = time.perf_counter() - t0
-    return {"value": nb * n / dt, "unit": "patches/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} train steps of batch 64 (7x7x145, fp32 numpy/OpenBLAS oracle restatement, "
-                      f"{dt:.1f} s); not a TensorFlow number"}
+    return nb * n / (time.perf_counter() - t0), n
+
+
+def _cpu_torch_oracle(alg, nb, seconds_budget):
+    """oracle/torch_ref.py: the same graph as a torch-CPU (oneDNN/MKL) autograd composition + torch Adam with the
+    TF1 epsilon placement folded into lr_t -- the closest stand-in for the reference's TF-CPU path."""
+    from oracle import models as OM, torch_ref as TR
+    rng = np.random.default_rng(1234)
+    params = OM.hypelcnn_init_params(7, 145, 15, alg, rng, np.float32)
+    P = {k: torch.tensor(v, requires_grad=not k.endswith(("moving_mean", "moving_variance")))
+         for k, v in params.items()}
+    train = [v for v in P.values() if v.requires_grad]
+    m = [torch.zeros_like(v) for v in train]
+    vv = [torch.zeros_like(v) for v in train]
+    x = torch.tensor(rng.random((nb, 7, 7, 145), dtype=np.float32))
+    onehot = torch.tensor(np.eye(15, dtype=np.float32)[rng.integers(0, 15, nb)])
+    keep = alg["drop_out_ratio"] if "drop_out_ratio" in alg else 0.5
+    step = [0]
+
+    def one():
+        out = TR.hypelcnn(P, x, 15, alg, True, masks=None)
+        logits, img = out[0], out[1]
+        loss = TR.hypelcnn_loss(logits, img, x, onehot).mean()
+        grads = torch.autograd.grad(loss, train)
+        step[0] += 1
+        t = step[0]
+        lr_t = alg["learning_rate"] * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+        with torch.no_grad():
+            torch._foreach_mul_(m, 0.9)
+            torch._foreach_add_(m, grads, alpha=0.1)
+            torch._foreach_mul_(vv, 0.999)
+            torch._foreach_addcmul_(vv, grads, grads, value=0.001)
+            den = torch._foreach_sqrt(vv)
+            torch._foreach_add_(den, 1e-8)
+            torch._foreach_addcdiv_(train, m, den, value=-lr_t)
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 200:
+            break
+    return nb * n / (time.perf_counter() - t0), n
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The identical train step restated on the host cores, on a bounded sample: batch 64 (BASELINE configs[0]
+    shape) repeated for ~seconds_budget per restatement.  Two restatements are timed and the FASTER
+    one is reported: the numpy oracle (oracle/train.py) and the torch-CPU composition (oracle/torch_ref.py)."""
+    alg = json.load(open(os.path.join(ROOT, "hypelcnn_amd", "nnmodel", "modelconfigs", "alg_param_hypelcnn.json")))
+    nb = 64
+    res = {}
+    res["numpy"] = _cpu_numpy_oracle(alg, nb, seconds_budget)
+    try:
+        res["torch_cpu"] = _cpu_torch_oracle(alg, nb, seconds_budget)
+    except Exception as e:  # the torch leg is optional evidence; never fail the bench line on it
+        res["torch_cpu"] = (0.0, 0)
+        print(f"bench.py: torch-CPU baseline failed: {e!r}", file=sys.stderr)
+    best = max(res, key=lambda k: res[k][0])
+    return {"value": res[best][0], "unit": "patches/s", "cores": torch.get_num_threads() if best == "torch_cpu"
+            else os.cpu_count(), "kind": "port",
+            "sample": f"{res[best][1]} train steps of batch 64 (7x7x145, fp32) with the {best} restatement of the "
+                      f"reference graph; numpy/OpenBLAS oracle {res['numpy'][0]:.1f} patches/s, torch-CPU (oneDNN) "
+                      f"composition {res['torch_cpu'][0]:.1f} patches/s; host has {os.cpu_count()} logical cores; "
+                      f"not a TensorFlow number"}
+
+
+def pmc_traffic(workload, nb):
+    """HBM bytes per seg_gemm launch from the PMC passes of this same command (FETCH_SIZE and WRITE_SIZE need
+    separate rocprofv3 passes, so they cannot be collected inside the bench run): read from the committed summary
+    profiles/r1_hbm_traffic.json (tools/pmc_traffic.py; corrections per MI355X_MICROARCH.md).  None if the summary
+    does not describe this workload/batch."""
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("workload") != workload or d.get("batch") != nb:
+            return None
+        return d["seg_gemm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def run_gan_workload(args, be, world, rank):
+    """cfg4 (CycleGAN, [N,1,1,64] pairs) / GAN half of cfg5 (CUT, [N,1,1,360]): one step = every sequential train
+    op of the wrapper (generator phase, discriminator phase, (feature-discriminator phase)) incl. Adam.  These
+    stacks are launch-latency / HBM bound: the line reports pairs/s and the algorithmic GB/s."""
+    from types import SimpleNamespace
+    from hypelcnn_amd.gan.wrapper_registry import get_wrapper_dict
+    from hypelcnn_amd.gan.wrappers import gan_common as C
+    kind, bands = ("cycle_gan", 64) if args.workload == "cyclegan" else ("cut_x2y", 360)
+    nb = args.batch or (2048 if kind == "cycle_gan" else 4096)
+    flags = SimpleNamespace(discriminator_reg_scale=1e-5, gen_disc_reg_scale=1e-4, embedded_feat_size=2, patches=6,
+                            cycle_consistency_loss_weight=10.0, identity_loss_weight=0.5, use_identity_loss=True,
+                            nce_loss_weight=10.0, tau=0.07, batch_size=nb)
+    wrapper = get_wrapper_dict(flags)[kind]
+    wrapper.backend = be
+    tower, xs, ys = C.new_gan_tower(bands)
+    model = wrapper.define_model(xs, ys)
+    loss = wrapper.define_loss(model)
+    ops = wrapper.define_train_ops(model, loss, max_number_of_steps=100000, generator_lr=2e-4,
+                                   discriminator_lr=1e-4, gen_discriminator_lr=1e-4)
+    ops.capture_graphs = not args.no_graph
+    sess = ops.ctx.session()
+    # the reference zero-initialises the generator (shadow_data_models.py:62-86), which makes every step trivial
+    # numerically but not computationally; keep it
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(1234 + rank)
+    x = torch.rand((nb, bands), generator=gen).cuda()
+    y = (x / (1.0 + torch.rand((1, bands), generator=gen).cuda())).contiguous()
+    return nb, bands, kind, (lambda: ops.run_step(x, y)), (lambda: float(sum(ops.losses().values())))
 
 
 def main():
@@ -93,7 +206,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step (0 = the workload's default)")
+    ap.add_argument("--workload", default="hypelcnn", choices=["hypelcnn", "dualcnn", "cyclegan", "cut"],
+                    help="hypelcnn = BASELINE.json headline (configs[1]); the others are extra evidence lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     args = ap.parse_args()
@@ -112,24 +227,31 @@ def main():
 
     from hypelcnn_amd.backend import HipBackend
     be = HipBackend()
-    ctx, train_step, lr, alg = build_model(args.batch, be)
-    ctx.seed = 1234
-    ctx.capture_graphs = not args.no_graph
-    sess = ctx.session()  # broadcasts rank-0 weights when world > 1
-    nb = args.batch
-    gen = torch.Generator(device="cpu")
-    gen.manual_seed(1234 + rank)
-    x = torch.rand((nb, 7, 7, 145), generator=gen).cuda()
-    lab = torch.randint(0, 15, (nb,), generator=gen)
-    onehot = torch.nn.functional.one_hot(lab, 15).float().cuda()
-    ct = train_step.compiled(nb)
-    ct.set_input("x", x)
-    ct.set_input("labels", onehot)
+    classifier = args.workload in CLASSIFIER_WORKLOADS
+    if classifier:
+        name, cfg, patch, chans, classes, dflt, mac = CLASSIFIER_WORKLOADS[args.workload]
+        nb = args.batch or dflt
+        ctx, train_step, lr, alg = build_model(nb, be, args.workload)
+        ctx.seed = 1234
+        ctx.capture_graphs = not args.no_graph
+        sess = ctx.session()  # broadcasts rank-0 weights when world > 1
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(1234 + rank)
+        x = torch.rand((nb, patch, patch, chans), generator=gen).cuda()
+        lab = torch.randint(0, classes, (nb,), generator=gen)
+        onehot = torch.nn.functional.one_hot(lab, classes).float().cuda()
+        ct = train_step.compiled(nb)
+        ct.set_input("x", x)
+        ct.set_input("labels", onehot)
 
-    def one_step():
-        ct.forward_backward()
-        sess.allreduce_gradients()
-        sess.adam_step(lr.eval(sess.global_step))
+        def one_step():
+            ct.forward_backward()
+            sess.allreduce_gradients()
+            sess.adam_step(lr.eval(sess.global_step))
+
+        loss_fn = ct.loss_value
+    else:
+        nb, bands, kind, one_step, loss_fn = run_gan_workload(args, be, world, rank)
 
     for _ in range(args.warmup):
         one_step()
@@ -147,37 +269,62 @@ def main():
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    loss = ct.loss_value()
+    loss = loss_fn()
     assert np.isfinite(loss), "non-finite loss"
 
     roof = None
     cpu = None
-    if rank == 0:
+    if rank == 0 and classifier:
         ev_steps = max(2, min(5, args.steps))
         ms, flops, n_launch = measure_gemm_events(ct, sess, lr, ev_steps)
         achieved = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "hypel_seg_gemm_f32 (fp32 v_mfma_f32_32x32x2)", "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "launches_per_step": n_launch // ev_steps,
+                "traffic": pmc_traffic(args.workload, nb), "launches_per_step": n_launch // ev_steps,
                 "avg_launch_us": ms * 1e3 / n_launch,
                 "gemm_ms_per_step": ms / ev_steps,
-                "algorithmic_gflop_per_step": flops / ev_steps / 1e9}
-        if world == 1 and not args.no_cpu_baseline:
+                "algorithmic_gflop_per_step": flops / ev_steps / 1e9,
+                "algorithmic_bytes_per_launch": measure_gemm_events.bytes_per_launch}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "hypelcnn":
             cpu = cpu_baseline()
+    if rank == 0 and not classifier:
+        # algorithmic HBM bytes per step: x and y read once (2*4*B*N); the achieved rate says how far
+        # from the HBM roofline a latency-bound stack of tiny kernels sits
+        alg_bytes = 2 * 4 * bands * nb
+        achieved = alg_bytes / (dt / args.steps) / 1e9
+        roof = {"bound": "hbm", "kernel": "gan phases (fused generator / discriminator GEMMs / losses)",
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "note": "launch-latency bound: whole-step rate, not a single kernel"}
     if world > 1:
         dist.barrier()
     if rank == 0:
-        out = {"metric": "HSI+LiDAR patches/sec fwd+bwd (GRSS2013 7x7x145)", "value": nb * world * args.steps / dt,
-               "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        if classifier:
+            metric = {"hypelcnn": "HSI+LiDAR patches/sec fwd+bwd (GRSS2013 7x7x145)",
+                      "dualcnn": "HSI+LiDAR patches/sec fwd+bwd (GRSS2018 11x11x49, DUALCNN)"}[args.workload]
+            cfg_d = {"workload": {"hypelcnn": "GRSS2013 HYPELCNNModel train step (fwd+bwd+TF1-Adam), 7x7 patch, 144 "
+                                              "HSI + 1 LiDAR bands, 15 classes, alg_param_hypelcnn.json, random-init "
+                                              "weights",
+                                  "dualcnn": "GRSS2018 DUALCNNModel train step (fwd+bwd+TF1-Adam), 11x11 patch, 48 "
+                                             "HSI + 1 LiDAR bands, 20 classes, alg_param_dualcnn.json, random-init "
+                                             "weights"}[args.workload],
+                     "batch_per_gpu": nb, "global_batch": nb * world,
+                     "parallelism": f"dp{world}" if world > 1 else "single",
+                     "hip_graph": ctx.capture_graphs, "loss": loss}
+            if mac:
+                cfg_d["mfma_ceiling_patches_per_s_per_gpu"] = PEAK_F32_MFMA_TFLOPS * 1e12 / (6 * mac)
+            unit = "patches/s"
+        else:
+            metric = f"spectral pairs/sec, full {kind} train step (all sequential train ops + Adam)"
+            cfg_d = {"workload": f"{kind} on [{nb},1,1,{bands}] synthetic pairs (y = x / ratio), reference "
+                                 "hyper-parameters (gan_train_for_shadow.py:44-49), zero-init generators",
+                     "batch_per_gpu": nb, "global_batch": nb * world,
+                     "parallelism": f"dp{world}" if world > 1 else "single", "hip_graph": not args.no_graph,
+                     "loss": loss, "steps_per_s": args.steps / dt}
+            unit = "pairs/s"
+        out = {"metric": metric, "value": nb * world * args.steps / dt,
+               "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "GRSS2013 HYPELCNNModel train step (fwd+bwd+TF1-Adam), 7x7 patch, 144 HSI + 1 "
-                                      "LiDAR bands, 15 classes, alg_param_hypelcnn.json, random-init weights",
-                          "batch_per_gpu": nb, "global_batch": nb * world,
-                          "parallelism": f"dp{world}" if world > 1 else "single",
-                          "hip_graph": ctx.capture_graphs, "loss": loss,
-                          "mfma_ceiling_patches_per_s_per_gpu": PEAK_F32_MFMA_TFLOPS * 1e12 / (6 * MAC_FWD_PER_PATCH)},
-               "roofline": roof, "cpu_baseline": cpu}
+               "dtype": "f32", "data": "synthetic", "config": cfg_d, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

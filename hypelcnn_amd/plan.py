@@ -124,6 +124,36 @@ class GemmTables:
         tarr = np.array([(g, m0) for _, g, m0, _ in tiles], TILE_DTYPE) if tiles else np.zeros(0, TILE_DTYPE)
         return garr, sarr, tarr, macs
 
+    def compulsory_bytes(self, n, lda, ta, ldb, tb):
+        """Algorithmic HBM bytes of the launch: every DISTINCT operand element read once, every output element
+        written once (overlapping tap windows of A and weights shared by groups count once)."""
+        def union(spans):
+            tot, end = 0, None
+            for lo, hi in sorted(spans):
+                if end is None or lo > end:
+                    tot += hi - lo
+                    end = hi
+                elif hi > end:
+                    tot += hi - end
+                    end = hi
+            return tot
+
+        a_sp, b_sp, c_el = {}, {}, set()
+        for c_off, gs, rows in self.groups:
+            c_el.add((c_off, rows))
+            for a_off, b_off, k in gs:
+                if ta:  # A stored [k, rows]
+                    a_sp.setdefault((a_off % lda, rows), []).append((a_off // lda, a_off // lda + k))
+                else:  # A stored [rows, k]
+                    a_sp.setdefault((a_off % lda, k), []).append((a_off // lda, a_off // lda + rows))
+                if tb:  # B stored [n, k]
+                    b_sp.setdefault((b_off % ldb, k), []).append((b_off // ldb, b_off // ldb + n))
+                else:  # B stored [k, n]
+                    b_sp.setdefault((b_off % ldb, n), []).append((b_off // ldb, b_off // ldb + k))
+        elems = sum(w * union(sp) for (_, w), sp in a_sp.items()) + sum(w * union(sp) for (_, w), sp in b_sp.items())
+        elems += sum(rows * n for _, rows in c_el)
+        return 4 * elems
+
 
 class TowerPlan:
     """Buffers + launch lists of one tower at one batch size."""
@@ -293,7 +323,7 @@ class TowerPlan:
         self.tables += [g_t, s_t, t_t]
         lst.append(Launch("seg_gemm_f32", (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n),
                                            Ref(g_t), Ref(s_t), Ref(t_t), int(len(tarr)), bias_ref, int(accumulate)),
-                          flops=2 * macs, tag=tag))
+                          flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag))
 
     # ------------------------------------------------------------------ build
     def _build(self):
