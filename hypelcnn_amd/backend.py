@@ -74,6 +74,9 @@ SIGNATURES = {
     "dropout_mask": [_P, _I64, _F, _U64, _P],
     "step_inc": [_P],
     "argmax_confusion": [_P, _I64, _I64, _I32, _P, _P, _P],
+    "gather_patches_f32": [_P, _P, _I64, _I64, _I32, _I32, _P, _I64, _I32, _P],
+    "augment_patches_f32": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "argmax_scatter": [_P, _I64, _I64, _I32, _P, _P, _I64],
     "lrn_fwd": [_P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64],
     "lrn_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64, _I32],
     "gan_generator_fwd": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64],

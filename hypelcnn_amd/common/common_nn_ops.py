@@ -221,6 +221,45 @@ class DeviceArrays:
         return 0 if self.data is None else self.data.shape[0]
 
 
+class SceneArrays:
+    """A data set that is never materialised: the padded, normalised scene resident in HBM plus the target list.
+    A batch is cut by ONE hypel_gather_patches_f32 launch (reference: GeneratorImporter._iterator_function, one
+    Python `get_data_point` per sample; importer/GeneratorImporter.py:19-21)."""
+
+    def __init__(self):
+        self.casi = self.lidar = self.points = self.labels = None
+        self.shape = None
+
+    def feed(self, data_set, targets, backend):
+        dev = backend.device
+        self.backend = backend
+        casi = numpy.ascontiguousarray(data_set.casi, dtype=numpy.float32)
+        self.casi = torch.from_numpy(casi).to(dev)
+        self.lidar = None
+        if data_set.lidar is not None:
+            self.lidar = torch.from_numpy(numpy.ascontiguousarray(data_set.lidar, dtype=numpy.float32)).to(dev)
+        t = numpy.asarray(targets)
+        self.points = torch.from_numpy(numpy.ascontiguousarray(t[:, :2], dtype=numpy.int32)).to(dev)
+        self.labels = torch.from_numpy(numpy.ascontiguousarray(t[:, 2]).astype(numpy.int64)).to(dev)
+        self.shape = tuple(data_set.get_data_shape())
+
+    def __len__(self):
+        return 0 if self.points is None else self.points.shape[0]
+
+    def gather(self, idx):
+        from hypelcnn_amd.backend import Ref
+        b = int(idx.shape[0])
+        p, _, c = self.shape
+        pts = self.points.index_select(0, idx).contiguous()
+        out = torch.empty((b, p, p, c), dtype=torch.float32, device=self.casi.device)
+        hp, wp, cc = self.casi.shape
+        cl = 0 if self.lidar is None else int(self.lidar.shape[2])
+        self.backend.call("gather_patches_f32", Ref(self.casi.reshape(-1)),
+                          None if self.lidar is None else Ref(self.lidar.reshape(-1)), int(hp), int(wp), int(cc), cl,
+                          Ref(pts.reshape(-1)), b, int(p), Ref(out.reshape(-1)))
+        return out, pts
+
+
 class BatchIterator:
     """make_initializable_iterator over shuffle_and_repeat / map / batch (training) or batch (eval).
 
@@ -249,8 +288,20 @@ class BatchIterator:
         return self.images, self.labels
 
     # -- session side --
-    def initializer(self, data, labels, device):
-        self.arrays.feed(data, labels, device)
+    def initializer(self, data, labels, backend):
+        self.backend = backend
+        self.arrays = DeviceArrays()
+        self.arrays.feed(data, labels, backend.device)
+        self._reset()
+
+    def initializer_scene(self, data_set, targets, backend):
+        """Generator-style data set (importer/GeneratorImporter.py): patches are cut from the resident scene."""
+        self.backend = backend
+        self.arrays = SceneArrays()
+        self.arrays.feed(data_set, targets, backend)
+        self._reset()
+
+    def _reset(self):
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(self.seed)
         self._epoch = 0
@@ -260,8 +311,8 @@ class BatchIterator:
     def _new_epoch(self):
         n = len(self.arrays)
         if self.shuffle:
-            return torch.randperm(n, generator=self._gen).to(self.arrays.data.device)
-        return torch.arange(n, device=self.arrays.data.device)
+            return torch.randperm(n, generator=self._gen).to(self.backend.device)
+        return torch.arange(n, device=self.backend.device)
 
     def next_batch(self):
         """Returns (x [b,P,P,C] float32, onehot [b,classes] float32, labels int64) or None when exhausted."""
@@ -286,10 +337,18 @@ class BatchIterator:
         if not idx_parts:
             return None
         idx = torch.cat(idx_parts) if len(idx_parts) > 1 else idx_parts[0]
-        x = self.arrays.data.index_select(0, idx)
         lab = self.arrays.labels.index_select(0, idx)
-        if self.augmentation_info is not None:
-            x = apply_augmentations(x, self.augmentation_info, self._gen)
+        augment = self.augmentation_info is not None and self.augmentation_info is not NO_AUGMENTATION
+        self.last_points = None
+        if isinstance(self.arrays, SceneArrays):
+            x, self.last_points = self.arrays.gather(idx)
+            if augment:
+                x = apply_augmentations(self.backend, x, torch.arange(x.shape[0], device=x.device),
+                                        self.augmentation_info, self._gen)
+        elif augment:
+            x = apply_augmentations(self.backend, self.arrays.data, idx, self.augmentation_info, self._gen)
+        else:
+            x = self.arrays.data.index_select(0, idx)
         onehot = torch.nn.functional.one_hot(lab, self.class_count).to(torch.float32)
         return x, onehot, lab
 
@@ -304,32 +363,52 @@ def simple_nn_iterator(data_set, batch_size):
     return BatchIterator(data_set.element_shape, data_set.class_count, batch_size, False, 1, None)
 
 
-def apply_augmentations(x, info, gen):
-    """Per-sample augmentation (reference :376-440): rot90 by k in {0,1,2} (never 270 degrees, :402),
-    shadow op with probability `augmentation_random_threshold`, left-right / up-down flips with p=0.5,
-    per-channel uniform shift in [-s, 0).  Host-side torch ops on the resident batch (SURVEY §8f "next":
-    a fused device kernel)."""
-    b = x.shape[0]
-    dev = x.device
+def draw_augmentations(b, c, info, gen):
+    """Host half of the map stage (reference :376-440): the per-sample random decisions, drawn in the order the
+    reference applies the maps -- rot90 by k in {0,1,2} (never 270 degrees, :402), shadow op with probability
+    `augmentation_random_threshold`, left-right / up-down flips with p = 0.5, per-channel U(-s, 0) shift."""
+    d = {}
     if info.perform_rotation_augmentation:
-        k = torch.randint(0, 3, (b,), generator=gen).to(dev)
-        r1 = torch.rot90(x, 1, dims=(1, 2))
-        r2 = torch.rot90(x, 2, dims=(1, 2))
-        kk = k.view(b, 1, 1, 1)
-        x = torch.where(kk == 1, r1, torch.where(kk == 2, r2, x))
+        d["rot_k"] = torch.randint(0, 3, (b,), generator=gen).to(torch.int32)
     if info.perform_shadow_augmentation and info.shadow_struct is not None:
-        pick = (torch.rand(b, generator=gen) < info.augmentation_random_threshold).to(dev).view(b, 1, 1, 1)
-        x = torch.where(pick, info.shadow_struct.shadow_op(x), x)
+        d["shadow_pick"] = (torch.rand(b, generator=gen) < info.augmentation_random_threshold).to(torch.uint8)
     if info.perform_reflection_augmentation:
-        lr = (torch.rand(b, generator=gen) < 0.5).to(dev).view(b, 1, 1, 1)
-        x = torch.where(lr, torch.flip(x, dims=(2,)), x)
-        ud = (torch.rand(b, generator=gen) < 0.5).to(dev).view(b, 1, 1, 1)
-        x = torch.where(ud, torch.flip(x, dims=(1,)), x)
+        d["flip_lr"] = (torch.rand(b, generator=gen) < 0.5).to(torch.uint8)
+        d["flip_ud"] = (torch.rand(b, generator=gen) < 0.5).to(torch.uint8)
     if info.perform_spectral_augmentation:
         s = float(info.perform_spectral_augmentation)
-        delta = (torch.rand(b, x.shape[3], generator=gen) * s - s).to(dev)
-        x = x + delta.view(b, 1, 1, -1)
-    return x.contiguous()
+        d["delta"] = (torch.rand(b, c, generator=gen) * s - s).contiguous()
+    return d
+
+
+def apply_augmentations(backend, data, idx, info, gen):
+    """Device half: ONE hypel_augment_patches_f32 launch gathers the batch `data[idx]` from the resident data set
+    and applies every drawn map on the way.  data: [N,P,P,C] device tensor, idx: int64 device."""
+    from hypelcnn_amd.backend import Ref
+    b = int(idx.shape[0])
+    _, p, _, c = data.shape
+    d = draw_augmentations(b, c, info, gen)
+    if not d:
+        return data.index_select(0, idx)
+    dev = {k: v.to(data.device) for k, v in d.items()}
+    ratio = alt = None
+    if "shadow_pick" in dev:
+        r = getattr(info.shadow_struct, "ratio", None)
+        if r is not None:
+            ratio = torch.as_tensor(numpy.asarray(r, numpy.float32)).to(data.device)
+        elif bool(d["shadow_pick"].any()):
+            alt = info.shadow_struct.shadow_op(data.index_select(0, idx)).contiguous()
+        else:
+            del dev["shadow_pick"]
+    out = torch.empty((b, p, p, c), dtype=torch.float32, device=data.device)
+
+    def ref(t):
+        return None if t is None else Ref(t.reshape(-1))
+
+    backend.call("augment_patches_f32", ref(data), ref(idx), b, int(p), int(c), ref(dev.get("rot_k")),
+                 ref(dev.get("shadow_pick")), ref(ratio), ref(alt), ref(dev.get("flip_lr")), ref(dev.get("flip_ud")),
+                 ref(dev.get("delta")), ref(out))
+    return out
 
 
 # ----------------------------------------------------------------------------- optimiser wiring (reference :208-240)
@@ -539,6 +618,48 @@ def calculate_accuracy(sess, nn_params, class_range):
     overall_accuracy, mean_per_class_accuracy, kappa = confusion_metrics(confusion_matrix)
     class_recall, class_precisions = calculate_class_accuracies_using_confusion(confusion_matrix, class_range)
     return overall_accuracy, class_recall, class_precisions, kappa, mean_per_class_accuracy
+
+
+def perform_prediction(sess, nn_params, prediction_result):
+    """reference :313-327: drain the iterator, argmax the logits, write the class of every target into the
+    [H, W] uint8 raster at (row = y, col = x).  The per-sample Python loop of the reference is ONE
+    hypel_argmax_scatter launch per batch into a device-resident raster, copied back once at the end."""
+    from hypelcnn_amd.backend import Ref
+    it = nn_params.input_iterator
+    y_conv = nn_params.predict_tensor
+    h, w = prediction_result.shape
+    raster = torch.from_numpy(numpy.ascontiguousarray(prediction_result, dtype=numpy.uint8)).to(sess.backend.device)
+    flat = raster.reshape(-1)
+    targets = numpy.asarray(nn_params.data_with_labels.targets)
+    done = 0
+    while True:
+        batch = it.next_batch()
+        if batch is None:
+            break
+        x = batch[0]
+        nb = x.shape[0]
+        ct = sess.compile(y_conv.tower, nb)
+        ct.set_input("x", x)
+        ct.forward()
+        st = ct.plan.storage_of(y_conv)
+        pts = it.last_points
+        if pts is None:  # resident-patch data set: the i-th sample of the epoch is the i-th target
+            pts = torch.from_numpy(numpy.ascontiguousarray(targets[done:done + nb, :2], dtype=numpy.int32)).to(
+                sess.backend.device)
+        sess.backend.call("argmax_scatter", Ref(ct.plan.buffers[st.buf], st.ch_off), st.ld, nb, y_conv.c,
+                          Ref(pts.reshape(-1)), Ref(flat), int(w))
+        done += nb
+    prediction_result[...] = raster.cpu().numpy()
+    return done
+
+
+def create_colored_image(target_image, color_list):
+    """reference :455-462 (vectorised): classes beyond the colour list stay black."""
+    colors = numpy.asarray(color_list, dtype=numpy.uint8).reshape(-1, 3)
+    out = numpy.zeros([target_image.shape[0], target_image.shape[1], 3], dtype=numpy.uint8)
+    valid = target_image < len(colors)
+    out[valid] = colors[target_image[valid]]
+    return out
 
 
 # ----------------------------------------------------------------------------- graph assembly (reference :330-373)

@@ -18,8 +18,10 @@ def create_simple_shadow_struct(shadow_ratio):
     def _r(inp):
         return torch.as_tensor(ratio, device=inp.device)
 
-    return ShadowOpHolder(shadow_op=lambda inp: inp / _r(inp), deshadow_op=lambda inp: inp * _r(inp),
-                          shadow_op_creater=lambda: None, shadow_op_initializer=lambda restorer, session: None)
+    holder = ShadowOpHolder(shadow_op=lambda inp: inp / _r(inp), deshadow_op=lambda inp: inp * _r(inp),
+                            shadow_op_creater=lambda: None, shadow_op_initializer=lambda restorer, session: None)
+    holder.ratio = ratio  # lets the fused augmentation kernel divide in flight instead of materialising shadow_op(x)
+    return holder
 
 
 class GeneratorAugmenter:

@@ -60,7 +60,7 @@ class InMemoryImporter(DataImporter):
 
     def init_tensors(self, session, tensor, nn_params):
         d = nn_params.data_with_labels
-        nn_params.input_iterator.initializer(d.data, d.labels, session.backend.device)
+        nn_params.input_iterator.initializer(d.data, d.labels, session.backend)
 
     def requires_separate_validation_branch(self):
         return True

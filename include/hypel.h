@@ -153,6 +153,31 @@ int hypel_step_inc(uint64_t* step_dev, hypel_stream_t stream);
 int hypel_argmax_confusion(const float* logits, int64_t ld, int64_t n, int32_t c, const int32_t* labels,
                            int32_t* pred, int32_t* confusion, hypel_stream_t stream);
 
+/* ---- data side: scene -> patches -> augmented batch; predictions -> label raster ---------------------------
+ * hypel_gather_patches_f32 replaces the per-target Python loop over BasicDataSet.get_data_point
+ * (common_nn_ops.py:169-185; importer/InMemoryImporter.py:27-38; importer/GeneratorImporter.py): casi
+ * [hp, wp, cc] and lidar [hp, wp, cl] (NULL when cl == 0) are the symmetric-padded, normalised scene in HBM;
+ * points int32 [n, 2] = (x, y) of the target = window origin in the padded scene; out [n, p, p, cc + cl].
+ *
+ * hypel_augment_patches_f32 replaces the tf.data map stage (common_nn_ops.py:376-440) and the batch gather in
+ * front of it: for sample s, source = x[idx[s]] (idx NULL = identity), rotated counter-clockwise by rot_k[s]
+ * quarter turns (the reference draws k in {0,1,2}, :402), shadowed when shadow_pick[s] (by division with
+ * shadow_ratio[c] -- create_simple_shadow_struct, gan_utilities.py:17-27 -- or by taking the sample from
+ * shadow_alt [n,p,p,c], the pre-computed generator output in batch order), flipped left/right and up/down when
+ * flip_lr[s] / flip_ud[s], shifted by delta[s, c] (spectral augmentation).  Every selector may be NULL.  The random
+ * decisions are drawn by the host iterator (seeded generator) and handed over as small device arrays.
+ *
+ * hypel_argmax_scatter replaces perform_prediction's per-sample Python loop (common_nn_ops.py:313-327):
+ * raster[y * raster_w + x] = argmax(logits[i]) for points[i] = (x, y). */
+int hypel_gather_patches_f32(const float* casi, const float* lidar, int64_t hp, int64_t wp, int32_t cc, int32_t cl,
+                             const int32_t* points, int64_t n, int32_t p, float* out, hypel_stream_t stream);
+int hypel_augment_patches_f32(const float* x, const int64_t* idx, int64_t n, int32_t p, int32_t c,
+                              const int32_t* rot_k, const uint8_t* shadow_pick, const float* shadow_ratio,
+                              const float* shadow_alt, const uint8_t* flip_lr, const uint8_t* flip_ud,
+                              const float* delta, float* out, hypel_stream_t stream);
+int hypel_argmax_scatter(const float* logits, int64_t ld, int64_t n, int32_t c, const int32_t* points,
+                         uint8_t* raster, int64_t raster_w, hypel_stream_t stream);
+
 /* ---- LRN (tf.nn.local_response_normalization, CONCNNModel.py:37,41) -------------------------------------- */
 int hypel_lrn_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t radius, float bias, float alpha,
                   float beta, float* y, int64_t ldy, hypel_stream_t stream);

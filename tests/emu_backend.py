@@ -100,6 +100,48 @@ class EmuBackend:
         i = _arr(inp)[: p * n * ld].reshape(p, n, ld)
         _arr(x)[: n * p * c].reshape(n, p, c)[...] = i[:, :, :c].transpose(1, 0, 2)
 
+    # ---- data side (specification written with numpy's own rot90 / flip, not with index arithmetic)
+    def k_gather_patches_f32(self, casi, lidar, hp, wp, cc, cl, points, n, p, out):
+        cs = _arr(casi)[: hp * wp * cc].reshape(hp, wp, cc)
+        ls = None if lidar is None else _arr(lidar)[: hp * wp * cl].reshape(hp, wp, cl)
+        pts = _arr(points, np.int32)[: 2 * n].reshape(n, 2)
+        o = _arr(out)[: n * p * p * (cc + cl)].reshape(n, p, p, cc + cl)
+        for i, (x0, y0) in enumerate(pts):
+            o[i, :, :, :cc] = cs[y0:y0 + p, x0:x0 + p]
+            if ls is not None:
+                o[i, :, :, cc:] = ls[y0:y0 + p, x0:x0 + p]
+
+    def k_augment_patches_f32(self, x, idx, n, p, c, rot_k, pick, ratio, alt, flip_lr, flip_ud, delta, out):
+        ix = np.arange(n) if idx is None else _arr(idx, np.int64)[:n]
+        xa = _arr(x)
+        o = _arr(out)[: n * p * p * c].reshape(n, p, p, c)
+        rk = None if rot_k is None else _arr(rot_k, np.int32)[:n]
+        pk = None if pick is None else _arr(pick, np.uint8)[:n]
+        fl = None if flip_lr is None else _arr(flip_lr, np.uint8)[:n]
+        fu = None if flip_ud is None else _arr(flip_ud, np.uint8)[:n]
+        dl = None if delta is None else _arr(delta)[: n * c].reshape(n, c)
+        al = None if alt is None else _arr(alt)[: n * p * p * c].reshape(n, p, p, c)
+        rt = None if ratio is None else _arr(ratio)[:c]
+        for s in range(n):
+            v = xa[ix[s] * p * p * c:(ix[s] + 1) * p * p * c].reshape(p, p, c)
+            if pk is not None and pk[s]:
+                v = al[s] if al is not None else v / rt
+            if rk is not None:
+                v = np.rot90(v, int(rk[s]), axes=(0, 1))
+            if fl is not None and fl[s]:
+                v = v[:, ::-1]
+            if fu is not None and fu[s]:
+                v = v[::-1]
+            if dl is not None:
+                v = v + dl[s]
+            o[s] = v
+
+    def k_argmax_scatter(self, logits, ld, n, c, points, raster, raster_w):
+        z = _mat(logits, ld, n, c)
+        pts = _arr(points, np.int32)[: 2 * n].reshape(n, 2)
+        r = _arr(raster, np.uint8)
+        r[pts[:, 1].astype(np.int64) * raster_w + pts[:, 0]] = np.argmax(z, axis=1).astype(np.uint8)
+
     def k_fill_f32(self, dst, count, value):
         _arr(dst)[:count] = value
 
