@@ -94,6 +94,27 @@ __global__ void fill_kernel(float* __restrict__ dst, int64_t count, float v) {
         dst[i] = v;
 }
 
+// Many slabs, few outputs (the per-block filter-gradient partials of the fused generator, bias gradients): one
+// wavefront per output, lanes stride over the slabs, fixed-order butterfly -> deterministic, and ~n_splits/64
+// dependent loads per lane instead of n_splits.
+__global__ void reduce_splits_wave_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
+                                          float* __restrict__ out, int64_t count, int accumulate,
+                                          const float* __restrict__ bias, int n, int64_t ldc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < count; i += n_waves) {
+        const int64_t o = ldc > 0 ? (i / n) * ldc + (i % n) : i;
+        float s = 0.0f;
+        for (int k = lane; k < n_splits; k += 64) s += partial[(int64_t)k * stride + o];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            if (bias) s += bias[(int)(i % n)];
+            out[o] = accumulate ? out[o] + s : s;
+        }
+    }
+}
+
 __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
                                      float* __restrict__ out, int64_t count, int accumulate,
                                      const float* __restrict__ bias, int n, int64_t ldc) {
@@ -642,8 +663,12 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
     HYPEL_REQUIRE(partial && out && n_splits >= 1 && count >= 0, "hypel_reduce_splits_f32");
     HYPEL_REQUIRE((bias == nullptr && ldc <= 0) || n > 0, "hypel_reduce_splits_f32");
     if (count == 0) return 0;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
-                       n_splits, out, count, accumulate, bias, n, ldc);
+    if (n_splits >= 32 && count <= 65536)
+        hipLaunchKernelGGL(reduce_splits_wave_kernel, dim3(hypel_grid_1d(count * 64, 256)), dim3(256), 0, ST, partial,
+                           stride, n_splits, out, count, accumulate, bias, n, ldc);
+    else
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
+                           n_splits, out, count, accumulate, bias, n, ldc);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
     return 0;
 }

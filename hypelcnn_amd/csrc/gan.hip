@@ -198,6 +198,293 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void gan_generator_bwd_kernel(
     }
 }
 
+// ===================================================================================================================
+// Register-tiled generator for wide spectra (bands > GEN_TILED_MIN; AVON: 360 bands = 384 k MAC per sample, which is
+// VALU work, not launch latency).  Same math, different schedule:
+//   * activation rows live in LDS with zero margins of H floats on both sides, so no tap needs a bounds check;
+//   * weights are re-laid in LDS in "offset space" d = j - pad_left, start rounded down to a multiple of 4 and zero
+//     filled, once as they are (forward conv, filter gradient) and once mirrored (input gradient);
+//   * a lane owns 4 CONTIGUOUS outputs (or 4 contiguous taps for the filter gradient) and walks the other index in
+//     steps of 4: two aligned ds_read_b128 (an 8-float window) + one broadcast b128 feed 16 FMAs, i.e. 0.19 LDS
+//     reads per FMA instead of 2, and 4 independent accumulators instead of one dependent chain.
+constexpr int GEN_TILED_MIN = 128;
+constexpr int GT_WAVES = 4;
+
+struct GenTiled {
+    int k[7], pl[7], woff[7];
+    int dmin[7], nch[7], wpoff[7];   // offset space of the taps: d in [dmin, dmin + 4 nch)
+    int emin[7], nchf[7], wfoff[7];  // mirrored taps: e = -d
+    int wtotal, wptotal, wftotal, layers, H, W, B4;
+};
+
+__host__ __device__ inline GenTiled gen_tiled(int bands, int only_encoder) {
+    GenTiled g;
+    const int ks[7] = {bands, bands / 2, bands / 4, bands / 8, bands / 4, bands / 2, bands};
+    int off = 0, offp = 0, offf = 0;
+    for (int i = 0; i < 7; ++i) {
+        const int k = ks[i], pl = (k - 1) / 2;
+        g.k[i] = k;
+        g.pl[i] = pl;
+        g.woff[i] = off;
+        off += k;
+        g.dmin[i] = (-pl) & ~3;  // floor to a multiple of 4 (two's complement)
+        g.nch[i] = ((k - 1 - pl) - g.dmin[i] + 4) / 4;
+        g.wpoff[i] = offp;
+        offp += 4 * g.nch[i];
+        g.emin[i] = (pl - k + 1) & ~3;
+        g.nchf[i] = (pl - g.emin[i] + 4) / 4;
+        g.wfoff[i] = offf;
+        offf += 4 * g.nchf[i];
+    }
+    g.wtotal = off;
+    g.wptotal = offp;
+    g.wftotal = offf;
+    g.layers = only_encoder ? 4 : 7;
+    g.B4 = (bands + 3) & ~3;
+    g.H = (bands / 2 + 4 + 3) & ~3;
+    g.W = g.H + g.B4 + g.H;
+    return g;
+}
+
+// block-wide: lay the filters out in offset space (zero filled)
+__device__ __forceinline__ void gt_stage_weights(const GenTiled& g, const float* __restrict__ w, float* __restrict__ wp,
+                                                 float* __restrict__ wf) {
+    for (int li = 0; li < 7; ++li) {
+        for (int c = threadIdx.x; c < 4 * g.nch[li]; c += blockDim.x) {
+            const int j = c + g.dmin[li] + g.pl[li];
+            wp[g.wpoff[li] + c] = (j >= 0 && j < g.k[li]) ? w[g.woff[li] + j] : 0.0f;
+        }
+        if (wf)
+            for (int c = threadIdx.x; c < 4 * g.nchf[li]; c += blockDim.x) {
+                const int j = g.pl[li] - (c + g.emin[li]);
+                wf[g.wfoff[li] + c] = (j >= 0 && j < g.k[li]) ? w[g.woff[li] + j] : 0.0f;
+            }
+    }
+}
+
+// acc[t] += sum_u wv[u] * win[t + u] over all 4-tap chunks: the quad of outputs at p0 of a SAME correlation of the
+// padded row `in` (element q at in[H + q]) with filters `wq` in offset space starting at `dmin`.
+__device__ __forceinline__ void gt_quad(const float* __restrict__ in, int H, int p0, const float* __restrict__ wq,
+                                        int dmin, int nch, float acc[4]) {
+    const float4* wv4 = reinterpret_cast<const float4*>(wq);
+    const float4* base = reinterpret_cast<const float4*>(in + H + p0 + dmin);
+    float4 lo = base[0];
+#pragma unroll 2
+    for (int c = 0; c < nch; ++c) {
+        const float4 hi = base[c + 1];
+        const float4 w4 = wv4[c];
+        const float win[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += wv[u] * win[t + u];
+        lo = hi;
+    }
+}
+
+// forward of one sample by one wave.  rows: padded activation rows, row(i) = rows + slot(i) * W.
+// FULL = keep all 7 rows (backward recompute, slot(i) = i), else 3 rolling rows (slot(i) = i % 3).
+// The last full-generator layer leaves the pre-tanh values in `pre` (padded row, element q at pre[H + q]).
+template <bool FULL>
+__device__ __forceinline__ void gt_forward_wave(const GenTiled& g, int bands, int lane, const float* __restrict__ wp,
+                                                const float* __restrict__ bs, float* __restrict__ rows,
+                                                uint8_t* __restrict__ slope, float* __restrict__ pre) {
+    const int hidden = g.layers == 7 ? 6 : 4;
+    const int H = g.H, W = g.W;
+    auto row = [&](int i) { return rows + (FULL ? i : i % 3) * W; };
+    for (int i = 1; i <= hidden; ++i) {
+        const float* in = row(i - 1);
+        const float* in2 = i >= 2 ? row(i - 2) : nullptr;
+        float* out = row(i);
+        for (int p0 = 4 * lane; p0 < bands; p0 += 256) {
+            float acc[4] = {bs[i - 1], bs[i - 1], bs[i - 1], bs[i - 1]};
+            gt_quad(in, H, p0, wp + g.wpoff[i - 1], g.dmin[i - 1], g.nch[i - 1], acc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int p = p0 + t;
+                if (p < bands) {
+                    const float c = acc[t];
+                    const bool pos = c > 0.0f;
+                    if (slope) slope[(i - 1) * bands + p] = pos ? 1 : 0;
+                    float v = (pos ? c : c * GEN_ALPHA) + in[H + p];
+                    if (in2) v += in2[H + p];
+                    out[H + p] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (g.layers == 7) {
+        const float* in = row(6);
+        for (int p0 = 4 * lane; p0 < bands; p0 += 256) {
+            float acc[4] = {bs[6], bs[6], bs[6], bs[6]};
+            gt_quad(in, H, p0, wp + g.wpoff[6], g.dmin[6], g.nch[6], acc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (p0 + t < bands) pre[H + p0 + t] = acc[t];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_fwd_tiled_kernel(
+    const float* __restrict__ x, int64_t ldx, int64_t n, int bands, const float* __restrict__ w,
+    const float* __restrict__ b, int only_encoder, float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GenTiled g = gen_tiled(bands, only_encoder);
+    float* wp = smem;                 // [wptotal]
+    float* bs = wp + g.wptotal;       // [8]
+    float* wave_base = bs + 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    gt_stage_weights(g, w, wp, nullptr);
+    if (threadIdx.x < 7) bs[threadIdx.x] = b[threadIdx.x];
+    float* rows = wave_base + (size_t)wave * 4 * g.W;  // 3 rolling rows + the pre-tanh row
+    float* pre = rows + 3 * g.W;
+    for (int i = lane; i < 4 * g.W; i += 64) rows[i] = 0.0f;  // margins stay zero for the whole kernel
+    __syncthreads();
+    for (int64_t s = (int64_t)blockIdx.x * GT_WAVES + wave; s < n; s += (int64_t)gridDim.x * GT_WAVES) {
+        for (int p = lane; p < bands; p += 64) rows[g.H + p] = x[s * ldx + p];
+        __builtin_amdgcn_wave_barrier();
+        gt_forward_wave<false>(g, bands, lane, wp, bs, rows, nullptr, pre);
+        const float* a4 = rows + (4 % 3) * g.W;
+        for (int p = lane; p < bands; p += 64)
+            out[s * ldo + p] = only_encoder ? a4[g.H + p] : tanhf(pre[g.H + p]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Backward (recompute + reverse walk), tiled.  Per wave in LDS: 7 padded activation rows, one padded dc row,
+// 3 rolling da rows, 6 x bands slope flags (bytes), the filter gradients in offset space.
+__global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_bwd_tiled_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
+    const float* __restrict__ w, const float* __restrict__ b, int only_encoder, float* __restrict__ dx, int64_t lddx,
+    int accumulate_dx, float* __restrict__ pw, float* __restrict__ pb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GenTiled g = gen_tiled(bands, only_encoder);
+    const int H = g.H, W = g.W, B4 = g.B4;
+    float* wp = smem;
+    float* wf = wp + g.wptotal;
+    float* bs = wf + g.wftotal;
+    float* wave_base = bs + 8;
+    const int slope_words = (6 * bands + 15) / 16 * 4;  // bytes rounded up to 16, in floats
+    const size_t per_wave = (size_t)8 * W + 3 * B4 + slope_words + g.wptotal + 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    gt_stage_weights(g, w, wp, wf);
+    if (threadIdx.x < 7) bs[threadIdx.x] = b[threadIdx.x];
+    float* rows = wave_base + wave * per_wave;  // a[0..6]
+    float* dc = rows + 7 * W;                   // padded
+    float* da = dc + W;                         // 3 rolling rows of B4
+    uint8_t* slope = reinterpret_cast<uint8_t*>(da + 3 * B4);
+    float* dwp = da + 3 * B4 + slope_words;     // [wptotal] offset-space filter gradients
+    float* db = dwp + g.wptotal;
+    for (int i = lane; i < 8 * W; i += 64) rows[i] = 0.0f;
+    for (int i = lane; i < g.wptotal; i += 64) dwp[i] = 0.0f;
+    if (lane < 8) db[lane] = 0.0f;
+    __syncthreads();
+    const int hidden = g.layers == 7 ? 6 : 4;
+    auto da_row = [&](int i) { return da + (i % 3) * B4; };
+
+    for (int64_t s = (int64_t)blockIdx.x * GT_WAVES + wave; s < n; s += (int64_t)gridDim.x * GT_WAVES) {
+        for (int p = lane; p < bands; p += 64) rows[H + p] = x[s * ldx + p];
+        __builtin_amdgcn_wave_barrier();
+        gt_forward_wave<true>(g, bands, lane, wp, bs, rows, slope, dc);
+
+        // given dc (padded row): db_li, dW_li (offset space), din[q] (+)= sum_e wf[e] dc[q + e]
+        auto layer_bwd = [&](int li, const float* in, float* din, bool assign) {
+            float sb = 0.0f;
+            for (int p = lane; p < bands; p += 64) sb += dc[H + p];
+            for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
+            if (lane == 0) db[li] += sb;
+            // filter gradient: the lane owns the 4 taps c0..c0+3 of offset space and walks the positions
+            for (int c0 = 4 * lane; c0 < 4 * g.nch[li]; c0 += 256) {
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float4* base = reinterpret_cast<const float4*>(in + H + g.dmin[li] + c0);
+                const float4* dc4 = reinterpret_cast<const float4*>(dc + H);
+                float4 lo = base[0];
+#pragma unroll 2
+                for (int pc = 0; pc < B4 / 4; ++pc) {
+                    const float4 hi = base[pc + 1];
+                    const float4 d4 = dc4[pc];
+                    const float win[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] += dv[t] * win[t + u];
+                    lo = hi;
+                }
+                float4* o4 = reinterpret_cast<float4*>(dwp + g.wpoff[li] + c0);
+                float4 cur = *o4;
+                cur.x += acc[0];
+                cur.y += acc[1];
+                cur.z += acc[2];
+                cur.w += acc[3];
+                *o4 = cur;
+            }
+            // input gradient
+            for (int q0 = 4 * lane; q0 < bands; q0 += 256) {
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                gt_quad(dc, H, q0, wf + g.wfoff[li], g.emin[li], g.nchf[li], acc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (q0 + t < bands) din[q0 + t] = assign ? acc[t] : din[q0 + t] + acc[t];
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        if (g.layers == 7) {
+            for (int p = lane; p < bands; p += 64) {
+                const float t = tanhf(dc[H + p]);
+                dc[H + p] = dout[s * lddo + p] * (1.0f - t * t);
+            }
+            __builtin_amdgcn_wave_barrier();
+            layer_bwd(6, rows + 6 * W, da_row(6), true);
+        } else {
+            float* d4 = da_row(4);
+            for (int p = lane; p < bands; p += 64) d4[p] = dout[s * lddo + p];
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int i = hidden; i >= 1; --i) {
+            const float* gi_row = da_row(i);
+            float* d1 = da_row(i - 1);
+            float* d2 = i >= 2 ? da_row(i - 2) : nullptr;
+            for (int p = lane; p < bands; p += 64) {
+                const float gi = gi_row[p];
+                d1[p] = (i == hidden) ? gi : d1[p] + gi;  // first touch of da[hidden-1]
+                if (d2) d2[p] = gi;                        // first touch of da[i-2]
+                dc[H + p] = slope[(i - 1) * bands + p] ? gi : gi * GEN_ALPHA;
+            }
+            __builtin_amdgcn_wave_barrier();
+            layer_bwd(i - 1, rows + (i - 1) * W, d1, false);
+        }
+        if (dx) {
+            const float* d0 = da_row(0);
+            for (int p = lane; p < bands; p += 64) {
+                float* d = dx + s * lddx + p;
+                *d = accumulate_dx ? *d + d0[p] : d0[p];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // combine the waves (fixed order), map offset space back to tap order, publish the block's partial sums
+    float* pwb = pw + (size_t)blockIdx.x * g.wtotal;
+    const size_t dw_at = (size_t)8 * W + 3 * B4 + slope_words;
+    for (int li = 0; li < 7; ++li)
+        for (int j = threadIdx.x; j < g.k[li]; j += blockDim.x) {
+            const int c = j - g.pl[li] - g.dmin[li];
+            float t = 0.0f;
+            for (int wv = 0; wv < GT_WAVES; ++wv) t += (wave_base + wv * per_wave + dw_at)[g.wpoff[li] + c];
+            pwb[g.woff[li] + j] = t;
+        }
+    if (threadIdx.x < 8) {
+        float t = 0.0f;
+        for (int wv = 0; wv < GT_WAVES; ++wv) t += (wave_base + wv * per_wave + dw_at + g.wptotal)[threadIdx.x];
+        pb[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------- losses
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -403,6 +690,18 @@ static size_t gen_bwd_lds(int bands, int only_encoder) {
     return sizeof(float) * ((size_t)g.wtotal + 8 + (size_t)GEN_WAVES * ((size_t)22 * bands + g.wtotal + 8));
 }
 
+static size_t gt_fwd_lds(int bands, int only_encoder) {
+    const GenTiled g = gen_tiled(bands, only_encoder);
+    return sizeof(float) * ((size_t)g.wptotal + 8 + (size_t)GT_WAVES * 4 * g.W);
+}
+
+static size_t gt_bwd_lds(int bands, int only_encoder) {
+    const GenTiled g = gen_tiled(bands, only_encoder);
+    const size_t slope_words = (size_t)(6 * bands + 15) / 16 * 4;
+    return sizeof(float) * ((size_t)g.wptotal + g.wftotal + 8 +
+                            (size_t)GT_WAVES * ((size_t)8 * g.W + 3 * g.B4 + slope_words + g.wptotal + 8));
+}
+
 extern "C" int hypel_gan_generator_blocks(int64_t n) {
     int64_t b = (n + GEN_WAVES - 1) / GEN_WAVES;
     if (b < 1) b = 1;
@@ -414,6 +713,16 @@ extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, i
                                        const float* b, int32_t only_encoder, float* out, int64_t ldo,
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(x && w && b && out && n > 0 && bands >= 8, "hypel_gan_generator_fwd");
+    if (bands > GEN_TILED_MIN && gt_fwd_lds(bands, only_encoder) <= 160 * 1024) {
+        const size_t tl = gt_fwd_lds(bands, only_encoder);
+        if (tl > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)gan_generator_fwd_tiled_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
+        hipLaunchKernelGGL(gan_generator_fwd_tiled_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * GT_WAVES), tl,
+                           ST, x, ldx, n, bands, w, b, only_encoder, out, ldo);
+        HYPEL_CHECK_LAUNCH("hypel_gan_generator_fwd");
+        return 0;
+    }
     const size_t lds = gen_fwd_lds(bands, only_encoder);
     HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_gan_generator_fwd");
     if (lds > 64 * 1024)
@@ -430,6 +739,16 @@ extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float*
                                        int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && bands >= 8, "hypel_gan_generator_bwd");
+    if (bands > GEN_TILED_MIN && gt_bwd_lds(bands, only_encoder) <= 160 * 1024) {
+        const size_t tl = gt_bwd_lds(bands, only_encoder);
+        if (tl > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)gan_generator_bwd_tiled_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
+        hipLaunchKernelGGL(gan_generator_bwd_tiled_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * GT_WAVES), tl,
+                           ST, x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb);
+        HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd");
+        return 0;
+    }
     const size_t lds = gen_bwd_lds(bands, only_encoder);
     HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_gan_generator_bwd");
     if (lds > 64 * 1024)

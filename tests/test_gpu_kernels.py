@@ -266,6 +266,15 @@ def test_optimizers_and_reduce(hip):
     b.arr("sout", rng.standard_normal(400).astype(np.float32))
     b.run("reduce_splits_f32", ("spart", 5), 400, 3, ("sout", 5), 140, 1, None, 7, 13)
     b.check("sout", rtol=1e-5, atol=1e-6)
+    # many slabs, few outputs (wave-per-output variant): plain, with bias + accumulate, and strided
+    b.arr("mpart", rng.standard_normal(300 * 500).astype(np.float32))
+    b.arr("mout", rng.standard_normal(500).astype(np.float32))
+    b.run("reduce_splits_f32", "mpart", 500, 300, "mout", 239, 0, None, 0, 0)
+    b.check("mout", rtol=1e-5, atol=1e-5)
+    b.run("reduce_splits_f32", "mpart", 500, 77, "mout", 450, 1, "rb", 90, 0)
+    b.check("mout", rtol=1e-5, atol=1e-5)
+    b.run("reduce_splits_f32", ("mpart", 3), 500, 64, ("mout", 3), 140, 1, None, 7, 13)
+    b.check("mout", rtol=1e-5, atol=1e-5)
     # K4: first Adam step from zero slots ~ -lr*sign(g)
     b.arr("p0", np.zeros(3, np.float32)); b.arr("g0", np.array([0.3, -2.0, 1e-3], np.float32))
     b.arr("m0", np.zeros(3, np.float32)); b.arr("v0", np.zeros(3, np.float32))
@@ -318,7 +327,8 @@ def test_argmax_confusion_and_lrn(hip):
 
 # ----------------------------------------------------------------------------------------------- GAN kernels
 @pytest.mark.parametrize("bands,n,only_enc", [(64, 37, 0), (64, 2048, 0), (144, 130, 0), (360, 70, 0), (64, 50, 1),
-                                              (360, 33, 1), (16, 5, 0)])
+                                              (360, 33, 1), (16, 5, 0), (130, 9, 0), (200, 50, 0), (258, 21, 1), (360, 4096, 0),
+                                              (128, 40, 0)])
 def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     rng = np.random.default_rng(bands + n)
     ks = [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
