@@ -339,7 +339,7 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.arr("bias", (rng.standard_normal(8) * 0.05).astype(np.float32))
     b.arr("out", np.zeros(n * bands, np.float32))
     b.run("gan_generator_fwd", "x", bands, n, bands, "w", "bias", only_enc, "out", bands)
-    b.check("out", rtol=2e-5, atol=2e-6)
+    b.check("out", rtol=5e-5, atol=5e-6)  # fp32 sums over up to 360 taps x 7 layers vs the float64 spec
     blocks = hip.gan_generator_blocks(n)
     assert blocks == b.emu.gan_generator_blocks(n)
     b.arr("dout", rng.standard_normal((n, bands)).astype(np.float32))
