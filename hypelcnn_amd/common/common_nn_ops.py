@@ -490,8 +490,7 @@ class TrainOp:
         ct = self.compiled(x.shape[0])
         ct.set_input("x", x)
         ct.set_input("labels", onehot)
-        ct.forward_backward()
-        sess.allreduce_gradients()
+        sess.train_step_exchange(ct)  # forward + backward (+ overlapped data-parallel gradient all-reduce)
         lr = self.learning_rate.eval(sess.global_step)
         if self.momentum is None:
             sess.adam_step(lr)

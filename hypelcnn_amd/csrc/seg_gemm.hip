@@ -284,7 +284,9 @@ extern "C" int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, 
     // (3 waves/SIMD -> 768) on every layer of the model by 1.1-1.7x: the grids here are only 1-4 "waves" of blocks,
     // so the finer grain wastes less of the last wave.  HYPEL_GEMM_BN128=1 restores 128x128 for n > 64.
     static const int bn128 = getenv("HYPEL_GEMM_BN128") ? atoi(getenv("HYPEL_GEMM_BN128")) : 0;
-    if (n <= 32)
+    // launches with fewer than ~one round of 128x64 blocks (level data gradients: 784) balance better as 128x32
+    static const int bn32_below = getenv("HYPEL_GEMM_BN32_BELOW") ? atoi(getenv("HYPEL_GEMM_BN32_BELOW")) : 1000;
+    if (n <= 32 || (int64_t)n_tiles * ((n + 63) / 64) < bn32_below)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, st);
     else if (n <= 64 || !bn128)

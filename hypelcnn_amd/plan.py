@@ -178,6 +178,7 @@ class TowerPlan:
         self.scratch_sizes = {"scratch_partial": 1, "scratch_wgrad": 1, "scratch_red": 2048, "sums": 2}
         self._pending_scratch = []
         self.param_written = set()  # variables whose gradient was already written in this plan (shared weights)
+        self.sync_points = []  # (index into bwd, lo, hi): grads[lo:hi] are final there (data-parallel overlap)
         self._build()
 
     # ---- which variables does this plan train / which tensors need a gradient (overridden by PhasePlan) ----
@@ -325,6 +326,30 @@ class TowerPlan:
                                            Ref(g_t), Ref(s_t), Ref(t_t), int(len(tarr)), bias_ref, int(accumulate)),
                           flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag))
 
+    def _dp_sync_node(self):
+        """Data-parallel overlap: the node index (walking backward) after which >= 60 % of the weight-gradient
+        bytes are final, with the flat range [lo, hi) they occupy.  Weights are laid out in creation order
+        (Session.finalize_variables), i.e. in node order, so that range is one contiguous tail."""
+        sized = []
+        for idx, node in enumerate(self.tower.nodes):
+            if isinstance(node, G.LinearNode):
+                ws = [b.w for b in node.branches]
+                if ws and all(w.trainable and w.offset is not None for w in ws):
+                    sized.append((idx, min(w.offset for w in ws), max(w.offset + w.size for w in ws)))
+        if len(sized) < 2:
+            return None
+        total = sum(hi - lo for _, lo, hi in sized)
+        hi_all = max(hi for _, _, hi in sized)
+        acc = 0
+        for k in range(len(sized) - 1, 0, -1):  # never the first layer: nothing would be left to overlap with
+            idx, lo, hi = sized[k]
+            acc += hi - lo
+            tail_lo = min(l for _, l, _ in sized[k:])
+            contiguous = sum(h - l for _, l, h in sized[k:]) == hi_all - tail_lo
+            if acc >= 0.6 * total and contiguous:
+                return idx, tail_lo, hi_all
+        return None
+
     # ------------------------------------------------------------------ build
     def _build(self):
         tw = self.tower
@@ -354,6 +379,7 @@ class TowerPlan:
         if self.loss is not None:
             self._emit_loss()
         if self.training and self.loss is not None:
+            sync_at = self._dp_sync_node() if getattr(self.sess, "dist", None) is not None else None
             for idx in range(len(tw.nodes) - 1, -1, -1):
                 node = tw.nodes[idx]
                 if isinstance(node, G.LinearNode):
@@ -362,6 +388,13 @@ class TowerPlan:
                     self._bwd_post(idx, node)
                 elif isinstance(node, G.LRNNode):
                     self._bwd_lrn(idx, node)
+                if sync_at is not None and idx == sync_at[0]:
+                    # every weight gradient at flat offsets >= sync_at[1] is final once the side stream is joined:
+                    # the session starts their all-reduce here, under the rest of the backward pass
+                    if getattr(self, "_side_open", False):
+                        self.bwd.append(Launch("_join", (), tag="join"))
+                        self._side_open = False
+                    self.sync_points.append((len(self.bwd), sync_at[1], sync_at[2]))
             if getattr(self, "_side_open", False):
                 self.bwd.append(Launch("_join", (), tag="join"))
             if tw.n_dropout and not self.external_masks:

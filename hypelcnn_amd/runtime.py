@@ -25,6 +25,8 @@ class CompiledTower:
         self.bwd = [backend.bind(l.name, l.args, l.stream) for l in plan.bwd]
         self._graph_fwd = None
         self._graph_all = None
+        self._segments = None  # graph replay callables of [fwd + bwd up to sync point 0], [.. sync point 1], ...
+        self.sync_points = list(getattr(plan, "sync_points", []))
 
     def serial_launches(self):
         """The same step with every launch on the main stream (no fork/join): per-kernel timing needs kernels that
@@ -75,20 +77,44 @@ class CompiledTower:
             for f in self.fwd:
                 f()
 
-    def forward_backward(self):
-        if self._graph_all is not None:
-            self._graph_all()
-        else:
-            for f in self.fwd:
-                f()
-            for f in self.bwd:
-                f()
+    def _segment_lists(self):
+        cuts = [i for i, _, _ in self.sync_points] + [len(self.bwd)]
+        out, start = [], 0
+        for k, c in enumerate(cuts):
+            out.append((self.fwd if k == 0 else []) + self.bwd[start:c])
+            start = c
+        return out
+
+    def forward_backward(self, hook=None):
+        """hook(k): called on the host right after the launches up to sync point k were issued (data-parallel
+        overlap: the session starts the all-reduce of the gradient range that is final at that point)."""
+        if not self.sync_points:
+            if self._graph_all is not None:
+                self._graph_all()
+            else:
+                for f in self.fwd:
+                    f()
+                for f in self.bwd:
+                    f()
+            return
+        segs = self._segments if self._segments is not None else self._segment_lists()
+        for k, seg in enumerate(segs):
+            if callable(seg):
+                seg()
+            else:
+                for f in seg:
+                    f()
+            if hook is not None and k < len(self.sync_points):
+                hook(k)
 
     def capture(self):
         """Capture forward (+ backward) into HIP graphs: one host call per step instead of ~300."""
         self.forward_backward() if self.bwd else self.forward()  # warm: first-use allocations / lazy module loads
         self.be.synchronize()
-        if self.bwd:
+        if self.bwd and self.sync_points:
+            self._segments = [self.be.capture(seg) for seg in self._segment_lists()]
+            self._graph_all = self._segments[0]  # "captured" marker for callers
+        elif self.bwd:
             self._graph_all = self.be.capture(self.fwd + self.bwd)
         else:
             self._graph_fwd = self.be.capture(self.fwd)
@@ -121,8 +147,9 @@ class Session:
 
     # ---- variables ----
     def finalize_variables(self, rng=None):
-        """Lay variables out in the flat buffers (weights first, then per-channel vectors, each in
-        creation order so that the vectors of a merged level are contiguous) and initialise them."""
+        """Lay variables out in the flat buffers (per optimiser group: per-channel vectors first, then the weights,
+        each in creation order so that the vectors of a merged level are contiguous and the weights of the layers
+        that finish their backward first form one contiguous tail) and initialise them."""
         order = self.store.order
         groups = []
         for v in order:
@@ -134,7 +161,7 @@ class Session:
         for gname in groups:  # one contiguous range per optimiser group (GAN: generator / discriminator / ...)
             lo = off
             members = [v for v in order if v.trainable and v.group == gname]
-            for v in [m for m in members if len(m.shape) > 1] + [m for m in members if len(m.shape) == 1]:
+            for v in [m for m in members if len(m.shape) == 1] + [m for m in members if len(m.shape) > 1]:
                 v.offset = off
                 off += v.size
                 self.trainable.append(v)
@@ -264,7 +291,9 @@ class Session:
     # ---- data parallel (new vs the reference: SURVEY §2.3 / §8e) ----
     def init_data_parallel(self, broadcast=True):
         import torch.distributed as dist
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        import os
+        selftest = os.environ.get("HYPEL_DP_SELFTEST") == "1"  # keep the collectives on a 1-rank communicator
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not selftest):
             self.dist = None
             return
         self.dist = (dist.get_world_size(), dist.get_rank())
@@ -278,6 +307,31 @@ class Session:
             return
         import torch.distributed as dist
         dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+        self.grads.mul_(1.0 / self.dist[0])
+
+    def train_step_exchange(self, ct, hook_ranges=True):
+        """forward + backward with the gradient exchange overlapped: at each sync point of the compiled tower the
+        finished tail of the flat gradient buffer goes out as an asynchronous all-reduce (RCCL runs it on its own
+        stream under the rest of the backward pass); the remaining head follows after the last launch.
+        Equivalent to forward_backward() + allreduce_gradients()."""
+        if self.dist is None or not ct.sync_points:
+            ct.forward_backward()
+            self.allreduce_gradients()
+            return
+        import torch.distributed as dist
+        works, covered_lo = [], self.grads.numel()
+        def hook(k):
+            nonlocal covered_lo
+            _, lo, hi = ct.sync_points[k]
+            hi = min(hi, covered_lo)
+            if hi > lo:
+                works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                covered_lo = lo
+        ct.forward_backward(hook=hook)
+        if covered_lo > 0:
+            works.append(dist.all_reduce(self.grads[:covered_lo], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
         self.grads.mul_(1.0 / self.dist[0])
 
     def average_state(self):

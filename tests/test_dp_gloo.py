@@ -45,9 +45,22 @@ def _worker(rank, world, port, outdir):
     sess = built.ctx.session()
     p0 = sess.params.clone()
     x, onehot = _data(rank)
-    U.run_train_step(built, x, onehot, {})
+    ct = U.run_train_step(built, x, onehot, {})
     local = sess.grads.clone()
     sess.allreduce_gradients()
+    plain = sess.grads.clone()
+    # the overlapped exchange (bucket at the plan's sync point + remaining head) must give the same gradients
+    assert ct.sync_points, "a data-parallel plan carries a sync point for the early all-reduce"
+    i_sync, lo, hi = ct.sync_points[0]
+    assert 0 < lo < hi == max(v.offset + v.size for v in sess.trainable if len(v.shape) > 1)
+    assert hi - lo >= 0.6 * sum(v.size for v in sess.trainable if len(v.shape) > 1)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, **kw: (calls.append(t.numel()), orig(t, **kw))[1]
+    sess.train_step_exchange(ct)
+    dist.all_reduce = orig
+    assert calls == [hi - lo, lo], calls
+    torch.testing.assert_close(sess.grads, plain, rtol=0, atol=0)
     sess.adam_step(3e-4)
     torch.save({"p0": p0, "local": local, "avg": sess.grads.clone(), "p1": sess.params.clone(),
                 "state": sess.state.clone()}, os.path.join(outdir, f"r{rank}.pt"))
