@@ -11,9 +11,12 @@ class ShadowOpHolder:
         self.deshadow_op = deshadow_op
 
 
-def create_simple_shadow_struct(shadow_ratio):
-    """Per-band ratio shadowing; the LiDAR channel (last) passes through (ratio 1)."""
-    ratio = numpy.append(numpy.asarray(shadow_ratio, numpy.float32), 1).astype(numpy.float32)
+def create_simple_shadow_struct(shadow_ratio, lidar_passthrough=True):
+    """Per-band ratio shadowing; the LiDAR channel (last) passes through (ratio 1).  The reference always appends
+    the 1 (gan_utilities.py:19), which only fits data sets with a LiDAR channel; HSI-only scenes switch it off."""
+    ratio = numpy.asarray(shadow_ratio, numpy.float32)
+    if lidar_passthrough:
+        ratio = numpy.append(ratio, 1).astype(numpy.float32)
 
     def _r(inp):
         return torch.as_tensor(ratio, device=inp.device)
@@ -60,13 +63,16 @@ class GeneratorAugmenter:
 def create_gan_struct(gan_inference_wrapper, model_base_dir, ckpt_relative_path, bands=None, backend=None):
     """Lazily built generator augmenters; `shadow_op_initializer` loads an .npz checkpoint keyed by TF names."""
     holders = {}
+    state = {"backend": backend}
 
     def _get(is_shadow):
         if is_shadow not in holders:
-            holders[is_shadow] = GeneratorAugmenter(gan_inference_wrapper, is_shadow, bands, backend)
+            holders[is_shadow] = GeneratorAugmenter(gan_inference_wrapper, is_shadow, bands, state["backend"])
         return holders[is_shadow]
 
     def _initializer(restorer, session):
+        if state["backend"] is None and session is not None:
+            state["backend"] = session.backend  # the augmenter runs on the classifier session's device
         path = model_base_dir + ckpt_relative_path
         with numpy.load(path if path.endswith(".npz") else path + ".npz") as z:
             variables = {k.replace("|", "/"): z[k] for k in z.files}

@@ -4,7 +4,8 @@ The reference's loaders (GRSS2013/2018, GULFPORT, AVON) need the contest rasters
 which exists in the build or test environment, so every benchmark and end-to-end test runs on this plugin.
 `path` selects the geometry, e.g. "grss2013" (144 HSI bands + LiDAR, 15 classes), "grss2018" (48 + LiDAR, 20),
 "avon" (360 bands, no LiDAR, 2 classes), optionally followed by ":key=value" overrides
-(h, w, bands, classes, lidar, seed, samples).  Each class has its own smooth spectrum and height, pixels are
+(h, w, bands, classes, lidar, seed, samples, gan_ckpt=<npz checkpoint of a shadow GAN for the generator-based
+shadow augmenters>).  Each class has its own smooth spectrum and height, pixels are
 class spectrum + noise laid out in blobs, so that a classifier can actually learn the scene."""
 import numpy
 
@@ -26,8 +27,8 @@ class SyntheticDataLoader(DataLoader):
         cfg = dict(PRESETS.get(parts[0], PRESETS["grss2013"]))
         cfg.update(seed=1234, samples=0.5)
         for kv in parts[1:]:
-            k, v = kv.split("=")
-            cfg[k] = float(v) if k == "samples" else int(v)
+            k, v = kv.split("=", 1)
+            cfg[k] = v if k == "gan_ckpt" else (float(v) if k == "samples" else int(v))
         self.cfg = cfg
         self._targets = None
 
@@ -59,8 +60,25 @@ class SyntheticDataLoader(DataLoader):
     def load_data(self, neighborhood, normalize):
         casi, lidar, labels = self._scene()
         self._labels = labels
-        return BasicDataSet(shadow_creator_dict=None, casi=casi, lidar=lidar, neighborhood=neighborhood,
-                            normalize=normalize)
+        data_set = BasicDataSet(shadow_creator_dict=None, casi=casi, lidar=lidar, neighborhood=neighborhood,
+                                normalize=normalize)
+        # the shadow augmenters the reference's loaders register (loader/GRSS2013DataLoader.py:24-34): the per-band
+        # ratio struct always, the generator-based ones when a trained shadow GAN checkpoint is given
+        from functools import partial
+        from hypelcnn_amd.gan.gan_utilities import create_gan_struct, create_simple_shadow_struct
+        _, shadow_ratio = self.load_shadow_map(neighborhood, data_set)
+        creators = {"simple": create_simple_shadow_struct(shadow_ratio) if lidar is not None
+                    else create_simple_shadow_struct(shadow_ratio, lidar_passthrough=False)}
+        ckpt = self.cfg.get("gan_ckpt")
+        if ckpt:
+            from hypelcnn_amd.gan.shadow_data_models import shadowdata_generator_model
+            from hypelcnn_amd.gan.wrappers.cycle_gan_wrapper import CycleGANInferenceWrapper
+            generator_fn = partial(shadowdata_generator_model, create_only_encoder=False, is_training=False)
+            for name in ("cycle_gan", "dcl_gan", "dcl_cycle_gan"):
+                creators[name] = create_gan_struct(CycleGANInferenceWrapper(generator_fn), "", ckpt,
+                                                   bands=casi.shape[2])
+        data_set.shadow_creator_dict = creators
+        return data_set
 
     def load_shadow_map(self, neighborhood, data_set):
         """load_shadow_map_common (reference common_nn_ops.py:567-571): padded map + per-band lit/shadow ratio."""

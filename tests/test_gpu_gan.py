@@ -61,3 +61,12 @@ def test_cyclegan_graph_replay_and_training_on_dummy_pairs(hip):
     fake_y = gen.value(loss.generate_outputs[0])
     assert float((fake_y - 0.5).abs().mean()) < 0.2, float(fake_y.mean())
     assert sess.global_step == 301
+
+
+def test_joint_gan_augmentation_and_classifier_loop_on_gpu(tmp_path):
+    """SURVEY cfg5 on the device: CycleGAN session -> checkpoint -> classifier whose input pipeline applies the
+    trained generator per pixel (one fused generator launch + the fused augmentation kernel)."""
+    from hypelcnn_amd.backend import HipBackend
+    from tests.test_training_loop_emu import run_joint_loop
+    res, seen = run_joint_loop(tmp_path, HipBackend, gan_steps=30, cls_steps=60)
+    assert res.test_accuracy > 0.5
