@@ -52,12 +52,12 @@ def measure_gemm_events(ct, sess, lr, steps):
     every hypel_seg_gemm_f32 launch, recorded on the stream the kernels are launched on."""
     launches = ct.serial_launches()
     total_ms, total_flops, n_launch = 0.0, 0, 0
-    measure_gemm_events.bytes_per_launch = (sum(l.bytes for l, _ in launches if l.name == "seg_gemm_f32") /
-                                            max(1, sum(1 for l, _ in launches if l.name == "seg_gemm_f32")))
+    measure_gemm_events.bytes_per_launch = (sum(l.bytes for l, _ in launches if l.name.startswith("seg_gemm")) /
+                                            max(1, sum(1 for l, _ in launches if l.name.startswith("seg_gemm"))))
     for _ in range(steps):
         evs = []
         for l, f in launches:
-            if l.name == "seg_gemm_f32":
+            if l.name.startswith("seg_gemm"):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 f()

@@ -27,16 +27,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
+#ifndef HYPEL_OCC_BN32
+#define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
+#endif
 
 template <int WM, int WN, int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(256, 3) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
                                                         const hypel_group_t* __restrict__ groups,
                                                         const hypel_seg_t* __restrict__ segs,
                                                         const hypel_tile_t* __restrict__ tiles, int n_tiles,
                                                         int n_ntiles, const float* __restrict__ bias,
-                                                        int accumulate) {
+                                                        int accumulate, const float* __restrict__ res, int64_t ldr,
+                                                        const int32_t* __restrict__ res_start) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
@@ -229,6 +233,10 @@ __global__ __launch_bounds__(256, 3) void seg_gemm_kernel(const float* __restric
     float* cbase = C + grp.c_off + (int64_t)m0 * ldc + n0;
     // bias is indexed by the absolute output column: groups of a merged level start at channel offsets
     const int bias_col0 = bias ? (int)(grp.c_off % ldc) + n0 : 0;
+    // residual-gradient addend (data gradient of a layer whose input is also its shortcut source): output element
+    // (row, c) additionally receives sum_{o in [res_start[c], res_start[c+1])} res[row][o] -- the transpose of the
+    // monotone channel map of scale_in_to_out -- from the row-aligned matrix `res` (same pixel-major row order as C)
+    const float* rbase = res ? res + (grp.c_off / ldc + m0) * ldr : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -237,6 +245,11 @@ __global__ __launch_bounds__(256, 3) void seg_gemm_kernel(const float* __restric
             const int col = (wn * TN + j) * 32 + l31;
             if (col >= cols_left) continue;
             const float bv = bias ? bias[bias_col0 + col] : 0.0f;
+            int o0 = n0 + col, o1 = n0 + col + 1;
+            if (res && res_start) {
+                o0 = res_start[n0 + col];
+                o1 = res_start[n0 + col + 1];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
@@ -244,6 +257,10 @@ __global__ __launch_bounds__(256, 3) void seg_gemm_kernel(const float* __restric
                     float* p = cbase + (int64_t)row * ldc + col;
                     float v = acc[i][j][e] + bv;
                     if (accumulate) v += *p;
+                    if (res) {
+                        const float* rr = rbase + (int64_t)row * ldr;
+                        for (int o = o0; o < o1; ++o) v += rr[o];
+                    }
                     *p = v;
                 }
             }
@@ -253,7 +270,8 @@ __global__ __launch_bounds__(256, 3) void seg_gemm_kernel(const float* __restric
 template <int WM, int WN, int TM, int TN>
 int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb, int tb, float* c, int64_t ldc,
                int n, const hypel_group_t* groups, const hypel_seg_t* segs, const hypel_tile_t* tiles, int n_tiles,
-               const float* bias, int accumulate, hipStream_t st) {
+               const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
+               hipStream_t st) {
     constexpr int BN = WN * TN * 32;
     const int n_nt = (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
@@ -261,7 +279,7 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
     static const int lds_pad = getenv("HYPEL_GEMM_LDS_PAD") ? atoi(getenv("HYPEL_GEMM_LDS_PAD")) : 0;
 #define HYPEL_GO(TA_, TB_)                                                                                         \
     hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_>), dim3(grid), dim3(256), lds_pad, st, a, lda, b, \
-                       ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate)
+                       ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr, res_start)
     if (!ta && !tb) HYPEL_GO(false, false);
     else if (!ta && tb) HYPEL_GO(false, true);
     else if (ta && !tb) HYPEL_GO(true, false);
@@ -272,10 +290,11 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
 
 }  // namespace
 
-extern "C" int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
-                                  int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
-                                  const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles,
-                                  const float* bias, int32_t accumulate, hypel_stream_t stream) {
+static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
+                             int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
+                             const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles, const float* bias,
+                             int32_t accumulate, const float* res, int64_t ldr, const int32_t* res_start,
+                             hypel_stream_t stream) {
     HYPEL_REQUIRE(a && b && c && groups && segs && tiles, "hypel_seg_gemm_f32");
     HYPEL_REQUIRE(n > 0 && n_tiles >= 0, "hypel_seg_gemm_f32");
     if (n_tiles == 0) return 0;
@@ -288,13 +307,31 @@ extern "C" int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, 
     static const int bn32_below = getenv("HYPEL_GEMM_BN32_BELOW") ? atoi(getenv("HYPEL_GEMM_BN32_BELOW")) : 1000;
     if (n <= 32 || (int64_t)n_tiles * ((n + 63) / 64) < bn32_below)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, st);
+                               accumulate, res, ldr, res_start, st);
     else if (n <= 64 || !bn128)
         launch_cfg<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, st);
+                               accumulate, res, ldr, res_start, st);
     else
         launch_cfg<2, 2, 2, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, st);
+                               accumulate, res, ldr, res_start, st);
     HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
     return 0;
+}
+
+extern "C" int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
+                                  int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
+                                  const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles,
+                                  const float* bias, int32_t accumulate, hypel_stream_t stream) {
+    return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                             accumulate, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
+                                      int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
+                                      const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles,
+                                      const float* bias, int32_t accumulate, const float* res, int64_t ldr,
+                                      const int32_t* res_start, hypel_stream_t stream) {
+    HYPEL_REQUIRE(res && ldr > 0, "hypel_seg_gemm_res_f32");
+    return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                             accumulate, res, ldr, res_start, stream);
 }

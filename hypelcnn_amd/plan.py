@@ -14,6 +14,8 @@ Layout decisions:
     filter gradient (same GEMM, transposed activations, split over batch rows with a
     deterministic second-stage reduction).
 """
+import os
+
 import numpy as np
 
 from . import graph as G
@@ -47,6 +49,7 @@ class Launch:
 
 
 USE_SIDE_STREAM = True
+FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 
 
 class Storage:
@@ -304,8 +307,9 @@ class TowerPlan:
         return out, S, c_min, count
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
-                   allow_split=True):
-        split = self._split_k(tables, n, lda, ta, ldb, tb, ldc) if allow_split else None
+                   allow_split=True, res=None):
+        """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32)."""
+        split = self._split_k(tables, n, lda, ta, ldb, tb, ldc) if allow_split and res is None else None
         if split is not None:
             stab, S, c_min, count = split
             pos = len(lst)
@@ -322,9 +326,13 @@ class TowerPlan:
             return
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
-        lst.append(Launch("seg_gemm_f32", (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n),
-                                           Ref(g_t), Ref(s_t), Ref(t_t), int(len(tarr)), bias_ref, int(accumulate)),
-                          flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag))
+        args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
+                Ref(t_t), int(len(tarr)), bias_ref, int(accumulate))
+        name = "seg_gemm_f32"
+        if res is not None:
+            name = "seg_gemm_res_f32"
+            args = args + (res[0], int(res[1]), res[2])
+        lst.append(Launch(name, args, flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag))
 
     def _dp_sync_node(self):
         """Data-parallel overlap: the node index (walking backward) after which >= 60 % of the weight-gradient
@@ -637,18 +645,42 @@ class TowerPlan:
             self.fwd.append(l3)
 
     # ------------------------------------------------------------------ backward
-    def _bwd_residuals(self, node, dz_ref, lddz, rows, c):
-        for (src, ridx) in node.residuals:
+    @staticmethod
+    def _chanmap_start(ridx, cin):
+        """Transpose of a monotone channel map: input channel ci receives output channels [start[ci], start[ci+1])."""
+        ridx = np.asarray(ridx)
+        assert (np.diff(ridx) >= 0).all(), "channel maps are monotone"
+        return np.searchsorted(ridx, np.arange(cin + 1), side="left").astype(np.int32)
+
+    def _foldable_residual(self, node):
+        """Index of a shortcut of `node` whose gradient can ride in the epilogue of the node's own data-gradient
+        GEMM: the shortcut source IS the convolution input (net = f(conv(net)) + map(net)), same pixel grid, plain
+        (un-cropped) storage on both sides."""
+        if not FOLD_RESIDUAL_GRAD or node.kind != "conv" or not node.has_post:
+            return None
+        src = node.sources[0]
+        if not self._needs_grad(src) or src.npix != node.out.npix:
+            return None
+        z_st = self.storage[id(node.out)]
+        if z_st.pixmap is not None or z_st.ch_off != 0 or z_st.ld != node.cout:
+            return None
+        if not self.storage_of(src).contiguous:
+            return None
+        for k, (rsrc, _) in enumerate(node.residuals):
+            if rsrc is src:
+                return k
+        return None
+
+    def _bwd_residuals(self, node, dz_ref, lddz, rows, c, skip=None):
+        for k, (src, ridx) in enumerate(node.residuals):
+            if k == skip:
+                continue
             if not self._needs_grad(src):
                 continue
             gst, acc = self._grad_target(src)
             sref = None
             if ridx is not None:
-                cin = src.c
-                ridx = np.asarray(ridx)
-                assert (np.diff(ridx) >= 0).all(), "channel maps are monotone"
-                start = np.searchsorted(ridx, np.arange(cin + 1), side="left").astype(np.int32)
-                t = self.be.upload(start)
+                t = self.be.upload(self._chanmap_start(ridx, src.c))
                 self.tables.append(t)
                 sref = Ref(t)
             self.bwd.append(Launch("chanmap_bwd", (dz_ref, lddz, rows, c, self._ref(gst.buf, gst.ch_off), gst.ld,
@@ -669,8 +701,23 @@ class TowerPlan:
         y_ref = self._ref(aux["y"].buf)
         dy = dz  # backward post-op runs in place
         trains = self._trains([b.w for b in node.branches])
+        fold = self._foldable_residual(node)
+        fold_res = None
+        if fold is not None:
+            # the shortcut gradient is added by the data-gradient epilogue, which therefore needs dZ intact: the
+            # post-op backward writes dY into its own buffer instead of over dZ
+            ridx = node.residuals[fold][1]
+            sref = None
+            if ridx is not None:
+                t = self.be.upload(self._chanmap_start(ridx, node.sources[0].c))
+                self.tables.append(t)
+                sref = Ref(t)
+            fold_res = (dz, c, sref)
+            if node.has_bn or (node.act and node.act.code != 0) or aux.get("mask") is not None:
+                self._alloc("dy:" + z_st.buf, rows * c)
+                dy = self._ref("dy:" + z_st.buf)
         if node.has_post:
-            self._bwd_residuals(node, dz, c, rows, c)
+            self._bwd_residuals(node, dz, c, rows, c, skip=fold)
             self._emit_post_bwd(node, aux, dz, y_ref, rows, c, dy, want_param=trains)
         elif node.has_bias and trains:
             self._emit_post_bwd(node, aux, dz, y_ref, rows, c, None, want_param=True)
@@ -709,7 +756,9 @@ class TowerPlan:
                                                          b.w.offset + (i * b.k + j) * src.c * cout, cout))
                             tb.add_group(gst.pix_off(pin), segs, nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
-                                    self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}")
+                                    self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}",
+                                    res=fold_res)
+                    fold_res = None
                     acc = 1
             # ---- filter gradient ----
             if trains:

@@ -73,6 +73,16 @@ int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
                        hypel_stream_t stream);
 
+/* hypel_seg_gemm_f32 with the shortcut gradient folded into the epilogue.  For `net = f(conv(net)) + scale_in_to_out(
+ * net)` (nnmodel/HYPELCNNModel.py:160-163,176-183) the gradient of `net` is conv-data-gradient + transpose of the
+ * channel map applied to dZ; instead of a separate gather pass plus a read-modify-write of the result, output
+ * element (row, col) additionally receives sum_{o in [res_start[col], res_start[col+1])} res[row_abs * ldr + o],
+ * row_abs = c_off / ldc + m0 + row (res has the row order of C: pixel-major).  res_start NULL = identity map. */
+int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb, int32_t trans_b,
+                           float* c, int64_t ldc, int32_t n, const hypel_group_t* groups, const hypel_seg_t* segs,
+                           const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
+                           const float* res, int64_t ldr, const int32_t* res_start, hypel_stream_t stream);
+
 /* out[o(i)] = (accumulate ? out[o(i)] : 0) + (bias ? bias[i mod n] : 0) + sum_s partial[s*stride + o(i)], s ascending
  * (deterministic second stage of every split launch: filter gradients, FC-shaped products whose output has too
  * few tiles to fill 256 CUs, and the tap-split heavy branches of a multi-kernel level).

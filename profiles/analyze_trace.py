@@ -34,7 +34,7 @@ for l in launches:
         dur += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
     out.append((l.name, l.tag, l.flops, dur, r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size')))
 tot = sum(o[3] for o in out)
-print("total kernel ns per step", tot, " gemm ns", sum(o[3] for o in out if o[0]=='seg_gemm_f32'))
+print("total kernel ns per step", tot, " gemm ns", sum(o[3] for o in out if o[0].startswith('seg_gemm')))
 print(f"{'name':18s} {'tag':34s} {'GFLOP':>8s} {'us':>8s} {'TF/s':>7s} grid")
 for o in out:
     if o[3] > 20000:
@@ -42,7 +42,7 @@ for o in out:
         print(f"{o[0]:18s} {o[1]:34s} {o[2]/1e9:8.2f} {o[3]/1e3:8.1f} {tf:7.1f} {o[4]}")
 bytag = {}
 for o in out:
-    key = o[0] if o[0] != 'seg_gemm_f32' else 'gemm:' + o[1].split(':')[0]
+    key = o[0] if not o[0].startswith('seg_gemm') else 'gemm:' + o[1].split(':')[0]
     bytag.setdefault(key, [0, 0, 0]); bytag[key][0] += o[3]; bytag[key][1] += o[2]; bytag[key][2] += 1
 for k, v in sorted(bytag.items(), key=lambda t: -t[1][0]):
     print(f"{k:28s} {v[0]/1e3:9.1f} us  n={v[2]:3d}  {v[1]/max(v[0],1)/1e3:6.1f} TF/s")

@@ -145,6 +145,25 @@ class EmuBackend:
     def k_fill_f32(self, dst, count, value):
         _arr(dst)[:count] = value
 
+    def k_seg_gemm_res_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate,
+                           res, ldr, res_start):
+        """Specification of the folded shortcut gradient: the plain product first, then the transposed channel
+        map of `res` added row by row (row order of C)."""
+        self.k_seg_gemm_f32(a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate)
+        C, R = _arr(c), _arr(res)
+        g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
+        t = tiles.t.numpy()[tiles.off:].view(TILE_DTYPE)[:n_tiles]
+        st = None if res_start is None else _arr(res_start, np.int32)[: n + 1]
+        for gi in sorted({int(tt["group"]) for tt in t}):
+            rows, co = int(g[gi]["rows"]), int(g[gi]["c_off"])
+            cm = np.lib.stride_tricks.as_strided(C[co:], (rows, n), (ldc * 4, 4))
+            r0 = co // ldc
+            for col in range(n):
+                o0, o1 = (col, col + 1) if st is None else (int(st[col]), int(st[col + 1]))
+                if o1 > o0:
+                    rm = np.lib.stride_tricks.as_strided(R[r0 * ldr + o0:], (rows, o1 - o0), (ldr * 4, 4))
+                    cm[:, col] += rm.astype(np.float64).sum(1).astype(np.float32)
+
     def k_seg_gemm_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate):
         A, B, C = _arr(a), _arr(b), _arr(c)
         g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)

@@ -120,6 +120,43 @@ def test_seg_gemm_multi_group_multi_segment(hip):
     assert (got[:, :25] == 0).all(), "columns outside the branch must stay untouched"
 
 
+@pytest.mark.parametrize("cin,cout,mapped,acc", [(120, 240, True, 0), (240, 120, True, 1), (60, 60, False, 0),
+                                                  (145, 480, True, 0)])
+def test_seg_gemm_res_epilogue(hip, cin, cout, mapped, acc):
+    """Data gradient with the folded shortcut gradient: dX[P*nb, cin] = dY @ W^T (+)= ... + map^T(dZ)."""
+    rng = np.random.default_rng(cin + cout)
+    nb, P = 70, 3
+    rows = P * nb
+    dy = rng.standard_normal((rows, cout)).astype(np.float32)
+    dz = rng.standard_normal((rows, cout)).astype(np.float32)
+    w = rng.standard_normal((cin, cout)).astype(np.float32)
+    ld = cin + 5
+    dx = rng.standard_normal((rows, ld)).astype(np.float32)
+    sc = cin / cout
+    idx = (np.arange(cout) // (cout // cin) if cout % cin == 0 else
+           np.minimum(np.round(np.arange(cout) * sc), cin - 1).astype(int))
+    start = np.searchsorted(idx, np.arange(cin + 1), side="left").astype(np.int32)
+    b = Both(hip)
+    # one group per pixel, writing at channel offset 2 of a wider gradient buffer
+    groups = [(p * nb * ld + 2, [(p * nb * cout, 0, cout)], nb) for p in range(P)]
+    garr, sarr, tarr, _ = _tables(b, groups).finalize(cin)
+    for nm, arr in (("dy", dy), ("dz", dz), ("w", w), ("dx", dx), ("g", garr), ("s", sarr), ("t", tarr),
+                    ("start", start)):
+        b.arr(nm, arr)
+    b.run("seg_gemm_res_f32", "dy", cout, 0, "w", cout, 1, "dx", ld, cin, "g", "s", "t", len(tarr), None, acc, "dz",
+          cout, "start" if mapped else None)
+    b.check("dx", rtol=2e-4, atol=2e-5)
+    got = b.h["dx"].cpu().numpy().reshape(rows, ld)
+    want = (dx[:, 2:2 + cin] if acc else 0) + dy @ w.T
+    if mapped:
+        for ci in range(cin):
+            want[:, ci] += dz[:, start[ci]:start[ci + 1]].sum(1)
+    else:
+        want = want + dz[:, :cin]
+    np.testing.assert_allclose(got[:, 2:2 + cin], want, rtol=2e-4, atol=2e-4)
+    np.testing.assert_array_equal(got[:, :2], dx[:, :2])
+
+
 def test_seg_gemm_empty_group_writes_zero(hip):
     b = Both(hip)
     garr, sarr, tarr, _ = _tables(b, [(0, [], 50)]).finalize(40)

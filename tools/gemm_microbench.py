@@ -32,7 +32,7 @@ def main():
     ct.set_input("labels", torch.nn.functional.one_hot(torch.randint(0, 15, (1024,)), 15).float().cuda())
     ct.forward_backward()  # fill every buffer with realistic data
     torch.cuda.synchronize()
-    items = [(l, f) for l, f in ct.serial_launches() if l.name == "seg_gemm_f32" and args.filter in l.tag]
+    items = [(l, f) for l, f in ct.serial_launches() if l.name.startswith("seg_gemm") and args.filter in l.tag]
     times = {l.tag: [] for l, _ in items}
     for r in range(args.rounds):
         for l, f in items:
