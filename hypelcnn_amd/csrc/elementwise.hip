@@ -3,6 +3,8 @@
 // losses, optimisers, dropout masks, metrics, LRN.  Every reduction is two-stage with a fixed
 // combination order (no float atomics) so that results are run-to-run deterministic -- the
 // "per-pixel class labels bit-exact" requirement of BASELINE.json needs that.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -115,6 +117,27 @@ __global__ void reduce_splits_wave_kernel(const float* __restrict__ partial, int
     }
 }
 
+// float4 variant (count, n, ldc, stride multiples of 4; 16-byte aligned bases)
+__global__ void reduce_splits_v4_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
+                                        float* __restrict__ out, int64_t count4, int accumulate,
+                                        const float* __restrict__ bias, int n, int64_t ldc) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = q * 4;
+        const int64_t o = ldc > 0 ? (i / n) * ldc + (i % n) : i;
+        float4 s = accumulate ? *reinterpret_cast<const float4*>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) {
+            const float* bp = bias + (int)(i % n);
+            s.x += bp[0]; s.y += bp[1]; s.z += bp[2]; s.w += bp[3];
+        }
+#pragma unroll 4
+        for (int k = 0; k < n_splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)k * stride + o);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + o) = s;
+    }
+}
+
 __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
                                      float* __restrict__ out, int64_t count, int accumulate,
                                      const float* __restrict__ bias, int n, int64_t ldc) {
@@ -166,6 +189,51 @@ __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __r
         float* po = partial + (int64_t)blockIdx.x * 2 * c;
         po[col] = shift + mean_d;
         po[c + col] = m2;
+    }
+}
+
+// float4 variant: block = 16 column quads x 16 row lanes.  Four times the bytes in flight per block: narrow layers
+// (c <= 128) launch only ~256-512 blocks, and at 8 KB in flight per CU the scalar kernel is latency bound.
+constexpr int STAT_V4_TY = 16;
+__global__ __launch_bounds__(256) void col_stats_partial_v4_kernel(const float* __restrict__ x, int64_t ld,
+                                                                    int64_t rows, int c, int chunk_rows,
+                                                                    float* __restrict__ partial) {
+    __shared__ float sh[2][STAT_V4_TY][STAT_TX];
+    const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int col = blockIdx.y * STAT_TX + tq * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = min(rows, r0 + (int64_t)chunk_rows);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s, shift = s;
+    if (col < c) {  // c % 4 == 0: a quad is entirely inside or outside
+        shift = *reinterpret_cast<const float4*>(x + r0 * ld + col);
+#pragma unroll 4
+        for (int64_t r = r0 + ty; r < r1; r += STAT_V4_TY) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ld + col);
+            const float dx = v.x - shift.x, dy = v.y - shift.y, dz = v.z - shift.z, dw = v.w - shift.w;
+            s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+            ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;
+        }
+    }
+    *reinterpret_cast<float4*>(&sh[0][ty][tq * 4]) = s;
+    *reinterpret_cast<float4*>(&sh[1][ty][tq * 4]) = ss;
+    __syncthreads();
+    if (threadIdx.x < STAT_TX) {
+        const int tx = threadIdx.x, cc = blockIdx.y * STAT_TX + tx;
+        if (cc < c) {
+            float ts = 0.0f, tss = 0.0f;
+#pragma unroll
+            for (int k = 0; k < STAT_V4_TY; ++k) {
+                ts += sh[0][k][tx];
+                tss += sh[1][k][tx];
+            }
+            const float cnt = (float)(r1 - r0);
+            const float mean_d = ts / cnt;
+            float m2 = tss - ts * mean_d;
+            if (m2 < 0.0f) m2 = 0.0f;
+            float* po = partial + (int64_t)blockIdx.x * 2 * c;
+            po[cc] = x[r0 * ld + cc] + mean_d;
+            po[c + cc] = m2;
+        }
     }
 }
 
@@ -329,6 +397,69 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
         float* po = partial + (int64_t)blockIdx.x * 2 * c;
         po[col] = t0;
         po[c + col] = t1;
+    }
+}
+
+// float4 x 16 row lanes (see col_stats_partial_v4_kernel)
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
+    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial) {
+    __shared__ float sh[2][STAT_V4_TY][STAT_TX];
+    const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int col = blockIdx.y * STAT_TX + tq * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = min(rows, r0 + (int64_t)chunk_rows);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < c) {
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mean) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mu[q] = mean[col + q];
+                rs[q] = rstd[col + q];
+                be[q] = beta[col + q];
+            }
+        }
+#pragma unroll 4
+        for (int64_t r = r0 + ty; r < r1; r += STAT_V4_TY) {
+            const float4 yv4 = *reinterpret_cast<const float4*>(y + r * ldy + col);
+            const float4 gv4 = *reinterpret_cast<const float4*>(dz + r * lddz + col);
+            float4 mv4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (mask) mv4 = *reinterpret_cast<const float4*>(mask + r * ldm + col);
+            const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w}, gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+            const float mv[4] = {mv4.x, mv4.y, mv4.z, mv4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float xhat = yv[q], pre = yv[q];
+                if (mean) {
+                    xhat = (yv[q] - mu[q]) * rs[q];
+                    pre = xhat + be[q];
+                }
+                float g = gv[q];
+                if (mask) g *= mv[q];
+                const float dyh = g * hypel_act_grad(pre, act, alpha);
+                s0[q] += dyh;
+                s1[q] += dyh * xhat;
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(&sh[0][ty][tq * 4]) = make_float4(s0[0], s0[1], s0[2], s0[3]);
+    *reinterpret_cast<float4*>(&sh[1][ty][tq * 4]) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    __syncthreads();
+    if (threadIdx.x < STAT_TX) {
+        const int tx = threadIdx.x, cc = blockIdx.y * STAT_TX + tx;
+        if (cc < c) {
+            float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < STAT_V4_TY; ++k) {
+                t0 += sh[0][k][tx];
+                t1 += sh[1][k][tx];
+            }
+            float* po = partial + (int64_t)blockIdx.x * 2 * c;
+            po[cc] = t0;
+            po[c + cc] = t1;
+        }
     }
 }
 
@@ -666,6 +797,11 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
     if (n_splits >= 32 && count <= 65536)
         hipLaunchKernelGGL(reduce_splits_wave_kernel, dim3(hypel_grid_1d(count * 64, 256)), dim3(256), 0, ST, partial,
                            stride, n_splits, out, count, accumulate, bias, n, ldc);
+    else if (!(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0) && (count % 4 == 0) &&
+             (stride % 4 == 0) && aligned16(partial) && aligned16(out) &&
+             ((ldc <= 0 && (!bias || n % 4 == 0)) || (ldc > 0 && ldc % 4 == 0 && n % 4 == 0)))
+        hipLaunchKernelGGL(reduce_splits_v4_kernel, dim3(hypel_grid_1d(count / 4, 256, 8192)), dim3(256), 0, ST,
+                           partial, stride, n_splits, out, count / 4, accumulate, bias, n, ldc);
     else
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
                            n_splits, out, count, accumulate, bias, n, ldc);
@@ -677,8 +813,14 @@ extern "C" int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows,
                                        float* partial, hypel_stream_t stream) {
     HYPEL_REQUIRE(x && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_col_stats_partial");
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
-    hipLaunchKernelGGL(col_stats_partial_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, x, ld,
-                       rows, c, chunk_rows, partial);
+    static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
+    const bool v4 = v4_on && (c % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    if (v4)
+        hipLaunchKernelGGL(col_stats_partial_v4_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST,
+                           x, ld, rows, c, chunk_rows, partial);
+    else
+        hipLaunchKernelGGL(col_stats_partial_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, x,
+                           ld, rows, c, chunk_rows, partial);
     HYPEL_CHECK_LAUNCH("hypel_col_stats_partial");
     return 0;
 }
@@ -728,8 +870,15 @@ extern "C" int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const floa
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && y && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_bn_act_bwd_reduce");
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, dz,
-                       lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial);
+    static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
+    const bool v4 = v4_on && (c % 4 == 0) && (lddz % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dz & 15) == 0) &&
+                    (((uintptr_t)y & 15) == 0) && (!mask || ((ldm % 4 == 0) && (((uintptr_t)mask & 15) == 0)));
+    if (v4)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_v4_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST,
+                           dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, dz,
+                           lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_reduce");
     return 0;
 }

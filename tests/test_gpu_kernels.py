@@ -303,6 +303,14 @@ def test_optimizers_and_reduce(hip):
     b.arr("sout", rng.standard_normal(400).astype(np.float32))
     b.run("reduce_splits_f32", ("spart", 5), 400, 3, ("sout", 5), 140, 1, None, 7, 13)
     b.check("sout", rtol=1e-5, atol=1e-6)
+    # float4 variant: bias with n % 4 == 0, and a strided window (24 rows x 8 columns, leading dimension 16)
+    b.arr("rb4", rng.standard_normal(100).astype(np.float32))
+    b.run("reduce_splits_f32", "part", 1000, 5, "out", 900, 1, "rb4", 100, 0)
+    b.check("out", rtol=1e-5, atol=1e-6)
+    b.arr("vpart", rng.standard_normal(6 * 400).astype(np.float32))
+    b.arr("vout", rng.standard_normal(400).astype(np.float32))
+    b.run("reduce_splits_f32", ("vpart", 4), 400, 6, ("vout", 4), 192, 1, None, 8, 16)
+    b.check("vout", rtol=1e-5, atol=1e-6)
     # many slabs, few outputs (wave-per-output variant): plain, with bias + accumulate, and strided
     b.arr("mpart", rng.standard_normal(300 * 500).astype(np.float32))
     b.arr("mout", rng.standard_normal(500).astype(np.float32))
