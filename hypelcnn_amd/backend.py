@@ -60,10 +60,12 @@ SIGNATURES = {
     "seg_gemm_res_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P],
     "reduce_splits_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I32, _I64],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
+    "bn_stats_f32": [_P, _I64, _I64, _I32, _I32, _P, _P, _F, _P, _P, _P, _P, _F],
     "bn_finalize": [_P, _I32, _I32, _I64, _I32, _F, _P, _P, _P, _P, _F],
     "rstd_from_var": [_P, _I32, _F, _P],
     "bn_act_fwd": [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64],
     "bn_act_bwd_reduce": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P],
+    "bn_act_bwd_sums": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P, _P, _P, _P, _I32],
     "bwd_reduce_finalize": [_P, _I32, _I32, _P, _P, _I32],
     "bn_act_bwd_apply": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _P, _I64],
     "chanmap_bwd": [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _I32],

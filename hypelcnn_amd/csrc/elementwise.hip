@@ -155,8 +155,115 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t 
 // ------------------------------------------------------------------------------------- BN statistics
 // grid = (n_chunks, ceil(c/64)); block = 64 x 4.  Shifted sums (shift = first row of the chunk) keep the
 // fp32 accumulation well conditioned; the chunk's (mean, M2) pair is then exact enough to Chan-merge in fp64.
+
+// float4 variant: block = 16 column quads x 16 row lanes.  Four times the bytes in flight per block: narrow layers
+// (c <= 128) launch only ~256-512 blocks, and at 8 KB in flight per CU the scalar kernel is latency bound.
+constexpr int STAT_V4_TY = 16;
+
+// Combine the chunk partials: mean = sum n_k mean_k / N, M2 = sum (M2_k + n_k (mean_k - mean)^2), both as fp64
+// sums with a FIXED association (16 strided lanes per channel, then an xor tree) -> deterministic, and ~20x
+// shorter than a serial Chan chain over ~200 chunks.  block = 16 channels x 16 lanes.
+__device__ __forceinline__ double lanes16_sum(double v, double* sh) {
+    // threads: ch = tid & 15, lane = tid >> 4 (0..15); wave holds 4 lanes of each channel
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const int w = threadIdx.x >> 6, ch = threadIdx.x & 15;
+    if ((threadIdx.x & 63) < 16) sh[w * 16 + ch] = v;
+    __syncthreads();
+    const double t = (sh[ch] + sh[16 + ch]) + (sh[32 + ch] + sh[48 + ch]);
+    __syncthreads();
+    return t;
+}
+
+// body of the statistics finaliser for the 16 channels [blk16*16, blk16*16+16); all 256 threads of a block call it
+__device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks,
+                                                 int chunk_rows, int64_t rows, int c, float eps,
+                                                 float* __restrict__ mean, float* __restrict__ rstd,
+                                                 float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                 float decay, double* sh) {
+    const int ch = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int col = blk16 * 16 + ch;
+    const bool ok = col < c;
+    const double n_total = (double)rows;
+    double s = 0.0;
+    for (int k = lane; k < n_chunks; k += 16) {
+        const int64_t r0 = (int64_t)k * chunk_rows;
+        const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
+        if (ok) s += n_k * (double)partial[(int64_t)k * 2 * c + col];
+    }
+    const double mean_a = lanes16_sum(s, sh) / n_total;
+    double m2 = 0.0;
+    for (int k = lane; k < n_chunks; k += 16) {
+        const int64_t r0 = (int64_t)k * chunk_rows;
+        const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
+        if (ok) {
+            const double d = (double)partial[(int64_t)k * 2 * c + col] - mean_a;
+            m2 += (double)partial[(int64_t)k * 2 * c + c + col] + n_k * d * d;
+        }
+    }
+    const double m2_a = lanes16_sum(m2, sh);
+    if (ok && lane == 0) {
+        const double var = m2_a / n_total;  // biased: what the fused batch norm normalises with
+        mean[col] = (float)mean_a;
+        rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
+        if (moving_mean) {
+            const double unbiased = n_total > 1.0 ? m2_a / (n_total - 1.0) : var;  // Bessel-corrected
+            moving_mean[col] = (float)((double)moving_mean[col] * decay + mean_a * (1.0 - (double)decay));
+            moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int n_chunks,
+                                                           int chunk_rows, int64_t rows, int c, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ moving_mean,
+                                                           float* __restrict__ moving_var, float decay) {
+    __shared__ double sh[64];
+    bn_finalize_body(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, moving_mean, moving_var,
+                     decay, sh);
+}
+
+// Fused statistics: the LAST block of a 64-channel stripe to publish its partials (ticket counter, self-resetting so
+// that a HIP-graph replay finds it at zero again) runs the finaliser for that stripe.  Which block that is varies
+// from run to run, what it computes does not: the partials are combined in the same fixed order.
+struct BnFin {
+    int* counters;  // [ceil(c/64)], zero before the first launch; NULL = partials only
+    float eps;
+    float* mean;
+    float* rstd;
+    float* moving_mean;
+    float* moving_var;
+    float decay;
+};
+
+__device__ __forceinline__ bool stripe_is_complete(int* counters) {
+    __shared__ int last;
+    __threadfence();  // this block's partials are visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(&counters[blockIdx.y], 1);
+        last = (t == (int)gridDim.x - 1);
+        if (last) counters[blockIdx.y] = 0;
+    }
+    __syncthreads();
+    if (last) __threadfence();  // acquire: the other blocks' partials
+    return last != 0;
+}
+
+__device__ __forceinline__ void bn_stats_tail(const BnFin& f, const float* partial, int chunk_rows, int64_t rows,
+                                              int c) {
+    __shared__ double shd[64];
+    if (f.counters == nullptr) return;
+    if (!stripe_is_complete(f.counters)) return;
+    for (int q = 0; q < STAT_TX / 16; ++q)
+        bn_finalize_body(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, chunk_rows, rows, c, f.eps, f.mean,
+                         f.rstd, f.moving_mean, f.moving_var, f.decay, shd);
+}
+
 __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t rows,
-                                                                 int c, int chunk_rows, float* __restrict__ partial) {
+                                                                 int c, int chunk_rows, float* __restrict__ partial,
+                                                                 BnFin fin) {
     __shared__ float sh[2][STAT_TY][STAT_TX];
     const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
     const int col = blockIdx.y * STAT_TX + tx;
@@ -190,14 +297,12 @@ __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __r
         po[col] = shift + mean_d;
         po[c + col] = m2;
     }
+    bn_stats_tail(fin, partial, chunk_rows, rows, c);
 }
 
-// float4 variant: block = 16 column quads x 16 row lanes.  Four times the bytes in flight per block: narrow layers
-// (c <= 128) launch only ~256-512 blocks, and at 8 KB in flight per CU the scalar kernel is latency bound.
-constexpr int STAT_V4_TY = 16;
 __global__ __launch_bounds__(256) void col_stats_partial_v4_kernel(const float* __restrict__ x, int64_t ld,
                                                                     int64_t rows, int c, int chunk_rows,
-                                                                    float* __restrict__ partial) {
+                                                                    float* __restrict__ partial, BnFin fin) {
     __shared__ float sh[2][STAT_V4_TY][STAT_TX];
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int col = blockIdx.y * STAT_TX + tq * 4;
@@ -235,60 +340,7 @@ __global__ __launch_bounds__(256) void col_stats_partial_v4_kernel(const float* 
             po[c + cc] = m2;
         }
     }
-}
-
-// Combine the chunk partials: mean = sum n_k mean_k / N, M2 = sum (M2_k + n_k (mean_k - mean)^2), both as fp64
-// sums with a FIXED association (16 strided lanes per channel, then an xor tree) -> deterministic, and ~20x
-// shorter than a serial Chan chain over ~200 chunks.  block = 16 channels x 16 lanes.
-__device__ __forceinline__ double lanes16_sum(double v, double* sh) {
-    // threads: ch = tid & 15, lane = tid >> 4 (0..15); wave holds 4 lanes of each channel
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    const int w = threadIdx.x >> 6, ch = threadIdx.x & 15;
-    if ((threadIdx.x & 63) < 16) sh[w * 16 + ch] = v;
-    __syncthreads();
-    const double t = (sh[ch] + sh[16 + ch]) + (sh[32 + ch] + sh[48 + ch]);
-    __syncthreads();
-    return t;
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int n_chunks,
-                                                           int chunk_rows, int64_t rows, int c, float eps,
-                                                           float* __restrict__ mean, float* __restrict__ rstd,
-                                                           float* __restrict__ moving_mean,
-                                                           float* __restrict__ moving_var, float decay) {
-    __shared__ double sh[64];
-    const int ch = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + ch;
-    const bool ok = col < c;
-    const double n_total = (double)rows;
-    double s = 0.0;
-    for (int k = lane; k < n_chunks; k += 16) {
-        const int64_t r0 = (int64_t)k * chunk_rows;
-        const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
-        if (ok) s += n_k * (double)partial[(int64_t)k * 2 * c + col];
-    }
-    const double mean_a = lanes16_sum(s, sh) / n_total;
-    double m2 = 0.0;
-    for (int k = lane; k < n_chunks; k += 16) {
-        const int64_t r0 = (int64_t)k * chunk_rows;
-        const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
-        if (ok) {
-            const double d = (double)partial[(int64_t)k * 2 * c + col] - mean_a;
-            m2 += (double)partial[(int64_t)k * 2 * c + c + col] + n_k * d * d;
-        }
-    }
-    const double m2_a = lanes16_sum(m2, sh);
-    if (ok && lane == 0) {
-        const double var = m2_a / n_total;  // biased: what the fused batch norm normalises with
-        mean[col] = (float)mean_a;
-        rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
-        if (moving_mean) {
-            const double unbiased = n_total > 1.0 ? m2_a / (n_total - 1.0) : var;  // Bessel-corrected
-            moving_mean[col] = (float)((double)moving_mean[col] * decay + mean_a * (1.0 - (double)decay));
-            moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
-        }
-    }
+    bn_stats_tail(fin, partial, chunk_rows, rows, c);
 }
 
 __global__ void rstd_from_var_kernel(const float* __restrict__ var, int c, float eps, float* __restrict__ rstd) {
@@ -365,10 +417,59 @@ __device__ __forceinline__ void bwd_elem(const float* __restrict__ dz, int64_t l
     dyh = g * hypel_act_grad(pre, act, alpha);
 }
 
+
+// float4 x 16 row lanes (see col_stats_partial_v4_kernel)
+
+__device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks, int c,
+                                                  float* __restrict__ sums, float* __restrict__ dparam,
+                                                  int accumulate, double* sh) {
+    const int ch = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int col = blk16 * 16 + ch;
+    const bool ok = col < c;
+    double a = 0.0, b = 0.0;
+    for (int k = lane; k < n_chunks; k += 16) {
+        if (ok) {
+            a += (double)partial[(int64_t)k * 2 * c + col];
+            b += (double)partial[(int64_t)k * 2 * c + c + col];
+        }
+    }
+    a = lanes16_sum(a, sh);
+    b = lanes16_sum(b, sh);
+    if (ok && lane == 0) {
+        sums[col] = (float)a;
+        sums[c + col] = (float)b;
+        if (dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + (float)a;
+    }
+}
+
+__global__ __launch_bounds__(256) void bwd_reduce_finalize_kernel(const float* __restrict__ partial, int n_chunks,
+                                                                   int c, float* __restrict__ sums,
+                                                                   float* __restrict__ dparam, int accumulate) {
+    __shared__ double sh[64];
+    bwd_finalize_body(blockIdx.x, partial, n_chunks, c, sums, dparam, accumulate, sh);
+}
+
+struct BwdFin {
+    int* counters;  // NULL = partials only
+    float* sums;
+    float* dparam;
+    int accumulate;
+};
+
+__device__ __forceinline__ void bwd_reduce_tail(const BwdFin& f, const float* partial, int c) {
+    __shared__ double shd[64];
+    if (f.counters == nullptr) return;
+    if (!stripe_is_complete(f.counters)) return;
+    for (int q = 0; q < STAT_TX / 16; ++q)
+        bwd_finalize_body(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, c, f.sums, f.dparam, f.accumulate,
+                          shd);
+}
+
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial) {
+    float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
+    BwdFin fin) {
     __shared__ float sh[2][STAT_TY][STAT_TX];
     const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
     const int col = blockIdx.y * STAT_TX + tx;
@@ -398,13 +499,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
         po[col] = t0;
         po[c + col] = t1;
     }
+    bwd_reduce_tail(fin, partial, c);
 }
 
-// float4 x 16 row lanes (see col_stats_partial_v4_kernel)
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
     const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial) {
+    float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
+    BwdFin fin) {
     __shared__ float sh[2][STAT_V4_TY][STAT_TX];
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int col = blockIdx.y * STAT_TX + tq * 4;
@@ -461,29 +563,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
             po[c + cc] = t1;
         }
     }
-}
-
-__global__ __launch_bounds__(256) void bwd_reduce_finalize_kernel(const float* __restrict__ partial, int n_chunks,
-                                                                   int c, float* __restrict__ sums,
-                                                                   float* __restrict__ dparam, int accumulate) {
-    __shared__ double sh[64];
-    const int ch = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + ch;
-    const bool ok = col < c;
-    double a = 0.0, b = 0.0;
-    for (int k = lane; k < n_chunks; k += 16) {
-        if (ok) {
-            a += (double)partial[(int64_t)k * 2 * c + col];
-            b += (double)partial[(int64_t)k * 2 * c + c + col];
-        }
-    }
-    a = lanes16_sum(a, sh);
-    b = lanes16_sum(b, sh);
-    if (ok && lane == 0) {
-        sums[col] = (float)a;
-        sums[c + col] = (float)b;
-        if (dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + (float)a;
-    }
+    bwd_reduce_tail(fin, partial, c);
 }
 
 template <int VEC>
@@ -809,19 +889,38 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
     return 0;
 }
 
-extern "C" int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows,
-                                       float* partial, hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_col_stats_partial");
+static int launch_col_stats(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows, float* partial,
+                            const BnFin& fin, hypel_stream_t stream) {
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
     static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
     const bool v4 = v4_on && (c % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
     if (v4)
         hipLaunchKernelGGL(col_stats_partial_v4_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST,
-                           x, ld, rows, c, chunk_rows, partial);
+                           x, ld, rows, c, chunk_rows, partial, fin);
     else
         hipLaunchKernelGGL(col_stats_partial_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, x,
-                           ld, rows, c, chunk_rows, partial);
+                           ld, rows, c, chunk_rows, partial, fin);
+    return 0;
+}
+
+extern "C" int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows,
+                                       float* partial, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_col_stats_partial");
+    launch_col_stats(x, ld, rows, c, chunk_rows, partial, BnFin{nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f},
+                     stream);
     HYPEL_CHECK_LAUNCH("hypel_col_stats_partial");
+    return 0;
+}
+
+extern "C" int hypel_bn_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows,
+                                  float* partial, int32_t* counters, float eps, float* mean, float* rstd,
+                                  float* moving_mean, float* moving_var, float decay, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && partial && counters && mean && rstd && rows > 0 && c > 0 && chunk_rows > 0,
+                  "hypel_bn_stats_f32");
+    HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_stats_f32");
+    launch_col_stats(x, ld, rows, c, chunk_rows, partial, BnFin{counters, eps, mean, rstd, moving_mean, moving_var, decay},
+                     stream);
+    HYPEL_CHECK_LAUNCH("hypel_bn_stats_f32");
     return 0;
 }
 
@@ -864,22 +963,45 @@ extern "C" int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32
     return 0;
 }
 
-extern "C" int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
-                                       int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
-                                       float alpha, const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
-                                       hypel_stream_t stream) {
-    HYPEL_REQUIRE(dz && y && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_bn_act_bwd_reduce");
+static int launch_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                             const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                             const float* mask, int64_t ldm, int32_t chunk_rows, float* partial, const BwdFin& fin,
+                             hypel_stream_t stream) {
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
     static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
     const bool v4 = v4_on && (c % 4 == 0) && (lddz % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dz & 15) == 0) &&
                     (((uintptr_t)y & 15) == 0) && (!mask || ((ldm % 4 == 0) && (((uintptr_t)mask & 15) == 0)));
     if (v4)
         hipLaunchKernelGGL(bn_act_bwd_reduce_v4_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST,
-                           dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial);
+                           dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
+                           fin);
     else
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, dz,
-                           lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial);
+                           lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial, fin);
+    return 0;
+}
+
+extern "C" int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                       int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
+                                       float alpha, const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && y && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_bn_act_bwd_reduce");
+    launch_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
+                      BwdFin{nullptr, nullptr, nullptr, 0}, stream);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_reduce");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                     int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
+                                     float alpha, const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
+                                     int32_t* counters, float* sums, float* dparam, int32_t accumulate,
+                                     hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && y && partial && counters && sums && rows > 0 && c > 0 && chunk_rows > 0,
+                  "hypel_bn_act_bwd_sums");
+    launch_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
+                      BwdFin{counters, sums, dparam, accumulate}, stream);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_sums");
     return 0;
 }
 

@@ -49,6 +49,7 @@ class Launch:
 
 
 USE_SIDE_STREAM = True
+FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "1") != "0"  # statistics kernels finalise themselves
 FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 
 
@@ -244,6 +245,16 @@ class TowerPlan:
             written = True
         self.grad_written[id(own)] = True
         return gst, 1 if written else 0
+
+    def _tickets(self, c):
+        """Zero-initialised int32 ticket counters of the fused statistics kernels (one per 64-channel stripe; the
+        finishing block resets its counter, so the buffer is shared by every launch of a stream)."""
+        import torch
+        n = (c + 63) // 64
+        cur = self.buffers.get("tickets")
+        if cur is None or cur.numel() < n:
+            self.buffers["tickets"] = self.be.zeros(max(n, 1024), torch.int32)
+        return Ref(self.buffers["tickets"])
 
     # ------------------------------------------------------------------ parameters
     def _p(self, var):
@@ -519,14 +530,25 @@ class TowerPlan:
             if node.training:
                 chunk = stat_chunk_rows(rows)
                 n_chunks = (rows + chunk - 1) // chunk
-                l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, chunk, None),
+                if not FUSED_STATS:
+                    l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, chunk, None),
+                                nbytes=4 * rows * c, tag="bn-stats")
+                    self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
+                    l2 = Launch("bn_finalize", (None, n_chunks, chunk, rows, c, float(node.bn_eps),
+                                                self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"), self._s(aux["mm"]),
+                                                self._s(aux["mv"]), float(node.bn_decay)), tag="bn-finalize")
+                    self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+                    self.fwd += [l1, l2]
+                # statistics + finaliser in one launch (the last block of a channel stripe finalises it)
+                l1 = Launch("bn_stats_f32", (self._ref(ybuf), c, rows, c, chunk, None, self._tickets(c),
+                                             float(node.bn_eps), self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"),
+                                             self._s(aux["mm"]), self._s(aux["mv"]), float(node.bn_decay)),
                             nbytes=4 * rows * c, tag="bn-stats")
                 self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                l2 = Launch("bn_finalize", (None, n_chunks, chunk, rows, c, float(node.bn_eps),
-                                            self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"), self._s(aux["mm"]),
-                                            self._s(aux["mv"]), float(node.bn_decay)), tag="bn-finalize")
-                self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
-                self.fwd += [l1, l2]
+                if FUSED_STATS:
+                    self.fwd.append(l1)
+                else:
+                    self._pending_scratch.pop()
                 aux["mean"] = self._ref(f"mean:{idx}")
             else:
                 self.fwd.append(Launch("rstd_from_var", (self._s(aux["mv"]), c, float(node.bn_eps),
@@ -797,16 +819,24 @@ class TowerPlan:
         if has_bn or dparam is not None:
             chunk = stat_chunk_rows(rows)
             n_chunks = (rows + chunk - 1) // chunk
-            l1 = Launch("bn_act_bwd_reduce", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
-                                              chunk, None), nbytes=8 * rows * c, tag="post-bwd-reduce")
-            self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
             pacc = 0
             if dparam is not None:
                 pacc = self._param_acc(aux["beta"] if has_bn else aux["bias"])
-            l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, pacc), tag="post-bwd-finalize")
-            self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
-            self._scratch(l2, 3, "sums", 2 * c)
-            self.bwd += [l1, l2]
+            if FUSED_STATS:
+                l1 = Launch("bn_act_bwd_sums", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
+                                                chunk, None, self._tickets(c), None, dparam, pacc),
+                            nbytes=8 * rows * c, tag="post-bwd-reduce")
+                self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
+                self._scratch(l1, 16, "sums", 2 * c)
+                self.bwd.append(l1)
+            else:
+                l1 = Launch("bn_act_bwd_reduce", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
+                                                  chunk, None), nbytes=8 * rows * c, tag="post-bwd-reduce")
+                self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
+                l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, pacc), tag="post-bwd-finalize")
+                self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+                self._scratch(l2, 3, "sums", 2 * c)
+                self.bwd += [l1, l2]
             sums = "pending"
         if dy is not None and (has_bn or code != 0 or mask is not None):
             l3 = Launch("bn_act_bwd_apply", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c, None, dy,

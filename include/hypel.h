@@ -100,6 +100,12 @@ int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows, int32_t c,
 int hypel_bn_finalize(const float* partial, int32_t n_chunks, int32_t chunk_rows, int64_t rows, int32_t c, float eps,
                       float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
                       hypel_stream_t stream);
+/* hypel_col_stats_partial + hypel_bn_finalize in ONE launch: the last block of each 64-channel stripe to publish
+ * its partials (ticket in counters[ceil(c/64)], int32, zero before the first call; the finishing block resets it,
+ * so a HIP-graph replay needs no memset) merges that stripe's partials in the same fixed chunk order. */
+int hypel_bn_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows, float* partial,
+                       int32_t* counters, float eps, float* mean, float* rstd, float* moving_mean, float* moving_var,
+                       float decay, hypel_stream_t stream);
 /* inference: rstd[c] = 1/sqrt(moving_var[c] + eps) */
 int hypel_rstd_from_var(const float* var, int32_t c, float eps, float* rstd, hypel_stream_t stream);
 
@@ -120,6 +126,11 @@ int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64
  * dparam (beta or bias gradient) = sums[0] (+= when accumulate). */
 int hypel_bwd_reduce_finalize(const float* partial, int32_t n_chunks, int32_t c, float* sums, float* dparam,
                               int32_t accumulate, hypel_stream_t stream);
+/* hypel_bn_act_bwd_reduce + hypel_bwd_reduce_finalize in one launch (same ticket scheme as hypel_bn_stats_f32). */
+int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                          const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                          const float* mask, int64_t ldm, int32_t chunk_rows, float* partial, int32_t* counters,
+                          float* sums, float* dparam, int32_t accumulate, hypel_stream_t stream);
 /* backward pass 2: dy = rstd*(dyh - sums0/M - xhat*sums1/M)   (or dy = dyh without normalisation).
  * dy may alias dz. */
 int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,

@@ -232,6 +232,19 @@ class EmuBackend:
             po[k, 0] = m
             po[k, 1] = ((blk - m) ** 2).sum(0)
 
+    def k_bn_stats_f32(self, x, ld, rows, c, chunk_rows, partial, counters, eps, mean, rstd, mm, mv, decay):
+        assert (_arr(counters, np.int32)[: (c + 63) // 64] == 0).all(), "ticket counters must be zero between launches"
+        self.k_col_stats_partial(x, ld, rows, c, chunk_rows, partial)
+        self.k_bn_finalize(partial, (rows + chunk_rows - 1) // chunk_rows, chunk_rows, rows, c, eps, mean, rstd, mm, mv,
+                           decay)
+
+    def k_bn_act_bwd_sums(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows,
+                          partial, counters, sums, dparam, accumulate):
+        assert (_arr(counters, np.int32)[: (c + 63) // 64] == 0).all()
+        self.k_bn_act_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows,
+                                 partial)
+        self.k_bwd_reduce_finalize(partial, (rows + chunk_rows - 1) // chunk_rows, c, sums, dparam, accumulate)
+
     def k_bn_finalize(self, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, mm, mv, decay):
         po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c).astype(np.float64)
         n_a, mean_a, m2_a = 0.0, np.zeros(c), np.zeros(c)

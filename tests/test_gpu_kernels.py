@@ -204,6 +204,41 @@ def test_bn_stats_and_finalize(hip, rows, c):
     np.testing.assert_allclose(b.h["rstd"].cpu().numpy(), 1 / np.sqrt(x64.var(0) + 1e-3), rtol=1e-5)
 
 
+@pytest.mark.parametrize("rows,c", [(50176 // 8, 480), (1000, 145), (333, 60), (64, 7105)])
+def test_fused_statistics_kernels_match_two_stage(hip, rows, c):
+    """hypel_bn_stats_f32 / hypel_bn_act_bwd_sums == partial kernel + finaliser, also on the second and third call
+    (the ticket counters must come back to zero by themselves)."""
+    rng = np.random.default_rng(rows + c)
+    b = Both(hip)
+    chunk = 64
+    nch = (rows + chunk - 1) // chunk
+    x = (rng.standard_normal((rows, c)) * 2 + rng.standard_normal(c)).astype(np.float32)
+    dz = rng.standard_normal((rows, c)).astype(np.float32)
+    b.arr("x", x)
+    b.arr("dz", dz)
+    b.arr("part", np.zeros(nch * 2 * c, np.float32))
+    b.arr("tick", np.zeros(256, np.int32))
+    for nm in ("mean", "rstd", "dbeta"):
+        b.arr(nm, np.zeros(c, np.float32))
+    b.arr("sums", np.zeros(2 * c, np.float32))
+    b.arr("beta", rng.standard_normal(c).astype(np.float32))
+    b.arr("mm", rng.standard_normal(c).astype(np.float32))
+    b.arr("mv", (rng.random(c) + 0.5).astype(np.float32))
+    for rep in range(3):
+        b.run("bn_stats_f32", "x", c, rows, c, chunk, "part", "tick", 1e-3, "mean", "rstd", "mm", "mv", 0.95)
+        for nm in ("mean", "rstd", "mm", "mv"):
+            b.check(nm, rtol=1e-5, atol=1e-6)
+        assert int(b.h["tick"].abs().sum()) == 0
+        b.run("bn_act_bwd_sums", "dz", c, "x", c, rows, c, "mean", "rstd", "beta", 1, 0.18, None, 0, chunk, "part", "tick",
+              "sums", "dbeta", rep > 0)
+        b.check("sums", rtol=2e-4, atol=2e-4)
+        b.check("dbeta", rtol=2e-4, atol=2e-4)
+        assert int(b.h["tick"].abs().sum()) == 0
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(b.h["mean"].cpu().numpy(), x64.mean(0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b.h["rstd"].cpu().numpy(), 1 / np.sqrt(x64.var(0) + 1e-3), rtol=1e-5)
+
+
 @pytest.mark.parametrize("act,use_bn,use_mask,nres", [(1, True, False, 2), (3, True, False, 0), (0, True, False, 0),
                                                      (1, False, True, 1), (2, False, False, 1), (4, False, False, 0),
                                                      (1, True, True, 0)])
