@@ -7,6 +7,10 @@
 
 #include "common.h"
 
+#ifndef HYPEL_TAIL_ACQUIRE
+#define HYPEL_TAIL_ACQUIRE 1
+#endif
+
 namespace {
 
 constexpr int STAT_TX = 64;  // threads along channels
@@ -161,6 +165,23 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t 
 constexpr int STAT_V4_TY = 16;
 
 // Combine the chunk partials: mean = sum n_k mean_k / N, M2 = sum (M2_k + n_k (mean_k - mean)^2), both as fp64
+// MI355X has one L2 per XCD and they are not coherent with each other inside a kernel: a device-scope fence per
+// block (what __threadfence() costs: an L2 write-back) made these kernels 10x slower.  Instead the few values that
+// cross blocks -- the chunk partials and the ticket -- are written and read with agent-scope atomics (write-through /
+// L2-bypassing accesses), and each writer drains its stores (s_waitcnt) before its block takes a ticket.
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COHERENT>
+__device__ __forceinline__ float ld_partial(const float* p) {
+#if HYPEL_TAIL_ACQUIRE
+    return *p;  // the finishing block invalidated its caches once (stripe_is_complete)
+#else
+    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+#endif
+}
+
 // sums with a FIXED association (16 strided lanes per channel, then an xor tree) -> deterministic, and ~20x
 // shorter than a serial Chan chain over ~200 chunks.  block = 16 channels x 16 lanes.
 __device__ __forceinline__ double lanes16_sum(double v, double* sh) {
@@ -176,6 +197,7 @@ __device__ __forceinline__ double lanes16_sum(double v, double* sh) {
 }
 
 // body of the statistics finaliser for the 16 channels [blk16*16, blk16*16+16); all 256 threads of a block call it
+template <bool COHERENT>
 __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks,
                                                  int chunk_rows, int64_t rows, int c, float eps,
                                                  float* __restrict__ mean, float* __restrict__ rstd,
@@ -189,7 +211,7 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
     for (int k = lane; k < n_chunks; k += 16) {
         const int64_t r0 = (int64_t)k * chunk_rows;
         const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
-        if (ok) s += n_k * (double)partial[(int64_t)k * 2 * c + col];
+        if (ok) s += n_k * (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + col);
     }
     const double mean_a = lanes16_sum(s, sh) / n_total;
     double m2 = 0.0;
@@ -197,8 +219,8 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
         const int64_t r0 = (int64_t)k * chunk_rows;
         const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
         if (ok) {
-            const double d = (double)partial[(int64_t)k * 2 * c + col] - mean_a;
-            m2 += (double)partial[(int64_t)k * 2 * c + c + col] + n_k * d * d;
+            const double d = (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + col) - mean_a;
+            m2 += (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + col) + n_k * d * d;
         }
     }
     const double m2_a = lanes16_sum(m2, sh);
@@ -220,8 +242,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                            float* __restrict__ moving_mean,
                                                            float* __restrict__ moving_var, float decay) {
     __shared__ double sh[64];
-    bn_finalize_body(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, moving_mean, moving_var,
-                     decay, sh);
+    bn_finalize_body<false>(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, moving_mean,
+                            moving_var, decay, sh);
 }
 
 // Fused statistics: the LAST block of a 64-channel stripe to publish its partials (ticket counter, self-resetting so
@@ -239,15 +261,17 @@ struct BnFin {
 
 __device__ __forceinline__ bool stripe_is_complete(int* counters) {
     __shared__ int last;
-    __threadfence();  // this block's partials are visible device-wide before the ticket is taken
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = atomicAdd(&counters[blockIdx.y], 1);
+        const int t = __hip_atomic_fetch_add(&counters[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (t == (int)gridDim.x - 1);
-        if (last) counters[blockIdx.y] = 0;
+        if (last) __hip_atomic_store(&counters[blockIdx.y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (last) __threadfence();  // acquire: the other blocks' partials
+#if HYPEL_TAIL_ACQUIRE
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     return last != 0;
 }
 
@@ -257,7 +281,7 @@ __device__ __forceinline__ void bn_stats_tail(const BnFin& f, const float* parti
     if (f.counters == nullptr) return;
     if (!stripe_is_complete(f.counters)) return;
     for (int q = 0; q < STAT_TX / 16; ++q)
-        bn_finalize_body(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, chunk_rows, rows, c, f.eps, f.mean,
+        bn_finalize_body<true>(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, chunk_rows, rows, c, f.eps, f.mean,
                          f.rstd, f.moving_mean, f.moving_var, f.decay, shd);
 }
 
@@ -294,8 +318,13 @@ __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __r
         float m2 = tss - ts * mean_d;
         if (m2 < 0.0f) m2 = 0.0f;
         float* po = partial + (int64_t)blockIdx.x * 2 * c;
-        po[col] = shift + mean_d;
-        po[c + col] = m2;
+        if (fin.counters) {
+            st_agent(po + col, shift + mean_d);
+            st_agent(po + c + col, m2);
+        } else {
+            po[col] = shift + mean_d;
+            po[c + col] = m2;
+        }
     }
     bn_stats_tail(fin, partial, chunk_rows, rows, c);
 }
@@ -336,8 +365,13 @@ __global__ __launch_bounds__(256) void col_stats_partial_v4_kernel(const float* 
             float m2 = tss - ts * mean_d;
             if (m2 < 0.0f) m2 = 0.0f;
             float* po = partial + (int64_t)blockIdx.x * 2 * c;
-            po[cc] = x[r0 * ld + cc] + mean_d;
-            po[c + cc] = m2;
+            if (fin.counters) {
+                st_agent(po + cc, x[r0 * ld + cc] + mean_d);
+                st_agent(po + c + cc, m2);
+            } else {
+                po[cc] = x[r0 * ld + cc] + mean_d;
+                po[c + cc] = m2;
+            }
         }
     }
     bn_stats_tail(fin, partial, chunk_rows, rows, c);
@@ -420,6 +454,7 @@ __device__ __forceinline__ void bwd_elem(const float* __restrict__ dz, int64_t l
 
 // float4 x 16 row lanes (see col_stats_partial_v4_kernel)
 
+template <bool COHERENT>
 __device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks, int c,
                                                   float* __restrict__ sums, float* __restrict__ dparam,
                                                   int accumulate, double* sh) {
@@ -429,8 +464,8 @@ __device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __rest
     double a = 0.0, b = 0.0;
     for (int k = lane; k < n_chunks; k += 16) {
         if (ok) {
-            a += (double)partial[(int64_t)k * 2 * c + col];
-            b += (double)partial[(int64_t)k * 2 * c + c + col];
+            a += (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + col);
+            b += (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + col);
         }
     }
     a = lanes16_sum(a, sh);
@@ -446,7 +481,7 @@ __global__ __launch_bounds__(256) void bwd_reduce_finalize_kernel(const float* _
                                                                    int c, float* __restrict__ sums,
                                                                    float* __restrict__ dparam, int accumulate) {
     __shared__ double sh[64];
-    bwd_finalize_body(blockIdx.x, partial, n_chunks, c, sums, dparam, accumulate, sh);
+    bwd_finalize_body<false>(blockIdx.x, partial, n_chunks, c, sums, dparam, accumulate, sh);
 }
 
 struct BwdFin {
@@ -461,7 +496,7 @@ __device__ __forceinline__ void bwd_reduce_tail(const BwdFin& f, const float* pa
     if (f.counters == nullptr) return;
     if (!stripe_is_complete(f.counters)) return;
     for (int q = 0; q < STAT_TX / 16; ++q)
-        bwd_finalize_body(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, c, f.sums, f.dparam, f.accumulate,
+        bwd_finalize_body<true>(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, c, f.sums, f.dparam, f.accumulate,
                           shd);
 }
 
@@ -496,8 +531,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
             t1 += sh[1][k][tx];
         }
         float* po = partial + (int64_t)blockIdx.x * 2 * c;
-        po[col] = t0;
-        po[c + col] = t1;
+        if (fin.counters) {
+            st_agent(po + col, t0);
+            st_agent(po + c + col, t1);
+        } else {
+            po[col] = t0;
+            po[c + col] = t1;
+        }
     }
     bwd_reduce_tail(fin, partial, c);
 }
@@ -559,8 +599,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
                 t1 += sh[1][k][tx];
             }
             float* po = partial + (int64_t)blockIdx.x * 2 * c;
-            po[cc] = t0;
-            po[c + cc] = t1;
+            if (fin.counters) {
+                st_agent(po + cc, t0);
+                st_agent(po + c + cc, t1);
+            } else {
+                po[cc] = t0;
+                po[c + cc] = t1;
+            }
         }
     }
     bwd_reduce_tail(fin, partial, c);

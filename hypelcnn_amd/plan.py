@@ -49,7 +49,10 @@ class Launch:
 
 
 USE_SIDE_STREAM = True
-FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "1") != "0"  # statistics kernels finalise themselves
+# Statistics kernels that finalise themselves (last block of a channel stripe, ticket counter): correct and tested,
+# but measured SLOWER on MI355X (8.65 vs 7.88 ms/step): every block pays the round trip of a device-scope atomic
+# through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
+FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
 FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 
 
