@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhypel_hip.so")
+# HYPEL_LIB_PATH: an alternative build of the same ABI (A/B experiments on one GPU box)
+LIB_PATH = os.environ.get("HYPEL_LIB_PATH") or os.path.join(_HERE, "csrc", "libhypel_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 GEMM_BM = 128

@@ -27,6 +27,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
+#ifndef HYPEL_GEMM_SETPRIO
+#define HYPEL_GEMM_SETPRIO 1
+#endif
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
@@ -198,6 +201,9 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
         // pipelines the ds_reads under the MFMAs).  Ragged shapes rely on the zero-filled LDS image; the
         // only skips are wave-uniform: a wave with no active tile, and the second half of a short k-tile.
         if (any_act) {
+#if HYPEL_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
+#endif
 #pragma unroll
             for (int k2 = 0; k2 < BK / 4; ++k2) {
                 float a[TM], b[TN];
@@ -226,6 +232,9 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
             }
+#if HYPEL_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     }
 

@@ -32,6 +32,7 @@ def stat_chunk_rows(rows):
     return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
 TARGET_BLOCKS = 1024
+WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
 MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
 
@@ -875,7 +876,7 @@ class TowerPlan:
         XCD streams its own rows of X and dY through its L2 once while all taps consume them (the per-tap
         formulation re-fetched them 10-20x).  Multi-tap levels use row ranges only; single-tap layers also cut the
         pixel list, otherwise the launch would have too few blocks."""
-        want = max(1, min(64, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
+        want = max(1, min(WGRAD_MAX_SPLITS, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
         max_row = max(1, self.nb // 64)
         s_row = min(want, max_row)
         if s_row >= 5:  # a multiple of 8 row ranges maps whole ranges onto the 8 XCDs
