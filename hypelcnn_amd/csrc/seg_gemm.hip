@@ -314,7 +314,13 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     static const int bn128 = getenv("HYPEL_GEMM_BN128") ? atoi(getenv("HYPEL_GEMM_BN128")) : 0;
     // launches with fewer than ~one round of 128x64 blocks (level data gradients: 784) balance better as 128x32
     static const int bn32_below = getenv("HYPEL_GEMM_BN32_BELOW") ? atoi(getenv("HYPEL_GEMM_BN32_BELOW")) : 1000;
-    if (n <= 32 || (int64_t)n_tiles * ((n + 63) / 64) < bn32_below)
+    // bits 8-9 of `accumulate`: tile-width hint of the caller (1 = 128x32, 2 = 128x64), measured per launch class
+    // (profiles/r1_gemm_tile_choice.txt): data gradients with >= 48 reduction columns per segment and launches with
+    // few blocks run faster on the narrow tile, wide filter gradients on the wide one
+    const int hint = (accumulate >> 8) & 3;
+    accumulate &= 1;
+    const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
+    if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st);
     else if (n <= 64 || !bn128)

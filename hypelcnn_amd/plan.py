@@ -54,6 +54,7 @@ USE_SIDE_STREAM = True
 # but measured SLOWER on MI355X (8.65 vs 7.88 ms/step): every block pays the round trip of a device-scope atomic
 # through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
 FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
+TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
 FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 
 
@@ -321,6 +322,21 @@ class TowerPlan:
                 out.add_group(s * count + (c_off - c_min), parts[s], rows)
         return out, S, c_min, count
 
+    @staticmethod
+    def _tile_hint(tables, n, ta, tb):
+        """Tile-width hint for hypel_seg_gemm_f32 (bits 8-9 of `accumulate`), from the per-launch A/B measurements in
+        profiles/r1_gemm_tile_choice.txt: 1 = 128x32, 2 = 128x64, 0 = library default."""
+        if n <= 32:
+            return 0
+        n_tiles = sum((rows + GEMM_BM - 1) // GEMM_BM for _, _, rows in tables.groups)
+        blocks64 = n_tiles * ((n + 63) // 64)
+        if tb and not ta:  # data gradient: narrow tiles unless the segments are short (per-k-tile overhead dominates)
+            ks = [k for _, segs, _ in tables.groups for _, _, k in segs]
+            return 1 if ks and sum(ks) / len(ks) >= 48 else 2
+        if ta:  # filter gradient: narrow tiles only to get enough blocks
+            return 1 if blocks64 < 768 else 2
+        return 1 if blocks64 < 768 else 2
+
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
                    allow_split=True, res=None):
         """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32)."""
@@ -341,8 +357,9 @@ class TowerPlan:
             return
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
+        hint = self._tile_hint(tables, n, ta, tb) if TILE_HINTS else 0
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
-                Ref(t_t), int(len(tarr)), bias_ref, int(accumulate))
+                Ref(t_t), int(len(tarr)), bias_ref, int(accumulate) | (hint << 8))
         name = "seg_gemm_f32"
         if res is not None:
             name = "seg_gemm_res_f32"

@@ -68,6 +68,8 @@ typedef struct { int64_t c_off; int32_t seg_begin; int32_t seg_count; int32_t ro
 typedef struct { int32_t group; int32_t m0; } hypel_tile_t;
 #define HYPEL_GEMM_BM 128
 
+/* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint
+ * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks) -- results do not depend on it. */
 int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb, int32_t trans_b,
                        float* c, int64_t ldc, int32_t n, const hypel_group_t* groups, const hypel_seg_t* segs,
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,

@@ -165,6 +165,7 @@ class EmuBackend:
                     cm[:, col] += rm.astype(np.float64).sum(1).astype(np.float32)
 
     def k_seg_gemm_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate):
+        accumulate &= 1  # bits 8-9 carry a tile-width hint that must not change the result
         A, B, C = _arr(a), _arr(b), _arr(c)
         g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
         s = segs.t.numpy()[segs.off:].view(SEG_DTYPE)
