@@ -79,6 +79,7 @@ SIGNATURES = {
     "step_inc": [_P],
     "argmax_confusion": [_P, _I64, _I64, _I32, _P, _P, _P],
     "gather_patches_f32": [_P, _P, _I64, _I64, _I32, _I32, _P, _I64, _I32, _P],
+    "gather_patches_2x_f32": [_P, _P, _I64, _I64, _I32, _I32, _I32, _P, _I64, _I32, _P],
     "augment_patches_f32": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     "argmax_scatter": [_P, _I64, _I64, _I32, _P, _P, _I64],
     "lrn_fwd": [_P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64],

@@ -242,6 +242,8 @@ class SceneArrays:
         self.points = torch.from_numpy(numpy.ascontiguousarray(t[:, :2], dtype=numpy.int32)).to(dev)
         self.labels = torch.from_numpy(numpy.ascontiguousarray(t[:, 2]).astype(numpy.int64)).to(dev)
         self.shape = tuple(data_set.get_data_shape())
+        self.casi_scale = int(getattr(data_set, "casi_scale", 1))  # 2: GRSS2018 (HSI at half the LiDAR resolution)
+        self.neighborhood = int(data_set.neighborhood)
 
     def __len__(self):
         return 0 if self.points is None else self.points.shape[0]
@@ -254,6 +256,11 @@ class SceneArrays:
         out = torch.empty((b, p, p, c), dtype=torch.float32, device=self.casi.device)
         hp, wp, cc = self.casi.shape
         cl = 0 if self.lidar is None else int(self.lidar.shape[2])
+        if self.casi_scale == 2:
+            self.backend.call("gather_patches_2x_f32", Ref(self.casi.reshape(-1)), Ref(self.lidar.reshape(-1)), int(wp),
+                              int(self.lidar.shape[1]), int(cc), cl, self.neighborhood, Ref(pts.reshape(-1)), b, int(p),
+                              Ref(out.reshape(-1)))
+            return out, pts
         self.backend.call("gather_patches_f32", Ref(self.casi.reshape(-1)),
                           None if self.lidar is None else Ref(self.lidar.reshape(-1)), int(hp), int(wp), int(cc), cl,
                           Ref(pts.reshape(-1)), b, int(p), Ref(out.reshape(-1)))
@@ -721,6 +728,47 @@ def read_targets_from_image(targets, class_range):
         rows = numpy.stack([xs.astype(int), ys.astype(int), numpy.full(len(xs), target_index, dtype=int)], axis=1)
         result = numpy.vstack([result, rows])
     return result
+
+
+# ----------------------------------------------------------------------------- sample splits (reference :497-543)
+def _stratified_split(rows, labels, **split_args):
+    from sklearn.model_selection import StratifiedShuffleSplit
+    first, second = next(StratifiedShuffleSplit(n_splits=1, **split_args).split(rows, labels))
+    return first, second
+
+
+def shuffle_training_data_using_ratio(result, train_data_ratio):
+    """Stratified (by class column 2) split into (train, validation); unseeded, like the reference."""
+    tr, va = _stratified_split(result[:, 0:1], result[:, 2], train_size=train_data_ratio)
+    return result[tr], result[va]
+
+
+def shuffle_training_data_using_size(class_count, result, train_data_size, validation_size):
+    """Per class: `train_data_size` random samples for training (90 % of the class when it is smaller), the rest --
+    or a random `validation_size` of the rest -- for validation."""
+    train_parts, val_parts = [], []
+    for sample_class in class_count:
+        ids = numpy.where(result[:, 2] == sample_class)[0]
+        if ids.size == 0:
+            continue
+        take = (ids.size * 9) // 10 if ids.size < train_data_size else train_data_size
+        chosen = numpy.random.choice(ids.size, take, replace=False)
+        rest = numpy.setdiff1d(numpy.arange(ids.size), chosen)
+        if validation_size is not None:
+            rest = rest[numpy.random.choice(rest.size, min(validation_size, rest.size), replace=False)]
+        train_parts.append(result[ids[chosen]])
+        val_parts.append(result[ids[rest]])
+    empty = numpy.empty([0, result.shape[1]], dtype=int)
+    return (numpy.vstack(train_parts) if train_parts else empty), (numpy.vstack(val_parts) if val_parts else empty)
+
+
+def shuffle_test_data_using_ratio(train_set, test_data_ratio):
+    """Stratified split of the training rows into (test, remaining train), random_state 0; empty test set for ratio 0."""
+    test_set = numpy.empty([0, train_set.shape[1]])
+    if test_data_ratio > 0:
+        tr, te = _stratified_split(train_set[:, 0:1], train_set[:, 2], test_size=test_data_ratio, random_state=0)
+        test_set, train_set = train_set[te], train_set[tr]
+    return test_set, train_set
 
 
 def calculate_shadow_ratio(casi, shadow_map, shadow_map_inverse):

@@ -38,6 +38,31 @@ __global__ void gather_patches_kernel(const float* __restrict__ casi, const floa
     }
 }
 
+// GRSS2018: the hyperspectral raster has HALF the resolution of the LiDAR raster the targets are given in
+// (loader/GRSS2018DataLoader.py:12-44): patch pixel (py, px) takes its spectrum from
+// casi[sy + py/2][sx + px/2] with s = coordinate/2 + nb - nb/2 (both rasters are padded by nb) and its height from
+// lidar[y + py][x + px].
+__global__ void gather_patches_2x_kernel(const float* __restrict__ casi, const float* __restrict__ lidar,
+                                         int64_t casi_wp, int64_t lidar_wp, int cc, int cl, int nb,
+                                         const int32_t* __restrict__ points, int64_t n, int p,
+                                         float* __restrict__ out) {
+    const int c = cc + cl;
+    const int npix = p * p;
+    const int64_t total = n * npix;
+    for (int64_t item = blockIdx.x; item < total; item += gridDim.x) {
+        const int64_t s = item / npix;
+        const int pix = (int)(item - s * npix);
+        const int py = pix / p, px = pix - py * p;
+        const int64_t x0 = points[2 * s], y0 = points[2 * s + 1];
+        const int64_t sx = (x0 >> 1) + nb - (nb >> 1), sy = (y0 >> 1) + nb - (nb >> 1);
+        const float* a = casi + ((sy + (py >> 1)) * casi_wp + sx + (px >> 1)) * cc;
+        float* o = out + item * c;
+        for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) o[ch] = a[ch];
+        const float* l = lidar + ((y0 + py) * lidar_wp + x0 + px) * cl;
+        for (int ch = threadIdx.x; ch < cl; ch += blockDim.x) o[cc + ch] = l[ch];
+    }
+}
+
 __global__ void augment_patches_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int64_t n, int p,
                                        int c, const int32_t* __restrict__ rot_k,
                                        const uint8_t* __restrict__ shadow_pick, const float* __restrict__ shadow_ratio,
@@ -110,6 +135,19 @@ extern "C" int hypel_gather_patches_f32(const float* casi, const float* lidar, i
     hipLaunchKernelGGL(gather_patches_kernel, dim3(hypel_grid_1d(n * p * p, 1, 256 * 32)), dim3(block), 0, ST, casi,
                        lidar, wp, cc, cl, points, n, p, out);
     HYPEL_CHECK_LAUNCH("hypel_gather_patches_f32");
+    return 0;
+}
+
+extern "C" int hypel_gather_patches_2x_f32(const float* casi, const float* lidar, int64_t casi_wp, int64_t lidar_wp,
+                                           int32_t cc, int32_t cl, int32_t neighborhood, const int32_t* points,
+                                           int64_t n, int32_t p, float* out, hypel_stream_t stream) {
+    HYPEL_REQUIRE(casi && lidar && points && out && n > 0 && p > 0 && cc > 0 && cl > 0 && neighborhood >= 0,
+                  "hypel_gather_patches_2x_f32");
+    const int c = cc + cl;
+    const int block = c >= 192 ? 256 : (c >= 96 ? 128 : 64);
+    hipLaunchKernelGGL(gather_patches_2x_kernel, dim3(hypel_grid_1d(n * p * p, 1, 256 * 32)), dim3(block), 0, ST, casi,
+                       lidar, casi_wp, lidar_wp, cc, cl, neighborhood, points, n, p, out);
+    HYPEL_CHECK_LAUNCH("hypel_gather_patches_2x_f32");
     return 0;
 }
 

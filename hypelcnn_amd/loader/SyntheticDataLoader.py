@@ -17,6 +17,8 @@ PRESETS = {
     "grss2018": dict(bands=48, classes=20, lidar=1, h=60, w=80, lo=380, hi=1050),
     "gulfport": dict(bands=64, classes=11, lidar=1, h=50, w=60, lo=368, hi=1043),
     "avon": dict(bands=360, classes=2, lidar=0, h=40, w=50, lo=400, hi=2500),
+    # the real GRSS2018 geometry: HSI at half the resolution of the LiDAR grid the samples live on
+    "grss2018hr": dict(bands=48, classes=20, lidar=1, h=60, w=80, lo=380, hi=1050, half_res=1),
 }
 
 
@@ -60,6 +62,16 @@ class SyntheticDataLoader(DataLoader):
     def load_data(self, neighborhood, normalize):
         casi, lidar, labels = self._scene()
         self._labels = labels
+        if self.cfg.get("half_res"):
+            from hypelcnn_amd.loader.GRSS2018DataLoader import GRSS2018DataSet
+            h, w = casi.shape[:2]
+            half = numpy.ascontiguousarray(casi[::2, ::2])
+            half = numpy.pad(half, ((0, (h + 1) // 2 + 1 - half.shape[0]), (0, (w + 1) // 2 + 1 - half.shape[1]), (0, 0)),
+                             mode="edge")
+            data_set = GRSS2018DataSet(shadow_creator_dict=None, casi=half, lidar=lidar, neighborhood=neighborhood,
+                                       normalize=normalize)
+            data_set.shadow_creator_dict = {}
+            return data_set
         data_set = BasicDataSet(shadow_creator_dict=None, casi=casi, lidar=lidar, neighborhood=neighborhood,
                                 normalize=normalize)
         # the shadow augmenters the reference's loaders register (loader/GRSS2013DataLoader.py:24-34): the per-band

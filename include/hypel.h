@@ -194,6 +194,11 @@ int hypel_argmax_confusion(const float* logits, int64_t ld, int64_t n, int32_t c
  * raster[y * raster_w + x] = argmax(logits[i]) for points[i] = (x, y). */
 int hypel_gather_patches_f32(const float* casi, const float* lidar, int64_t hp, int64_t wp, int32_t cc, int32_t cl,
                              const int32_t* points, int64_t n, int32_t p, float* out, hypel_stream_t stream);
+/* GRSS2018DataSet.get_data_point (loader/GRSS2018DataLoader.py:12-44): casi [*, casi_wp, cc] has half the
+ * resolution of lidar [*, lidar_wp, cl]; both are padded by `neighborhood`; points are LiDAR-grid coordinates. */
+int hypel_gather_patches_2x_f32(const float* casi, const float* lidar, int64_t casi_wp, int64_t lidar_wp, int32_t cc,
+                                int32_t cl, int32_t neighborhood, const int32_t* points, int64_t n, int32_t p,
+                                float* out, hypel_stream_t stream);
 int hypel_augment_patches_f32(const float* x, const int64_t* idx, int64_t n, int32_t p, int32_t c,
                               const int32_t* rot_k, const uint8_t* shadow_pick, const float* shadow_ratio,
                               const float* shadow_alt, const uint8_t* flip_lr, const uint8_t* flip_ud,

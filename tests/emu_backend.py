@@ -111,6 +111,19 @@ class EmuBackend:
             if ls is not None:
                 o[i, :, :, cc:] = ls[y0:y0 + p, x0:x0 + p]
 
+    def k_gather_patches_2x_f32(self, casi, lidar, casi_wp, lidar_wp, cc, cl, nb, points, n, p, out):
+        ca, la = _arr(casi), _arr(lidar)
+        pts = _arr(points, np.int32)[: 2 * n].reshape(n, 2)
+        o = _arr(out)[: n * p * p * (cc + cl)].reshape(n, p, p, cc + cl)
+        for i, (x0, y0) in enumerate(pts):
+            sx, sy = int(x0 * 0.5) + nb - int(nb * 0.5), int(y0 * 0.5) + nb - int(nb * 0.5)
+            for py in range(p):
+                for px in range(p):
+                    q = ((sy + int(py * 0.5)) * casi_wp + sx + int(px * 0.5)) * cc
+                    o[i, py, px, :cc] = ca[q:q + cc]
+                    q = ((y0 + py) * lidar_wp + x0 + px) * cl
+                    o[i, py, px, cc:] = la[q:q + cl]
+
     def k_augment_patches_f32(self, x, idx, n, p, c, rot_k, pick, ratio, alt, flip_lr, flip_ud, delta, out):
         ix = np.arange(n) if idx is None else _arr(idx, np.int64)[:n]
         xa = _arr(x)

@@ -12,8 +12,10 @@ function called below is pure numpy / pure Python in the reference:
   utilities/stat_extractor.py:24-62,91-110 calc_kappa, extract_accuracy_metrics
   gan/gan_sampling_methods.py:191-201      DummySampler
   common/cmd_parser.py                     flag defaults
+  loader/GRSS2018DataLoader.py:10-44       GRSS2018DataSet.get_data_point (half-resolution HSI under full-resolution
+                                           LiDAR; numba.jit replaced by a pass-through decorator)
 
-Output: tests/golden/reference_numpy_side.npz + reference_numpy_side.json (data only).
+Output: tests/golden/reference_numpy_side.npz + reference_numpy_side.json, reference_grss2018.npz (data only).
 """
 import importlib.abc
 import importlib.machinery
@@ -66,6 +68,8 @@ def main():
     sys.meta_path.insert(0, _Finder())
     sys.path.insert(0, REF)
     import tensorflow as tf  # the stand-in
+    import numba
+    numba.jit = lambda *a, **k: (lambda f: f)  # the loops are plain Python; numba only compiles them
 
     captured = {}
 
@@ -193,6 +197,25 @@ def main():
     # ---- is_integer_num ----------------------------------------------------------------
     from common import common_ops
     meta["is_integer_num"] = [[repr(v), bool(common_ops.is_integer_num(v))] for v in (1, 2.0, 2.5, 1 / (145 / 120), "3")]
+
+    # ---- GRSS2018DataSet: HSI at half the LiDAR resolution (own fixture file, own RNG stream) ----------------
+    from loader.GRSS2018DataLoader import GRSS2018DataSet
+    rng18 = numpy.random.RandomState(2018)
+    g18 = {}
+    for tag, (h, w, c, nb) in {"a": (14, 18, 5, 2), "b": (10, 12, 3, 5)}.items():
+        lidar = (rng18.rand(h, w, 1).astype(numpy.float32) * 30.0 + 5.0)
+        casi = rng18.rand((h + 1) // 2 + 1, (w + 1) // 2 + 1, c).astype(numpy.float32) * 3000.0
+        ds = GRSS2018DataSet(shadow_creator_dict=None, casi=casi.copy(), lidar=lidar.copy(), neighborhood=nb,
+                             normalize=True)
+        pts = [(0, 0), (w - 1, h - 1), (3, 5), (w - 1, 0), (0, h - 1), (w // 2, h // 2), (1, 1), (2, 7)]
+        g18[f"{tag}_casi"] = casi
+        g18[f"{tag}_lidar"] = lidar
+        g18[f"{tag}_nb"] = numpy.asarray(nb)
+        g18[f"{tag}_points"] = numpy.asarray(pts, dtype=numpy.int32)
+        g18[f"{tag}_patches"] = numpy.stack([ds.get_data_point(px, py) for px, py in pts]).astype(numpy.float32)
+        g18[f"{tag}_data_shape"] = numpy.asarray(ds.get_data_shape())
+        g18[f"{tag}_scene_shape"] = numpy.asarray(ds.get_scene_shape())
+    numpy.savez_compressed(os.path.join(OUT, "reference_grss2018.npz"), **g18)
 
     numpy.savez_compressed(os.path.join(OUT, "reference_numpy_side.npz"), **arrays)
     with open(os.path.join(OUT, "reference_numpy_side.json"), "w") as f:

@@ -274,3 +274,58 @@ def test_gpu_full_scene_inference_matches_emulation(hip, tmp_path):
     # same checkpoint, fp32 GEMM order differs from the float64-accumulating emulation: labels may flip only where two
     # logits are within rounding of each other
     assert (raster_gpu == raster_emu).mean() > 0.995
+
+
+# ------------------------------------------------------------------------------------------------ GRSS2018 (2x)
+@pytest.fixture(scope="module")
+def golden18():
+    return np.load(os.path.join(HERE, "golden", "reference_grss2018.npz"))
+
+
+def _grss2018(g, tag):
+    from hypelcnn_amd.loader.GRSS2018DataLoader import GRSS2018DataSet
+    return GRSS2018DataSet(shadow_creator_dict=None, casi=g[f"{tag}_casi"].copy(), lidar=g[f"{tag}_lidar"].copy(),
+                           neighborhood=int(g[f"{tag}_nb"]), normalize=True)
+
+
+def test_grss2018_dataset_and_gather_match_reference_patches(golden18):
+    """Host get_data_point and the device gather (emulated) against patches captured from the reference's
+    GRSS2018DataSet (half-resolution HSI under the LiDAR grid)."""
+    g = golden18
+    be = EmuBackend()
+    for tag in ("a", "b"):
+        ds = _grss2018(g, tag)
+        assert list(ds.get_data_shape()) == list(g[f"{tag}_data_shape"])
+        assert list(ds.get_scene_shape()) == list(g[f"{tag}_scene_shape"])
+        pts = g[f"{tag}_points"]
+        host = np.stack([ds.get_data_point(int(px), int(py)) for px, py in pts]).astype(np.float32)
+        np.testing.assert_array_equal(host, g[f"{tag}_patches"])
+        sa = cno.SceneArrays()
+        sa.feed(ds, np.concatenate([pts, np.zeros((len(pts), 1), pts.dtype)], axis=1), be)
+        got, _ = sa.gather(torch.arange(len(pts)))
+        np.testing.assert_array_equal(got.numpy(), g[f"{tag}_patches"])
+
+
+def test_two_resolution_scene_trains_through_both_importers(tmp_path):
+    global SCENE
+    old = SCENE
+    SCENE = "grss2018hr:h=20:w=26:bands=6:classes=3:samples=0.6"
+    try:
+        r1, _, _ = _train(tmp_path / "a", "InMemoryImporter", EmuBackend(), steps=8)
+        r2, _, _ = _train(tmp_path / "b", "GeneratorImporter", EmuBackend(), steps=8)
+    finally:
+        SCENE = old
+    assert np.isfinite(r1.loss) and r1.loss == r2.loss
+
+
+@pytest.mark.gpu
+def test_gpu_gather_2x_bit_exact(hip, golden18):
+    g = golden18
+    for tag in ("a", "b"):
+        ds = _grss2018(g, tag)
+        pts = g[f"{tag}_points"]
+        sa = cno.SceneArrays()
+        sa.feed(ds, np.concatenate([pts, np.zeros((len(pts), 1), pts.dtype)], axis=1), hip)
+        got, _ = sa.gather(torch.arange(len(pts), device=hip.device))
+        hip.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), g[f"{tag}_patches"])
