@@ -67,10 +67,14 @@ class SummaryWriter:
 
 
 def latest_checkpoint(log_dir):
-    files = glob.glob(os.path.join(log_dir, "model.ckpt-*.npz")) if log_dir else []
-    if not files:
-        return None
-    return max(files, key=lambda p: int(re.search(r"ckpt-(\d+)\.npz$", p).group(1)))
+    """Newest model.ckpt-N in the directory: .npz files of this build or TensorFlow bundles (returned as prefix)."""
+    cands = []
+    if log_dir:
+        for f in glob.glob(os.path.join(log_dir, "model.ckpt-*.npz")):
+            cands.append((int(re.search(r"ckpt-(\d+)\.npz$", f).group(1)), 1, f))
+        for f in glob.glob(os.path.join(log_dir, "model.ckpt-*.index")):
+            cands.append((int(re.search(r"ckpt-(\d+)\.index$", f).group(1)), 0, f[:-len(".index")]))
+    return max(cands)[2] if cands else None
 
 
 def save_checkpoint(sess, log_dir, step):
@@ -86,8 +90,26 @@ def save_checkpoint(sess, log_dir, step):
 
 
 def restore_checkpoint(sess, path):
+    """`path`: an .npz written by save_checkpoint, or the prefix of a TensorFlow bundle (model.ckpt-N with its .index /
+    .data-00000-of-00001 files, what the reference's Saver writes) -- read without TensorFlow."""
+    from hypelcnn_amd.common import tf_checkpoint
+    if not path.endswith(".npz") and tf_checkpoint.is_checkpoint(path):
+        tf_checkpoint.variables_to_session(sess, tf_checkpoint.read_checkpoint(path))
+        return
     with numpy.load(path) as z:
         sess.load_state_dict({k.replace("|", "/"): z[k] for k in z.files})
+
+
+def export_tf_checkpoint(sess, prefix):
+    """Writes the session as a TensorFlow checkpoint bundle (variables, global_step, Adam slots under the TF1 names)
+    plus the `checkpoint` state file tf.train.latest_checkpoint reads."""
+    from hypelcnn_amd.common import tf_checkpoint
+    sess.average_state()
+    tf_checkpoint.write_checkpoint(prefix, tf_checkpoint.session_to_variables(sess))
+    with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"), "w") as f:
+        base = os.path.basename(prefix)
+        f.write(f'model_checkpoint_path: "{base}"\nall_model_checkpoint_paths: "{base}"\n')
+    return prefix
 
 
 class ValidationHook:

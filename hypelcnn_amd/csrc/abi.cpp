@@ -35,6 +35,40 @@ extern "C" int hypel_device_info(int32_t* n_cu, int32_t* n_xcd) {
     return 0;
 }
 
+// CRC-32C (Castagnoli), slicing-by-8, host side: TensorFlow checkpoint bundles carry a masked CRC-32C per tensor and
+// per index block (tensorflow/core/lib/hash/crc32c.h); Python has no fast implementation of this polynomial.
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_ready = false;
+static void crc_init() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+        g_crc_tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+    g_crc_ready = true;
+}
+
+extern "C" uint32_t hypel_crc32c(uint32_t crc, const void* data, uint64_t n) {
+    if (!g_crc_ready) crc_init();
+    const uint8_t* p = (const uint8_t*)data;
+    uint32_t c = crc ^ 0xffffffffu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = g_crc_tab[7][lo & 0xff] ^ g_crc_tab[6][(lo >> 8) & 0xff] ^ g_crc_tab[5][(lo >> 16) & 0xff] ^
+            g_crc_tab[4][lo >> 24] ^ g_crc_tab[3][hi & 0xff] ^ g_crc_tab[2][(hi >> 8) & 0xff] ^
+            g_crc_tab[1][(hi >> 16) & 0xff] ^ g_crc_tab[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = g_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+}
+
 static int dep(hipStream_t from, hipStream_t to, const char* what) {
     hipEvent_t ev = nullptr;
     hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);

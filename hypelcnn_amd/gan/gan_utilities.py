@@ -74,8 +74,12 @@ def create_gan_struct(gan_inference_wrapper, model_base_dir, ckpt_relative_path,
         if state["backend"] is None and session is not None:
             state["backend"] = session.backend  # the augmenter runs on the classifier session's device
         path = model_base_dir + ckpt_relative_path
-        with numpy.load(path if path.endswith(".npz") else path + ".npz") as z:
-            variables = {k.replace("|", "/"): z[k] for k in z.files}
+        from hypelcnn_amd.common import tf_checkpoint
+        if not path.endswith(".npz") and tf_checkpoint.is_checkpoint(path):  # a TensorFlow bundle, e.g. the published
+            variables = tf_checkpoint.read_checkpoint(path)                  # shadow_gen_model/cycle_gan/model.ckpt-5000
+        else:
+            with numpy.load(path if path.endswith(".npz") else path + ".npz") as z:
+                variables = {k.replace("|", "/"): z[k] for k in z.files}
         for flag in (True, False):
             _get(flag).load(variables)
 

@@ -41,6 +41,10 @@ const char* hypel_last_error(void);
 /* number of compute units / XCDs of the current device (host query, for table building) */
 int hypel_device_info(int32_t* n_cu, int32_t* n_xcd);
 
+/* host helper: CRC-32C (Castagnoli) of `n` bytes continued from `crc` (0 to start); used by the TensorFlow checkpoint
+ * bundle reader/writer (monitored_session_runner.py:164-171 saves, cycle_gan_wrapper.py:140-147 restores such files) */
+uint32_t hypel_crc32c(uint32_t crc, const void* data, uint64_t n);
+
 /* ---- layout ------------------------------------------------------------------------------- */
 /* x[N][P][C] (NHWC with P=H*W) -> out[P][N][ld] (pad columns zeroed).  Replaces the
  * feed_dict/prefetch_to_device hand-over (InMemoryImporter.py:80-83, common_nn_ops.py:200). */

@@ -1,0 +1,127 @@
+"""TensorFlow checkpoint bundles without TensorFlow (hypelcnn_amd/common/tf_checkpoint.py): known-answer bytes for
+every primitive of the format, round trips, corruption detection, and the session glue (a classifier trained on the
+kernel emulation exported as a bundle and restored into a fresh session / an inference graph)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from hypelcnn_amd.common import tf_checkpoint as T
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 test vectors for CRC-32C
+    assert T.crc32c(b"123456789") == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA
+    assert T.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.crc32c(b"6789", T.crc32c(b"12345")) == 0xE3069283          # incremental
+    # masking (crc32c.h): rotate right 15, add 0xa282ead8; unmask inverts it
+    assert T.mask_crc(0) == 0xA282EAD8
+    for c in (0, 1, 0xE3069283, 0xFFFFFFFF, 0x12345678):
+        assert T.unmask_crc(T.mask_crc(c)) == c
+    assert T.mask_crc(0xE3069283) != 0xE3069283
+
+
+def test_varints_and_protobuf_known_bytes():
+    assert T.put_varint(0) == b"\x00" and T.put_varint(127) == b"\x7f" and T.put_varint(128) == b"\x80\x01"
+    assert T.put_varint(300) == b"\xac\x02"                               # the protobuf documentation's example
+    for v in (0, 1, 127, 128, 300, 2 ** 31, 2 ** 63 - 1):
+        assert T.get_varint(T.put_varint(v) + b"\xff", 0) == (v, len(T.put_varint(v)))
+    # BundleHeaderProto{num_shards: 1, version{producer: 1}} = 08 01 1a 02 08 01
+    assert T.encode_header(1) == bytes.fromhex("08011a020801")
+    # BundleEntryProto{dtype: DT_FLOAT, shape{dim{size:3} dim{size:5}}, offset: 60, size: 60, crc32c: 0x01020304}
+    e = T.encode_entry(1, (3, 5), 0, 60, 60, 0x01020304)
+    assert e == bytes.fromhex("0801" "1208" "12020803" "12020805" "203c" "283c" "35" "04030201")
+    d = T.decode_entry(e)
+    assert (d["dtype"], d["shape"], d["shard_id"], d["offset"], d["size"], d["crc32c"]) == (1, (3, 5), 0, 60, 60,
+                                                                                          0x01020304)
+    assert T.decode_entry(T.encode_entry(9, (), 0, 0, 8, 7))["shape"] == ()   # scalar (global_step)
+
+
+def test_table_block_layout_known_bytes(tmp_path):
+    # one data block with prefix compression: keys "", "ab", "abc" -> shared lengths 0, 0, 2
+    block = T._build_block([(b"", b"H"), (b"ab", b"1"), (b"abc", b"22")])
+    assert block == (bytes([0, 0, 1]) + b"H" + bytes([0, 2, 1]) + b"ab1" + bytes([2, 1, 2]) + b"c22"
+                     + struct.pack("<II", 0, 1))
+    assert list(T._block_entries(block)) == [(b"", b"H"), (b"ab", b"1"), (b"abc", b"22")]
+    p = str(tmp_path / "t.index")
+    T.write_index(p, [(b"", b"H"), (b"ab", b"1"), (b"abc", b"22")])
+    raw = open(p, "rb").read()
+    assert raw[:len(block)] == block and raw[len(block)] == 0                     # uncompressed block type
+    assert struct.unpack_from("<I", raw, len(block) + 1)[0] == T.mask_crc(T.crc32c(block + b"\x00"))
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xdb4775248b80fb57 and len(raw[-48:]) == 48
+    assert T.read_index(p) == {b"": b"H", b"ab": b"1", b"abc": b"22"}
+
+
+def test_bundle_round_trip_many_blocks_and_corruption(tmp_path):
+    rng = np.random.default_rng(0)
+    variables = {f"nn_core/layer_{i}/weights": rng.standard_normal((3, 3, 7, i + 1)).astype(np.float32)
+                 for i in range(150)}                                           # > 1 index data block
+    variables["global_step"] = np.asarray(12345, np.int64)
+    variables["flags"] = np.asarray([True, False, True])
+    variables["nn_core/empty"] = np.zeros((0, 4), np.float32)
+    prefix = str(tmp_path / "model.ckpt-12345")
+    T.write_checkpoint(prefix, variables)
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    back = T.read_checkpoint(prefix)
+    assert set(back) == set(variables)
+    for k, v in variables.items():
+        assert back[k].dtype == np.asarray(v).dtype and back[k].shape == np.asarray(v).shape
+        np.testing.assert_array_equal(back[k], v)
+    only = T.read_checkpoint(prefix, names={"global_step"})
+    assert list(only) == ["global_step"] and int(only["global_step"]) == 12345
+    # flipped data byte -> tensor checksum error; flipped index byte -> block checksum error
+    data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    data[100] ^= 0x40
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    with pytest.raises(ValueError, match="tensor checksum"):
+        T.read_checkpoint(prefix)
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[10] ^= 0x01
+    open(prefix + ".index", "wb").write(idx)
+    with pytest.raises(ValueError, match="block checksum"):
+        T.read_checkpoint(prefix)
+
+
+def test_session_export_and_restore_through_tf_bundle(tmp_path):
+    from hypelcnn_amd.classify import monitored_session_runner as M
+    from tests import parity_util as U
+    from tests.emu_backend import EmuBackend
+    alg = {"drop_out_ratio": 0.7, "filter_count": 16, "learning_rate": 3e-3, "learning_rate_decay_factor": 0.96,
+           "learning_rate_decay_step": 350, "lrelu_alpha": 0.18, "optimizer": "AdamOptimizer", "bn_decay": 0.9,
+           "l2regularizer_scale": 1e-5, "spectral_hierarchy_level": 1, "spatial_hierarchy_level": 1,
+           "degradation_coeff": 3, "use_residual": True}
+    rng = np.random.default_rng(3)
+    x = rng.random((8, 3, 3, 5)).astype(np.float32)
+    onehot = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 8)]
+
+    def fresh(seed):
+        built = U.build("HYPELCNNModel", 3, 5, 3, alg, EmuBackend(), with_eval=False)
+        built.ctx.seed = seed
+        return built, built.ctx.session()
+
+    b1, s1 = fresh(1)
+    for _ in range(3):
+        U.run_train_step(b1, x, onehot, {})
+        s1.adam_step(3e-3)
+    prefix = M.export_tf_checkpoint(s1, str(tmp_path / "model.ckpt-3"))
+    names = set(T.read_index(prefix + ".index"))
+    assert {b"", b"global_step", b"beta1_power", b"nn_core/conv_enc_0/weights", b"nn_core/conv_enc_0/weights/Adam",
+            b"nn_core/conv_enc_0/weights/Adam_1", b"nn_core/fc_final/BatchNorm/moving_variance"} <= names
+    assert M.latest_checkpoint(str(tmp_path)) == prefix
+    b2, s2 = fresh(2)
+    assert not np.array_equal(s2.params.numpy(), s1.params.numpy())
+    M.restore_checkpoint(s2, prefix)
+    np.testing.assert_array_equal(s2.params.numpy(), s1.params.numpy())
+    np.testing.assert_array_equal(s2.state.numpy(), s1.state.numpy())
+    np.testing.assert_array_equal(s2.slot_m.numpy(), s1.slot_m.numpy())
+    np.testing.assert_array_equal(s2.slot_v.numpy(), s1.slot_v.numpy())
+    assert s2.global_step == s1.global_step == 3
+    # the next step from the restored session is the step the original session takes
+    for b, s in ((b1, s1), (b2, s2)):
+        U.run_train_step(b, x, onehot, {})
+        s.adam_step(3e-3)
+    np.testing.assert_array_equal(s2.params.numpy(), s1.params.numpy())
