@@ -26,7 +26,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
+#ifndef HYPEL_GEMM_BK
+#define HYPEL_GEMM_BK 32  // reduction columns per LDS tile (a multiple of 16)
+#endif
+constexpr int BK = HYPEL_GEMM_BK;
 #ifndef HYPEL_GEMM_SETPRIO
 #define HYPEL_GEMM_SETPRIO 1
 #endif
@@ -204,22 +207,13 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
 #if HYPEL_GEMM_SETPRIO
             __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
 #endif
+            // 16 reduction columns (8 MFMA k-steps) at a time; the chunks of a short k-tile beyond kvalid are skipped
+            // by a wave-uniform branch
 #pragma unroll
-            for (int k2 = 0; k2 < BK / 4; ++k2) {
-                float a[TM], b[TN];
+            for (int q = 0; q < BK / 16; ++q) {
+                if (q > 0 && kvalid <= q * 16) break;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bs[b_rd + j * B_TILE + k2 * B_KSTEP];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            if (kvalid > BK / 2) {
-#pragma unroll
-                for (int k2 = BK / 4; k2 < BK / 2; ++k2) {
+                for (int k2 = q * 8; k2 < q * 8 + 8; ++k2) {
                     float a[TM], b[TN];
 #pragma unroll
                     for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
@@ -319,6 +313,11 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     // few blocks run faster on the narrow tile, wide filter gradients on the wide one
     const int hint = (accumulate >> 8) & 3;
     accumulate &= 1;
+    static const int noepi = getenv("HYPEL_GEMM_NOEPI") ? atoi(getenv("HYPEL_GEMM_NOEPI")) : 0;  // timing experiments
+    if (noepi) {
+        accumulate = 0;
+        res = nullptr;
+    }
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
     if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
