@@ -323,18 +323,24 @@ class TowerPlan:
         return out, S, c_min, count
 
     @staticmethod
-    def _tile_hint(tables, n, ta, tb):
+    def _tile_hint(tables, n, ta, tb, folded):
         """Tile-width hint for hypel_seg_gemm_f32 (bits 8-9 of `accumulate`), from the per-launch A/B measurements in
-        profiles/r1_gemm_tile_choice.txt: 1 = 128x32, 2 = 128x64, 0 = library default."""
+        profiles/r1_gemm_tile_choice*.txt (HYPELCNN at N=1024 and DUALCNN at N=512): 1 = 128x32, 2 = 128x64.
+        Wide tiles win whenever a launch has plenty of blocks; narrow ones balance small launches, and the data
+        gradients that also gather the shortcut gradient in their epilogue (more, shorter epilogues overlap better)."""
         if n <= 32:
             return 0
         n_tiles = sum((rows + GEMM_BM - 1) // GEMM_BM for _, _, rows in tables.groups)
         blocks64 = n_tiles * ((n + 63) // 64)
-        if tb and not ta:  # data gradient: narrow tiles unless the segments are short (per-k-tile overhead dominates)
+        if tb and not ta:
             ks = [k for _, segs, _ in tables.groups for _, _, k in segs]
-            return 1 if ks and sum(ks) / len(ks) >= 48 else 2
-        if ta:  # filter gradient: narrow tiles only to get enough blocks
-            return 1 if blocks64 < 768 else 2
+            if ks and sum(ks) / len(ks) < 48:  # short segments: per-k-tile overhead dominates, keep the wide tile
+                return 2
+            if folded and blocks64 < 4000:
+                return 1
+            return 1 if blocks64 < 900 else 2
+        if ta:
+            return 1 if blocks64 < 900 else 2
         return 1 if blocks64 < 768 else 2
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
@@ -357,7 +363,7 @@ class TowerPlan:
             return
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
-        hint = self._tile_hint(tables, n, ta, tb) if TILE_HINTS else 0
+        hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
                 Ref(t_t), int(len(tarr)), bias_ref, int(accumulate) | (hint << 8))
         name = "seg_gemm_f32"

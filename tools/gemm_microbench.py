@@ -20,16 +20,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--filter", type=str, default="")
+    ap.add_argument("--workload", type=str, default="hypelcnn", choices=list(bench.CLASSIFIER_WORKLOADS))
     args = ap.parse_args()
     from hypelcnn_amd.backend import HipBackend
     be = HipBackend()
-    ctx, train_step, lr, alg = bench.build_model(1024, be)
+    _, _, patch, chans, classes, nb, _ = bench.CLASSIFIER_WORKLOADS[args.workload]
+    ctx, train_step, lr, alg = bench.build_model(nb, be, args.workload)
     ctx.capture_graphs = False
     sess = ctx.session()
-    ct = train_step.compiled(1024)
-    x = torch.rand((1024, 7, 7, 145)).cuda()
+    ct = train_step.compiled(nb)
+    x = torch.rand((nb, patch, patch, chans)).cuda()
     ct.set_input("x", x)
-    ct.set_input("labels", torch.nn.functional.one_hot(torch.randint(0, 15, (1024,)), 15).float().cuda())
+    ct.set_input("labels", torch.nn.functional.one_hot(torch.randint(0, classes, (nb,)), classes).float().cuda())
     ct.forward_backward()  # fill every buffer with realistic data
     torch.cuda.synchronize()
     items = [(l, f) for l, f in ct.serial_launches() if l.name.startswith("seg_gemm") and args.filter in l.tag]
@@ -48,7 +50,9 @@ def main():
         med = float(np.median(t))
         tot += med
         if med > 40:
-            print(f"{l.tag:34s} {l.flops / 1e9:7.2f} GF  med {med:8.1f} us  min {t.min():8.1f} us  {l.flops / med / 1e6:6.1f} TF/s")
+            a = l.args
+            print(f"{l.tag:34s} {l.flops / 1e9:7.2f} GF  med {med:8.1f} us  min {t.min():8.1f} us  {l.flops / med / 1e6:6.1f} TF/s"
+                  f"  n={a[8]} tiles={a[12]} ta={a[2]} tb={a[5]}")
     flops = sum(l.flops for l, _ in items)
     print(f"TOTAL {tot / 1e3:.3f} ms  {flops / tot / 1e6:.1f} TF/s")
 
