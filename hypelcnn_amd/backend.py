@@ -62,6 +62,8 @@ SIGNATURES = {
     "reduce_splits_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I32, _I64],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
     "bn_stats_f32": [_P, _I64, _I64, _I32, _I32, _P, _P, _F, _P, _P, _P, _P, _F],
+    "bn_act_small_fwd": [_P, _I64, _I64, _I32, _F, _P, _I32, _F, _P, _I64, _P, _P, _P, _P, _F, _P, _I64],
+    "bn_act_small_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _I32],
     "bn_finalize": [_P, _I32, _I32, _I64, _I32, _F, _P, _P, _P, _P, _F],
     "rstd_from_var": [_P, _I32, _F, _P],
     "bn_act_fwd": [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64],

@@ -821,6 +821,106 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t count, flo
     }
 }
 
+// ------------------------------------------------------------------------------------- small-rows BN
+// Fully-connected tail of the models: activations are [N x C] with N = the batch (1024 rows), so every channel's
+// statistics fit in ONE block.  A block owns a 32-channel stripe for ALL rows: statistics, finaliser and the
+// normalise/activate pass (forward), or the two reductions and the gradient (backward), in a single launch instead
+// of three -- no cross-block dependency, hence none of the cross-XCD coherence cost of the ticket scheme.
+constexpr int SMALL_TX = 32;  // channels per block
+constexpr int SMALL_TY = 8;   // row lanes
+
+__device__ __forceinline__ float small_lane_sum(float v, float (*sh)[SMALL_TX]) {
+    const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
+    __syncthreads();
+    sh[ty][tx] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SMALL_TY; ++k) t += sh[k][tx];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_act_small_fwd_kernel(
+    const float* __restrict__ y, int64_t ldy, int rows, int c, float eps, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay,
+    float* __restrict__ z, int64_t ldz) {
+    __shared__ float sh[SMALL_TY][SMALL_TX];
+    const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
+    const int col = blockIdx.x * SMALL_TX + tx;
+    const bool ok = col < c;
+    const float shift = ok ? y[col] : 0.0f;  // first row: keeps the fp32 sums well conditioned
+    float s = 0.0f, ss = 0.0f;
+    if (ok) {
+#pragma unroll 8
+        for (int r = ty; r < rows; r += SMALL_TY) {
+            const float d = y[(int64_t)r * ldy + col] - shift;
+            s += d;
+            ss += d * d;
+        }
+    }
+    const double ts = (double)small_lane_sum(s, sh);
+    const double tss = (double)small_lane_sum(ss, sh);
+    const double n = (double)rows;
+    const double mean = (double)shift + ts / n;
+    double m2 = tss - ts * ts / n;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / n;
+    const float mu = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
+    if (ok && ty == 0) {
+        mean_out[col] = mu;
+        rstd_out[col] = rs;
+        if (moving_mean) {
+            const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+            moving_mean[col] = (float)((double)moving_mean[col] * decay + mean * (1.0 - (double)decay));
+            moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
+        }
+    }
+    if (ok) {
+        const float be = beta[col];
+#pragma unroll 8
+        for (int r = ty; r < rows; r += SMALL_TY) {
+            float v = hypel_act((y[(int64_t)r * ldy + col] - mu) * rs + be, act, alpha);
+            if (mask) v *= mask[(int64_t)r * ldm + col];
+            z[(int64_t)r * ldz + col] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_small_bwd_kernel(
+    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int rows, int c,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ dy, int64_t lddy,
+    float* __restrict__ dparam, int accumulate) {
+    __shared__ float sh[SMALL_TY][SMALL_TX];
+    const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
+    const int col = blockIdx.x * SMALL_TX + tx;
+    const bool ok = col < c;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (ok) {
+#pragma unroll 4
+        for (int r = ty; r < rows; r += SMALL_TY) {
+            float dyh, xhat;
+            bwd_elem(dz, lddz, y, ldy, r, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
+            s0 += dyh;
+            s1 += dyh * xhat;
+        }
+    }
+    const float t0 = small_lane_sum(s0, sh);
+    const float t1 = small_lane_sum(s1, sh);
+    if (ok) {
+        if (ty == 0 && dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + t0;
+        const float inv_m = 1.0f / (float)rows, rs = rstd[col];
+        const float m0 = t0 * inv_m, m1 = t1 * inv_m;
+#pragma unroll 4
+        for (int r = ty; r < rows; r += SMALL_TY) {
+            float dyh, xhat;
+            bwd_elem(dz, lddz, y, ldy, r, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
+            dy[(int64_t)r * lddy + col] = rs * (dyh - m0 - xhat * m1);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- metrics
 __global__ void argmax_confusion_kernel(const float* __restrict__ logits, int64_t ld, int64_t n, int c,
                                         const int32_t* __restrict__ labels, int32_t* __restrict__ pred,
@@ -1047,6 +1147,31 @@ extern "C" int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float*
     launch_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
                       BwdFin{counters, sums, dparam, accumulate}, stream);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_sums");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, float eps,
+                                      const float* beta, int32_t act, float alpha, const float* mask, int64_t ldm,
+                                      float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
+                                      float* z, int64_t ldz, hypel_stream_t stream) {
+    HYPEL_REQUIRE(y && beta && mean && rstd && z && rows > 0 && rows <= 65536 && c > 0, "hypel_bn_act_small_fwd");
+    HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_act_small_fwd");
+    hipLaunchKernelGGL(bn_act_small_fwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(256), 0, ST, y, ldy,
+                       (int)rows, c, eps, beta, act, alpha, mask, ldm, mean, rstd, moving_mean, moving_var, decay, z,
+                       ldz);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_small_fwd");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_small_bwd(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                      int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
+                                      float alpha, const float* mask, int64_t ldm, float* dy, int64_t lddy,
+                                      float* dparam, int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && y && mean && rstd && beta && dy && rows > 0 && rows <= 65536 && c > 0,
+                  "hypel_bn_act_small_bwd");
+    hipLaunchKernelGGL(bn_act_small_bwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(256), 0, ST, dz, lddz, y,
+                       ldy, (int)rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy, dparam, accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_small_bwd");
     return 0;
 }
 

@@ -55,6 +55,8 @@ USE_SIDE_STREAM = True
 # through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
 FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
 TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
+SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
+SMALL_BN_ROWS = 4096
 FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 
 
@@ -554,7 +556,11 @@ class TowerPlan:
         if node.has_bn:
             self._alloc(f"mean:{idx}", c)
             self._alloc(f"rstd:{idx}", c)
-            if node.training:
+            if node.training and self._small_bn(node, rows):
+                # short matrix (rows = batch): statistics + finaliser + activation in ONE launch (_emit_post_fwd)
+                aux["small_bn"] = True
+                aux["mean"] = self._ref(f"mean:{idx}")
+            elif node.training:
                 chunk = stat_chunk_rows(rows)
                 n_chunks = (rows + chunk - 1) // chunk
                 if not FUSED_STATS:
@@ -621,12 +627,23 @@ class TowerPlan:
             out.append((None, 0, None))
         return out
 
+    def _small_bn(self, node, rows):
+        """Batch norm over a short matrix (the fully-connected tail: rows = batch) with no shortcut to add: one block
+        per channel stripe covers every row, so the whole BN + activation is one launch per direction."""
+        return SMALL_BN and rows <= SMALL_BN_ROWS and not node.residuals and node.has_post
+
     def _emit_post_fwd(self, idx, node, y_ref, ldy, rows, c, aux, z_ref):
         has_bn = isinstance(node, G.LinearNode) and node.has_bn
         mask = self._mask_ref(idx, node, rows, c)
         aux["mask"] = mask
         (r1, ld1, i1), (r2, ld2, i2) = self._res_args(node)
         act = node.act
+        if aux.get("small_bn"):
+            self.fwd.append(Launch("bn_act_small_fwd", (
+                y_ref, ldy, rows, c, float(node.bn_eps), aux["beta_ref"], act.code if act else 0,
+                act.alpha if act else 0.0, mask, c, aux["mean"], aux["rstd"], self._s(aux["mm"]), self._s(aux["mv"]),
+                float(node.bn_decay), z_ref, c), nbytes=12 * rows * c, tag="post-fwd-small"))
+            return
         self.fwd.append(Launch("bn_act_fwd", (
             y_ref, ldy, rows, c, aux.get("mean") if has_bn else None, aux.get("rstd") if has_bn else None,
             aux.get("beta_ref") if has_bn else None, act.code if act else 0, act.alpha if act else 0.0, mask, c,
@@ -842,6 +859,12 @@ class TowerPlan:
                 dparam = self._g(aux["beta"])
             elif node.has_bias:
                 dparam = self._g(aux["bias"])
+        if aux.get("small_bn") and has_bn and dy is not None:
+            pacc = self._param_acc(aux["beta"]) if dparam is not None else 0
+            self.bwd.append(Launch("bn_act_small_bwd", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
+                                                        dy, c, dparam, pacc), nbytes=16 * rows * c,
+                                   tag="post-bwd-small"))
+            return
         sums = None
         if has_bn or dparam is not None:
             chunk = stat_chunk_rows(rows)

@@ -112,6 +112,18 @@ int hypel_bn_finalize(const float* partial, int32_t n_chunks, int32_t chunk_rows
 int hypel_bn_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows, float* partial,
                        int32_t* counters, float eps, float* mean, float* rstd, float* moving_mean, float* moving_var,
                        float decay, hypel_stream_t stream);
+/* Batch norm of a SHORT matrix (rows = the batch: the fully-connected tail, HYPELCNNModel.py:80-94) in one launch per
+ * direction: a block owns a 32-channel stripe for all rows, so statistics + finaliser + normalise/activate/dropout
+ * (forward) and both reductions + the gradient (backward; dy may alias dz) need no second kernel.
+ * Same definitions as hypel_col_stats_partial/hypel_bn_finalize/hypel_bn_act_fwd resp. the three backward calls. */
+int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, float eps, const float* beta,
+                           int32_t act, float alpha, const float* mask, int64_t ldm, float* mean, float* rstd,
+                           float* moving_mean, float* moving_var, float decay, float* z, int64_t ldz,
+                           hypel_stream_t stream);
+int hypel_bn_act_small_bwd(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                           const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                           const float* mask, int64_t ldm, float* dy, int64_t lddy, float* dparam,
+                           int32_t accumulate, hypel_stream_t stream);
 /* inference: rstd[c] = 1/sqrt(moving_var[c] + eps) */
 int hypel_rstd_from_var(const float* var, int32_t c, float eps, float* rstd, hypel_stream_t stream);
 

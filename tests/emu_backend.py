@@ -259,6 +259,28 @@ class EmuBackend:
                                  partial)
         self.k_bwd_reduce_finalize(partial, (rows + chunk_rows - 1) // chunk_rows, c, sums, dparam, accumulate)
 
+    def k_bn_act_small_fwd(self, y, ldy, rows, c, eps, beta, act, alpha, mask, ldm, mean, rstd, mm, mv, decay, z, ldz):
+        ym = _mat(y, ldy, rows, c).astype(np.float64)
+        mu = ym.mean(0)
+        var = ym.var(0)
+        _arr(mean)[:c] = mu.astype(np.float32)
+        _arr(rstd)[:c] = (1.0 / np.sqrt(var + eps)).astype(np.float32)
+        if mm is not None:
+            unbiased = var * rows / max(rows - 1, 1)
+            _arr(mm)[:c] = (_arr(mm)[:c].astype(np.float64) * decay + mu * (1 - decay)).astype(np.float32)
+            _arr(mv)[:c] = (_arr(mv)[:c].astype(np.float64) * decay + unbiased * (1 - decay)).astype(np.float32)
+        self.k_bn_act_fwd(y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, None, 0, None, None, 0, None, z, ldz)
+
+    def k_bn_act_small_bwd(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy, dparam,
+                           accumulate):
+        dyh, xhat = self._dyh(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm)
+        s0, s1 = dyh.sum(0), (dyh * xhat).sum(0)
+        if dparam is not None:
+            dp = _arr(dparam)
+            dp[:c] = (dp[:c] if accumulate else 0) + s0.astype(np.float32)
+        g = _arr(rstd)[:c] * (dyh - s0 / rows - xhat * s1 / rows)
+        _mat(dy, lddy, rows, c)[...] = g.astype(np.float32)
+
     def k_bn_finalize(self, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, mm, mv, decay):
         po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c).astype(np.float64)
         n_a, mean_a, m2_a = 0.0, np.zeros(c), np.zeros(c)

@@ -204,6 +204,35 @@ def test_bn_stats_and_finalize(hip, rows, c):
     np.testing.assert_allclose(b.h["rstd"].cpu().numpy(), 1 / np.sqrt(x64.var(0) + 1e-3), rtol=1e-5)
 
 
+@pytest.mark.parametrize("rows,c,act,use_mask", [(1024, 980, 1, True), (1024, 15, 0, False), (1024, 7105, 3, False),
+                                                  (77, 45, 1, False), (4096, 33, 2, True), (1, 5, 1, False)])
+def test_small_rows_bn_kernels(hip, rows, c, act, use_mask):
+    """One-launch BN + activation (forward) and BN backward for short matrices vs the numpy specification."""
+    rng = np.random.default_rng(rows + c)
+    b = Both(hip)
+    ld = c + 3
+    b.arr("y", (rng.standard_normal((rows, ld)) * 1.5 + rng.standard_normal(ld) * 2).astype(np.float32))
+    b.arr("dz", rng.standard_normal((rows, ld)).astype(np.float32))
+    b.arr("beta", rng.standard_normal(c).astype(np.float32))
+    b.arr("mask", (rng.random((rows, c)) < 0.7).astype(np.float32) / 0.7)
+    for nm in ("mean", "rstd"):
+        b.arr(nm, np.zeros(c, np.float32))
+    b.arr("mm", rng.standard_normal(c).astype(np.float32))
+    b.arr("mv", (rng.random(c) + 0.5).astype(np.float32))
+    b.arr("z", np.zeros(rows * ld, np.float32))
+    b.arr("dy", np.zeros(rows * ld, np.float32))
+    b.arr("dbeta", rng.standard_normal(c).astype(np.float32))
+    m = "mask" if use_mask else None
+    b.run("bn_act_small_fwd", "y", ld, rows, c, 1e-3, "beta", act, 0.18, m, c, "mean", "rstd", "mm", "mv", 0.95, "z", ld)
+    for nm in ("mean", "rstd", "mm", "mv"):
+        b.check(nm, rtol=2e-5, atol=2e-6)
+    b.check("z", rtol=1e-4, atol=1e-5)
+    b.run("bn_act_small_bwd", "dz", ld, "y", ld, rows, c, "mean", "rstd", "beta", act, 0.18, m, c, "dy", ld, "dbeta", 1)
+    b.check("dy", rtol=2e-4, atol=2e-5)
+    b.check("dbeta", rtol=2e-4, atol=2e-4)
+    assert (b.h["z"].cpu().numpy().reshape(rows, ld)[:, c:] == 0).all(), "pad columns untouched"
+
+
 @pytest.mark.parametrize("rows,c", [(50176 // 8, 480), (1000, 145), (333, 60), (64, 7105)])
 def test_fused_statistics_kernels_match_two_stage(hip, rows, c):
     """hypel_bn_stats_f32 / hypel_bn_act_bwd_sums == partial kernel + finaliser, also on the second and third call
