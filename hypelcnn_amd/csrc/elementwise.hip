@@ -826,10 +826,12 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t count, flo
 // statistics fit in ONE block.  A block owns a 32-channel stripe for ALL rows: statistics, finaliser and the
 // normalise/activate pass (forward), or the two reductions and the gradient (backward), in a single launch instead
 // of three -- no cross-block dependency, hence none of the cross-XCD coherence cost of the ticket scheme.
-constexpr int SMALL_TX = 32;  // channels per block
-constexpr int SMALL_TY = 8;   // row lanes
+constexpr int SMALL_TX = 32;    // channels per block
+constexpr int SMALL_TY = 32;    // row lanes (block = 1024 threads)
+constexpr int SMALL_R = 32;     // rows per thread, kept in registers between the reduction and the apply pass
+constexpr int SMALL_MAX_ROWS = SMALL_TY * SMALL_R;
 
-__device__ __forceinline__ float small_lane_sum(float v, float (*sh)[SMALL_TX]) {
+__device__ __forceinline__ float small_lane_sum(float v, float (*sh)[SMALL_TX + 1]) {
     const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
     __syncthreads();
     sh[ty][tx] = v;
@@ -840,24 +842,45 @@ __device__ __forceinline__ float small_lane_sum(float v, float (*sh)[SMALL_TX]) 
     return t;
 }
 
-__global__ __launch_bounds__(256) void bn_act_small_fwd_kernel(
+// All loads of a thread's rows are issued back to back (one memory round trip instead of rows/TY dependent ones:
+// a single-block-per-stripe kernel is otherwise pure latency) and the values stay in registers for the second phase.
+// Loads are unconditional (clamped row / column, validity applied arithmetically) so that the compiler emits one
+// straight-line burst instead of a guarded branch per element.
+template <bool FULL>  // FULL: rows == SMALL_MAX_ROWS, no row guards at all
+__device__ __forceinline__ void bn_act_small_fwd_body(
     const float* __restrict__ y, int64_t ldy, int rows, int c, float eps, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay,
-    float* __restrict__ z, int64_t ldz) {
-    __shared__ float sh[SMALL_TY][SMALL_TX];
+    float* __restrict__ z, int64_t ldz, float (*sh)[SMALL_TX + 1]) {
     const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
     const int col = blockIdx.x * SMALL_TX + tx;
     const bool ok = col < c;
-    const float shift = ok ? y[col] : 0.0f;  // first row: keeps the fp32 sums well conditioned
-    float s = 0.0f, ss = 0.0f;
-    if (ok) {
-#pragma unroll 8
-        for (int r = ty; r < rows; r += SMALL_TY) {
-            const float d = y[(int64_t)r * ldy + col] - shift;
-            s += d;
-            ss += d * d;
+    const int colc = ok ? col : c - 1;
+    float v[SMALL_R], mk[SMALL_R];
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        const int r = ty + i * SMALL_TY;
+        const int rc = FULL ? r : min(r, rows - 1);
+        v[i] = y[(int64_t)rc * ldy + colc];
+    }
+    if (mask) {
+#pragma unroll
+        for (int i = 0; i < SMALL_R; ++i) {
+            const int r = ty + i * SMALL_TY;
+            const int rc = FULL ? r : min(r, rows - 1);
+            mk[i] = mask[(int64_t)rc * ldm + colc];
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SMALL_R; ++i) mk[i] = 1.0f;
+    }
+    const float shift = y[colc];  // first row: keeps the fp32 sums well conditioned
+    float s = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        const float d = (FULL || ty + i * SMALL_TY < rows) ? v[i] - shift : 0.0f;
+        s += d;
+        ss += d * d;
     }
     const double ts = (double)small_lane_sum(s, sh);
     const double tss = (double)small_lane_sum(ss, sh);
@@ -876,49 +899,101 @@ __global__ __launch_bounds__(256) void bn_act_small_fwd_kernel(
             moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
         }
     }
-    if (ok) {
-        const float be = beta[col];
-#pragma unroll 8
-        for (int r = ty; r < rows; r += SMALL_TY) {
-            float v = hypel_act((y[(int64_t)r * ldy + col] - mu) * rs + be, act, alpha);
-            if (mask) v *= mask[(int64_t)r * ldm + col];
-            z[(int64_t)r * ldz + col] = v;
+    if (!ok) return;
+    const float be = beta[col];
+    if (act == HYPEL_ACT_LRELU) {  // the common case without the per-element activation switch
+#pragma unroll
+        for (int i = 0; i < SMALL_R; ++i) {
+            const float p = (v[i] - mu) * rs + be;
+            v[i] = (p > 0.0f ? p : p * alpha) * mk[i];
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SMALL_R; ++i) v[i] = hypel_act((v[i] - mu) * rs + be, act, alpha) * mk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        const int r = ty + i * SMALL_TY;
+        if (FULL || r < rows) z[(int64_t)r * ldz + col] = v[i];
     }
 }
 
-__global__ __launch_bounds__(256) void bn_act_small_bwd_kernel(
+__global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
+    const float* __restrict__ y, int64_t ldy, int rows, int c, float eps, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay,
+    float* __restrict__ z, int64_t ldz) {
+    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
+    if (rows == SMALL_MAX_ROWS)
+        bn_act_small_fwd_body<true>(y, ldy, rows, c, eps, beta, act, alpha, mask, ldm, mean_out, rstd_out,
+                                    moving_mean, moving_var, decay, z, ldz, sh);
+    else
+        bn_act_small_fwd_body<false>(y, ldy, rows, c, eps, beta, act, alpha, mask, ldm, mean_out, rstd_out,
+                                     moving_mean, moving_var, decay, z, ldz, sh);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void bn_act_small_bwd_body(
+    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int rows, int c,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ dy, int64_t lddy,
+    float* __restrict__ dparam, int accumulate, float (*sh)[SMALL_TX + 1]) {
+    const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
+    const int col = blockIdx.x * SMALL_TX + tx;
+    const bool ok = col < c;
+    const int colc = ok ? col : c - 1;
+    float g[SMALL_R], xh[SMALL_R];  // dyh and xhat of this thread's rows
+    const float mu = mean[colc], rs = rstd[colc], be = beta[colc];
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        const int r = ty + i * SMALL_TY;
+        const int rc = FULL ? r : min(r, rows - 1);
+        xh[i] = y[(int64_t)rc * ldy + colc];
+        g[i] = dz[(int64_t)rc * lddz + colc];
+    }
+    if (mask) {
+#pragma unroll
+        for (int i = 0; i < SMALL_R; ++i) {
+            const int r = ty + i * SMALL_TY;
+            const int rc = FULL ? r : min(r, rows - 1);
+            g[i] *= mask[(int64_t)rc * ldm + colc];
+        }
+    }
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        xh[i] = (xh[i] - mu) * rs;
+        const float p = xh[i] + be;
+        const float slope = act == HYPEL_ACT_LRELU ? (p > 0.0f ? 1.0f : alpha) : hypel_act_grad(p, act, alpha);
+        g[i] = (FULL || ty + i * SMALL_TY < rows) ? g[i] * slope : 0.0f;
+        s0 += g[i];
+        s1 += g[i] * xh[i];
+    }
+    const float t0 = small_lane_sum(s0, sh);
+    const float t1 = small_lane_sum(s1, sh);
+    if (!ok) return;
+    if (ty == 0 && dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + t0;
+    const float inv_m = 1.0f / (float)rows;
+    const float m0 = t0 * inv_m, m1 = t1 * inv_m;
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        const int r = ty + i * SMALL_TY;
+        if (FULL || r < rows) dy[(int64_t)r * lddy + col] = rs * (g[i] - m0 - xh[i] * m1);
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
     const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ dy, int64_t lddy,
     float* __restrict__ dparam, int accumulate) {
-    __shared__ float sh[SMALL_TY][SMALL_TX];
-    const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
-    const int col = blockIdx.x * SMALL_TX + tx;
-    const bool ok = col < c;
-    float s0 = 0.0f, s1 = 0.0f;
-    if (ok) {
-#pragma unroll 4
-        for (int r = ty; r < rows; r += SMALL_TY) {
-            float dyh, xhat;
-            bwd_elem(dz, lddz, y, ldy, r, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
-            s0 += dyh;
-            s1 += dyh * xhat;
-        }
-    }
-    const float t0 = small_lane_sum(s0, sh);
-    const float t1 = small_lane_sum(s1, sh);
-    if (ok) {
-        if (ty == 0 && dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + t0;
-        const float inv_m = 1.0f / (float)rows, rs = rstd[col];
-        const float m0 = t0 * inv_m, m1 = t1 * inv_m;
-#pragma unroll 4
-        for (int r = ty; r < rows; r += SMALL_TY) {
-            float dyh, xhat;
-            bwd_elem(dz, lddz, y, ldy, r, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
-            dy[(int64_t)r * lddy + col] = rs * (dyh - m0 - xhat * m1);
-        }
-    }
+    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
+    if (rows == SMALL_MAX_ROWS)
+        bn_act_small_bwd_body<true>(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy,
+                                    dparam, accumulate, sh);
+    else
+        bn_act_small_bwd_body<false>(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy,
+                                     dparam, accumulate, sh);
 }
 
 // ------------------------------------------------------------------------------------- metrics
@@ -1154,9 +1229,10 @@ extern "C" int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows,
                                       const float* beta, int32_t act, float alpha, const float* mask, int64_t ldm,
                                       float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
                                       float* z, int64_t ldz, hypel_stream_t stream) {
-    HYPEL_REQUIRE(y && beta && mean && rstd && z && rows > 0 && rows <= 65536 && c > 0, "hypel_bn_act_small_fwd");
+    HYPEL_REQUIRE(y && beta && mean && rstd && z && rows > 0 && rows <= SMALL_MAX_ROWS && c > 0,
+                  "hypel_bn_act_small_fwd");
     HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_act_small_fwd");
-    hipLaunchKernelGGL(bn_act_small_fwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(256), 0, ST, y, ldy,
+    hipLaunchKernelGGL(bn_act_small_fwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(1024), 0, ST, y, ldy,
                        (int)rows, c, eps, beta, act, alpha, mask, ldm, mean, rstd, moving_mean, moving_var, decay, z,
                        ldz);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_small_fwd");
@@ -1167,9 +1243,9 @@ extern "C" int hypel_bn_act_small_bwd(const float* dz, int64_t lddz, const float
                                       int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
                                       float alpha, const float* mask, int64_t ldm, float* dy, int64_t lddy,
                                       float* dparam, int32_t accumulate, hypel_stream_t stream) {
-    HYPEL_REQUIRE(dz && y && mean && rstd && beta && dy && rows > 0 && rows <= 65536 && c > 0,
+    HYPEL_REQUIRE(dz && y && mean && rstd && beta && dy && rows > 0 && rows <= SMALL_MAX_ROWS && c > 0,
                   "hypel_bn_act_small_bwd");
-    hipLaunchKernelGGL(bn_act_small_bwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(256), 0, ST, dz, lddz, y,
+    hipLaunchKernelGGL(bn_act_small_bwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(1024), 0, ST, dz, lddz, y,
                        ldy, (int)rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy, dparam, accumulate);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_small_bwd");
     return 0;

@@ -313,11 +313,6 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     // few blocks run faster on the narrow tile, wide filter gradients on the wide one
     const int hint = (accumulate >> 8) & 3;
     accumulate &= 1;
-    static const int noepi = getenv("HYPEL_GEMM_NOEPI") ? atoi(getenv("HYPEL_GEMM_NOEPI")) : 0;  // timing experiments
-    if (noepi) {
-        accumulate = 0;
-        res = nullptr;
-    }
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
     if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,

@@ -56,7 +56,7 @@ USE_SIDE_STREAM = True
 FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
 TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
 SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
-SMALL_BN_ROWS = 4096
+SMALL_BN_ROWS = 1024  # hypel_bn_act_small_*: rows kept in registers (32 row lanes x 32 rows)
 FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 
 
@@ -563,25 +563,23 @@ class TowerPlan:
             elif node.training:
                 chunk = stat_chunk_rows(rows)
                 n_chunks = (rows + chunk - 1) // chunk
-                if not FUSED_STATS:
+                mean_ref, rstd_ref = self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}")
+                if FUSED_STATS:  # one launch: the last block of a channel stripe finalises it (see FUSED_STATS)
+                    l1 = Launch("bn_stats_f32", (self._ref(ybuf), c, rows, c, chunk, None, self._tickets(c),
+                                                 float(node.bn_eps), mean_ref, rstd_ref, self._s(aux["mm"]),
+                                                 self._s(aux["mv"]), float(node.bn_decay)),
+                                nbytes=4 * rows * c, tag="bn-stats")
+                    self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
+                    self.fwd.append(l1)
+                else:
                     l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, chunk, None),
                                 nbytes=4 * rows * c, tag="bn-stats")
                     self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                    l2 = Launch("bn_finalize", (None, n_chunks, chunk, rows, c, float(node.bn_eps),
-                                                self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"), self._s(aux["mm"]),
-                                                self._s(aux["mv"]), float(node.bn_decay)), tag="bn-finalize")
+                    l2 = Launch("bn_finalize", (None, n_chunks, chunk, rows, c, float(node.bn_eps), mean_ref, rstd_ref,
+                                                self._s(aux["mm"]), self._s(aux["mv"]), float(node.bn_decay)),
+                                tag="bn-finalize")
                     self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
                     self.fwd += [l1, l2]
-                # statistics + finaliser in one launch (the last block of a channel stripe finalises it)
-                l1 = Launch("bn_stats_f32", (self._ref(ybuf), c, rows, c, chunk, None, self._tickets(c),
-                                             float(node.bn_eps), self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"),
-                                             self._s(aux["mm"]), self._s(aux["mv"]), float(node.bn_decay)),
-                            nbytes=4 * rows * c, tag="bn-stats")
-                self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                if FUSED_STATS:
-                    self.fwd.append(l1)
-                else:
-                    self._pending_scratch.pop()
                 aux["mean"] = self._ref(f"mean:{idx}")
             else:
                 self.fwd.append(Launch("rstd_from_var", (self._s(aux["mv"]), c, float(node.bn_eps),

@@ -114,7 +114,7 @@ int hypel_bn_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t c, int3
                        float decay, hypel_stream_t stream);
 /* Batch norm of a SHORT matrix (rows = the batch: the fully-connected tail, HYPELCNNModel.py:80-94) in one launch per
  * direction: a block owns a 32-channel stripe for all rows, so statistics + finaliser + normalise/activate/dropout
- * (forward) and both reductions + the gradient (backward; dy may alias dz) need no second kernel.
+ * (forward) and both reductions + the gradient (backward; dy may alias dz) need no second kernel.  rows <= 1024.
  * Same definitions as hypel_col_stats_partial/hypel_bn_finalize/hypel_bn_act_fwd resp. the three backward calls. */
 int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, float eps, const float* beta,
                            int32_t act, float alpha, const float* mask, int64_t ldm, float* mean, float* rstd,
