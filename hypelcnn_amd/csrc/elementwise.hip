@@ -133,7 +133,7 @@ __global__ void reduce_splits_v4_kernel(const float* __restrict__ partial, int64
             const float* bp = bias + (int)(i % n);
             s.x += bp[0]; s.y += bp[1]; s.z += bp[2]; s.w += bp[3];
         }
-#pragma unroll 4
+#pragma unroll 8
         for (int k = 0; k < n_splits; ++k) {
             const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)k * stride + o);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -151,6 +151,7 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t 
         const int64_t o = ldc > 0 ? (i / n) * ldc + (i % n) : i;
         float s = accumulate ? out[o] : 0.0f;
         if (bias) s += bias[(int)(i % n)];
+#pragma unroll 8
         for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * stride + o];
         out[o] = s;
     }
@@ -197,6 +198,9 @@ __device__ __forceinline__ double lanes16_sum(double v, double* sh) {
 }
 
 // body of the statistics finaliser for the 16 channels [blk16*16, blk16*16+16); all 256 threads of a block call it
+// The chunk partials are read in bursts of 16 per lane with clamped (always valid) addresses, so the loads of a
+// burst are all in flight together; a plain `for k` loop made this kernel a chain of ~2 x n_chunks/16 dependent
+// memory round trips (14 us for 256 chunks).
 template <bool COHERENT>
 __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks,
                                                  int chunk_rows, int64_t rows, int c, float eps,
@@ -206,21 +210,40 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
     const int ch = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int col = blk16 * 16 + ch;
     const bool ok = col < c;
+    const int colc = ok ? col : c - 1;
     const double n_total = (double)rows;
+    const int64_t last_rows = rows - (int64_t)(n_chunks - 1) * chunk_rows;
     double s = 0.0;
-    for (int k = lane; k < n_chunks; k += 16) {
-        const int64_t r0 = (int64_t)k * chunk_rows;
-        const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
-        if (ok) s += n_k * (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + col);
+    for (int k0 = 0; k0 < n_chunks; k0 += 256) {
+        float m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = min(k0 + lane + 16 * j, n_chunks - 1);
+            m[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + colc);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + lane + 16 * j;
+            const double n_k = k < n_chunks - 1 ? (double)chunk_rows : (k == n_chunks - 1 ? (double)last_rows : 0.0);
+            s += n_k * (double)m[j];
+        }
     }
     const double mean_a = lanes16_sum(s, sh) / n_total;
     double m2 = 0.0;
-    for (int k = lane; k < n_chunks; k += 16) {
-        const int64_t r0 = (int64_t)k * chunk_rows;
-        const double n_k = (double)(min(rows, r0 + (int64_t)chunk_rows) - r0);
-        if (ok) {
-            const double d = (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + col) - mean_a;
-            m2 += (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + col) + n_k * d * d;
+    for (int k0 = 0; k0 < n_chunks; k0 += 256) {
+        float m[16], q[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = min(k0 + lane + 16 * j, n_chunks - 1);
+            m[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + colc);
+            q[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + colc);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + lane + 16 * j;
+            const double n_k = k < n_chunks - 1 ? (double)chunk_rows : (k == n_chunks - 1 ? (double)last_rows : 0.0);
+            const double d = (double)m[j] - mean_a;
+            m2 += k < n_chunks ? (double)q[j] + n_k * d * d : 0.0;
         }
     }
     const double m2_a = lanes16_sum(m2, sh);
@@ -461,11 +484,21 @@ __device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __rest
     const int ch = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int col = blk16 * 16 + ch;
     const bool ok = col < c;
+    const int colc = ok ? col : c - 1;
     double a = 0.0, b = 0.0;
-    for (int k = lane; k < n_chunks; k += 16) {
-        if (ok) {
-            a += (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + col);
-            b += (double)ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + col);
+    for (int k0 = 0; k0 < n_chunks; k0 += 256) {  // bursts of 16 independent loads per lane (see bn_finalize_body)
+        float pa[16], pb[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = min(k0 + lane + 16 * j, n_chunks - 1);
+            pa[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + colc);
+            pb[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + colc);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool in = k0 + lane + 16 * j < n_chunks;
+            a += in ? (double)pa[j] : 0.0;
+            b += in ? (double)pb[j] : 0.0;
         }
     }
     a = lanes16_sum(a, sh);

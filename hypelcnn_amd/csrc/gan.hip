@@ -566,21 +566,22 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w
 }
 
 // tf.math.l2_normalize(x) with axis=None: the norm of the WHOLE [rows x c] tensor (shadow_data_models.py:147).
-// One block; stat[0] = sum x^2, stat[1] = rsqrt(max(sum, 1e-12)).
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int c,
+// One block of 1024 threads (the tensor is [N x E] with E = 2: 8 k elements); stat[0] = sum x^2, stat[1] = rsqrt(max(sum, 1e-12)).
+__global__ __launch_bounds__(1024) void l2norm_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int c,
                                                           float* __restrict__ y, int64_t ldy,
                                                           float* __restrict__ stat) {
-    __shared__ double sh[256];
+    __shared__ double sh[1024];
     __shared__ float inv_s;
     const int64_t total = rows * c;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < total; i += 256) {
+#pragma unroll 4
+    for (int64_t i = threadIdx.x; i < total; i += 1024) {
         const float v = x[(i / c) * ldx + (i % c)];
         s += (double)v * v;
     }
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
@@ -593,23 +594,24 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
     }
     __syncthreads();
     const float inv = inv_s;
-    for (int64_t i = threadIdx.x; i < total; i += 256) y[(i / c) * ldy + (i % c)] = x[(i / c) * ldx + (i % c)] * inv;
+    for (int64_t i = threadIdx.x; i < total; i += 1024) y[(i / c) * ldy + (i % c)] = x[(i / c) * ldx + (i % c)] * inv;
 }
 
 // dx = g*inv - x * (sum g.x) * inv^3   (dx = g*inv when the clamp is active)
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(1024) void l2norm_bwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ dy, int64_t lddy, int64_t rows,
                                                           int c, const float* __restrict__ stat,
                                                           float* __restrict__ dx, int64_t lddx, int accumulate) {
-    __shared__ double sh[256];
+    __shared__ double sh[1024];
     __shared__ float dot_s;
     const int64_t total = rows * c;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < total; i += 256)
+#pragma unroll 4
+    for (int64_t i = threadIdx.x; i < total; i += 1024)
         s += (double)x[(i / c) * ldx + (i % c)] * (double)dy[(i / c) * lddy + (i % c)];
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     __syncthreads();
     const float inv = stat[1];
     const float coef = stat[0] > 1e-12f ? dot_s * inv * inv * inv : 0.0f;
-    for (int64_t i = threadIdx.x; i < total; i += 256) {
+    for (int64_t i = threadIdx.x; i < total; i += 1024) {
         const float g = dy[(i / c) * lddy + (i % c)] * inv - x[(i / c) * ldx + (i % c)] * coef;
         float* p = dx + (i / c) * lddx + (i % c);
         *p = accumulate ? *p + g : g;
@@ -790,7 +792,7 @@ extern "C" int hypel_l2_reg(const float* w, int64_t count, float scale, float* l
 extern "C" int hypel_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, float* y, int64_t ldy,
                                 float* stat, hypel_stream_t stream) {
     HYPEL_REQUIRE(x && y && stat && rows > 0 && c > 0, "hypel_l2norm_fwd");
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(1), dim3(256), 0, ST, x, ldx, rows, c, y, ldy, stat);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(1), dim3(1024), 0, ST, x, ldx, rows, c, y, ldy, stat);
     HYPEL_CHECK_LAUNCH("hypel_l2norm_fwd");
     return 0;
 }
@@ -799,7 +801,7 @@ extern "C" int hypel_l2norm_bwd(const float* x, int64_t ldx, const float* dy, in
                                 const float* stat, float* dx, int64_t lddx, int32_t accumulate,
                                 hypel_stream_t stream) {
     HYPEL_REQUIRE(x && dy && dx && stat && rows > 0 && c > 0, "hypel_l2norm_bwd");
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(1), dim3(256), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(1), dim3(1024), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
                        accumulate);
     HYPEL_CHECK_LAUNCH("hypel_l2norm_bwd");
     return 0;
