@@ -315,6 +315,13 @@ class BatchIterator:
         self._pos = 0
         self._order = self._new_epoch()
 
+    @staticmethod
+    def _dp():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_world_size(), dist.get_rank()
+        return 1, 0
+
     def _new_epoch(self):
         n = len(self.arrays)
         if self.shuffle:
@@ -326,8 +333,11 @@ class BatchIterator:
         n = len(self.arrays)
         if n == 0:
             return None
+        # data parallel: every rank walks the SAME seeded permutation, draws the global batch
+        # (batch_size per rank x world) and keeps the samples rank::world of it -- disjoint shards, no communication
+        world, rank = self._dp()
         idx_parts = []
-        need = self.batch_size
+        need = self.batch_size * world
         while need > 0:
             if self._pos >= n:
                 self._epoch += 1
@@ -344,6 +354,10 @@ class BatchIterator:
         if not idx_parts:
             return None
         idx = torch.cat(idx_parts) if len(idx_parts) > 1 else idx_parts[0]
+        if world > 1:
+            idx = idx[rank::world]
+            if idx.numel() == 0:  # ragged tail shorter than the world size: this rank sits the batch out
+                return None
         lab = self.arrays.labels.index_select(0, idx)
         augment = self.augmentation_info is not None and self.augmentation_info is not NO_AUGMENTATION
         self.last_points = None
@@ -561,6 +575,13 @@ class MetricOpsHolder:
         self._keep = lab32
         return ct
 
+    def allreduce(self):
+        """Sum the int32 confusion matrices of the ranks (one small collective at the end of an evaluation)."""
+        import torch.distributed as dist
+        if self._confusion_dev is not None and dist.is_available() and dist.is_initialized() and \
+                dist.get_world_size() > 1:
+            dist.all_reduce(self._confusion_dev, op=dist.ReduceOp.SUM)
+
     @property
     def confusion(self):
         k = self.num_classes
@@ -620,6 +641,7 @@ def calculate_accuracy(sess, nn_params, class_range):
         if batch is None:
             break
         m.combined_metric_update_op(batch)
+    m.allreduce()  # data parallel: every rank evaluated its shard of the batches
     confusion_matrix = m.confusion
     overall_accuracy, mean_per_class_accuracy, kappa = confusion_metrics(confusion_matrix)
     class_recall, class_precisions = calculate_class_accuracies_using_confusion(confusion_matrix, class_range)

@@ -71,14 +71,20 @@ class PairIterator:
         self.pos = 0
 
     def next_batch(self):
-        if self.pos + self.batch_size > self.order.numel():
+        # data parallel: the ranks share the seeded order, draw the global batch (batch_size per rank x world) and keep
+        # the pairs rank::world of it
+        import torch.distributed as dist
+        world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() \
+            else (1, 0)
+        take = self.batch_size * world
+        if self.pos + take > self.order.numel():
             return None
-        idx = self.order[self.pos:self.pos + self.batch_size]
-        self.pos += self.batch_size
+        idx = self.order[self.pos:self.pos + take][rank::world]
+        self.pos += take
         x, y = self.normal.index_select(0, idx), self.shadow.index_select(0, idx)
         if self.rate > 0 and self.ratio is not None:
-            u1 = (torch.rand(self.batch_size, generator=self.gen) * 0.98 + 0.01).to(x.device).unsqueeze(1)
-            u2 = (torch.rand(self.batch_size, generator=self.gen) * 0.98 + 0.01).to(x.device).unsqueeze(1)
+            u1 = (torch.rand(take, generator=self.gen) * 0.98 + 0.01)[rank::world].to(x.device).unsqueeze(1)
+            u2 = (torch.rand(take, generator=self.gen) * 0.98 + 0.01)[rank::world].to(x.device).unsqueeze(1)
             x = torch.where(u1 < self.rate, y * self.ratio, x)
             y = torch.where(u2 < self.rate, x / self.ratio, y)
         return x.contiguous(), y.contiguous()

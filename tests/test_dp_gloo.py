@@ -81,3 +81,48 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert torch.equal(r0["p1"], r1["p1"]), "parameters stay in lock-step"
     assert not torch.equal(r0["state"], r1["state"]), "BN moving statistics are per-rank until averaged"
     assert torch.equal(torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt"))
+
+
+def _iter_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hypelcnn_amd.common import common_nn_ops as cno
+    from tests.emu_backend import EmuBackend
+    data = np.arange(23 * 1 * 1 * 2, dtype=np.float32).reshape(23, 1, 1, 2)
+    labels = np.arange(23) % 3
+    it = cno.BatchIterator((1, 1, 2), 3, 4, True, 1, None)
+    it.initializer(data, labels, EmuBackend())
+    got = []
+    while True:
+        b = it.next_batch()
+        if b is None:
+            break
+        got.append(b[0][:, 0, 0, 0].numpy().copy())
+    # evaluation: sharded batches + one all-reduce of the confusion matrix
+    conf = torch.zeros(9, dtype=torch.int32)
+    ev = cno.BatchIterator((1, 1, 2), 3, 5, False, 1, None)
+    ev.initializer(data, labels, EmuBackend())
+    while True:
+        b = ev.next_batch()
+        if b is None:
+            break
+        for lab in b[2].tolist():
+            conf[lab * 3 + lab] += 1
+    dist.all_reduce(conf)
+    torch.save({"batches": got, "conf": conf}, os.path.join(outdir, f"it{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_iterator_shards_are_disjoint_and_complete(tmp_path):
+    port = _free_port()
+    mp.spawn(_iter_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "it0.pt", weights_only=False), torch.load(tmp_path / "it1.pt", weights_only=False)
+    a = np.concatenate(r0["batches"]) if r0["batches"] else np.zeros(0)
+    b = np.concatenate(r1["batches"]) if r1["batches"] else np.zeros(0)
+    assert len(set(a.tolist()) & set(b.tolist())) == 0, "shards must be disjoint"
+    assert sorted(a.tolist() + b.tolist()) == [2.0 * i for i in range(23)], "one epoch covers every sample once"
+    assert all(len(x) == 4 for x in r0["batches"][:-1]), "per-rank batch size is the configured batch size"
+    assert torch.equal(r0["conf"], r1["conf"]) and int(r0["conf"].sum()) == 23
