@@ -309,8 +309,10 @@ class BatchIterator:
         self._reset()
 
     def _reset(self):
-        self._gen = torch.Generator(device="cpu")
+        self._gen = torch.Generator(device="cpu")  # epoch permutations: identical on every rank (see next_batch)
         self._gen.manual_seed(self.seed)
+        self._aug_gen = torch.Generator(device="cpu")  # augmentation draws: a stream of their own, per rank
+        self._aug_gen.manual_seed(self.seed + 7919 * (self._dp()[1] + 1))
         self._epoch = 0
         self._pos = 0
         self._order = self._new_epoch()
@@ -365,9 +367,9 @@ class BatchIterator:
             x, self.last_points = self.arrays.gather(idx)
             if augment:
                 x = apply_augmentations(self.backend, x, torch.arange(x.shape[0], device=x.device),
-                                        self.augmentation_info, self._gen)
+                                        self.augmentation_info, self._aug_gen)
         elif augment:
-            x = apply_augmentations(self.backend, self.arrays.data, idx, self.augmentation_info, self._gen)
+            x = apply_augmentations(self.backend, self.arrays.data, idx, self.augmentation_info, self._aug_gen)
         else:
             x = self.arrays.data.index_select(0, idx)
         onehot = torch.nn.functional.one_hot(lab, self.class_count).to(torch.float32)

@@ -241,16 +241,21 @@ class Session:
         key = (id(tower), int(nb), id(loss), external_masks)
         ct = self._compiled.get(key)
         if ct is None:
-            plan = TowerPlan(tower, nb, self, loss=loss, external_masks=external_masks, seed=self.seed)
+            plan = TowerPlan(tower, nb, self, loss=loss, external_masks=external_masks, seed=self._rank_seed())
             ct = CompiledTower(plan, self.backend)
             self._compiled[key] = ct
         return ct
+
+    def _rank_seed(self):
+        """Philox key of the dropout masks: per rank under data parallelism (different samples, different masks)."""
+        return self.seed + (1000003 * self.dist[1] if self.dist is not None else 0)
 
     def compile_phase(self, tower, nb, terms=(), train_groups=(), outputs=(), key=None):
         k = ("phase", id(tower), int(nb), key)
         ct = self._compiled.get(k)
         if ct is None:
-            plan = PhasePlan(tower, nb, self, terms=terms, train_groups=train_groups, outputs=outputs, seed=self.seed)
+            plan = PhasePlan(tower, nb, self, terms=terms, train_groups=train_groups, outputs=outputs,
+                             seed=self._rank_seed())
             ct = CompiledTower(plan, self.backend)
             self._compiled[k] = ct
         return ct
