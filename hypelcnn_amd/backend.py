@@ -91,6 +91,8 @@ SIGNATURES = {
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
     "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
     "l2norm_fwd": [_P, _I64, _I64, _I32, _P, _I64, _P],
+    "l2norm_parts_fwd": [_P, _I64, _I64, _I32, _I32, _P, _I64, _P],
+    "l2norm_parts_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _I64, _I32],
     "l2norm_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I64, _I32],
     "nce_loss": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
 }

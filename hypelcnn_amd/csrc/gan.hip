@@ -572,6 +572,9 @@ __global__ __launch_bounds__(1024) void l2norm_fwd_kernel(const float* __restric
                                                           float* __restrict__ stat) {
     __shared__ double sh[1024];
     __shared__ float inv_s;
+    x += (int64_t)blockIdx.x * c;  // block p normalises part p: columns [p*c, (p+1)*c)
+    y += (int64_t)blockIdx.x * c;
+    stat += 2 * blockIdx.x;
     const int64_t total = rows * c;
     double s = 0.0;
 #pragma unroll 4
@@ -604,6 +607,10 @@ __global__ __launch_bounds__(1024) void l2norm_bwd_kernel(const float* __restric
                                                           float* __restrict__ dx, int64_t lddx, int accumulate) {
     __shared__ double sh[1024];
     __shared__ float dot_s;
+    x += (int64_t)blockIdx.x * c;
+    dy += (int64_t)blockIdx.x * c;
+    dx += (int64_t)blockIdx.x * c;
+    stat += 2 * blockIdx.x;
     const int64_t total = rows * c;
     double s = 0.0;
 #pragma unroll 4
@@ -789,22 +796,33 @@ extern "C" int hypel_l2_reg(const float* w, int64_t count, float scale, float* l
     return 0;
 }
 
+extern "C" int hypel_l2norm_parts_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t parts, float* y,
+                                      int64_t ldy, float* stat, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && y && stat && rows > 0 && c > 0 && parts > 0, "hypel_l2norm_parts_fwd");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, rows, c, y, ldy, stat);
+    HYPEL_CHECK_LAUNCH("hypel_l2norm_parts_fwd");
+    return 0;
+}
+
+extern "C" int hypel_l2norm_parts_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows,
+                                      int32_t c, int32_t parts, const float* stat, float* dx, int64_t lddx,
+                                      int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && dy && dx && stat && rows > 0 && c > 0 && parts > 0, "hypel_l2norm_parts_bwd");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
+                       accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_l2norm_parts_bwd");
+    return 0;
+}
+
 extern "C" int hypel_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, float* y, int64_t ldy,
                                 float* stat, hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && y && stat && rows > 0 && c > 0, "hypel_l2norm_fwd");
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(1), dim3(1024), 0, ST, x, ldx, rows, c, y, ldy, stat);
-    HYPEL_CHECK_LAUNCH("hypel_l2norm_fwd");
-    return 0;
+    return hypel_l2norm_parts_fwd(x, ldx, rows, c, 1, y, ldy, stat, stream);
 }
 
 extern "C" int hypel_l2norm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,
                                 const float* stat, float* dx, int64_t lddx, int32_t accumulate,
                                 hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && dy && dx && stat && rows > 0 && c > 0, "hypel_l2norm_bwd");
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(1), dim3(1024), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
-                       accumulate);
-    HYPEL_CHECK_LAUNCH("hypel_l2norm_bwd");
-    return 0;
+    return hypel_l2norm_parts_bwd(x, ldx, dy, lddy, rows, c, 1, stat, dx, lddx, accumulate, stream);
 }
 
 extern "C" int hypel_nce_loss(const float* g, int64_t ldg, const float* r, int64_t ldr, int64_t n, int32_t p,

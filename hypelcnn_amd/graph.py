@@ -16,6 +16,8 @@ Fusion happens while the graph is being recorded (peephole, no pattern-matching 
 """
 import math
 
+import os
+
 import numpy as np
 
 ACT_CODES = {None: 0, "lrelu": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
@@ -94,6 +96,7 @@ class Variable:
         self.offset = None  # element offset in the flat parameter / state buffer (set by the session)
         self.group = "default"  # optimiser group: variables of one group are contiguous in the flat buffers
         self.l2_scale = 0.0  # tf_slim.l2_regularizer scale attached to this variable (0 = none)
+        self.order_key = None  # layout position override (tuple); None = creation order (see Session.finalize_variables)
 
 
 # tf.compat.v1.variable_scope: name prefixes + default-name uniquification.  Re-entering a scope restarts the
@@ -269,6 +272,7 @@ class LinearNode:
         self.dropout_keep = None
         self.residuals = []
         self.out = None
+        self.in_slices = None  # kind "blockdense": (channel offset, width) of the source slice each branch reads
 
     @property
     def has_bn(self):
@@ -370,6 +374,7 @@ def _defaults(kwargs):
     return out
 
 
+MERGE_PATCH_MLPS = os.environ.get("HYPEL_MERGE_PATCH_MLPS", "1") != "0"
 _UNSET = object()
 batch_norm = "batch_norm"  # normalizer_fn marker (tf_slim.batch_norm: center=True, scale=False, eps=1e-3)
 
@@ -566,8 +571,82 @@ def shadow_generator(netinput, create_only_encoder, is_training=True):
     return node.out
 
 
+def _dense_chain(t):
+    """The plain fully-connected layers between a channel slice of some tensor and `t` (each consumed only by the
+    next one), first layer first; None when `t` is not the end of such a chain."""
+    chain, cur = [], t
+    while True:
+        n = cur.node
+        if not (isinstance(n, LinearNode) and n.kind == "dense" and len(n.branches) == 1 and len(n.sources) == 1
+                and not n.has_bn and n.has_bias and not n.residuals and n.dropout_keep is None and cur.root is None
+                and cur.consumers == (0 if not chain else 1)):
+            return None
+        chain.append(n)
+        src = n.sources[0]
+        if src.root is not None and src.node is None:  # the channel slice the chain starts from
+            return chain[::-1]
+        cur = src
+
+
+def _merge_patch_mlps(embeddings):
+    """shadowdata_feature_discriminator_model runs one small MLP per band slice (shadow_data_models.py:133-146): P
+    chains of L tiny fully-connected layers = P*L GEMM launches plus as many epilogues, each far below a microsecond
+    of work.  Layer l of all P chains has the same output width, so the P products are ONE grouped GEMM (a block
+    diagonal matrix; groups differ in the input slice and the weights) and their bias/activation ONE epilogue on the
+    [N, P*cout] result.  The nodes are replaced by L "blockdense" nodes; variables keep their TensorFlow names but
+    are laid out layer-major so that the biases (and weights) of a merged layer are contiguous."""
+    chains = [_dense_chain(e) for e in embeddings]
+    if any(c is None for c in chains) or len(chains) < 2 or len({len(c) for c in chains}) != 1:
+        return None
+    depth = len(chains[0])
+    tower = embeddings[0].tower
+    first_srcs = [c[0].sources[0] for c in chains]
+    root = first_srcs[0].root
+    if any(s.root is not root or s.pixmap is not None or s.hw is not None for s in first_srcs):
+        return None
+    slices = [(s.ch_off - root.ch_off if root.root is not None else s.ch_off, s.c) for s in first_srcs]
+    if (sorted(slices) != slices or any(a[0] + a[1] != b[0] for a, b in zip(slices, slices[1:])) or slices[0][0] != 0
+            or slices[-1][0] + slices[-1][1] != root.c):
+        return None  # the slices must tile the whole source in patch order
+    for l in range(depth):
+        nodes = [c[l] for c in chains]
+        if len({n.branches[0].cout for n in nodes}) != 1 or len({(n.act.code, n.act.alpha) if n.act else None
+                                                                  for n in nodes}) != 1:
+            return None
+    # ---- rewrite ----
+    all_vars = [v for c in chains for n in c for v in (n.branches[0].w, n.branches[0].bias)]
+    anchor = min(tower.store.order.index(v) for v in all_vars)
+    pos = min(tower.nodes.index(n) for c in chains for n in c)
+    for c in chains:
+        for n in c:
+            tower.nodes.remove(n)
+            n.out.absorbed = True
+    for s in first_srcs:  # the slices each counted one use of the root
+        root.consumers -= 1
+    src, prev_cout, out = root, None, None
+    for l in range(depth):
+        nodes = [c[l] for c in chains]
+        branches = [n.branches[0] for n in nodes]
+        for pi, b in enumerate(branches):
+            if b.w.order_key is None:
+                b.w.order_key = (anchor, 1, l, pi)
+                b.bias.order_key = (anchor, 0, l, pi)
+        merged = LinearNode("blockdense", [src.use()], branches, nodes[0].act, nodes[0].bn_decay, nodes[0].bn_eps,
+                            nodes[0].training)
+        cout = branches[0].cout
+        merged.in_slices = slices if l == 0 else [(pi * prev_cout, prev_cout) for pi in range(len(branches))]
+        merged.out = SymTensor(tower, None, cout * len(branches), node=merged)
+        tower.nodes.insert(pos + l, merged)
+        src, prev_cout, out = merged.out, cout, merged.out
+    return out, len(chains), prev_cout
+
+
 def feature_stack(embeddings):
     tower = embeddings[0].tower
+    merged = _merge_patch_mlps(embeddings) if MERGE_PATCH_MLPS else None
+    if merged is not None:
+        out, parts, width = merged
+        embeddings = [out.slice_channels(i * width, (i + 1) * width) for i in range(parts)]
     node = FeatStackNode([e.use() for e in embeddings])
     node.out = SymTensor(tower, None, sum(e.c for e in embeddings), node=node)
     node.out.parts = len(embeddings)

@@ -538,6 +538,18 @@ class TowerPlan:
                                                                      S - 1, self._ref(ybuf, off), rows_all * cout, 1,
                                                                      None, cout, c),
                                                nbytes=4 * rows_all * cout * (S + 1), tag="tap-split-reduce"))
+        elif node.kind == "blockdense":
+            # P independent small dense maps (one per band slice) as ONE grouped GEMM: group p reads the source columns
+            # of its slice, multiplies by its own weights and writes columns [p*cout, (p+1)*cout) of the output
+            src = node.sources[0]
+            s_st = self.storage_of(src)
+            cout = node.branches[0].cout
+            tb = GemmTables()
+            for pi, (off, width) in enumerate(node.in_slices):
+                tb.add_group(pi * cout, [(s_st.pix_off(0) + off, node.branches[pi].w.offset, width)], nb)
+            self._emit_gemm(self.fwd, tb, cout, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), cout, 0,
+                            self._ref(ybuf), c, bias_ref, 0, f"fwd:{node.branches[0].scope}+{len(node.branches) - 1}",
+                            allow_split=False)
         else:  # dense
             b = node.branches[0]
             rowbase = 0
@@ -827,6 +839,23 @@ class TowerPlan:
             # ---- filter gradient ----
             if trains:
                 self._on_side(lambda: self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w))
+        elif node.kind == "blockdense":
+            src = node.sources[0]
+            s_st = self.storage_of(src)
+            cout = node.branches[0].cout
+            if self._needs_grad(src):
+                gst, acc = self._grad_target(src)
+                by_width = {}
+                for pi, (off, width) in enumerate(node.in_slices):
+                    by_width.setdefault(width, []).append((pi, off))
+                for width, items in by_width.items():  # the last slice may be ragged: one launch per input width
+                    tb = GemmTables()
+                    for pi, off in items:
+                        tb.add_group(gst.pix_off(0) + off, [(pi * cout, node.branches[pi].w.offset, cout)], nb)
+                    self._emit_gemm(self.bwd, tb, width, dy, c, 0, Ref(self.sess.params), cout, 1, self._ref(gst.buf),
+                                    gst.ld, None, acc, f"dgrad:{node.branches[0].scope}+", allow_split=False)
+            if trains:
+                self._on_side(lambda: self._wgrad_blockdense(idx, node, s_st, dy, c, cout))
         else:
             b = node.branches[0]
             rowbase = 0
@@ -1035,6 +1064,30 @@ class TowerPlan:
             self._emit_wgrad(build, blocks, max_segs, slab, lo, c, self._ref(s_st.buf), s_st.ld, dy, c,
                              f"wgrad:{b.scope}", acc=acc)
             rowbase += src.npix * src.c
+
+    def _wgrad_blockdense(self, idx, node, s_st, dy, c, cout):
+        """dW_p = X[:, slice_p]^T dY[:, p*cout:(p+1)*cout] for every slice p in one launch (the weights of a merged
+        layer are contiguous: one slab per batch-row split, one reduction)."""
+        ws = [b.w for b in node.branches]
+        lo = ws[0].offset
+        slab = sum(w.size for w in ws)
+        group_list = [(w.offset - lo, off, pi * cout, width) for pi, (w, (off, width)) in
+                      enumerate(zip(ws, node.in_slices))]
+        blocks = sum((width + GEMM_BM - 1) // GEMM_BM for _, _, _, width in group_list) * ((cout + 63) // 64)
+
+        def build(S, lda=s_st.ld, ldb=c, base=s_st.pix_off(0)):
+            tb = GemmTables()
+            for si, (p0, p1, r0, r1) in enumerate(self._split_ranges(1, S[0] * S[1], 1)):
+                for (loc, a_off, b_off, width) in group_list:
+                    segs = [(base + a_off + r0 * lda, b_off + r0 * ldb, r1 - r0)] if r1 > r0 else []
+                    tb.add_group(si * slab + loc, segs, width, key=si)
+            return tb
+
+        acc = self._param_acc(ws[0])
+        for w in ws[1:]:
+            self.param_written.add(w.name)
+        self._emit_wgrad(build, blocks, 1, slab, lo, cout, self._ref(s_st.buf), s_st.ld, dy, c,
+                         f"wgrad:{node.branches[0].scope}+", acc=acc)
 
     def _bwd_post(self, idx, node):
         out, src = node.out, node.src
@@ -1245,6 +1298,12 @@ class PhasePlan(TowerPlan):
         out = node.out
         st = self._new_value(out, f"z:{idx}")
         self._alloc(f"l2stat:{idx}", 2 * len(node.srcs))
+        if self._adjacent_parts(node):
+            s0 = self.storage_of(node.srcs[0])
+            self.fwd.append(Launch("l2norm_parts_fwd", (self._ref(s0.buf, s0.ch_off), s0.ld, self.nb, node.srcs[0].c,
+                                                        len(node.srcs), self._ref(st.buf), st.ld,
+                                                        self._ref(f"l2stat:{idx}")), tag="l2norm"))
+            return
         off = 0
         for p, src in enumerate(node.srcs):
             s_st = self.storage_of(src)
@@ -1253,9 +1312,29 @@ class PhasePlan(TowerPlan):
                                    tag="l2norm"))
             off += src.c
 
+    def _adjacent_parts(self, node):
+        """The stacked embeddings are equal-width neighbouring column blocks of one buffer (merged slice MLPs)."""
+        srcs = node.srcs
+        own = srcs[0].owner
+        return (len(srcs) > 1 and all(s.owner is own and s.root is not None and s.c == srcs[0].c for s in srcs)
+                and all(s.ch_off == srcs[0].ch_off + i * srcs[0].c for i, s in enumerate(srcs))
+                and all(self._needs_grad(s) == self._needs_grad(srcs[0]) for s in srcs))
+
     def _bwd_featstack(self, idx, node):
         out = node.out
         st = self.storage[id(out)]
+        if self._adjacent_parts(node):
+            if self._needs_grad(node.srcs[0]):
+                s0 = self.storage_of(node.srcs[0])
+                accs = [self._grad_target(s) for s in node.srcs]
+                gst, acc = accs[0]
+                assert all(a[1] == acc for a in accs), "parts of one buffer share the accumulate state"
+                self.bwd.append(Launch("l2norm_parts_bwd", (self._ref(s0.buf, s0.ch_off), s0.ld,
+                                                            self._ref("g:" + st.buf), st.ld, self.nb, node.srcs[0].c,
+                                                            len(node.srcs), self._ref(f"l2stat:{idx}"),
+                                                            self._ref(gst.buf, gst.ch_off), gst.ld, acc),
+                                       tag="l2norm-bwd"))
+            return
         off = 0
         for p, src in enumerate(node.srcs):
             if self._needs_grad(src):
@@ -1302,13 +1381,23 @@ class PhasePlan(TowerPlan):
         self.fwd.append(l)
 
     def _emit_regularisers(self):
-        """tfgan.gan_loss adds the trained scope's regularisation losses (shadow_data_models.py:96,129)."""
-        seen = set()
+        """tfgan.gan_loss adds the trained scope's regularisation losses (shadow_data_models.py:96,129).  Variables
+        that are neighbours in the flat buffer and share the scale go out as one launch (sum of squares is additive)."""
+        seen, items = set(), []
         for node in self.needed:
             for v in self._node_vars(node):
                 if v.l2_scale and v.group in self.train_groups and v.name not in seen and v.name in self.param_written:
                     seen.add(v.name)
-                    l = Launch("l2_reg", (self._p(v), v.size, float(v.l2_scale), self._ref("loss"), 1, self._g(v), None),
-                               tag="l2-reg")
-                    self._scratch(l, 6, "scratch_red")
-                    self.bwd.append(l)
+                    items.append((v.offset, v.size, float(v.l2_scale)))
+        items.sort()
+        runs = []
+        for off, size, scale in items:
+            if runs and runs[-1][0] + runs[-1][1] == off and runs[-1][2] == scale:
+                runs[-1][1] += size
+            else:
+                runs.append([off, size, scale])
+        for off, size, scale in runs:
+            l = Launch("l2_reg", (Ref(self.sess.params, off), size, scale, self._ref("loss"), 1,
+                                  Ref(self.sess.grads, off), None), tag="l2-reg")
+            self._scratch(l, 6, "scratch_red")
+            self.bwd.append(l)

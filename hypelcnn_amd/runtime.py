@@ -161,6 +161,9 @@ class Session:
         for gname in groups:  # one contiguous range per optimiser group (GAN: generator / discriminator / ...)
             lo = off
             members = [v for v in order if v.trainable and v.group == gname]
+            # creation order, except where the graph builder merged sibling layers and asked for their variables to
+            # sit next to each other (Variable.order_key)
+            members.sort(key=lambda v: v.order_key if v.order_key is not None else (order.index(v),))
             for v in [m for m in members if len(m.shape) == 1] + [m for m in members if len(m.shape) > 1]:
                 v.offset = off
                 off += v.size

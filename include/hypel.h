@@ -254,6 +254,13 @@ int hypel_l2_reg(const float* w, int64_t count, float scale, float* loss, int32_
                  float* ws, hypel_stream_t stream);
 /* tf.math.l2_normalize(axis=None) over the whole [rows x c] tensor (shadow_data_models.py:147).
  * stat[0] = sum x^2, stat[1] = rsqrt(max(sum, 1e-12)). */
+/* `parts` adjacent [rows x c] column blocks of one matrix, each normalised by its own whole-block norm, in one
+ * launch (the stacked slice embeddings of the feature discriminator); stat holds 2 floats per part. */
+int hypel_l2norm_parts_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t parts, float* y, int64_t ldy,
+                           float* stat, hypel_stream_t stream);
+int hypel_l2norm_parts_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,
+                           int32_t parts, const float* stat, float* dx, int64_t lddx, int32_t accumulate,
+                           hypel_stream_t stream);
 int hypel_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, float* y, int64_t ldy, float* stat,
                      hypel_stream_t stream);
 int hypel_l2norm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,

@@ -612,6 +612,16 @@ def _k_l2norm_bwd(self, x, ldx, dy, lddy, rows, c, stat, dx, lddx, accumulate):
         d[...] = res.astype(np.float32)
 
 
+def _k_l2norm_parts_fwd(self, x, ldx, rows, c, parts, y, ldy, stat):
+    for p in range(parts):
+        _k_l2norm_fwd(self, x + p * c, ldx, rows, c, y + p * c, ldy, stat + 2 * p)
+
+
+def _k_l2norm_parts_bwd(self, x, ldx, dy, lddy, rows, c, parts, stat, dx, lddx, accumulate):
+    for p in range(parts):
+        _k_l2norm_bwd(self, x + p * c, ldx, dy + p * c, lddy, rows, c, stat + 2 * p, dx + p * c, lddx, accumulate)
+
+
 def _k_nce_loss(self, g, ldg, r, ldr, n, p, e, tau, weight, loss, accumulate_loss, dg, lddg, acc_dg, dr, lddr, acc_dr,
                 ws):
     gv = _mat(g, ldg, n, p * e).astype(np.float64).reshape(n, p, e)
@@ -638,6 +648,8 @@ def _k_nce_loss(self, g, ldg, r, ldr, n, p, e, tau, weight, loss, accumulate_los
                 m[...] = upd
 
 
+EmuBackend.k_l2norm_parts_fwd = _k_l2norm_parts_fwd
+EmuBackend.k_l2norm_parts_bwd = _k_l2norm_parts_bwd
 EmuBackend.k_gan_generator_fwd = _k_gan_generator_fwd
 EmuBackend.k_gan_generator_bwd = _k_gan_generator_bwd
 EmuBackend.k_gan_loss = _k_gan_loss

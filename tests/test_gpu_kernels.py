@@ -465,6 +465,22 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.check("db", rtol=2e-4, atol=2e-5)
 
 
+def test_l2norm_parts(hip):
+    rng = np.random.default_rng(5)
+    rows, e, parts = 4096, 2, 6
+    b = Both(hip)
+    b.arr("x", rng.standard_normal((rows, parts * e)).astype(np.float32))
+    b.arr("dy", rng.standard_normal((rows, parts * e)).astype(np.float32))
+    b.arr("y", np.zeros(rows * parts * e, np.float32))
+    b.arr("dx", rng.standard_normal(rows * parts * e).astype(np.float32))
+    b.arr("stat", np.zeros(2 * parts, np.float32))
+    b.run("l2norm_parts_fwd", "x", parts * e, rows, e, parts, "y", parts * e, "stat")
+    b.check("y", rtol=1e-5, atol=1e-7)
+    b.check("stat", rtol=1e-5, atol=1e-7)
+    b.run("l2norm_parts_bwd", "x", parts * e, "dy", parts * e, rows, e, parts, "stat", "dx", parts * e, 1)
+    b.check("dx", rtol=1e-4, atol=1e-6)
+
+
 def test_gan_losses_l2norm_nce(hip):
     rng = np.random.default_rng(11)
     rows, c = 2048, 32
