@@ -116,23 +116,30 @@ class GANTrainOps:
             ct.capture()
         return ct
 
-    def _feed(self, ct, x, y):
+    def _feed(self, ct, x, y, fed=None):
+        """Copy the batch into the phase's input buffers.  The buffers are shared between the phases of a session
+        (PhasePlan); `fed` (a set owned by one run_step call) makes only the first phase that reads an input pay for
+        the copy."""
         b = ct.plan.buffers
-        if "in:x" in b:
-            ct.set_input("x", x)
-        if "in:y" in b:
-            ct.set_input("y", y)
+        for name, t in (("x", x), ("y", y)):
+            if "in:" + name in b:
+                key = (name, b["in:" + name].data_ptr())
+                if fed is None or key not in fed:
+                    ct.set_input(name, t)
+                    if fed is not None:
+                        fed.add(key)
 
     def run_step(self, x, y):
         sess = self.ctx.session()
+        fed = set()
         nb = x.shape[0]
         step = sess.global_step
         for phase in self.loss.phases:
             ct = self._compiled(sess, phase, nb)
-            self._feed(ct, x, y)
+            self._feed(ct, x, y, fed)
             if phase.pool:
                 gen = sess.compile_phase(self.loss.tower, nb, outputs=[t for _, t in phase.pool], key="generate")
-                self._feed(gen, x, y)
+                self._feed(gen, x, y, fed)
                 gen.forward()
                 for name, t in phase.pool:
                     fresh = gen.value(t)

@@ -1210,7 +1210,9 @@ class PhasePlan(TowerPlan):
             if id(t) not in used_inputs:
                 continue
             assert t.hw is None, "GAN inputs are [N, B]"
-            self._alloc("in:" + name, nb * t.c)
+            # the phases of one GAN step read the same batch: they share one device buffer per input, fed once per step
+            shared = self.sess.shared_inputs.setdefault((name, nb, t.c), self.be.zeros(nb * t.c))
+            self.buffers["in:" + name] = shared
             self.storage[id(t)] = Storage("in:" + name, nb, t.c, None, 0, t.c, 1)
         self._alloc("loss", 1)
         for idx, node in enumerate(self.tower.nodes):

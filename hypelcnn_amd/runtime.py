@@ -143,6 +143,7 @@ class Session:
         self.stateful = []
         self.global_step = 0
         self._compiled = {}
+        self.shared_inputs = {}  # (name, rows, c) -> device buffer shared by every GAN phase plan
         self.dist = None  # (world_size, rank) once init_data_parallel() ran
 
     # ---- variables ----
