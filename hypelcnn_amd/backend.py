@@ -88,8 +88,6 @@ SIGNATURES = {
     "lrn_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64, _I32],
     "gan_generator_fwd": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64],
     "gan_generator_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P],
-    "gan_discriminator_fwd": [_P, _I64, _I64, _I32, _P, _P, _F, _P, _I64],
-    "gan_discriminator_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _F, _P, _I64, _I32, _P, _P],
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
     "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
     "l2norm_fwd": [_P, _I64, _I64, _I32, _P, _I64, _P],
@@ -127,8 +125,6 @@ def load_library(path=LIB_PATH):
     lib.hypel_device_info.argtypes = [ctypes.POINTER(_I32), ctypes.POINTER(_I32)]
     lib.hypel_gan_generator_blocks.argtypes = [_I64]
     lib.hypel_gan_generator_blocks.restype = ctypes.c_int
-    lib.hypel_gan_discriminator_supported.argtypes = [_I32]
-    lib.hypel_gan_discriminator_supported.restype = ctypes.c_int
     return lib
 
 
@@ -177,9 +173,6 @@ class HipBackend:
 
     def gan_generator_blocks(self, n):
         return int(self.lib.hypel_gan_generator_blocks(int(n)))
-
-    def gan_discriminator_supported(self, bands):
-        return bool(self.lib.hypel_gan_discriminator_supported(int(bands)))
 
     # -- launches --
     def bind(self, name, args, stream=None):

@@ -565,179 +565,6 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w
     if (threadIdx.x == 0) ws[blockIdx.x] = t;
 }
 
-// ===================================================================================================================
-// Fused discriminator (gan/shadow_data_models.py:93-123) for narrow spectra: flatten -> FC B->B -> FC B->B ->
-// FC B->B/2, leaky-ReLU(0.1) after the first two.  At B = 64 the three layers are 10 k MAC per sample: as GEMM +
-// epilogue launches the network costs ~23 kernel launches per application with gradients, each at the launch-latency
-// floor.  Here one wavefront runs a sample end to end out of LDS (weights and their transposes resident), and the
-// backward kernel keeps the filter gradients of its samples in registers (lane n owns column n of every dW).
-constexpr int DIS_WAVES = 4;
-constexpr int DIS_MAX_B = 64;  // one lane per hidden unit; W + W^T of all layers must fit the LDS
-
-struct DisLayout {
-    int in[3], out[3], woff[3], boff[3], wtotal, btotal;
-};
-__host__ __device__ inline DisLayout dis_layout(int b) {
-    DisLayout d;
-    const int ins[3] = {b, b, b}, outs[3] = {b, b, b / 2};
-    int wo = 0, bo = 0;
-    for (int i = 0; i < 3; ++i) {
-        d.in[i] = ins[i];
-        d.out[i] = outs[i];
-        d.woff[i] = wo;
-        d.boff[i] = bo;
-        wo += ins[i] * outs[i];
-        bo += outs[i];
-    }
-    d.wtotal = wo;
-    d.btotal = bo;
-    return d;
-}
-
-// one layer for one sample: out[n] = bias[n] + sum_k in[k] * W[k][n]   (lane n; W row-major [in x out] in LDS)
-__device__ __forceinline__ float dis_dot(const float* __restrict__ in, const float* __restrict__ w, int kin, int nout,
-                                         int lane, float bias) {
-    float acc = bias;
-    if (lane < nout) {
-#pragma unroll 8
-        for (int k = 0; k < kin; ++k) acc += in[k] * w[k * nout + lane];
-    }
-    return acc;
-}
-
-__global__ __launch_bounds__(64 * DIS_WAVES) void gan_discriminator_fwd_kernel(
-    const float* __restrict__ x, int64_t ldx, int64_t n, int bands, const float* __restrict__ w,
-    const float* __restrict__ b, float alpha, float* __restrict__ out, int64_t ldo) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DisLayout d = dis_layout(bands);
-    float* ws = smem;               // [wtotal]
-    float* bs = ws + d.wtotal;      // [btotal]
-    float* wave_base = bs + ((d.btotal + 3) & ~3);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < d.wtotal; i += blockDim.x) ws[i] = w[i];
-    for (int i = threadIdx.x; i < d.btotal; i += blockDim.x) bs[i] = b[i];
-    __syncthreads();
-    float* h = wave_base + (size_t)wave * 3 * DIS_MAX_B;  // x, h1, h2 of the current sample
-    for (int64_t s = (int64_t)blockIdx.x * DIS_WAVES + wave; s < n; s += (int64_t)gridDim.x * DIS_WAVES) {
-        if (lane < bands) h[lane] = x[s * ldx + lane];
-        __builtin_amdgcn_wave_barrier();
-        for (int l = 0; l < 3; ++l) {
-            const float c = dis_dot(h + l * DIS_MAX_B, ws + d.woff[l], d.in[l], d.out[l], lane,
-                                    lane < d.out[l] ? bs[d.boff[l] + lane] : 0.0f);
-            if (l < 2) {
-                if (lane < d.out[l]) h[(l + 1) * DIS_MAX_B + lane] = c > 0.0f ? c : c * alpha;
-                __builtin_amdgcn_wave_barrier();
-            } else if (lane < d.out[l]) {
-                out[s * ldo + lane] = c;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// Backward: recompute the two hidden layers, then
-//   d3 = dout;            dW3[k][n] += h2[k] d3[n];  db3 += d3;  g2[k] = sum_n W3[k][n] d3[n]
-//   d2 = g2 * slope(c2);  dW2[k][n] += h1[k] d2[n];  db2 += d2;  g1[k] = sum_n W2[k][n] d2[n]
-//   d1 = g1 * slope(c1);  dW1[k][n] += x[k]  d1[n];  db1 += d1;  dx[k] = sum_n W1[k][n] d1[n]
-// Lane n keeps column n of the three dW in registers over all samples of its wave (3 x 64 accumulators); the input
-// gradients read the TRANSPOSED weights from LDS (lane k walks row k of W^T: conflict free).
-__global__ __launch_bounds__(64 * DIS_WAVES) void gan_discriminator_bwd_kernel(
-    const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
-    const float* __restrict__ w, const float* __restrict__ b, float alpha, float* __restrict__ dx, int64_t lddx,
-    int accumulate_dx, float* __restrict__ pw, float* __restrict__ pb) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DisLayout d = dis_layout(bands);
-    float* ws = smem;                    // W  [in x out] per layer
-    float* wt = ws + d.wtotal;           // W^T [out x in] per layer
-    float* bs = wt + d.wtotal;
-    float* wave_base = bs + ((d.btotal + 3) & ~3);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < d.wtotal; i += blockDim.x) ws[i] = w[i];
-    for (int l = 0; l < 3; ++l)
-        for (int i = threadIdx.x; i < d.in[l] * d.out[l]; i += blockDim.x) {
-            const int k = i / d.out[l], nn = i - k * d.out[l];
-            wt[d.woff[l] + nn * d.in[l] + k] = w[d.woff[l] + i];
-        }
-    for (int i = threadIdx.x; i < d.btotal; i += blockDim.x) bs[i] = b[i];
-    __syncthreads();
-    float* h = wave_base + (size_t)wave * 5 * DIS_MAX_B;  // x, h1, h2, delta (current layer), slope scratch
-    float* delta = h + 3 * DIS_MAX_B;
-    float dw[3][DIS_MAX_B];
-    float db[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int k = 0; k < DIS_MAX_B; ++k) dw[l][k] = 0.0f;
-
-    for (int64_t s = (int64_t)blockIdx.x * DIS_WAVES + wave; s < n; s += (int64_t)gridDim.x * DIS_WAVES) {
-        if (lane < bands) h[lane] = x[s * ldx + lane];
-        __builtin_amdgcn_wave_barrier();
-        float slope[2];
-#pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            const float c = dis_dot(h + l * DIS_MAX_B, ws + d.woff[l], d.in[l], d.out[l], lane,
-                                    lane < d.out[l] ? bs[d.boff[l] + lane] : 0.0f);
-            slope[l] = c > 0.0f ? 1.0f : alpha;
-            if (lane < d.out[l]) h[(l + 1) * DIS_MAX_B + lane] = c * slope[l];
-            __builtin_amdgcn_wave_barrier();
-        }
-        float dl = lane < d.out[2] ? dout[s * lddo + lane] : 0.0f;  // delta of the layer being processed, lane = unit n
-#pragma unroll
-        for (int l = 2; l >= 0; --l) {
-            const float* hin = h + l * DIS_MAX_B;
-            db[l] += dl;
-#pragma unroll
-            for (int k = 0; k < DIS_MAX_B; ++k)
-                if (k < d.in[l]) dw[l][k] += hin[k] * dl;
-            // gradient w.r.t. this layer's input: lane k = input unit
-            if (lane < d.out[l]) delta[lane] = dl;
-            __builtin_amdgcn_wave_barrier();
-            float g = 0.0f;
-            if (lane < d.in[l]) {
-                const float* wrow = wt + d.woff[l] + lane;  // W^T[nn][lane] at stride in[l]
-#pragma unroll 8
-                for (int nn = 0; nn < d.out[l]; ++nn) g += wrow[nn * d.in[l]] * delta[nn];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (l > 0) {
-                dl = lane < d.out[l - 1] ? g * slope[l - 1] : 0.0f;
-            } else if (dx && lane < bands) {
-                float* p = dx + s * lddx + lane;
-                *p = accumulate_dx ? *p + g : g;
-            }
-        }
-    }
-    // combine the waves of the block in a fixed order through LDS and publish the block's partial sums
-    __syncthreads();
-    float* red = smem;  // the weights are no longer needed: [DIS_WAVES][wtotal] needs wtotal*4 <= 2*wtotal + ... floats
-    float* pwb = pw + (size_t)blockIdx.x * d.wtotal;
-    float* pbb = pb + (size_t)blockIdx.x * d.btotal;
-    for (int l = 0; l < 3; ++l) {
-        // stage one layer at a time: [DIS_WAVES][in x out]
-        const int sz = d.in[l] * d.out[l];
-        __syncthreads();
-        if (lane < d.out[l]) {
-#pragma unroll
-            for (int k = 0; k < DIS_MAX_B; ++k)
-                if (k < d.in[l]) red[(size_t)wave * sz + k * d.out[l] + lane] = dw[l][k];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < sz; i += blockDim.x) {
-            float t = 0.0f;
-            for (int wv = 0; wv < DIS_WAVES; ++wv) t += red[(size_t)wv * sz + i];
-            pwb[d.woff[l] + i] = t;
-        }
-        __syncthreads();
-        if (lane < d.out[l]) red[wave * DIS_MAX_B + lane] = db[l];
-        __syncthreads();
-        if (threadIdx.x < d.out[l]) {
-            float t = 0.0f;
-            for (int wv = 0; wv < DIS_WAVES; ++wv) t += red[wv * DIS_MAX_B + threadIdx.x];
-            pbb[d.boff[l] + threadIdx.x] = t;
-        }
-    }
-}
-
 // tf.math.l2_normalize(x) with axis=None: the norm of the WHOLE [rows x c] tensor (shadow_data_models.py:147).
 // One block of 1024 threads (the tensor is [N x E] with E = 2: 8 k elements); stat[0] = sum x^2, stat[1] = rsqrt(max(sum, 1e-12)).
 __global__ __launch_bounds__(1024) void l2norm_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int c,
@@ -939,53 +766,6 @@ extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float*
     hipLaunchKernelGGL(gan_generator_bwd_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * GEN_WAVES), lds, ST, x,
                        ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb);
     HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd");
-    return 0;
-}
-
-static size_t dis_fwd_lds(int bands) {
-    const DisLayout d = dis_layout(bands);
-    return sizeof(float) * ((size_t)d.wtotal + ((d.btotal + 3) & ~3) + (size_t)DIS_WAVES * 3 * DIS_MAX_B);
-}
-static size_t dis_bwd_lds(int bands) {
-    const DisLayout d = dis_layout(bands);
-    size_t base = (size_t)2 * d.wtotal + ((d.btotal + 3) & ~3) + (size_t)DIS_WAVES * 5 * DIS_MAX_B;
-    const size_t red = (size_t)DIS_WAVES * bands * bands;  // staging of one layer's dW per wave
-    if (red > base) base = red;
-    return sizeof(float) * base;
-}
-
-extern "C" int hypel_gan_discriminator_supported(int32_t bands) {
-    return bands >= 2 && bands <= DIS_MAX_B && bands % 2 == 0 && dis_bwd_lds(bands) <= 160 * 1024;
-}
-
-extern "C" int hypel_gan_discriminator_fwd(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w,
-                                           const float* b, float alpha, float* out, int64_t ldo,
-                                           hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && w && b && out && n > 0 && hypel_gan_discriminator_supported(bands),
-                  "hypel_gan_discriminator_fwd");
-    const size_t lds = dis_fwd_lds(bands);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)gan_discriminator_fwd_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gan_discriminator_fwd_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * DIS_WAVES), lds,
-                       ST, x, ldx, n, bands, w, b, alpha, out, ldo);
-    HYPEL_CHECK_LAUNCH("hypel_gan_discriminator_fwd");
-    return 0;
-}
-
-extern "C" int hypel_gan_discriminator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n,
-                                           int32_t bands, const float* w, const float* b, float alpha, float* dx,
-                                           int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
-                                           hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && hypel_gan_discriminator_supported(bands),
-                  "hypel_gan_discriminator_bwd");
-    const size_t lds = dis_bwd_lds(bands);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)gan_discriminator_bwd_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gan_discriminator_bwd_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * DIS_WAVES), lds,
-                       ST, x, ldx, dout, lddo, n, bands, w, b, alpha, dx, lddx, accumulate_dx, pw, pb);
-    HYPEL_CHECK_LAUNCH("hypel_gan_discriminator_bwd");
     return 0;
 }
 

@@ -12,9 +12,6 @@ def shadowdata_generator_model(netinput, create_only_encoder, is_training=True):
 
 def shadowdata_discriminator_model(generated_data, generator_input, is_training, scale):
     """flatten -> FC B->B -> FC B->B -> FC B->B/2 (linear); leaky-ReLU 0.1, He init, L2(scale) on the first two."""
-    fused = g.shadow_discriminator(generated_data, scale, alpha=0.1)  # narrow spectra: one launch per direction
-    if fused is not None:
-        return fused
     with g.arg_scope([g.fully_connected], weights_initializer=g.he_truncated_init(),
                      weights_regularizer=g.l2_regularizer(scale), activation_fn=g.leaky_relu(0.1)):
         band_size = generated_data.c

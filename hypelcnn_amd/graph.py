@@ -320,18 +320,6 @@ class GeneratorNode:
         self.out = None
 
 
-class DiscriminatorNode:
-    """Whole shadowdata_discriminator_model as ONE fused op for narrow spectra (gan/shadow_data_models.py:93-123):
-    [N,B] -> FC B->B -> FC B->B -> FC B->B/2, leaky-ReLU(alpha) after the first two."""
-
-    def __init__(self, src, weights, biases, alpha):
-        self.src = src
-        self.weights = weights  # 3 Variables [in, out]
-        self.biases = biases  # 3 Variables [out]
-        self.alpha = alpha
-        self.out = None
-
-
 class FeatStackNode:
     """tf.math.l2_normalize (whole-tensor norm) of each slice embedding [N,E], stacked to [N, P*E]
     (gan/shadow_data_models.py:147-149)."""
@@ -386,7 +374,6 @@ def _defaults(kwargs):
     return out
 
 
-FUSE_DISCRIMINATOR = os.environ.get("HYPEL_FUSE_DISCRIMINATOR", "1") != "0"
 MERGE_PATCH_MLPS = os.environ.get("HYPEL_MERGE_PATCH_MLPS", "1") != "0"
 _UNSET = object()
 batch_norm = "batch_norm"  # normalizer_fn marker (tf_slim.batch_norm: center=True, scale=False, eps=1e-3)
@@ -652,31 +639,6 @@ def _merge_patch_mlps(embeddings):
         tower.nodes.insert(pos + l, merged)
         src, prev_cout, out = merged.out, cout, merged.out
     return out, len(chains), prev_cout
-
-
-FUSED_DISCRIMINATOR_MAX_BANDS = 64  # hypel_gan_discriminator_supported: one lane per hidden unit, W + W^T in LDS
-
-
-def shadow_discriminator(generated_data, scale, alpha=0.1):
-    """Records the fused discriminator when the spectrum is narrow enough, else returns None (the caller then builds
-    the three fully_connected layers).  Variables get the names the three tf_slim layers would get."""
-    b = generated_data.c
-    if not FUSE_DISCRIMINATOR or b > FUSED_DISCRIMINATOR_MAX_BANDS or b % 2 or generated_data.hw is not None:
-        return None
-    tower = generated_data.tower
-    st = tower.store
-    ws, bs = [], []
-    for cin, cout, reg in ((b, b, scale), (b, b, scale), (b, b // 2, None)):
-        scope = unique_default_name("fully_connected")
-        w = st.get(f"{scope}/weights", (cin, cout), he_truncated_init(), True)
-        if reg:
-            w.l2_scale = float(reg)
-        ws.append(w)
-        bs.append(st.get(f"{scope}/biases", (cout,), zeros_init(), True))
-    node = DiscriminatorNode(generated_data.use(), ws, bs, float(alpha))
-    node.out = SymTensor(tower, None, b // 2, node=node)
-    tower.nodes.append(node)
-    return node.out
 
 
 def feature_stack(embeddings):

@@ -1168,7 +1168,7 @@ class PhasePlan(TowerPlan):
                 if b.bias is not None:
                     out.append(b.bias)
             return out
-        if isinstance(node, (G.GeneratorNode, G.DiscriminatorNode)):
+        if isinstance(node, G.GeneratorNode):
             return list(node.weights) + list(node.biases)
         return []
 
@@ -1222,8 +1222,6 @@ class PhasePlan(TowerPlan):
                 self._fwd_linear(idx, node)
             elif isinstance(node, G.GeneratorNode):
                 self._fwd_generator(idx, node)
-            elif isinstance(node, G.DiscriminatorNode):
-                self._fwd_discriminator(idx, node)
             elif isinstance(node, G.FeatStackNode):
                 self._fwd_featstack(idx, node)
             elif isinstance(node, G.PostNode):
@@ -1243,8 +1241,6 @@ class PhasePlan(TowerPlan):
                     self._bwd_linear(idx, node)
                 elif isinstance(node, G.GeneratorNode):
                     self._bwd_generator(idx, node)
-                elif isinstance(node, G.DiscriminatorNode):
-                    self._bwd_discriminator(idx, node)
                 elif isinstance(node, G.FeatStackNode):
                     self._bwd_featstack(idx, node)
                 elif isinstance(node, G.PostNode):
@@ -1297,45 +1293,6 @@ class PhasePlan(TowerPlan):
             self._scratch(l2, 0, "scratch_gen_w", blocks * wtotal)
             l3 = Launch("reduce_splits_f32", (None, 8, blocks, self._g(b0), 7, wacc, None, 0, 0), tag="gen-db")
             self._scratch(l3, 0, "scratch_gen_b", blocks * 8)
-            self.bwd += [l2, l3]
-
-    # ---- fused discriminator ----
-    def _fwd_discriminator(self, idx, node):
-        src, out = node.src, node.out
-        if not self.be.gan_discriminator_supported(src.c):
-            raise NotImplementedError(f"fused discriminator does not support {src.c} bands")
-        s_st = self.storage_of(src)
-        st = self._new_value(out, f"z:{idx}")
-        w0, b0, _ = self._gen_refs(node)
-        self.fwd.append(Launch("gan_discriminator_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c,
-                                                         self._p(w0), self._p(b0), node.alpha, self._ref(st.buf),
-                                                         st.ld), nbytes=6 * self.nb * src.c, tag="dis-fwd"))
-
-    def _bwd_discriminator(self, idx, node):
-        src, out = node.src, node.out
-        s_st = self.storage_of(src)
-        z_st = self.storage[id(out)]
-        w0, b0, wtotal = self._gen_refs(node)
-        btotal = sum(b.size for b in node.biases)
-        blocks = self.be.gan_generator_blocks(self.nb)
-        dx, lddx, acc = None, 0, 0
-        if self._needs_grad(src):
-            gst, acc = self._grad_target(src)
-            dx, lddx = self._ref(gst.buf, gst.ch_off), gst.ld
-        l1 = Launch("gan_discriminator_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
-                                              z_st.ld, self.nb, src.c, self._p(w0), self._p(b0), node.alpha, dx, lddx,
-                                              acc, None, None), nbytes=10 * self.nb * src.c, tag="dis-bwd")
-        self._scratch(l1, 12, "scratch_dis_w", blocks * wtotal)
-        self._scratch(l1, 13, "scratch_dis_b", blocks * btotal)
-        self.bwd.append(l1)
-        if self._trains(node.weights):
-            wacc = self._param_acc(w0)
-            for v in list(node.weights[1:]) + list(node.biases):
-                self.param_written.add(v.name)
-            l2 = Launch("reduce_splits_f32", (None, wtotal, blocks, self._g(w0), wtotal, wacc, None, 0, 0), tag="dis-dw")
-            self._scratch(l2, 0, "scratch_dis_w", blocks * wtotal)
-            l3 = Launch("reduce_splits_f32", (None, btotal, blocks, self._g(b0), btotal, wacc, None, 0, 0), tag="dis-db")
-            self._scratch(l3, 0, "scratch_dis_b", blocks * btotal)
             self.bwd += [l2, l3]
 
     # ---- feature stack (global l2 normalise per slice, stacked) ----

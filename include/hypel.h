@@ -243,18 +243,6 @@ int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, int32_t band
 int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,
                             const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
                             int32_t accumulate_dx, float* pw, float* pb, hypel_stream_t stream);
-/* shadowdata_discriminator_model (gan/shadow_data_models.py:93-123) as ONE launch per direction for narrow spectra
- * (hypel_gan_discriminator_supported(bands): even, <= 64): FC B->B, FC B->B, FC B->B/2 with leaky-ReLU(alpha) after
- * the first two.  w = the three weight matrices [in x out] back to back, b = the three bias vectors back to back
- * (fully_connected, fully_connected_1, fully_connected_2 in creation order).  The backward kernel recomputes the
- * hidden layers and writes per-block partial sums pw[blocks][2.5 B^2], pb[blocks][2.5 B], blocks =
- * hypel_gan_generator_blocks(n), to be summed by hypel_reduce_splits_f32; dx (nullable) (+)= input gradient. */
-int hypel_gan_discriminator_supported(int32_t bands);
-int hypel_gan_discriminator_fwd(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w, const float* b,
-                                float alpha, float* out, int64_t ldo, hypel_stream_t stream);
-int hypel_gan_discriminator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,
-                                const float* w, const float* b, float alpha, float* dx, int64_t lddx,
-                                int32_t accumulate_dx, float* pw, float* pb, hypel_stream_t stream);
 /* tensorflow_gan losses: mode 0: weight*mean((a-target)^2) (least squares, pass weight/2),
  * mode 1: weight*mean(|a-b|) (cycle consistency / absolute_difference), mode 2: weight*mean(a) (Wasserstein).
  * loss[0] (+)= value; da / db (nullable) (+)= gradient.  ws >= 1024 floats. */

@@ -612,60 +612,6 @@ def _k_l2norm_bwd(self, x, ldx, dy, lddy, rows, c, stat, dx, lddx, accumulate):
         d[...] = res.astype(np.float32)
 
 
-def _dis_layout(bands):
-    ins, outs = [bands, bands, bands], [bands, bands, bands // 2]
-    woff = np.concatenate([[0], np.cumsum([i * o for i, o in zip(ins, outs)])]).astype(int)
-    boff = np.concatenate([[0], np.cumsum(outs)]).astype(int)
-    return ins, outs, woff, boff
-
-
-def _dis_forward(xs, wv, bv, bands, alpha):
-    ins, outs, woff, boff = _dis_layout(bands)
-    hs, slopes = [xs], []
-    for l in range(3):
-        c = hs[-1] @ wv[woff[l]:woff[l + 1]].reshape(ins[l], outs[l]) + bv[boff[l]:boff[l + 1]]
-        if l < 2:
-            sl = np.where(c > 0, 1.0, alpha)
-            slopes.append(sl)
-            hs.append(c * sl)
-        else:
-            out = c
-    return hs, slopes, out
-
-
-def _k_gan_discriminator_fwd(self, x, ldx, n, bands, w, b, alpha, out, ldo):
-    ins, outs, woff, boff = _dis_layout(bands)
-    xs = _mat(x, ldx, n, bands).astype(np.float64)
-    _, _, o = _dis_forward(xs, _arr(w)[:woff[3]].astype(np.float64), _arr(b)[:boff[3]].astype(np.float64), bands, alpha)
-    _mat(out, ldo, n, bands // 2)[...] = o.astype(np.float32)
-
-
-def _k_gan_discriminator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, alpha, dx, lddx, accumulate_dx, pw, pb):
-    ins, outs, woff, boff = _dis_layout(bands)
-    xs = _mat(x, ldx, n, bands).astype(np.float64)
-    wv, bv = _arr(w)[:woff[3]].astype(np.float64), _arr(b)[:boff[3]].astype(np.float64)
-    hs, slopes, _ = _dis_forward(xs, wv, bv, bands, alpha)
-    dl = _mat(dout, lddo, n, bands // 2).astype(np.float64)
-    blocks = _emu_generator_blocks(n)
-    pwm = _arr(pw)[: blocks * woff[3]].reshape(blocks, woff[3])
-    pbm = _arr(pb)[: blocks * boff[3]].reshape(blocks, boff[3])
-    pwm[...] = 0
-    pbm[...] = 0
-    for l in (2, 1, 0):
-        W = wv[woff[l]:woff[l + 1]].reshape(ins[l], outs[l])
-        pwm[0, woff[l]:woff[l + 1]] = (hs[l].T @ dl).reshape(-1).astype(np.float32)  # whole sum in block 0's slab
-        pbm[0, boff[l]:boff[l + 1]] = dl.sum(0).astype(np.float32)
-        g = dl @ W.T
-        if l > 0:
-            dl = g * slopes[l - 1]
-    if dx is not None:
-        dm = _mat(dx, lddx, n, bands)
-        if accumulate_dx:
-            dm += g.astype(np.float32)
-        else:
-            dm[...] = g.astype(np.float32)
-
-
 def _k_l2norm_parts_fwd(self, x, ldx, rows, c, parts, y, ldy, stat):
     for p in range(parts):
         _k_l2norm_fwd(self, x + p * c, ldx, rows, c, y + p * c, ldy, stat + 2 * p)
@@ -702,9 +648,6 @@ def _k_nce_loss(self, g, ldg, r, ldr, n, p, e, tau, weight, loss, accumulate_los
                 m[...] = upd
 
 
-EmuBackend.k_gan_discriminator_fwd = _k_gan_discriminator_fwd
-EmuBackend.k_gan_discriminator_bwd = _k_gan_discriminator_bwd
-EmuBackend.gan_discriminator_supported = lambda self, bands: 2 <= bands <= 64 and bands % 2 == 0
 EmuBackend.k_l2norm_parts_fwd = _k_l2norm_parts_fwd
 EmuBackend.k_l2norm_parts_bwd = _k_l2norm_parts_bwd
 EmuBackend.k_gan_generator_fwd = _k_gan_generator_fwd

@@ -465,34 +465,6 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.check("db", rtol=2e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("bands,n", [(64, 2048), (64, 37), (16, 5), (48, 300)])
-def test_gan_discriminator_fwd_bwd(hip, bands, n):
-    rng = np.random.default_rng(bands + n)
-    wtot = bands * bands * 2 + bands * (bands // 2)
-    btot = 2 * bands + bands // 2
-    b = Both(hip)
-    assert hip.gan_discriminator_supported(bands) and not hip.gan_discriminator_supported(360)
-    b.arr("x", rng.random((n, bands)).astype(np.float32))
-    b.arr("w", (rng.standard_normal(wtot) * np.sqrt(2.0 / bands)).astype(np.float32))
-    b.arr("bias", (rng.standard_normal(btot) * 0.1).astype(np.float32))
-    b.arr("out", np.zeros(n * (bands // 2), np.float32))
-    b.run("gan_discriminator_fwd", "x", bands, n, bands, "w", "bias", 0.1, "out", bands // 2)
-    b.check("out", rtol=5e-5, atol=5e-6)
-    blocks = hip.gan_generator_blocks(n)
-    b.arr("dout", rng.standard_normal((n, bands // 2)).astype(np.float32))
-    b.arr("dx", rng.standard_normal((n, bands)).astype(np.float32))
-    b.arr("pw", np.zeros(blocks * wtot, np.float32))
-    b.arr("pb", np.zeros(blocks * btot, np.float32))
-    b.arr("dw", np.zeros(wtot, np.float32))
-    b.arr("db", np.zeros(btot, np.float32))
-    b.run("gan_discriminator_bwd", "x", bands, "dout", bands // 2, n, bands, "w", "bias", 0.1, "dx", bands, 1, "pw", "pb")
-    b.check("dx", rtol=1e-4, atol=1e-5)
-    b.run("reduce_splits_f32", "pw", wtot, blocks, "dw", wtot, 0, None, 0, 0)
-    b.run("reduce_splits_f32", "pb", btot, blocks, "db", btot, 0, None, 0, 0)
-    b.check("dw", rtol=2e-4, atol=2e-5)
-    b.check("db", rtol=2e-4, atol=2e-5)
-
-
 def test_l2norm_parts(hip):
     rng = np.random.default_rng(5)
     rows, e, parts = 4096, 2, 6
