@@ -61,9 +61,12 @@ def check_phase_gradients(cfg, ops, params, x, y, tol=2e-4):
         ref_loss, ref_grads = OG.phase_gradients(cfg, params, x, y, phase.name)
         got_loss = ct.loss_value()
         assert abs(got_loss - ref_loss) < tol * max(1.0, abs(ref_loss)), (phase.name, got_loss, ref_loss)
+        g_all = max(np.abs(g).max() for g in ref_grads.values())
         for k, g in ref_grads.items():
             got = sess.get_gradient(k)
-            scale = max(np.abs(g).max(), 1e-7)
+            # a gradient that is analytically zero (last bias under the Wasserstein loss: +1/N and -1/N per sample)
+            # is compared at the rounding level of the terms that cancel, not relative to itself
+            scale = max(np.abs(g).max(), 1e-5 * g_all, 1e-7)
             err = np.abs(got - g).max() / scale
             worst = max(worst, err)
             assert err < tol, (phase.name, k, err)
