@@ -542,6 +542,14 @@ def optimize_nn(deep_nn_template, images, labels, device_id, name_prefix, algori
 
 
 # ----------------------------------------------------------------------------- metrics (reference :243-310)
+def _capture_forward(ctx, sess, ct):
+    """Evaluation / inference towers replay one HIP graph per batch instead of ~100 launches (the host would
+    otherwise be the bottleneck of full-scene inference)."""
+    if (ctx is None or ctx.capture_graphs) and getattr(sess.backend, "name", "") == "hip" and not ct.bwd \
+            and ct._graph_fwd is None:
+        ct.capture()
+
+
 class MetricOpsHolder:
     """Streaming OA / mean-per-class accuracy / Cohen kappa / confusion matrix.  The confusion matrix is
     accumulated on the device by hypel_argmax_confusion; the scalar metrics are its host-side functions
@@ -568,6 +576,7 @@ class MetricOpsHolder:
         x, _, lab = batch
         nb = x.shape[0]
         ct = sess.compile(self.tower, nb)
+        _capture_forward(self.ctx, sess, ct)
         ct.set_input("x", x)
         ct.forward()
         st = ct.plan.storage_of(self.y_conv)
@@ -669,6 +678,7 @@ def perform_prediction(sess, nn_params, prediction_result):
         x = batch[0]
         nb = x.shape[0]
         ct = sess.compile(y_conv.tower, nb)
+        _capture_forward(None, sess, ct)
         ct.set_input("x", x)
         ct.forward()
         st = ct.plan.storage_of(y_conv)
