@@ -5,7 +5,7 @@ which exists in the build or test environment, so every benchmark and end-to-end
 `path` selects the geometry, e.g. "grss2013" (144 HSI bands + LiDAR, 15 classes), "grss2018" (48 + LiDAR, 20),
 "avon" (360 bands, no LiDAR, 2 classes), optionally followed by ":key=value" overrides
 (h, w, bands, classes, lidar, seed, samples, gan_ckpt=<npz checkpoint of a shadow GAN for the generator-based
-shadow augmenters>).  Each class has its own smooth spectrum and height, pixels are
+shadow augmenters>, base_dir=<directory that get_model_base_dir reports, e.g. where TFRecord exports live>).  Each class has its own smooth spectrum and height, pixels are
 class spectrum + noise laid out in blobs, so that a classifier can actually learn the scene."""
 import numpy
 
@@ -30,7 +30,7 @@ class SyntheticDataLoader(DataLoader):
         cfg.update(seed=1234, samples=0.5)
         for kv in parts[1:]:
             k, v = kv.split("=", 1)
-            cfg[k] = v if k == "gan_ckpt" else (float(v) if k == "samples" else int(v))
+            cfg[k] = v if k in ("gan_ckpt", "base_dir") else (float(v) if k == "samples" else int(v))
         self.cfg = cfg
         self._targets = None
 
@@ -119,7 +119,8 @@ class SyntheticDataLoader(DataLoader):
         return range(0, self.cfg["classes"])
 
     def get_model_base_dir(self):
-        return ""
+        base = self.cfg.get("base_dir", "")
+        return base + "/" if base and not base.endswith("/") else base
 
     def get_samples_color_list(self):
         rng = numpy.random.RandomState(7)

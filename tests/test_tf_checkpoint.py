@@ -5,6 +5,7 @@ import json
 import os
 import struct
 
+import numpy
 import numpy as np
 import pytest
 
@@ -125,3 +126,70 @@ def test_session_export_and_restore_through_tf_bundle(tmp_path):
         U.run_train_step(b, x, onehot, {})
         s.adam_step(3e-3)
     np.testing.assert_array_equal(s2.params.numpy(), s1.params.numpy())
+
+
+# ------------------------------------------------------------------------------------------------ TFRecord files
+def test_tfrecord_example_known_bytes():
+    from hypelcnn_amd.common.tfrecord_io import decode_example, encode_example
+    # hand-assembled tf.train.Example{features{feature{key:"a" value{int64_list{value:[3]}}}}}
+    want = bytes([0x0a, 0x0c, 0x0a, 0x0a, 0x0a, 0x01, ord("a"), 0x12, 0x05, 0x1a, 0x03, 0x0a, 0x01, 0x03])
+    assert encode_example({"a": numpy.asarray([3])}) == want
+    got = decode_example(want)
+    assert got["a"].tolist() == [3]
+    # float_list packed: field 2 -> 0x12, inner field 1 wire type 2
+    ex = encode_example({"f": numpy.asarray([1.0, -2.5], numpy.float32)})
+    assert ex[-8:] == numpy.asarray([1.0, -2.5], "<f4").tobytes()
+    assert decode_example(ex)["f"].tolist() == [1.0, -2.5]
+    # unpacked repeated encodings (older writers) decode too: int64_list{value:1 value:-1}
+    neg = bytes([0x08, 0x01, 0x08] + [0xff] * 9 + [0x01])
+    unpacked = b"\x0a" + bytes([len(neg) + 9]) + b"\x0a" + bytes([len(neg) + 7]) + b"\x0a\x01k\x12" + \
+        bytes([len(neg) + 2]) + b"\x1a" + bytes([len(neg)]) + neg
+    assert decode_example(unpacked)["k"].tolist() == [1, -1]
+    assert decode_example(encode_example({"b": [b"xy", b""], "n": numpy.asarray([-7, 1 << 40])}))["n"].tolist() == \
+        [-7, 1 << 40]
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_tfrecord_framing_round_trip(tmp_path, compressed):
+    import struct
+    from hypelcnn_amd.common.tf_checkpoint import crc32c, mask_crc
+    from hypelcnn_amd.common.tfrecord_io import read_records, write_records
+    path = str(tmp_path / "x.tfrecord")
+    payloads = [b"", b"abc", bytes(range(256)) * 40]
+    assert write_records(path, payloads, compressed) == 3
+    assert list(read_records(path)) == payloads
+    if not compressed:
+        raw = open(path, "rb").read()
+        # first record: zero length, crc of eight zero bytes, no payload, crc of the empty string (masked 0 -> delta)
+        assert raw[:8] == b"\0" * 8 and struct.unpack("<I", raw[8:12])[0] == mask_crc(crc32c(b"\0" * 8))
+        assert struct.unpack("<I", raw[12:16])[0] == 0xa282ead8
+        bad = bytearray(raw)
+        bad[16 + 12 + 1] ^= 1  # a payload byte of the second record
+        open(path, "wb").write(bytes(bad))
+        with pytest.raises(ValueError):
+            list(read_records(path))
+
+
+def test_tfrecord_importer_matches_in_memory(tmp_path):
+    """utilities/tfrecord_writer export -> TFRecordImporter gives the in-memory importer's arrays back."""
+    from hypelcnn_amd.common.common_nn_ops import get_importer_from_name
+    from hypelcnn_amd.utilities import tfrecord_writer
+    from hypelcnn_amd.importer.TFRecordImporter import TFRecordImporter
+    out = str(tmp_path / "rec")
+    spec = "grss2018:h=24:w=28:bands=12:classes=4"
+    tfrecord_writer.main(["--loader_name", "SyntheticDataLoader", "--path", spec, "--neighborhood", "1",
+                          "--train_ratio", "0.2", "--target_path", out, "--compressed", "True"])
+    mem = get_importer_from_name("InMemoryImporter").read_data_set("SyntheticDataLoader", spec, 0.2, 0.05, 1, True)
+    imp = get_importer_from_name("TFRecordImporter")
+    assert isinstance(imp, TFRecordImporter) and imp.requires_separate_validation_branch() is False
+    train, test, val, shadow, class_range, scene_shape, colors = imp.read_data_set(
+        "SyntheticDataLoader", spec + ":base_dir=" + out, 0.2, 0.05, 1, True)
+    assert shadow is None and scene_shape is None and class_range == range(0, 4)
+    for info, ref in ((train, mem[0]), (test, mem[1]), (val, mem[2])):
+        assert tuple(info.data.shape) == ref.data.shape
+        data, labels = imp.load_file(info.path, tuple(info.data.shape[1:]))
+        numpy.testing.assert_array_equal(data, ref.data)
+        numpy.testing.assert_array_equal(labels, ref.labels)
+    testing_t, training_t, validation_t = imp.convert_data_to_tensor(test, train, val, class_range)
+    assert validation_t is testing_t and training_t.dataset.element_shape == (3, 3, 13)
+    assert training_t.dataset.class_count == 4

@@ -50,6 +50,19 @@ def test_end_to_end_training_learns_and_resumes(tmp_path):
     assert res2.test_accuracy > 0.85
 
 
+def test_training_through_tfrecord_importer(tmp_path):
+    """--importer_name TFRecordImporter on an export of the same scene trains like the in-memory importer."""
+    from hypelcnn_amd.utilities import tfrecord_writer
+    scene = "grss2013:h=24:w=30:bands=10:classes=3:samples=0.6"
+    rec = str(tmp_path / "records")
+    tfrecord_writer.export("SyntheticDataLoader", scene, 0.1, 1, rec)
+    flags = _flags(tmp_path, 101, ["--importer_name", "TFRecordImporter", "--path", scene + ":base_dir=" + rec])
+    model = T.get_model_from_name(flags.model_name)
+    log_dir = os.path.join(flags.base_log_path, "tfrecord")
+    res = T.perform_an_episode(flags, dict(ALG), model, log_dir, backend=EmuBackend())
+    assert res.test_accuracy > 0.85 and res.validation_accuracy > 0.85, (res.test_accuracy, res.validation_accuracy)
+
+
 def test_log_suffix_format(tmp_path):
     flags = _flags(tmp_path, 1, ["--augment_data_with_shadow", "simple", "--augment_data_with_spectral", "0.05"])
     s = T.get_log_suffix(flags)
