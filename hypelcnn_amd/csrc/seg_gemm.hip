@@ -33,6 +33,9 @@ constexpr int BK = HYPEL_GEMM_BK;
 #ifndef HYPEL_GEMM_SETPRIO
 #define HYPEL_GEMM_SETPRIO 1
 #endif
+#ifndef HYPEL_GEMM_CLK
+#define HYPEL_GEMM_CLK 0  // 1: tools/gemm_quantisation.py --clk reads the shader clock the kernel actually ran at
+#endif
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
@@ -83,6 +86,9 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#if HYPEL_GEMM_CLK  // diagnostic build: shader-clock and 100 MHz wall counters over this block's k loop, returned through `bias`
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+#endif
     // wave index as a SCALAR: every predicate derived from it is wave-uniform and compiles to s_cbranch,
     // not to exec-masked regions around the MFMAs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -232,6 +238,14 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
         }
     }
 
+#if HYPEL_GEMM_CLK
+    if (tid == 0 && bias) {
+        long long* dbg = (long long*)bias + 2 * (size_t)blockIdx.x;
+        dbg[0] = clock64() - clk0;
+        dbg[1] = wall_clock64() - wall0;
+    }
+    bias = nullptr;
+#endif
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
     float* cbase = C + grp.c_off + (int64_t)m0 * ldc + n0;
     // bias is indexed by the absolute output column: groups of a merged level start at channel offsets
