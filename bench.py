@@ -235,6 +235,11 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # HYPEL_DIST_BACKEND=gloo: rehearse the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices;
+    # RCCL refuses that).  The driver's runs use nccl (= RCCL), one rank per GPU.
+    backend_name = os.environ.get("HYPEL_DIST_BACKEND", "nccl")
+    if backend_name != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     # HYPEL_DP_SELFTEST=1 under `torch.distributed.run --nproc-per-node 1`: drive the whole RCCL path on a 1-rank
@@ -242,7 +247,10 @@ def main():
     use_dist = world > 1 or (os.environ.get("HYPEL_DP_SELFTEST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend_name)
 
     from hypelcnn_amd.backend import HipBackend
     be = HipBackend()
@@ -289,6 +297,14 @@ def main():
         dt = float(t[0])
     loss = loss_fn()
     assert np.isfinite(loss), "non-finite loss"
+    in_sync = None
+    if use_dist and classifier:
+        # data-parallel invariant: every rank holds bit-identical weights after the same all-reduced updates
+        digest = torch.stack([sess.params.double().sum(), sess.params.double().abs().max()])
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
 
     roof = None
     cpu = None
@@ -328,6 +344,8 @@ def main():
                      "batch_per_gpu": nb, "global_batch": nb * world,
                      "parallelism": f"dp{world}" if world > 1 else "single",
                      "hip_graph": ctx.capture_graphs, "loss": loss}
+            if in_sync is not None:
+                cfg_d["dp_weights_identical_across_ranks"] = in_sync
             if mac:
                 cfg_d["mfma_ceiling_patches_per_s_per_gpu"] = PEAK_F32_MFMA_TFLOPS * 1e12 / (6 * mac)
             unit = "patches/s"
