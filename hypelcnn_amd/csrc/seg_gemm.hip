@@ -34,7 +34,7 @@ constexpr int BK = HYPEL_GEMM_BK;
 #define HYPEL_GEMM_SETPRIO 1
 #endif
 #ifndef HYPEL_GEMM_CLK
-#define HYPEL_GEMM_CLK 0  // 1: tools/gemm_quantisation.py --clk reads the shader clock the kernel actually ran at
+#define HYPEL_GEMM_CLK 0  // tools/gemm_quantisation.py: 1 = --clk (shader clock the kernel ran at), 2 = --timeline
 #endif
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
@@ -241,8 +241,13 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
 #if HYPEL_GEMM_CLK
     if (tid == 0 && bias) {
         long long* dbg = (long long*)bias + 2 * (size_t)blockIdx.x;
+#if HYPEL_GEMM_CLK == 2  // absolute 100 MHz times of the block's start and end: occupancy timeline of a launch
+        dbg[0] = wall0;
+        dbg[1] = wall_clock64();
+#else
         dbg[0] = clock64() - clk0;
         dbg[1] = wall_clock64() - wall0;
+#endif
     }
     bias = nullptr;
 #endif

@@ -5,7 +5,8 @@ time is a staircase in the number of blocks loses its last partial round, a line
 
   python tools/gemm_quantisation.py [--k 480] [--n 480] [--hint 0|1|2]
   HYPEL_LIB_PATH=<build with -DHYPEL_GEMM_CLK=1> python tools/gemm_quantisation.py --clk [--burst N]
-      additionally reads the shader clock each launch actually ran at (clock64 / wall_clock64 inside the kernel).
+      additionally reads the shader clock each launch actually ran at (clock64 / wall_clock64 inside the kernel);
+      a -DHYPEL_GEMM_CLK=2 build with --timeline prints how many blocks are inside their k loop over the launch.
 Results: profiles/r1_gemm_loop_breakdown.txt."""
 import argparse
 import os
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--hint", type=int, default=2)
     ap.add_argument("--tiles", type=str, default="64,128,192,256,320,384,392,448,512,640,768,1024,1536,2048")
     ap.add_argument("--rounds", type=int, default=9)
+    ap.add_argument("--timeline", action="store_true", help="library built with -DHYPEL_GEMM_CLK=2: blocks alive over time")
     ap.add_argument("--burst", type=int, default=0, help="with --clk: N back-to-back launches, clock of each")
     ap.add_argument("--clk", action="store_true", help="library built with -DHYPEL_GEMM_CLK=1: report the shader clock")
     args = ap.parse_args()
@@ -43,9 +45,9 @@ def main():
         tb.add_group(0, [(0, 0, k)], rows)
         garr, sarr, tarr, macs = tb.finalize(n)
         g_t, s_t, t_t = be.upload(garr), be.upload(sarr), be.upload(tarr)
-        dbg = torch.zeros(4 * tiles * ((n + width - 1) // width), device="cuda") if args.clk else None
+        dbg = torch.zeros(4 * tiles * ((n + width - 1) // width), device="cuda") if (args.clk or args.timeline) else None
         f = be.bind("seg_gemm_f32", (Ref(a), k, 0, Ref(b), n, 0, Ref(c), n, n, Ref(g_t), Ref(s_t), Ref(t_t),
-                                     len(tarr), Ref(dbg) if args.clk else None, args.hint << 8))
+                                     len(tarr), Ref(dbg) if dbg is not None else None, args.hint << 8))
         if args.burst:
             nblk = tiles * ((n + width - 1) // width)
             bufs = [torch.zeros(4 * nblk, device="cuda") for _ in range(args.burst)]
@@ -78,6 +80,19 @@ def main():
         med = float(np.median(ts[2:]))
         blocks = tiles * ((n + width - 1) // width)
         clk = ""
+        if args.timeline:
+            d = dbg.cpu().numpy().view(np.int64).reshape(-1, 2)
+            d = d[d[:, 1] > 0].astype(np.float64) / 100.0  # us
+            t0, t1 = d[:, 0].min(), d[:, 1].max()
+            edges = np.linspace(t0, t1, 41)
+            alive = [int(((d[:, 0] <= t) & (d[:, 1] > t)).sum()) for t in 0.5 * (edges[1:] + edges[:-1])]
+            life = d[:, 1] - d[:, 0]
+            order = np.argsort(d[:, 0])
+            print(f"  timeline over {t1 - t0:.1f} us (k-loop only): blocks alive per 1/40 slice: {alive}")
+            print(f"  block life us: first 10% started {np.median(life[order[:len(order) // 10]]):.1f}, "
+                  f"middle {np.median(life[order[len(order) * 4 // 10: len(order) * 6 // 10]]):.1f}, "
+                  f"last 10% started {np.median(life[order[-len(order) // 10:]]):.1f}; "
+                  f"last start at {d[:, 0].max() - t0:.1f} us")
         if args.clk:
             d = dbg.cpu().numpy().view(np.int64).reshape(-1, 2)
             d = d[d[:, 1] > 0]
