@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--filter", type=str, default="")
     ap.add_argument("--workload", type=str, default="hypelcnn", choices=list(bench.CLASSIFIER_WORKLOADS))
+    ap.add_argument("--timeline", action="store_true",
+                    help="HYPEL_LIB_PATH build with -DHYPEL_GEMM_CLK=2: blocks inside their k loop over each launch "
+                         "(launches without a bias only; the debug buffer travels in the bias argument)")
     args = ap.parse_args()
     from hypelcnn_amd.backend import HipBackend
     be = HipBackend()
@@ -44,6 +47,28 @@ def main():
             b.record()
             torch.cuda.synchronize()
             times[l.tag].append(a.elapsed_time(b) * 1e3)
+    if args.timeline:
+        from hypelcnn_amd.backend import Ref
+        for l, _ in items:
+            a = list(l.args)
+            if a[13] is not None or l.flops < 2e9:
+                continue
+            width = 32 if ((a[14] >> 8) & 3) == 1 or a[8] <= 32 else 64
+            nblk = a[12] * ((a[8] + width - 1) // width)
+            dbg = torch.zeros(4 * nblk, device="cuda")
+            a[13] = Ref(dbg)
+            f = be.bind(l.name, tuple(a))
+            f()
+            torch.cuda.synchronize()
+            f()
+            torch.cuda.synchronize()
+            d = dbg.cpu().numpy().view(np.int64).reshape(-1, 2)
+            d = d[d[:, 1] > 0].astype(np.float64) / 100.0
+            t0, t1 = d[:, 0].min(), d[:, 1].max()
+            edges = np.linspace(t0, t1, 31)
+            alive = [int(((d[:, 0] <= t) & (d[:, 1] > t)).sum()) for t in 0.5 * (edges[1:] + edges[:-1])]
+            print(f"{l.tag:34s} {nblk:6d} blocks {t1 - t0:7.1f} us  last start {d[:, 0].max() - t0:6.1f}  alive {alive}")
+        return
     tot = 0.0
     for l, _ in items:
         t = np.array(times[l.tag][2:])
