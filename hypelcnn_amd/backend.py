@@ -25,7 +25,8 @@ GEMM_BM = 128
 SEG_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("k", "<i4"), ("reserved", "<i4")])
 GROUP_DTYPE = np.dtype([("c_off", "<i8"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("rows", "<i4"),
                         ("reserved", "<i4")])
-TILE_DTYPE = np.dtype([("group", "<i4"), ("m0", "<i4")])
+TILE_DTYPE = np.dtype([("group", "<i4"), ("m0", "<i4"), ("rows", "<i4"), ("seg_begin", "<i4"), ("seg_count", "<i4"),
+                       ("k0", "<i4"), ("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8")])
 
 
 class Ref:

@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     const int tile_id = lid / n_ntiles;
     const int n0 = (lid - tile_id * n_ntiles) * BN;
     if (tile_id >= n_tiles) return;
+    // one record per tile: the group's fields and its first segment travel with it (no tiles -> groups -> segs chain
+    // in front of the first operand loads)
     const hypel_tile_t tile = tiles[tile_id];
-    const hypel_group_t grp = groups[tile.group];
+    struct { int64_t c_off; int seg_begin, seg_count, rows; } grp = {tile.c_off, tile.seg_begin, tile.seg_count, tile.rows};
     const int m0 = tile.m0;
     const int rows_left = grp.rows - m0;  // valid rows in this tile (may exceed BM)
     const int cols_left = n - n0;
@@ -137,7 +139,11 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     hypel_seg_t seg;
     seg.a_off = 0; seg.b_off = 0; seg.k = 0; seg.reserved = 0;
     bool have = ls < s_end;
-    if (have) seg = segs[ls];
+    if (have) {
+        seg.a_off = tile.a_off0;
+        seg.b_off = tile.b_off0;
+        seg.k = tile.k0;
+    }
 
     // Staging loads are raw buffer loads: the tile base lives in a scalar descriptor, each thread keeps ONE
     // 32-bit offset per operand and the per-load row step is a scalar soffset.  An invalid element is fetched

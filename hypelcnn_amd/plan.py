@@ -135,7 +135,11 @@ class GemmTables:
         # Filter-gradient launches pass key = split index (= batch-row range), for the same reason.
         tiles.sort(key=lambda t: (t[3], -t[0]))
         sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
-        tarr = np.array([(g, m0) for _, g, m0, _ in tiles], TILE_DTYPE) if tiles else np.zeros(0, TILE_DTYPE)
+        tarr = np.zeros(len(tiles), TILE_DTYPE)
+        for i, (_, g, m0, _) in enumerate(tiles):  # each record repeats what a block needs to start its tile
+            c_off, gs, rows = self.groups[g]
+            a0, b0, k0 = gs[0] if gs else (0, 0, 0)
+            tarr[i] = (g, m0, rows, garr[g]["seg_begin"], len(gs), k0, c_off, a0, b0)
         return garr, sarr, tarr, macs
 
     def compulsory_bytes(self, n, lda, ta, ldb, tb):

@@ -66,10 +66,16 @@ int hypel_fill_f32(float* dst, int64_t count, float value, hypel_stream_t stream
  * tf.gradients derives inside create_train_op (common_nn_ops.py:232).
  * bias (optional) is indexed by the ABSOLUTE output column, (c_off mod ldc) + j, so the branches of a
  * merged multi-kernel level (groups starting at different channel offsets) share one launch.
- * `tiles` lists the (group, first row) of every 128-row output tile; tables live on the device. */
+ * `tiles` lists every 128-row output tile: its group and first row, plus a copy of what the kernel needs to start the
+ * tile (the group's rows / segment range / c_off and the first segment), so that a block reads ONE record before its
+ * first operand loads instead of chasing tiles -> groups -> segs; tables live on the device. */
 typedef struct { int64_t a_off; int64_t b_off; int32_t k; int32_t reserved; } hypel_seg_t;
 typedef struct { int64_t c_off; int32_t seg_begin; int32_t seg_count; int32_t rows; int32_t reserved; } hypel_group_t;
-typedef struct { int32_t group; int32_t m0; } hypel_tile_t;
+typedef struct {
+    int32_t group; int32_t m0;                         /* output rows [m0, min(m0 + 128, rows)) of groups[group] */
+    int32_t rows; int32_t seg_begin; int32_t seg_count; /* copies of groups[group] */
+    int32_t k0; int64_t c_off; int64_t a_off0; int64_t b_off0; /* c_off copy; segs[seg_begin] copy (0 if none) */
+} hypel_tile_t;
 #define HYPEL_GEMM_BM 128
 
 /* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint

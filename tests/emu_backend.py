@@ -190,6 +190,14 @@ class EmuBackend:
         for gi, m0s in seen.items():
             rows = int(g[gi]["rows"])
             assert sorted(m0s) == list(range(0, rows, 128)), (gi, m0s, rows)
+        for tt in t:  # every tile record repeats its group and first segment (include/hypel.h)
+            gg = g[int(tt["group"])]
+            assert (int(tt["rows"]), int(tt["seg_begin"]), int(tt["seg_count"]), int(tt["c_off"])) == \
+                (int(gg["rows"]), int(gg["seg_begin"]), int(gg["seg_count"]), int(gg["c_off"]))
+            if int(gg["seg_count"]):
+                s0 = s[int(gg["seg_begin"])]
+                assert (int(tt["a_off0"]), int(tt["b_off0"]), int(tt["k0"])) == \
+                    (int(s0["a_off"]), int(s0["b_off"]), int(s0["k"]))
         bv = _arr(bias)
         for gi in seen:
             grp = g[gi]
