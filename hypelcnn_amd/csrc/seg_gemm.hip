@@ -23,6 +23,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -40,7 +41,10 @@ constexpr int BK = HYPEL_GEMM_BK;
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
 
-template <int WM, int WN, int TM, int TN, bool TA, bool TB>
+// NARROW: 128x16 blocks on v_mfma_f32_16x16x4_f32 for n <= 16 (the Cout = 15 level of HYPELCNN, fc_final): each wave
+// owns 32 rows x 16 columns as two 16x16 accumulators, so a 15-column output wastes 1/16 of the MFMA work instead of
+// the 17/32 it wastes on a 32-wide tile.
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false>
 __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
@@ -51,16 +55,20 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
                                                         int accumulate, const float* __restrict__ res, int64_t ldr,
                                                         const int32_t* __restrict__ res_start) {
     constexpr int BM = WM * TM * 32;
-    constexpr int BN = WN * TN * 32;
+    constexpr int BN = NARROW ? 16 : WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
+    static_assert(!NARROW || (WM == 4 && TM == 1 && TN == 1), "narrow variant: 4 x 1 waves of 32 x 16");
     // LDS images (rows x pitch), global row order preserved
     constexpr int A_ROWS = TA ? BK : BM;
     constexpr int A_COLS = TA ? BM : BK;
-    constexpr int A_PITCH = TA ? BM : BK + 1;
+    // pitches: a fragment read must hit 32 distinct banks per half-wave.  32x32x2 fragments read 32 rows at one k
+    // (odd pitch 33 for the k-contiguous image); 16x16x4 fragments read 16 rows x 2 k per half-wave (pitch 34 resp.
+    // 16 extra floats per k row of the transposed image)
+    constexpr int A_PITCH = TA ? (NARROW ? BM + 16 : BM) : (NARROW ? BK + 2 : BK + 1);
     constexpr int B_ROWS = TB ? BN : BK;
     constexpr int B_COLS = TB ? BK : BN;
-    constexpr int B_PITCH = TB ? BK + 1 : BN;
+    constexpr int B_PITCH = TB ? (NARROW ? BK + 2 : BK + 1) : BN;
     constexpr int A_PER_THREAD = A_ROWS * A_COLS / 256;
     constexpr int B_PER_THREAD = B_ROWS * B_COLS / 256;
     constexpr int A_RSTEP = 256 / A_COLS;
@@ -101,13 +109,21 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     const int a_col = tid % A_COLS, a_row0 = tid / A_COLS;
     const int b_col = tid % B_COLS, b_row0 = tid / B_COLS;
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[NARROW ? 1 : TM][NARROW ? 1 : TN];
+    f32x4 acc16[2];  // NARROW: rows [0,16) and [16,32) of the wave's 32 x 16 tile
+    if constexpr (NARROW) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int e = 0; e < 4; ++e) acc16[t][e] = 0.0f;
+    } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    }
 
     // wave-uniform activity of each 32x32 accumulator tile
     bool row_act[TM], col_act[TN];
@@ -124,8 +140,14 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     }
     const bool any_act = any_row && any_col;
     // per-lane LDS read bases (k advances by immediate offsets in the unrolled loop)
-    const int a_rd = TA ? (lhi * A_PITCH + wm * TM * 32 + l31) : ((wm * TM * 32 + l31) * A_PITCH + lhi);
-    const int b_rd = TB ? ((wn * TN * 32 + l31) * B_PITCH + lhi) : (lhi * B_PITCH + wn * TN * 32 + l31);
+    const int l15 = lane & 15, lq = lane >> 4;  // 16x16x4 fragments: row / column = lane & 15, k = lane >> 4
+    const int a_rd = NARROW ? (TA ? (lq * A_PITCH + wm * 32 + l15) : ((wm * 32 + l15) * A_PITCH + lq))
+                            : (TA ? (lhi * A_PITCH + wm * TM * 32 + l31) : ((wm * TM * 32 + l31) * A_PITCH + lhi));
+    const int b_rd = NARROW ? (TB ? (l15 * B_PITCH + lq) : (lq * B_PITCH + l15))
+                            : (TB ? ((wn * TN * 32 + l31) * B_PITCH + lhi) : (lhi * B_PITCH + wn * TN * 32 + l31));
+    constexpr int A_K4STEP = TA ? 4 * A_PITCH : 4;     // NARROW: LDS distance of one k4 step / of the second 16 rows
+    constexpr int A_TILE16 = TA ? 16 : 16 * A_PITCH;
+    constexpr int B_K4STEP = TB ? 4 : 4 * B_PITCH;
     constexpr int A_KSTEP = TA ? 2 * A_PITCH : 2;      // LDS distance of one k2 step
     constexpr int A_TILE = TA ? 32 : 32 * A_PITCH;     // LDS distance between the wave's 32-row tiles
     constexpr int B_KSTEP = TB ? 2 : 2 * B_PITCH;
@@ -219,23 +241,39 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
 #if HYPEL_GEMM_SETPRIO
             __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
 #endif
+            if constexpr (NARROW) {
+                // 16 reduction columns (4 k4-steps) at a time, as below
+#pragma unroll
+                for (int q = 0; q < BK / 16; ++q) {
+                    if (q > 0 && kvalid <= q * 16) break;
+#pragma unroll
+                    for (int k4 = q * 4; k4 < q * 4 + 4; ++k4) {
+                        const float b = Bs[b_rd + k4 * B_K4STEP];
+                        const float a0 = As[a_rd + k4 * A_K4STEP];
+                        const float a1 = As[a_rd + A_TILE16 + k4 * A_K4STEP];
+                        acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc16[0], 0, 0, 0);
+                        acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc16[1], 0, 0, 0);
+                    }
+                }
+            } else {
             // 16 reduction columns (8 MFMA k-steps) at a time; the chunks of a short k-tile beyond kvalid are skipped
-            // by a wave-uniform branch
-#pragma unroll
-            for (int q = 0; q < BK / 16; ++q) {
-                if (q > 0 && kvalid <= q * 16) break;
-#pragma unroll
-                for (int k2 = q * 8; k2 < q * 8 + 8; ++k2) {
-                    float a[TM], b[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = Bs[b_rd + j * B_TILE + k2 * B_KSTEP];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                // by a wave-uniform branch
+    #pragma unroll
+                for (int q = 0; q < BK / 16; ++q) {
+                    if (q > 0 && kvalid <= q * 16) break;
+    #pragma unroll
+                    for (int k2 = q * 8; k2 < q * 8 + 8; ++k2) {
+                        float a[TM], b[TN];
+    #pragma unroll
+                        for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j) b[j] = Bs[b_rd + j * B_TILE + k2 * B_KSTEP];
+    #pragma unroll
+                        for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
                 }
             }
 #if HYPEL_GEMM_SETPRIO
@@ -265,13 +303,23 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     // (row, c) additionally receives sum_{o in [res_start[c], res_start[c+1])} res[row][o] -- the transpose of the
     // monotone channel map of scale_in_to_out -- from the row-aligned matrix `res` (same pixel-major row order as C)
     const float* rbase = res ? res + (grp.c_off / ldc + m0) * ldr : nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (!(row_act[i] && col_act[j])) continue;
-            const int col = (wn * TN + j) * 32 + l31;
-            if (col >= cols_left) continue;
+    // one output element: bias, optional read-modify-write, optional shortcut-gradient gather
+    auto put = [&](int row, int col, float accv, float bv, int o0, int o1) {
+        if (row < rows_left) {
+            float* p = cbase + (int64_t)row * ldc + col;
+            float v = accv + bv;
+            if (accumulate) v += *p;
+            if (res) {
+                const float* rr = rbase + (int64_t)row * ldr;
+                for (int o = o0; o < o1; ++o) v += rr[o];
+            }
+            *p = v;
+        }
+    };
+    if constexpr (NARROW) {
+        // C/D layout of 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
+        const int col = l15;
+        if (row_act[0] && col < cols_left) {
             const float bv = bias ? bias[bias_col0 + col] : 0.0f;
             int o0 = n0 + col, o1 = n0 + col + 1;
             if (res && res_start) {
@@ -279,35 +327,45 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
                 o1 = res_start[n0 + col + 1];
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                if (row < rows_left) {
-                    float* p = cbase + (int64_t)row * ldc + col;
-                    float v = acc[i][j][e] + bv;
-                    if (accumulate) v += *p;
-                    if (res) {
-                        const float* rr = rbase + (int64_t)row * ldr;
-                        for (int o = o0; o < o1; ++o) v += rr[o];
-                    }
-                    *p = v;
-                }
-            }
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) put(wm * 32 + t * 16 + 4 * lq + e, col, acc16[t][e], bv, o0, o1);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!(row_act[i] && col_act[j])) continue;
+                const int col = (wn * TN + j) * 32 + l31;
+                if (col >= cols_left) continue;
+                const float bv = bias ? bias[bias_col0 + col] : 0.0f;
+                int o0 = n0 + col, o1 = n0 + col + 1;
+                if (res && res_start) {
+                    o0 = res_start[n0 + col];
+                    o1 = res_start[n0 + col + 1];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    put((wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi, col, acc[i][j][e], bv, o0, o1);
+            }
+    }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool NARROW = false>
 int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb, int tb, float* c, int64_t ldc,
                int n, const hypel_group_t* groups, const hypel_seg_t* segs, const hypel_tile_t* tiles, int n_tiles,
                const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
                hipStream_t st) {
-    constexpr int BN = WN * TN * 32;
+    constexpr int BN = NARROW ? 16 : WN * TN * 32;
     const int n_nt = (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
     // diagnostic: unused dynamic LDS lowers the number of resident blocks per CU (occupancy experiments)
     static const int lds_pad = getenv("HYPEL_GEMM_LDS_PAD") ? atoi(getenv("HYPEL_GEMM_LDS_PAD")) : 0;
 #define HYPEL_GO(TA_, TB_)                                                                                         \
-    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_>), dim3(grid), dim3(256), lds_pad, st, a, lda, b, \
-                       ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr, res_start)
+    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW>), dim3(grid), dim3(256), lds_pad, st, a, \
+                       lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,     \
+                       res_start)
     if (!ta && !tb) HYPEL_GO(false, false);
     else if (!ta && tb) HYPEL_GO(false, true);
     else if (ta && !tb) HYPEL_GO(true, false);
@@ -339,7 +397,12 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const int hint = (accumulate >> 8) & 3;
     accumulate &= 1;
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
-    if (n <= 32 || narrow)
+    // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (HYPEL_GEMM_MFMA16=0: 128x32)
+    static const int mfma16 = getenv("HYPEL_GEMM_MFMA16") ? atoi(getenv("HYPEL_GEMM_MFMA16")) : 1;
+    if (n <= 16 && mfma16)
+        launch_cfg<4, 1, 1, 1, true>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                                     accumulate, res, ldr, res_start, st);
+    else if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st);
     else if (n <= 64 || !bn128)

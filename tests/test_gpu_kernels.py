@@ -72,6 +72,12 @@ def _tables(b, groups):
     (60, 1000, 60, 1, 0, 0, False),
     (15, 77, 45, 1, 0, 1, False),
     (130, 33, 70, 1, 1, 0, False),
+    # n <= 16: the 128x16 blocks on the 16x16x4 MFMA, all four operand layouts, ragged K / rows, k-tile halves
+    (300, 120, 15, 0, 0, 0, True),
+    (120, 1085, 15, 1, 0, 0, False),   # level-2 filter gradient: M = Cin = 120, n = 15
+    (257, 49, 16, 0, 1, 1, False),
+    (40, 17, 9, 1, 1, 0, True),
+    (129, 7, 1, 0, 0, 1, False),
 ])
 def test_seg_gemm_single_segment(hip, rows, k, n, ta, tb_, acc, bias):
     rng = np.random.default_rng(rows * 7 + k)
