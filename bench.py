@@ -312,7 +312,7 @@ def main():
         ev_steps = max(2, min(5, args.steps))
         ms, flops, n_launch = measure_gemm_events(ct, sess, lr, ev_steps)
         achieved = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "hypel_seg_gemm_f32 (fp32 v_mfma_f32_32x32x2)", "achieved": achieved,
+        roof = {"bound": "mfma", "kernel": "hypel_seg_gemm_f32 (fp32 MFMA: v_mfma_f32_32x32x2, 16x16x4 for n <= 16)", "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": pmc_traffic(args.workload, nb), "launches_per_step": n_launch // ev_steps,
                 "avg_launch_us": ms * 1e3 / n_launch,
