@@ -37,6 +37,11 @@ constexpr int BK = HYPEL_GEMM_BK;
 #ifndef HYPEL_GEMM_CLK
 #define HYPEL_GEMM_CLK 0  // tools/gemm_quantisation.py: 1 = --clk (shader clock the kernel ran at), 2 = --timeline
 #endif
+#ifndef HYPEL_GEMM_CHUNK
+#define HYPEL_GEMM_CHUNK 8  // granularity (reduction columns) at which a short k-tile stops issuing MFMAs
+#endif
+constexpr int CHUNK = HYPEL_GEMM_CHUNK;
+static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
@@ -242,12 +247,12 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
             __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
 #endif
             if constexpr (NARROW) {
-                // 16 reduction columns (4 k4-steps) at a time, as below
+                // CHUNK reduction columns at a time, as below
 #pragma unroll
-                for (int q = 0; q < BK / 16; ++q) {
-                    if (q > 0 && kvalid <= q * 16) break;
+                for (int q = 0; q < BK / CHUNK; ++q) {
+                    if (q > 0 && kvalid <= q * CHUNK) break;
 #pragma unroll
-                    for (int k4 = q * 4; k4 < q * 4 + 4; ++k4) {
+                    for (int k4 = q * (CHUNK / 4); k4 < (q + 1) * (CHUNK / 4); ++k4) {
                         const float b = Bs[b_rd + k4 * B_K4STEP];
                         const float a0 = As[a_rd + k4 * A_K4STEP];
                         const float a1 = As[a_rd + A_TILE16 + k4 * A_K4STEP];
@@ -259,10 +264,10 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
             // 16 reduction columns (8 MFMA k-steps) at a time; the chunks of a short k-tile beyond kvalid are skipped
                 // by a wave-uniform branch
     #pragma unroll
-                for (int q = 0; q < BK / 16; ++q) {
-                    if (q > 0 && kvalid <= q * 16) break;
+                for (int q = 0; q < BK / CHUNK; ++q) {
+                    if (q > 0 && kvalid <= q * CHUNK) break;
     #pragma unroll
-                    for (int k2 = q * 8; k2 < q * 8 + 8; ++k2) {
+                    for (int k2 = q * (CHUNK / 2); k2 < (q + 1) * (CHUNK / 2); ++k2) {
                         float a[TM], b[TN];
     #pragma unroll
                         for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
