@@ -66,8 +66,10 @@ __device__ __forceinline__ void ew_loop(int64_t rows, int c, int tx_log2, F body
     const int tx = threadIdx.x & (TX - 1);
     const int ty = threadIdx.x >> tx_log2;
     const int cv = c / VEC;
-    for (int64_t row = (int64_t)blockIdx.x * TY + ty; row < rows; row += (int64_t)gridDim.x * TY)
-        for (int cvi = tx; cvi < cv; cvi += TX) body(row, cvi * VEC);
+    // columns outside, rows inside: a thread's column is fixed while it walks down the rows, so the per-channel
+    // operands of the body (statistics, beta, channel-map indices) are loop invariant and get hoisted
+    for (int cvi = tx; cvi < cv; cvi += TX)
+        for (int64_t row = (int64_t)blockIdx.x * TY + ty; row < rows; row += (int64_t)gridDim.x * TY) body(row, cvi * VEC);
 }
 
 // ------------------------------------------------------------------------------------- layout
