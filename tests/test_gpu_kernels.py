@@ -274,6 +274,29 @@ def test_fused_statistics_kernels_match_two_stage(hip, rows, c):
     np.testing.assert_allclose(b.h["rstd"].cpu().numpy(), 1 / np.sqrt(x64.var(0) + 1e-3), rtol=1e-5)
 
 
+@pytest.mark.parametrize("cin,c,ld_pad", [(60, 120, 0), (240, 120, 0), (60, 120, 2), (240, 120, 4), (30, 120, 0),
+                                           (120, 120, 0), (145, 120, 0), (62, 124, 1)])
+def test_post_op_forward_channel_maps(hip, cin, c, ld_pad):
+    """The shortcut add of bn_act_fwd for every kind of scale_in_to_out map: repeat (Cout = r Cin), every other channel
+    (Cout = Cin / 2), identity via indices, irregular gather; with padded source rows."""
+    rng = np.random.default_rng(cin * 3 + c + ld_pad)
+    rows, ld = 301, cin + ld_pad
+    b = Both(hip)
+    b.arr("y", rng.standard_normal((rows, c)).astype(np.float32))
+    b.arr("r1", rng.standard_normal((rows, ld)).astype(np.float32))
+    if c % cin == 0:
+        idx = (np.arange(c) // (c // cin)).astype(np.int32)
+    else:
+        idx = np.minimum(np.round(np.arange(c) * cin / c), cin - 1).astype(np.int32)
+    b.arr("idx", idx)
+    b.arr("mean", rng.standard_normal(c).astype(np.float32) * 0.1)
+    b.arr("rstd", (rng.random(c) + 0.5).astype(np.float32))
+    b.arr("beta", rng.standard_normal(c).astype(np.float32) * 0.1)
+    b.arr("z", np.zeros(rows * c, np.float32))
+    b.run("bn_act_fwd", "y", c, rows, c, "mean", "rstd", "beta", 1, 0.18, None, 0, "r1", ld, "idx", None, 0, None, "z", c)
+    b.check("z", rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("act,use_bn,use_mask,nres", [(1, True, False, 2), (3, True, False, 0), (0, True, False, 0),
                                                      (1, False, True, 1), (2, False, False, 1), (4, False, False, 0),
                                                      (1, True, True, 0)])
