@@ -33,6 +33,7 @@ def stat_chunk_rows(rows):
 WGRAD_ROW_CHUNK = 512
 TARGET_BLOCKS = 1024
 WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
+SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel-part splitting also for biased convs
 MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
 L2_CHUNK_BYTES = int(float(os.environ.get("HYPEL_L2_CHUNK_MB", "3.5")) * (1 << 20))  # X working set an XCD's L2 keeps
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
@@ -510,7 +511,7 @@ class TowerPlan:
             # stored behind Y in the same buffer) and a strided reduce adds Y_1.. into Y.
             splits = {}
             kparts = 1
-            if bias_ref is None and nb >= TAP_SPLIT_MIN_BATCH:
+            if (bias_ref is None or SPLIT_BIASED) and nb >= TAP_SPLIT_MIN_BATCH:
                 for b in node.branches:
                     taps = min(b.k, h) * min(b.k, w)
                     if taps > MAX_TAPS_PER_TILE:
@@ -533,9 +534,12 @@ class TowerPlan:
             choff = 0
             by_cout = {}
             for b in node.branches:
-                by_cout.setdefault(b.cout, []).append((b, choff))
+                # with a bias, split branches go into a launch of their own (no bias in the GEMM: the reduce adds it)
+                key = (b.cout, bias_ref is not None and splits.get(id(b), 1) > 1)
+                by_cout.setdefault(key, []).append((b, choff))
                 choff += b.cout
-            for cout, items in by_cout.items():
+            for (cout, split_launch), items in by_cout.items():
+                biased_launch = not split_launch
                 tb = GemmTables()
                 for b, off in items:
                     if b.k == 1 and s_st.contiguous:
@@ -556,13 +560,16 @@ class TowerPlan:
                                 tb.add_group((kp * S_tap + si) * rows_all * c + p * nb * c + off, chunk, nb, subkey=kp)
                 # the kernel indexes bias by (c_off % ldc) + column, so merged branches share one launch
                 self._emit_gemm(self.fwd, tb, cout, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), cout, 0,
-                                self._ref(ybuf), c, bias_ref, 0, f"fwd:{items[0][0].scope}", allow_split=False)
+                                self._ref(ybuf), c, bias_ref if biased_launch else None, 0,
+                                f"fwd:{items[0][0].scope}" + ("/split" if not biased_launch and bias_ref is not None else ""),
+                                allow_split=False)
                 for b, off in items:
                     S = splits.get(id(b), 1)
                     if S > 1:
+                        # a split branch of a biased convolution gets its bias here (every partial copy would add it)
                         self.fwd.append(Launch("reduce_splits_f32", (self._ref(ybuf, rows_all * c + off), rows_all * c,
                                                                      S - 1, self._ref(ybuf, off), rows_all * cout, 1,
-                                                                     None, cout, c),
+                                                                     None if bias_ref is None else bias_ref + off, cout, c),
                                                nbytes=4 * rows_all * cout * (S + 1), tag="tap-split-reduce"))
         elif node.kind == "blockdense":
             # P independent small dense maps (one per band slice) as ONE grouped GEMM: group p reads the source columns
