@@ -34,6 +34,7 @@ WGRAD_ROW_CHUNK = 512
 TARGET_BLOCKS = 1024
 WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
 SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel-part splitting also for biased convs
+DGRAD_MAX_SEGS = int(os.environ.get("HYPEL_DGRAD_MAX_SEGS", "18"))  # segments per data-gradient tile (0 = never split)
 MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
 L2_CHUNK_BYTES = int(float(os.environ.get("HYPEL_L2_CHUNK_MB", "3.5")) * (1 << 20))  # X working set an XCD's L2 keeps
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
@@ -849,6 +850,7 @@ class TowerPlan:
                         b, off = items[0]
                         tb.add_group(gst.pix_off(0), [(off, b.w.offset, cout)], src.npix * nb)
                     else:
+                        per_pixel = []
                         for pin in range(h * w):
                             iy, ix = pin // w, pin % w
                             segs = []
@@ -863,6 +865,35 @@ class TowerPlan:
                                         if 0 <= ox < w:
                                             segs.append(((oy * w + ox) * nb * c + off,
                                                          b.w.offset + (i * b.k + j) * src.c * cout, cout))
+                            per_pixel.append(segs)
+                        # Segment splitting, the data-gradient twin of the forward tap splitting: an input pixel of a
+                        # multi-kernel level sums up to sum(k^2) segments (165 for the five kernels of DUALCNN) and its
+                        # block runs that much longer than a corner pixel's.  The segment list is cut into S chunks
+                        # that write partial copies of dX (same layout, in scratch), processed chunk after chunk
+                        # inside a row chunk, and a reduce adds them.  Not with a folded shortcut gradient (one epilogue).
+                        max_segs = max(len(sg) for sg in per_pixel)
+                        S = 1
+                        if (DGRAD_MAX_SEGS > 0 and fold_res is None and nb >= TAP_SPLIT_MIN_BATCH and gst.contiguous
+                                and gst.ch_off == 0 and gst.ld == src.c and max_segs > DGRAD_MAX_SEGS):
+                            S = -(-max_segs // DGRAD_MAX_SEGS)
+                        if S > 1:
+                            copy = h * w * nb * gst.ld
+                            for pin, segs in enumerate(per_pixel):
+                                for si in range(S):
+                                    chunk = segs[len(segs) * si // S:len(segs) * (si + 1) // S]
+                                    tb.add_group(si * copy + gst.pix_off(pin), chunk, nb, subkey=si)
+                            pos = len(self.bwd)
+                            self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
+                                            self._ref(gst.buf), gst.ld, None, 0, f"dgrad:{items[0][0].scope}/split")
+                            self._scratch(self.bwd[pos], 6, "scratch_dgrad", S * copy)
+                            l2 = Launch("reduce_splits_f32", (None, copy, S, self._ref(gst.buf), h * w * nb * src.c,
+                                                              acc, None, src.c, gst.ld),
+                                        nbytes=4 * h * w * nb * src.c * (S + 1), tag="dgrad-split-reduce")
+                            self._scratch(l2, 0, "scratch_dgrad", S * copy)
+                            self.bwd.append(l2)
+                            acc = 1
+                            continue
+                        for pin, segs in enumerate(per_pixel):
                             tb.add_group(gst.pix_off(pin), segs, nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
                                     self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}",
