@@ -33,6 +33,7 @@ def stat_chunk_rows(rows):
 WGRAD_ROW_CHUNK = 512
 TARGET_BLOCKS = 1024
 WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
+WGRAD_MIN_SPLITS = int(os.environ.get("HYPEL_WGRAD_MIN_SPLITS", "0"))  # 0 = one split per 64 batch rows once a launch fills the device unsplit
 SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel-part splitting also for biased convs
 DGRAD_MAX_SEGS = int(os.environ.get("HYPEL_DGRAD_MAX_SEGS", "18"))  # segments per data-gradient tile (0 = never split)
 MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
@@ -1015,6 +1016,13 @@ class TowerPlan:
         pixel list, otherwise the launch would have too few blocks."""
         want = max(1, min(WGRAD_MAX_SPLITS, (TARGET_BLOCKS + base_blocks - 1) // max(base_blocks, 1)))
         max_row = max(1, self.nb // 64)
+        # 64-row ranges also when the unsplit launch already fills the device: with split-major tile order an XCD then streams one
+        # row range of X and dY for all taps instead of whole pixel blocks per tap (DUALCNN levels, 165 taps x 10 x 8
+        # blocks unsplit: 82 -> 117 TFLOP/s with 8 row ranges)
+        if WGRAD_MIN_SPLITS > 0:
+            want = max(want, min(WGRAD_MAX_SPLITS, WGRAD_MIN_SPLITS))
+        elif base_blocks >= TARGET_BLOCKS:
+            want = max(want, min(WGRAD_MAX_SPLITS, max_row))
         s_row = min(want, max_row)
         if s_row >= 5:  # a multiple of 8 row ranges maps whole ranges onto the 8 XCDs
             s_row = min(max(8, max_row // 8 * 8), (s_row + 7) // 8 * 8)
