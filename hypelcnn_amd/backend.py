@@ -78,6 +78,9 @@ SIGNATURES = {
     "sum_f32": [_P, _I64, _F, _P, _P],
     "adam_tf1": [_P, _P, _P, _P, _I64, _F, _F, _F, _F],
     "momentum_tf1": [_P, _P, _P, _I64, _F, _F],
+    "adam_tf1_guarded": [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P],
+    "momentum_tf1_guarded": [_P, _P, _P, _I64, _F, _F, _P],
+    "loss_guard_f32": [_P, _P, _P],
     "dropout_mask": [_P, _I64, _F, _U64, _P],
     "step_inc": [_P],
     "argmax_confusion": [_P, _I64, _I64, _I32, _P, _P, _P],

@@ -195,6 +195,14 @@ def run_monitored_session(cross_entropy, log_dir, class_range, save_checkpoint_s
         except StopIteration:  # the epoch-limited iterator is exhausted (tf.errors.OutOfRangeError)
             break
         iteration = sess.global_step
+        # NanTensorHook(fail_on_nan_loss=False) (:151), every step: the device flags a non-finite loss, the guarded
+        # optimiser has already refused that update; here the host only reads flag copies that are one step old, so
+        # the loop stays asynchronous.  Under data parallelism the flag rode in the gradient all-reduce: every rank
+        # stops at the same iteration.
+        bad = sess.nonfinite_step()
+        if bad is not None:
+            print(f"NaN loss at step {bad}: stopping")
+            break
         evaluated = validation_hook.after_run(sess, iteration)
         evaluated = test_hook.after_run(sess, iteration) or evaluated
         if evaluated or iteration % TEST_ITERATION_COUNT == 0:
@@ -205,9 +213,12 @@ def run_monitored_session(cross_entropy, log_dir, class_range, save_checkpoint_s
             if summary_fn is not None:
                 writer.add(summary_fn(sess, iteration))
         if save_checkpoint_steps and iteration % save_checkpoint_steps == 0:
+            if sess.nonfinite_step(sync=True) is not None:  # never write a checkpoint past a non-finite step
+                print(f"NaN loss at step {sess.nonfinite_step()}: stopping")
+                break
             save_checkpoint(sess, log_dir, iteration)
     test_hook.end(sess, sess.global_step)
-    if log_dir:
+    if log_dir and sess.nonfinite_step(sync=True) is None:
         save_checkpoint(sess, log_dir, sess.global_step)
     return TrainingResult(validation_accuracy=validation_hook.validation_accuracy,
                           test_accuracy=test_hook.testing_accuracy, loss=test_hook.loss)

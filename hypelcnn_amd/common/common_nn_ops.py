@@ -290,6 +290,8 @@ class BatchIterator:
         self._pos = 0
         self._epoch = 0
         self._gen = None
+        self.collective = False  # True: every batch ends in a data-parallel collective (training_nn_iterator)
+        self.last_global_count = None  # samples of the global batch the last next_batch() was a shard of
 
     def get_next(self):
         return self.images, self.labels
@@ -356,9 +358,17 @@ class BatchIterator:
         if not idx_parts:
             return None
         idx = torch.cat(idx_parts) if len(idx_parts) > 1 else idx_parts[0]
+        self.last_global_count = int(idx.numel())
         if world > 1:
+            if self.collective and idx.numel() < world:
+                # Training steps end in collectives, so every rank must take part in every step or none: the ragged
+                # tail of an epoch-limited run that is shorter than the world size (at most world - 1 samples, once,
+                # at the very end) is dropped on ALL ranks -- each rank walks the same permutation and reaches this
+                # decision without communication.  Longer tails are sharded unevenly and weighted by
+                # nb_rank / nb_global in the loss gradient (TowerPlan._emit_loss).
+                return None
             idx = idx[rank::world]
-            if idx.numel() == 0:  # ragged tail shorter than the world size: this rank sits the batch out
+            if idx.numel() == 0:  # evaluation (no per-batch collective): this rank sits the batch out
                 return None
         lab = self.arrays.labels.index_select(0, idx)
         augment = self.augmentation_info is not None and self.augmentation_info is not NO_AUGMENTATION
@@ -378,7 +388,9 @@ class BatchIterator:
 
 def training_nn_iterator(data_set, augmentation_info, batch_size, num_epochs, device, prefetch_size):
     """reference :188-201"""
-    return BatchIterator(data_set.element_shape, data_set.class_count, batch_size, True, num_epochs, augmentation_info)
+    it = BatchIterator(data_set.element_shape, data_set.class_count, batch_size, True, num_epochs, augmentation_info)
+    it.collective = True  # its batches feed train steps (gradient all-reduce under data parallelism)
+    return it
 
 
 def simple_nn_iterator(data_set, batch_size):
@@ -496,9 +508,9 @@ class TrainOp:
         if self.momentum is None and opt != "AdamOptimizer":
             raise ValueError(f"unknown optimizer {opt!r}")
 
-    def compiled(self, nb):
+    def compiled(self, nb, global_nb=None):
         sess = self.ctx.session()
-        ct = sess.compile(self.tower, nb, loss=self.loss, external_masks=self.ctx.external_masks)
+        ct = sess.compile(self.tower, nb, loss=self.loss, external_masks=self.ctx.external_masks, global_nb=global_nb)
         if self.ctx.capture_graphs and getattr(sess.backend, "name", "") == "hip" and ct._graph_all is None:
             ct.capture()
         return ct
@@ -510,7 +522,7 @@ class TrainOp:
             if batch is None:
                 raise StopIteration
         x, onehot, _ = batch
-        ct = self.compiled(x.shape[0])
+        ct = self.compiled(x.shape[0], getattr(self.iterator, "last_global_count", None))
         ct.set_input("x", x)
         ct.set_input("labels", onehot)
         sess.train_step_exchange(ct)  # forward + backward (+ overlapped data-parallel gradient all-reduce)
@@ -659,10 +671,13 @@ def calculate_accuracy(sess, nn_params, class_range):
     return overall_accuracy, class_recall, class_precisions, kappa, mean_per_class_accuracy
 
 
-def perform_prediction(sess, nn_params, prediction_result):
+def perform_prediction(sess, nn_params, prediction_result, margin_result=None):
     """reference :313-327: drain the iterator, argmax the logits, write the class of every target into the
     [H, W] uint8 raster at (row = y, col = x).  The per-sample Python loop of the reference is ONE
-    hypel_argmax_scatter launch per batch into a device-resident raster, copied back once at the end."""
+    hypel_argmax_scatter launch per batch into a device-resident raster, copied back once at the end.
+    `margin_result` (optional float32 [H, W], not in the reference): receives the gap between the two largest
+    logits of every classified pixel -- the confidence map the label-parity tests use to tell a genuine label
+    difference from a tie within fp32 rounding."""
     from hypelcnn_amd.backend import Ref
     it = nn_params.input_iterator
     y_conv = nn_params.predict_tensor
@@ -688,6 +703,10 @@ def perform_prediction(sess, nn_params, prediction_result):
                 sess.backend.device)
         sess.backend.call("argmax_scatter", Ref(ct.plan.buffers[st.buf], st.ch_off), st.ld, nb, y_conv.c,
                           Ref(pts.reshape(-1)), Ref(flat), int(w))
+        if margin_result is not None:
+            top2 = torch.topk(ct.value(y_conv).reshape(nb, -1), 2, dim=1).values
+            p = pts.reshape(-1, 2).cpu().numpy()
+            margin_result[p[:, 1], p[:, 0]] = (top2[:, 0] - top2[:, 1]).cpu().numpy()
         done += nb
     prediction_result[...] = raster.cpu().numpy()
     return done

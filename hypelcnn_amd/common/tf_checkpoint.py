@@ -324,29 +324,52 @@ def write_checkpoint(prefix, variables):
 
 
 # ------------------------------------------------------------------------------------------------ session glue
-ADAM_SLOT_SUFFIXES = ("/Adam", "/Adam_1")  # tf.compat.v1.train.AdamOptimizer slot variable names (m, v)
+# Slot / accumulator names of the reference's optimisers.  The classifier builds
+# `AdamOptimizer(lr, name="nn_core/Adam")` (or MomentumOptimizer(name="nn_core/Momentum")) inside
+# name_scope("training_optimizer") (reference common/common_nn_ops.py:215-230): TF1 names the slots
+# `<variable>/nn_core/Adam`, `<variable>/nn_core/Adam_1` (`<variable>/nn_core/Momentum`) and the power accumulators
+# `training_optimizer/beta1_power`, `training_optimizer/beta2_power` -- which is why the reference's Saver restores
+# include=["training_optimizer"] (classify/monitored_session_runner.py:164-168).  The GAN optimisers keep the default
+# name "Adam" (gan/wrappers/gan_common.py:264-265): `<variable>/Adam`, `<variable>/Adam_1`.
+CLASSIFIER_OPTIMIZER = "nn_core/Adam"
+CLASSIFIER_MOMENTUM = "nn_core/Momentum"
+CLASSIFIER_ACCUMULATOR_SCOPE = "training_optimizer"
+# spellings accepted on read, most specific first: (m suffix, v suffix or None for single-slot optimisers)
+SLOT_SPELLINGS = (("/nn_core/Adam", "/nn_core/Adam_1"), ("/Adam", "/Adam_1"), ("/nn_core/Momentum", None),
+                  ("/Momentum", None))
 
 
-def session_to_variables(sess):
-    """The session's state under the names a TF1 Saver would use: variables, global_step, Adam slots per variable,
-    beta1_power / beta2_power."""
+def session_to_variables(sess, optimizer_name=CLASSIFIER_OPTIMIZER, accumulator_scope=CLASSIFIER_ACCUMULATOR_SCOPE,
+                         beta1=0.9, beta2=0.999, momentum=False):
+    """The session's state under the names a TF1 Saver would use: variables, global_step, the optimiser slots per
+    variable (`<var>/<optimizer_name>`, `<var>/<optimizer_name>_1`) and, for Adam, the beta power accumulators under
+    `accumulator_scope` with the session's beta1 / beta2 (GAN sessions: optimizer_name="Adam", beta1=0.5)."""
     d = {v.name: sess.get_variable(v.name) for v in sess.store.order}
     d["global_step"] = numpy.asarray(sess.global_step, numpy.int64)
     m = sess.slot_m.detach().cpu().numpy()
     vv = sess.slot_v.detach().cpu().numpy()
+    if momentum and optimizer_name == CLASSIFIER_OPTIMIZER:
+        optimizer_name = CLASSIFIER_MOMENTUM
     for v in sess.trainable:
-        d[v.name + ADAM_SLOT_SUFFIXES[0]] = m[v.offset:v.offset + v.size].reshape(v.shape).copy()
-        d[v.name + ADAM_SLOT_SUFFIXES[1]] = vv[v.offset:v.offset + v.size].reshape(v.shape).copy()
-    t = sess.global_step
-    d["beta1_power"] = numpy.asarray(0.9 ** (t + 1), numpy.float32)
-    d["beta2_power"] = numpy.asarray(0.999 ** (t + 1), numpy.float32)
+        d[f"{v.name}/{optimizer_name}"] = m[v.offset:v.offset + v.size].reshape(v.shape).copy()
+        if not momentum:
+            d[f"{v.name}/{optimizer_name}_1"] = vv[v.offset:v.offset + v.size].reshape(v.shape).copy()
+    if not momentum:
+        t = sess.global_step
+        pre = accumulator_scope + "/" if accumulator_scope else ""
+        # TF1 Adam keeps beta^(t+1) after t updates (initialised to beta, multiplied once per apply_gradients)
+        d[pre + "beta1_power"] = numpy.asarray(beta1 ** (t + 1), numpy.float32)
+        d[pre + "beta2_power"] = numpy.asarray(beta2 ** (t + 1), numpy.float32)
     return d
 
 
 def variables_to_session(sess, variables):
     """Loads what the session holds (other names -- e.g. the training-only reconstruction head when restoring an
-    inference graph -- are ignored, as a Saver built from get_variables_to_restore does)."""
+    inference graph -- are ignored, as a Saver built from get_variables_to_restore does).  Optimiser slots are
+    accepted under every spelling in SLOT_SPELLINGS; a checkpoint that says global_step > 0 but carries no slots
+    gets a warning (Adam's bias correction would then assume step t with zero moments)."""
     import torch
+    import warnings
     for v in sess.store.order:
         if v.name in variables:
             sess.set_variable(v.name, variables[v.name])
@@ -355,13 +378,23 @@ def variables_to_session(sess, variables):
     if sess.slot_m is not None:
         m = sess.slot_m.detach().cpu().numpy().copy()
         vv = sess.slot_v.detach().cpu().numpy().copy()
-        touched = False
+        touched = 0
         for v in sess.trainable:
-            a, b = variables.get(v.name + ADAM_SLOT_SUFFIXES[0]), variables.get(v.name + ADAM_SLOT_SUFFIXES[1])
-            if a is not None and b is not None:
+            for sm, sv in SLOT_SPELLINGS:
+                a = variables.get(v.name + sm)
+                b = variables.get(v.name + sv) if sv is not None else None
+                if a is None or (sv is not None and b is None):
+                    continue
                 m[v.offset:v.offset + v.size] = numpy.asarray(a, numpy.float32).reshape(-1)
-                vv[v.offset:v.offset + v.size] = numpy.asarray(b, numpy.float32).reshape(-1)
-                touched = True
+                if b is not None:
+                    vv[v.offset:v.offset + v.size] = numpy.asarray(b, numpy.float32).reshape(-1)
+                touched += 1
+                break
         if touched:
             sess.slot_m.copy_(torch.from_numpy(m))
             sess.slot_v.copy_(torch.from_numpy(vv))
+        if touched < len(sess.trainable) and sess.global_step > 0 and \
+                any(v.name in variables for v in sess.trainable):
+            warnings.warn(f"checkpoint at global_step {sess.global_step} carries optimiser slots for {touched} of "
+                          f"{len(sess.trainable)} trainable variables: the missing moments start from zero while "
+                          f"the bias correction assumes step {sess.global_step}")

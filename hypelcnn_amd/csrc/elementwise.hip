@@ -794,8 +794,13 @@ __global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------- optimisers
+// `skip` (nullable): a device flag written by hypel_loss_guard_f32 (non-zero = the step's loss was not finite).  The
+// optimiser then leaves parameters and slots untouched -- create_train_op's check_numerics refuses the update the
+// same way (common_nn_ops.py:232) -- without the host having to look at the loss before launching it.
 __global__ void adam_tf1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                float* __restrict__ v, int64_t count, float lr_t, float b1, float b2, float eps) {
+                                float* __restrict__ v, int64_t count, float lr_t, float b1, float b2, float eps,
+                                const float* __restrict__ skip) {
+    if (skip && *skip != 0.0f) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -807,7 +812,8 @@ __global__ void adam_tf1_kernel(float* __restrict__ p, const float* __restrict__
 }
 
 __global__ void momentum_tf1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ a,
-                                    int64_t count, float lr, float mu) {
+                                    int64_t count, float lr, float mu, const float* __restrict__ skip) {
+    if (skip && *skip != 0.0f) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const float ai = mu * a[i] + g[i];
         a[i] = ai;
@@ -828,6 +834,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         k0 += W0; k1 += W1;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// flag[0] = 1 if any of the (up to two) scalar losses is NaN/Inf, else 0.  The flag lives in the element behind the
+// flat gradient buffer, so the data-parallel gradient all-reduce (sum) hands every rank the same verdict.
+__global__ void loss_guard_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const bool ok = isfinite(a[0]) && (b == nullptr || isfinite(b[0]));
+        flag[0] = ok ? 0.0f : 1.0f;
+    }
 }
 
 __global__ void step_inc_kernel(uint64_t* step) {
@@ -1362,22 +1377,40 @@ extern "C" int hypel_sum_f32(const float* x, int64_t count, float scale, float* 
     return 0;
 }
 
-extern "C" int hypel_adam_tf1(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1,
-                              float beta2, float eps, hypel_stream_t stream) {
+extern "C" int hypel_adam_tf1_guarded(float* p, const float* g, float* m, float* v, int64_t count, float lr_t,
+                                      float beta1, float beta2, float eps, const float* skip, hypel_stream_t stream) {
     HYPEL_REQUIRE(p && g && m && v && count >= 0, "hypel_adam_tf1");
     if (count == 0) return 0;
     hipLaunchKernelGGL(adam_tf1_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, p, g, m, v, count, lr_t,
-                       beta1, beta2, eps);
+                       beta1, beta2, eps, skip);
     HYPEL_CHECK_LAUNCH("hypel_adam_tf1");
+    return 0;
+}
+
+extern "C" int hypel_adam_tf1(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1,
+                              float beta2, float eps, hypel_stream_t stream) {
+    return hypel_adam_tf1_guarded(p, g, m, v, count, lr_t, beta1, beta2, eps, nullptr, stream);
+}
+
+extern "C" int hypel_momentum_tf1_guarded(float* p, const float* g, float* a, int64_t count, float lr, float mu,
+                                          const float* skip, hypel_stream_t stream) {
+    HYPEL_REQUIRE(p && g && a && count >= 0, "hypel_momentum_tf1");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(momentum_tf1_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, p, g, a, count, lr, mu,
+                       skip);
+    HYPEL_CHECK_LAUNCH("hypel_momentum_tf1");
     return 0;
 }
 
 extern "C" int hypel_momentum_tf1(float* p, const float* g, float* a, int64_t count, float lr, float mu,
                                   hypel_stream_t stream) {
-    HYPEL_REQUIRE(p && g && a && count >= 0, "hypel_momentum_tf1");
-    if (count == 0) return 0;
-    hipLaunchKernelGGL(momentum_tf1_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, p, g, a, count, lr, mu);
-    HYPEL_CHECK_LAUNCH("hypel_momentum_tf1");
+    return hypel_momentum_tf1_guarded(p, g, a, count, lr, mu, nullptr, stream);
+}
+
+extern "C" int hypel_loss_guard_f32(const float* loss_a, const float* loss_b, float* flag, hypel_stream_t stream) {
+    HYPEL_REQUIRE(loss_a && flag, "hypel_loss_guard_f32");
+    hipLaunchKernelGGL(loss_guard_kernel, dim3(1), dim3(64), 0, ST, loss_a, loss_b, flag);
+    HYPEL_CHECK_LAUNCH("hypel_loss_guard_f32");
     return 0;
 }
 

@@ -42,7 +42,7 @@ TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitt
 
 
 class Launch:
-    __slots__ = ("name", "args", "flops", "bytes", "tag", "stream")
+    __slots__ = ("name", "args", "flops", "bytes", "tag", "stream", "kparts")
 
     def __init__(self, name, args, flops=0, nbytes=0, tag="", stream=0):
         self.name = name
@@ -51,6 +51,7 @@ class Launch:
         self.bytes = nbytes
         self.tag = tag
         self.stream = stream  # 0 = main, 1 = side (concurrent filter gradients)
+        self.kparts = 1  # channel parts the reduction dimension of a level forward was cut into (diagnostic)
 
 
 USE_SIDE_STREAM = True
@@ -179,9 +180,11 @@ class GemmTables:
 class TowerPlan:
     """Buffers + launch lists of one tower at one batch size."""
 
-    def __init__(self, tower, nb, session, loss=None, labels_c=None, external_masks=False, seed=1234):
+    def __init__(self, tower, nb, session, loss=None, labels_c=None, external_masks=False, seed=1234, global_nb=None):
         self.tower = tower
         self.nb = int(nb)
+        # data parallel: samples in the GLOBAL batch this rank's nb samples are a shard of (None = nb x world)
+        self.global_nb = global_nb
         self.sess = session
         self.be = session.backend
         self.training = tower.is_training
@@ -543,12 +546,14 @@ class TowerPlan:
             for (cout, split_launch), items in by_cout.items():
                 biased_launch = not split_launch
                 tb = GemmTables()
+                kp_used = 1
                 for b, off in items:
                     if b.k == 1 and s_st.contiguous:
                         tb.add_group(off, [(s_st.pix_off(0), b.w.offset, src.c)], out.npix * nb)
                         continue
                     S = splits.get(id(b), 1)
                     kp_n = kparts if S >= kparts and S % kparts == 0 and kparts > 1 else 1
+                    kp_used = max(kp_used, kp_n)
                     S_tap = S // kp_n
                     kcuts = [min(src.c, (src.c * q // kp_n + 15) // 16 * 16) for q in range(kp_n)] + [src.c]
                     for p in range(h * w):
@@ -561,10 +566,13 @@ class TowerPlan:
                                 chunk = segs[len(segs) * si // S_tap:len(segs) * (si + 1) // S_tap]
                                 tb.add_group((kp * S_tap + si) * rows_all * c + p * nb * c + off, chunk, nb, subkey=kp)
                 # the kernel indexes bias by (c_off % ldc) + column, so merged branches share one launch
+                pos = len(self.fwd)
                 self._emit_gemm(self.fwd, tb, cout, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), cout, 0,
                                 self._ref(ybuf), c, bias_ref if biased_launch else None, 0,
                                 f"fwd:{items[0][0].scope}" + ("/split" if not biased_launch and bias_ref is not None else ""),
                                 allow_split=False)
+                if len(self.fwd) > pos:
+                    self.fwd[pos].kparts = kp_used
                 for b, off in items:
                     S = splits.get(id(b), 1)
                     if S > 1:
@@ -732,9 +740,17 @@ class TowerPlan:
             gst, acc = self._grad_target(logits)
             assert acc == 0
             dl, lddl = self._ref(gst.buf, gst.ch_off), gst.ld
+        # data parallel: the gradient of the GLOBAL mean loss = sum over ranks of (nb_rank / nb_global) x the local
+        # mean-loss gradients (= 1/world for equal shards; the ragged last batch of an epoch-limited run gives ranks
+        # unequal shards).  The factor goes in here, at the source, so the exchange is a plain SUM all-reduce with no
+        # rescaling pass over the 32 MB buffer afterwards (the reported loss values stay local means)
+        dist = getattr(self.sess, "dist", None)
+        gworld = 1.0
+        if dist is not None:
+            gworld = nb / float(self.global_nb) if self.global_nb else 1.0 / dist[0]
         self.fwd.append(Launch("softmax_xent", (self._ref(l_st.buf, l_st.ch_off), l_st.ld, nb, logits.c,
                                                 self._ref(lab_st.buf), lab_st.ld, self._ref("loss_ps"), dl, lddl,
-                                                1.0 / nb), tag="loss"))
+                                                gworld / nb), tag="loss"))
         l2 = Launch("sum_f32", (self._ref("loss_ps"), nb, 1.0 / nb, self._ref("loss_ce"), None), tag="loss")
         self._scratch(l2, 4, "scratch_red")
         self.fwd.append(l2)
@@ -751,9 +767,14 @@ class TowerPlan:
                 assert acc == 0
                 da, ldda = self._ref(gst.buf), gst.ld
             l3 = Launch("mse", (self._ref(a_st.buf), a_st.ld, self._ref("in:" + src.name), feat, nb, feat,
-                                self._ref("loss_mse"), da, ldda, 1.0, None), nbytes=12 * nb * feat, tag="loss")
+                                self._ref("loss_mse"), da, ldda, gworld, None), nbytes=12 * nb * feat, tag="loss")
             self._scratch(l3, 10, "scratch_red")
             self.fwd.append(l3)
+        if self.training and hasattr(self.sess, "guard_ref"):
+            # NanTensorHook / check_numerics on the device: flag behind the gradient buffer, read by the optimiser
+            self.fwd.append(Launch("loss_guard_f32", (self._ref("loss_ce"),
+                                                      self._ref("loss_mse") if ps.extra_mse is not None else None,
+                                                      self.sess.guard_ref()), tag="loss-guard"))
 
     # ------------------------------------------------------------------ backward
     @staticmethod
@@ -1078,6 +1099,10 @@ class TowerPlan:
             lo = min(b.w.offset for b, _ in items)
             hi = max(b.w.offset + b.w.size for b, _ in items)
             slab = hi - lo
+            if slab != sum(b.w.size for b, _ in items):
+                # the reduce overwrites the whole slab: sibling branches of another width in between would be clobbered
+                raise RuntimeError(f"filter-gradient slab of {items[0][0].scope}: branches with {cout} filters are not "
+                                   f"contiguous in the parameter buffer")
             group_list = []  # (local c_off, [(a_off, b_off)] pixel pairs)
             for b, off in items:
                 pb = (b.k - 1) // 2

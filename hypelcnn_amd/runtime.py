@@ -181,7 +181,10 @@ class Session:
             off += v.size
         be = self.backend
         self.params = be.zeros(n_train)
-        self.grads = be.zeros(n_train)
+        # one extra element BEHIND the gradients: the non-finite-loss flag of the step (hypel_loss_guard_f32).  It
+        # rides in the gradient all-reduce, so every data-parallel rank sees the same verdict and skips the update
+        self.grads = be.zeros(n_train + 1)
+        self.n_train = n_train
         self.slot_m = be.zeros(n_train)
         self.slot_v = be.zeros(n_train)
         self.state = be.zeros(max(off, 1))
@@ -241,11 +244,15 @@ class Session:
             self.slot_v.copy_(torch.from_numpy(np.asarray(d["training_optimizer/v"], np.float32)))
 
     # ---- towers ----
-    def compile(self, tower, nb, loss=None, external_masks=False):
-        key = (id(tower), int(nb), id(loss), external_masks)
+    def compile(self, tower, nb, loss=None, external_masks=False, global_nb=None):
+        """global_nb: size of the global batch `nb` is this rank's shard of (data parallel; None = nb x world)."""
+        if self.dist is None or (global_nb is not None and int(global_nb) == int(nb) * self.dist[0]):
+            global_nb = None
+        key = (id(tower), int(nb), id(loss), external_masks, global_nb)
         ct = self._compiled.get(key)
         if ct is None:
-            plan = TowerPlan(tower, nb, self, loss=loss, external_masks=external_masks, seed=self._rank_seed())
+            plan = TowerPlan(tower, nb, self, loss=loss, external_masks=external_masks, seed=self._rank_seed(),
+                             global_nb=global_nb)
             ct = CompiledTower(plan, self.backend)
             self._compiled[key] = ct
         return ct
@@ -285,17 +292,60 @@ class Session:
                 view.mul_(1.0 / self.dist[0])
 
     # ---- optimiser (common_nn_ops.py:223-230) ----
+    def guard_ref(self):
+        """Device address of the step's non-finite-loss flag (the element behind the flat gradient buffer)."""
+        return Ref(self.grads, self.n_train)
+
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
         t = self.global_step + 1
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-        self.backend.call("adam_tf1", Ref(self.params), Ref(self.grads), Ref(self.slot_m), Ref(self.slot_v),
-                          self.params.numel(), float(lr_t), float(beta1), float(beta2), float(eps))
+        self.backend.call("adam_tf1_guarded", Ref(self.params), Ref(self.grads), Ref(self.slot_m), Ref(self.slot_v),
+                          self.params.numel(), float(lr_t), float(beta1), float(beta2), float(eps), self.guard_ref())
         self.global_step += 1
+        self._post_guard()
 
     def momentum_step(self, lr, mu):
-        self.backend.call("momentum_tf1", Ref(self.params), Ref(self.grads), Ref(self.slot_m), self.params.numel(),
-                          float(lr), float(mu))
+        self.backend.call("momentum_tf1_guarded", Ref(self.params), Ref(self.grads), Ref(self.slot_m),
+                          self.params.numel(), float(lr), float(mu), self.guard_ref())
         self.global_step += 1
+        self._post_guard()
+
+    # ---- non-finite loss guard (NanTensorHook, monitored_session_runner.py:151; check_numerics, common_nn_ops.py:232)
+    def _post_guard(self):
+        """After every optimiser launch: copy the step's flag into pinned host memory, asynchronously, and remember
+        an event.  `nonfinite_step()` later looks at copies that are at least one step old, so the loop never drains
+        the device queue to learn about a NaN -- and it does not have to: the guarded optimiser has already refused
+        the update on the device."""
+        if not hasattr(self, "_guard_q"):
+            self._guard_q = []
+            self._guard_bad = None
+        if self.grads.device.type != "cuda":
+            self._guard_q.append((self.global_step, float(self.grads[self.n_train]), None))
+            return
+        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        host.copy_(self.grads[self.n_train:self.n_train + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._guard_q.append((self.global_step, host, ev))
+
+    def nonfinite_step(self, sync=False):
+        """global_step value after the first step whose loss was NaN/Inf, or None.  Without `sync` only flag copies
+        older than the newest one are inspected (the host waits at most for the step before the one in flight; under
+        data parallelism every rank therefore decides at the same iteration, on the same all-reduced flag)."""
+        if getattr(self, "_guard_bad", None) is not None:
+            return self._guard_bad
+        q = getattr(self, "_guard_q", [])
+        keep = 0 if sync else 1
+        while len(q) > keep:
+            step, host, ev = q.pop(0)
+            if ev is not None:
+                ev.synchronize()
+                host = float(host[0])
+            if host != 0.0:
+                self._guard_bad = step
+                q.clear()
+                return step
+        return None
 
     # ---- data parallel (new vs the reference: SURVEY §2.3 / §8e) ----
     def init_data_parallel(self, broadcast=True):
@@ -315,8 +365,8 @@ class Session:
         if self.dist is None:
             return
         import torch.distributed as dist
+        # the plan scales the loss gradient by 1/world at its source (TowerPlan._emit_loss), so the SUM is the mean
         dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
-        self.grads.mul_(1.0 / self.dist[0])
 
     def train_step_exchange(self, ct, hook_ranges=True):
         """forward + backward with the gradient exchange overlapped: at each sync point of the compiled tower the
@@ -328,20 +378,33 @@ class Session:
             self.allreduce_gradients()
             return
         import torch.distributed as dist
-        works, covered_lo = [], self.grads.numel()
-        def hook(k):
-            nonlocal covered_lo
-            _, lo, hi = ct.sync_points[k]
-            hi = min(hi, covered_lo)
+        works, covered = [], []  # reduced ranges [lo, hi) of the flat buffer (incl. the flag element at its end)
+        total = self.grads.numel()
+
+        def reduce_range(lo, hi):
+            for clo, chi in covered:  # clip against what already went out
+                if lo >= clo and hi <= chi:
+                    return
+                if lo < chi and hi > clo:
+                    if lo < clo:
+                        reduce_range(lo, clo)
+                    if hi > chi:
+                        reduce_range(chi, hi)
+                    return
             if hi > lo:
                 works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-                covered_lo = lo
+                covered.append((lo, hi))
+
+        def hook(k):
+            _, lo, hi = ct.sync_points[k]
+            if hi == self.n_train:  # the flag behind the gradients was written by the forward pass: final as well
+                hi = total
+            reduce_range(lo, hi)
+
         ct.forward_backward(hook=hook)
-        if covered_lo > 0:
-            works.append(dist.all_reduce(self.grads[:covered_lo], op=dist.ReduceOp.SUM, async_op=True))
+        reduce_range(0, total)  # whatever no sync point covered: the head, and any range behind the last LinearNode
         for w in works:
             w.wait()
-        self.grads.mul_(1.0 / self.dist[0])
 
     def average_state(self):
         """BN moving statistics are per-rank (local batch statistics); average them before

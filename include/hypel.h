@@ -185,6 +185,17 @@ int hypel_adam_tf1(float* p, const float* g, float* m, float* v, int64_t count, 
                    float eps, hypel_stream_t stream);
 /* TF1 Momentum: a = mu*a + g; p -= lr*a. */
 int hypel_momentum_tf1(float* p, const float* g, float* a, int64_t count, float lr, float mu, hypel_stream_t stream);
+/* Non-finite loss guard -- NanTensorHook (classify/monitored_session_runner.py:151) + check_numerics inside
+ * create_train_op (common/common_nn_ops.py:232), moved onto the device so that the step loop never waits for
+ * the loss: flag[0] = 1.0f if loss_a[0] (or loss_b[0], nullable) is NaN/Inf, else 0.0f.  The session keeps
+ * the flag in the element BEHIND the flat gradient buffer, so the data-parallel all-reduce (sum) of the gradients
+ * gives every rank the same verdict.  The *_guarded optimisers return without touching p / slots when
+ * skip[0] != 0 (skip NULL = unguarded). */
+int hypel_loss_guard_f32(const float* loss_a, const float* loss_b, float* flag, hypel_stream_t stream);
+int hypel_adam_tf1_guarded(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1,
+                           float beta2, float eps, const float* skip, hypel_stream_t stream);
+int hypel_momentum_tf1_guarded(float* p, const float* g, float* a, int64_t count, float lr, float mu, const float* skip,
+                               hypel_stream_t stream);
 
 /* ---- dropout mask (tf_slim.dropout): mask in {0, 1/keep}, Philox4x32-10 counter RNG ----------------------
  * counter = (element group, *step_dev), key = seed: the step lives on the device so that a captured

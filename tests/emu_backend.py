@@ -408,6 +408,18 @@ class EmuBackend:
         vv[...] = np.float32(b2) * vv + np.float32(1 - b2) * gv * gv
         pv -= np.float32(lr_t) * mv / (np.sqrt(vv) + np.float32(eps))
 
+    def k_loss_guard_f32(self, loss_a, loss_b, flag):
+        ok = np.isfinite(_arr(loss_a)[0]) and (loss_b is None or np.isfinite(_arr(loss_b)[0]))
+        _arr(flag)[0] = 0.0 if ok else 1.0
+
+    def k_adam_tf1_guarded(self, p, g, m, v, count, lr_t, b1, b2, eps, skip):
+        if skip is None or _arr(skip)[0] == 0:
+            self.k_adam_tf1(p, g, m, v, count, lr_t, b1, b2, eps)
+
+    def k_momentum_tf1_guarded(self, p, g, a, count, lr, mu, skip):
+        if skip is None or _arr(skip)[0] == 0:
+            self.k_momentum_tf1(p, g, a, count, lr, mu)
+
     def k_momentum_tf1(self, p, g, a, count, lr, mu):
         pv, gv, av = (_arr(t)[:count] for t in (p, g, a))
         av[...] = np.float32(mu) * av + gv

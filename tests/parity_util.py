@@ -178,3 +178,54 @@ def run_eval(built, x):
     ct.set_input("x", torch.as_tensor(x, dtype=torch.float32).to(dev))
     ct.forward()
     return ct.value(built.eval_out.y_conv).cpu().numpy()
+
+
+def torch_reference_step(model_name, params, x, onehot, masks, classes, alg, threads=None):
+    """The float64 oracle through oracle/torch_ref.py (torch-CPU autograd composition; agrees with oracle/models.py
+    to 1e-12, tests/test_oracle_selfcheck.py) -- used where the numpy tape is too slow (full-size DUALCNN: 81 GFLOP
+    per patch).  Same result dict as oracle.train.forward_backward (no per-layer trace)."""
+    from oracle import torch_ref as TR
+    old = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        P = {k: torch.tensor(v, dtype=torch.float64,
+                             requires_grad=not k.endswith(("moving_mean", "moving_variance"))) for k, v in params.items()}
+        xt = torch.tensor(x, dtype=torch.float64)
+        oh = torch.tensor(onehot, dtype=torch.float64)
+        mk = {k: torch.tensor(v, dtype=torch.float64) for k, v in (masks or {}).items()}
+        nm = {}
+        if model_name == "HYPELCNNModel":
+            logits, img, nm = TR.hypelcnn(P, xt, classes, alg, True, mk)
+            loss = TR.hypelcnn_loss(logits, img, xt, oh)
+        else:
+            fwd = TR.dualcnn if model_name == "DUALCNNModel" else TR.concnn
+            logits = fwd(P, xt, classes, alg, True, mk)
+            loss = (-(oh * torch.log_softmax(logits, -1)).sum(-1)).mean()
+        names = [k for k, v in P.items() if v.requires_grad]
+        grads = torch.autograd.grad(loss, [P[k] for k in names])
+        return {"logits": logits.detach().numpy(), "loss": float(loss.detach()),
+                "grads": {k: g.numpy() for k, g in zip(names, grads)},
+                "new_moving": {k: v.detach().numpy() for k, v in nm.items()}}
+    finally:
+        torch.set_num_threads(old)
+
+
+def compare_with_reference(built, ct, ref, tol_logit=1e-3, tol_grad=2e-3):
+    """Product after one forward+backward vs a precomputed oracle result dict.  Returns (logit err, worst (name, rel
+    err), {name: rel err})."""
+    sess = built.ctx.session()
+    logits = ct.value(built.y_conv).cpu().numpy()
+    err = float(np.abs(logits - ref["logits"]).max())
+    assert err < tol_logit * max(1.0, np.abs(ref["logits"]).max()), f"logits max abs err {err}"
+    assert abs(ct.loss_value() - ref["loss"]) < tol_logit * max(1.0, abs(ref["loss"])), (ct.loss_value(), ref["loss"])
+    errs = {}
+    for k, g in ref["grads"].items():
+        got = sess.get_gradient("nn_core/" + k)
+        errs[k] = float(np.abs(got - g).max() / max(np.abs(g).max(), 1e-6))
+    worst = max(errs.items(), key=lambda t: t[1])
+    assert worst[1] < tol_grad, f"gradient {worst[0]} rel err {worst[1]}"
+    for k, v in ref["new_moving"].items():
+        got = sess.get_variable("nn_core/" + k)
+        assert np.abs(got - v).max() < 1e-4 * max(1.0, np.abs(v).max()), k
+    return err, worst, errs

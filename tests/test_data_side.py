@@ -269,11 +269,25 @@ def test_gpu_gather_and_scatter_bit_exact(hip, h, w, cc, cl, p, n):
 @pytest.mark.gpu
 def test_gpu_full_scene_inference_matches_emulation(hip, tmp_path):
     res, log_dir, alg_path = _train(tmp_path, "GeneratorImporter", hip, steps=60)
+    from hypelcnn_amd.classify import infer_for_classification as I
     raster_gpu, _ = _infer(tmp_path, log_dir, alg_path, hip, "all", batch=128)
-    raster_emu, _ = _infer(tmp_path / "emu", log_dir, alg_path, EmuBackend(), "all", batch=128)
-    # same checkpoint, fp32 GEMM order differs from the float64-accumulating emulation: labels may flip only where two
-    # logits are within rounding of each other
-    assert (raster_gpu == raster_emu).mean() > 0.995
+    margin = np.full(raster_gpu.shape, np.inf, np.float32)
+    real = I.perform_prediction
+    I.perform_prediction = lambda s, p, r: real(s, p, r, margin_result=margin)
+    try:
+        raster_emu, _ = _infer(tmp_path / "emu", log_dir, alg_path, EmuBackend(), "all", batch=128)
+    finally:
+        I.perform_prediction = real
+    # same checkpoint; the fp32 GEMM order differs from the float64-accumulating emulation.  north_star: per-pixel
+    # labels bit-exact -- asserted for every pixel whose two best logits (emulation) are more than 1e-4 apart, i.e.
+    # clear of fp32 rounding; the remaining near-ties are counted
+    assert np.isfinite(margin).all()
+    clear = margin > 1e-4
+    np.testing.assert_array_equal(raster_gpu[clear], raster_emu[clear])
+    n_tie = int((~clear).sum())
+    print(f"\nfull-scene labels: {int(clear.sum())} pixels exact, {n_tie} near-ties (top-2 gap <= 1e-4), of which "
+          f"{int((raster_gpu != raster_emu).sum())} differ")
+    assert n_tie <= 0.005 * margin.size
 
 
 # ------------------------------------------------------------------------------------------------ GRSS2018 (2x)

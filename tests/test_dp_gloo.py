@@ -59,8 +59,38 @@ def _worker(rank, world, port, outdir):
     dist.all_reduce = lambda t, **kw: (calls.append(t.numel()), orig(t, **kw))[1]
     sess.train_step_exchange(ct)
     dist.all_reduce = orig
-    assert calls == [hi - lo, lo], calls
+    # [tail of the weights + the non-finite-loss flag behind them] first, then the head
+    assert calls == [hi - lo + 1, lo], calls
     torch.testing.assert_close(sess.grads, plain, rtol=0, atol=0)
+    # a sync point that does not reach the end of the buffer (a trailing variable no LinearNode owns): the
+    # exchange must still cover every element
+    ct.sync_points[0] = (i_sync, lo, hi - 10)
+    calls.clear()
+    dist.all_reduce = lambda t, **kw: (calls.append(t.numel()), orig(t, **kw))[1]
+    sess.train_step_exchange(ct)
+    dist.all_reduce = orig
+    assert sum(calls) == sess.grads.numel() and len(calls) == 3, calls
+    torch.testing.assert_close(sess.grads, plain, rtol=0, atol=0)
+    ct.sync_points[0] = (i_sync, lo, hi)
+    assert float(sess.grads[sess.n_train]) == 0.0 and sess.nonfinite_step(sync=True) is None
+    # ragged global batch (5 samples over 2 ranks: 3 + 2): each rank weights its local mean-loss gradient by
+    # nb_rank / nb_global instead of 1 / world
+    nb_r = 3 - rank
+    xr, ohr = x[:nb_r], onehot[:nb_r]
+    ct_eq = sess.compile(built.train_tower, nb_r, loss=built.train_step.loss, external_masks=True)
+    ct_rg = sess.compile(built.train_tower, nb_r, loss=built.train_step.loss, external_masks=True, global_nb=5)
+    assert ct_eq is not ct_rg
+    outs = []
+    for c in (ct_eq, ct_rg):
+        c.set_input("x", torch.as_tensor(xr))
+        c.set_input("labels", torch.as_tensor(ohr))
+        c.forward_backward()
+        outs.append(sess.grads[:sess.n_train].clone())
+    # (batch norm over 2-3 rows amplifies fp32 rounding: compare at 1e-5 of the largest gradient)
+    torch.testing.assert_close(outs[1], outs[0] * ((nb_r / 5) / 0.5), rtol=1e-4,
+                               atol=1e-5 * float(outs[0].abs().max()))
+    U.run_train_step(built, x, onehot, {})
+    sess.allreduce_gradients()
     sess.adam_step(3e-4)
     torch.save({"p0": p0, "local": local, "avg": sess.grads.clone(), "p1": sess.params.clone(),
                 "state": sess.state.clone()}, os.path.join(outdir, f"r{rank}.pt"))
@@ -77,7 +107,8 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert torch.equal(r0["p0"], r1["p0"]), "rank-0 weights must be broadcast"
     assert not torch.equal(r0["local"], r1["local"]), "shards differ, so local gradients differ"
     assert torch.equal(r0["avg"], r1["avg"])
-    torch.testing.assert_close(r0["avg"], (r0["local"] + r1["local"]) / 2, rtol=1e-6, atol=1e-9)
+    # the 1/world of the global mean is applied at the loss (no rescaling pass after the all-reduce)
+    torch.testing.assert_close(r0["avg"], r0["local"] + r1["local"], rtol=1e-6, atol=1e-9)
     assert torch.equal(r0["p1"], r1["p1"]), "parameters stay in lock-step"
     assert not torch.equal(r0["state"], r1["state"]), "BN moving statistics are per-rank until averaged"
     assert torch.equal(torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt"))
@@ -111,7 +142,22 @@ def _iter_worker(rank, world, port, outdir):
         for lab in b[2].tolist():
             conf[lab * 3 + lab] += 1
     dist.all_reduce(conf)
-    torch.save({"batches": got, "conf": conf}, os.path.join(outdir, f"it{rank}.pt"))
+    # training iterator (its batches end in collectives): a tail shorter than the world size is dropped on EVERY
+    # rank (17 samples, global batch 8: 8 + 8 + 1 -> two batches per rank); a longer tail is sharded unevenly and
+    # reports the global count the loss gradient is weighted with
+    tails = {}
+    for n in (17, 19):
+        tr = cno.BatchIterator((1, 1, 2), 3, 4, True, 1, None)
+        tr.collective = True
+        tr.initializer(data[:n], labels[:n], EmuBackend())
+        sizes = []
+        while True:
+            b = tr.next_batch()
+            if b is None:
+                break
+            sizes.append((int(b[0].shape[0]), tr.last_global_count))
+        tails[n] = sizes
+    torch.save({"batches": got, "conf": conf, "tails": tails}, os.path.join(outdir, f"it{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -126,3 +172,5 @@ def test_two_rank_iterator_shards_are_disjoint_and_complete(tmp_path):
     assert sorted(a.tolist() + b.tolist()) == [2.0 * i for i in range(23)], "one epoch covers every sample once"
     assert all(len(x) == 4 for x in r0["batches"][:-1]), "per-rank batch size is the configured batch size"
     assert torch.equal(r0["conf"], r1["conf"]) and int(r0["conf"].sum()) == 23
+    assert r0["tails"][17] == r1["tails"][17] == [(4, 8), (4, 8)], "a 1-sample tail is dropped on both ranks"
+    assert r0["tails"][19] == [(4, 8), (4, 8), (2, 3)] and r1["tails"][19] == [(4, 8), (4, 8), (1, 3)]

@@ -70,3 +70,70 @@ def test_joint_gan_augmentation_and_classifier_loop_on_gpu(tmp_path):
     from tests.test_training_loop_emu import run_joint_loop
     res, seen = run_joint_loop(tmp_path, HipBackend, gan_steps=30, cls_steps=60)
     assert res.test_accuracy > 0.5
+
+
+def _snapshot(sess):
+    return {k: getattr(sess, k).clone() for k in ("params", "slot_m", "slot_v", "state")}, sess.global_step
+
+
+def _restore(sess, snap):
+    for k, v in snap[0].items():
+        getattr(sess, k).copy_(v)
+    sess.global_step = snap[1]
+
+
+def test_cut_full_step_batch4096_eager_equals_graph(hip):
+    """GAN half of BASELINE configs[4] at its size (CUT x2y on [4096,1,1,360] pairs, patches 6, E 2, tau 0.07): the
+    float64 oracle checks the same phases at N = 48 (test_phase_gradients_match_oracle[cut_y2x-360]); at N = 4096 a
+    full step (generator, discriminator and feature-discriminator phases + 3 Adam updates) is checked by
+    size-independent properties: eager launches == HIP-graph replay == a second run, bit for bit, all finite, and
+    every optimiser group moved."""
+    bands, n = 360, 4096
+    cfg = OG.GanConfig("cut_x2y", bands, patches=6, max_steps=1000)
+    params = U.fp32(OG.init_gan_params("cut_x2y", bands, np.random.default_rng(7), patches=6, dtype=np.float64,
+                                       zero_generator=False))
+    x, y = _data(n, bands, 9)
+    xt = torch.as_tensor(x.reshape(n, -1), dtype=torch.float32).cuda()
+    yt = torch.as_tensor(y.reshape(n, -1), dtype=torch.float32).cuda()
+    wrapper, model, loss, ops = U.build(cfg, n, hip)
+    ops.use_pool = False  # the tensor pool draws from a host RNG: pass the fresh fakes through
+    sess = ops.ctx.session()
+    U.inject(sess, params)
+    snap = _snapshot(sess)
+    ops.capture_graphs = False
+    ops.run_step(xt, yt)
+    torch.cuda.synchronize()
+    p_eager, l_eager = sess.params.clone(), ops.losses()
+    assert torch.isfinite(p_eager).all() and all(np.isfinite(v) for v in l_eager.values()), l_eager
+    for gname, (lo, hi) in sess.group_ranges.items():
+        assert not torch.equal(p_eager[lo:hi], snap[0]["params"][lo:hi]), f"group {gname} did not move"
+    _restore(sess, snap)
+    ops.run_step(xt, yt)
+    torch.cuda.synchronize()
+    assert torch.equal(sess.params, p_eager), "a CUT step must be deterministic"
+    _restore(sess, snap)
+    ops.capture_graphs = True
+    ops.run_step(xt, yt)  # captures every phase, then replays
+    torch.cuda.synchronize()
+    _restore(sess, snap)
+    ops.run_step(xt, yt)
+    torch.cuda.synchronize()
+    assert torch.equal(sess.params, p_eager), "HIP-graph replay must equal the eager step"
+    assert ops.losses() == l_eager
+
+
+def test_cfg5_joint_loop_at_avon_shape_on_gpu(tmp_path):
+    """BASELINE configs[4] end to end at the AVON shape: B = 360 bands, no LiDAR, 2 classes; the CUT-based DCL-GAN
+    trains the shadow generators, the classifier (full alg_param_hypelcnn.json, 7x7x360 patches) then trains with the
+    generator applied to all 49 pixels of a patch w.p. 0.5 (gan/gan_utilities.py:30-43, gan_common.py:282-304)."""
+    import json
+    import os
+    from hypelcnn_amd.backend import HipBackend
+    from tests.test_training_loop_emu import run_joint_loop
+    cfg_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hypelcnn_amd", "nnmodel", "modelconfigs")
+    alg = json.load(open(os.path.join(cfg_dir, "alg_param_hypelcnn.json")))
+    alg["learning_rate"] = 1e-3
+    res, seen = run_joint_loop(tmp_path, HipBackend, gan_steps=20, cls_steps=80, gan_type="dcl_gan",
+                               scene="avon:h=40:w=50:bands=360:samples=0.6", neighborhood=3, alg=alg, batch=64,
+                               gan_batch=64)
+    assert np.isfinite(res.loss) and res.test_accuracy > 0.6, (res.loss, res.test_accuracy)

@@ -2,7 +2,8 @@
 against the oracle (float64) on identical seeded inputs, weights and dropout masks.
 
 Tolerances (BASELINE.json north_star): logits within 1e-3 (fp32), class labels bit-exact.
-Gradients are compared relative to each tensor's max magnitude (2e-3)."""
+Gradients are compared relative to each tensor's max magnitude: 1e-4 on the small cases, 5e-4 at the full model
+sizes (fp32 sums over up to 2e5 products)."""
 import json
 import os
 
@@ -71,7 +72,9 @@ def test_small_models_train_step(hip, model_name, patch, ch, classes, alg, nb):
         assert np.abs(li - ri["logits"]).max() < 1e-3 * max(1.0, np.abs(ri["logits"]).max())
         return
     ct = U.run_train_step(built, x, onehot, masks)
-    U.compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg)
+    ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg, tol_logit=2e-4,
+                                     tol_grad=1e-4)
+    print(f"\n{model_name} nb={nb}: logits {err:.2e}, worst grad {worst}")
 
 
 def test_grss2013_hypelcnn_batch64_cfg1(hip):
@@ -83,19 +86,28 @@ def test_grss2013_hypelcnn_batch64_cfg1(hip):
     # class labels bit-exact (training-mode logits)
     got = ct.value(built.y_conv).cpu().numpy()
     assert (got.argmax(1) == ref["logits"].argmax(1)).all()
-    # one TF1-Adam step: the first step moves every weight by ~lr*sign(g) (K4), so a looser absolute bound
-    # (2*lr) holds even where a kink flip changed a tiny gradient's sign
+    # one TF1-Adam step at model level.  The first step moves every weight by ~lr*sign(g) (K4), so the update is
+    # discontinuous where a gradient is within fp32 rounding of zero, and a leaky-ReLU kink flip (see parity_util)
+    # moves a few gradients by a discrete amount.  The device update is therefore checked (a) exactly -- oracle Adam
+    # applied to the DEVICE gradients (pinned to the oracle's by compare_step above) must give the device parameters
+    # to fp32 rounding -- and (b) against the oracle trainer's parameters: > 99 % of all elements within 1 % of lr
+    g_dev = {k: sess.get_gradient("nn_core/" + k).astype(np.float64) for k in ref["grads"]}
     trainer_p = {k: v.copy() for k, v in params.items()}
     tr = OT.ClassifierTrainer("HYPELCNNModel", trainer_p, 15, alg)
     tr.train_step(x.astype(np.float64), onehot.astype(np.float64), masks)
-    sess.adam_step(built.lr.eval(0))
-    n_bad = n_all = 0
-    for k, v in tr.params.items():
+    lr0 = built.lr.eval(0)
+    sess.adam_step(lr0)
+    n_close = n_all = 0
+    for k, g in ref["grads"].items():
         gotp = sess.get_variable("nn_core/" + k)
-        assert np.abs(gotp - v).max() <= 2.01 * alg["learning_rate"] + 1e-4 * np.abs(v).max(), k
-        n_bad += int((np.abs(gotp - v) > 1e-5 * max(1.0, np.abs(v).max())).sum())
-        n_all += v.size
-    assert n_bad / n_all < 0.02, (n_bad, n_all)
+        exp = params[k].copy()
+        OT.adam_tf1_step(exp, g_dev[k], np.zeros_like(exp), np.zeros_like(exp), lr0, 1)
+        assert np.abs(gotp - exp).max() <= 2e-7 * max(1.0, np.abs(exp).max()) + 1e-3 * lr0, k
+        assert np.abs(gotp - tr.params[k]).max() <= 2.01 * lr0 + 2e-7 * max(1.0, np.abs(exp).max()), k
+        n_close += int((np.abs(gotp - tr.params[k]) <= 1e-2 * lr0 + 2e-7 * max(1.0, np.abs(exp).max())).sum())
+        n_all += g.size
+    print(f"\nmodel-level Adam vs oracle trainer: {n_all - n_close} of {n_all} elements differ by more than 1 % of lr")
+    assert n_close / n_all > 0.99, (n_close, n_all)
     # inference tower: labels bit-exact, logits within 1e-3 relative to their scale
     li = U.run_eval(built, x)
     p2 = {k: sess.get_variable("nn_core/" + k).astype(np.float64) for k in params}
@@ -183,3 +195,138 @@ def test_end_to_end_training_on_gpu(tmp_path):
     res = T.perform_an_episode(flags, dict(ALG), model, log_dir)
     assert np.isfinite(res.loss) and res.test_accuracy > 0.85 and res.validation_accuracy > 0.85
     assert "model.ckpt-150.npz" in os.listdir(log_dir)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Large-batch planner paths against the oracle: the split policies of plan.py switch on at
+# nb >= 64 (forward tap / channel-part split incl. biased convolutions, data-gradient segment split) and at
+# nb >= 128 on device-filling launches (64-row filter-gradient ranges).
+def _tags(ct):
+    return [l.tag for l in ct.plan.fwd + ct.plan.bwd]
+
+
+@pytest.fixture(scope="module")
+def dual_full(hip):
+    """BASELINE configs[2] model: alg_param_dualcnn.json (filter_count 480, 258 M parameters), 11x11x(48+1), 20
+    classes; 512 seeded patches with dropout masks."""
+    alg = _alg("alg_param_dualcnn.json")
+    built, sess, params, x, onehot, masks = _case(hip, "DUALCNNModel", 11, 49, 20, alg, 512, 2018)
+    return alg, built, sess, params, x, onehot, masks
+
+
+def _run_chunk(built, x, onehot, masks, lo, hi):
+    ct = U.run_train_step(built, x[lo:hi], onehot[lo:hi], {k: v[lo:hi] for k, v in masks.items()})
+    sess = built.ctx.session()
+    return ct, sess.grads.clone(), ct.value(built.y_conv).clone(), ct.loss_value()
+
+
+def test_grss2018_dualcnn_full_size_batch64_vs_oracle(hip, dual_full):
+    """Full-size DUALCNN at nb = 64 against the float64 oracle (torch-CPU composition of oracle/torch_ref.py): logits
+    1e-3, labels exact, every gradient tensor.  The plan must contain the split launches whose numbers DESIGN quotes."""
+    alg, built, sess, params, x, onehot, masks = dual_full
+    ct, g, logits, loss = _run_chunk(built, x, onehot, masks, 0, 64)
+    tags = _tags(ct)
+    assert "tap-split-reduce" in tags and any(t.endswith("/split") and t.startswith("fwd:") for t in tags)
+    assert "dgrad-split-reduce" in tags
+    assert any(l.kparts > 1 for l in ct.plan.fwd), "no level forward was cut into channel parts"
+    import time
+    t0 = time.time()
+    ref = U.torch_reference_step("DUALCNNModel", params, x[:64], onehot[:64], {k: v[:64] for k, v in masks.items()},
+                                 20, alg, threads=min(64, os.cpu_count() or 8))
+    t_ref = time.time() - t0
+    err, worst, errs = U.compare_with_reference(built, ct, ref, tol_logit=1e-3, tol_grad=5e-4)
+    assert (logits.cpu().numpy().argmax(1) == ref["logits"].argmax(1)).all()
+    print(f"\nDUALCNN full size nb=64 vs fp64 oracle ({t_ref:.0f} s): logits {err:.2e}, worst grad {worst}")
+
+
+@pytest.mark.parametrize("nb", [128, 512])
+def test_grss2018_dualcnn_large_batches_equal_oracle_checked_chunks(hip, dual_full, nb):
+    """nb = 128 (adds the 64-row filter-gradient ranges) and nb = 512 (the per-GPU batch bench.py --workload dualcnn
+    and configs[2] run at): DUALCNN has no batch statistics, so the step on nb patches must equal the 64-patch steps
+    (the first of which the previous test pins to the oracle) -- logits row for row, gradient = mean of the chunk
+    gradients -- up to fp32 summation order."""
+    alg, built, sess, params, x, onehot, masks = dual_full
+    g_sum, logit_parts, loss_sum = None, [], 0.0
+    for lo in range(0, nb, 64):
+        _, g, lg, ls = _run_chunk(built, x, onehot, masks, lo, lo + 64)
+        g_sum = g.double() if g_sum is None else g_sum + g.double()
+        logit_parts.append(lg)
+        loss_sum += ls
+    ct, g, logits, loss = _run_chunk(built, x, onehot, masks, 0, nb)
+    tags = _tags(ct)
+    assert "wgrad-reduce" in tags and "dgrad-split-reduce" in tags and "tap-split-reduce" in tags
+    rows = [l.args[2] for l in ct.plan.bwd if l.tag == "wgrad-reduce"]
+    assert max(rows) >= nb // 64, f"no filter gradient was cut into 64-row ranges: {rows}"
+    want = (g_sum / (nb // 64)).float()
+    scale = float(want.abs().max())
+    rel = float((g - want).abs().max()) / scale
+    # per variable, relative to that variable's largest gradient
+    worst = ("", 0.0)
+    for v in sess.trainable:
+        sl = slice(v.offset, v.offset + v.size)
+        m = float(want[sl].abs().max())
+        e = float((g[sl] - want[sl]).abs().max()) / max(m, 1e-12)
+        if e > worst[1]:
+            worst = (v.name, e)
+    lg = torch.cat(logit_parts)
+    lerr = float((logits - lg).abs().max())
+    print(f"\nDUALCNN nb={nb} vs 64-patch chunks: grads {rel:.2e} of max, worst variable {worst}, logits {lerr:.2e}")
+    assert worst[1] < 2e-4, worst
+    assert lerr < 1e-4 * max(1.0, float(lg.abs().max()))
+    assert torch.equal(logits.argmax(1), lg.argmax(1))
+    assert abs(loss - loss_sum / (nb // 64)) < 1e-5 * max(1.0, abs(loss))
+
+
+def test_grss2013_hypelcnn_batch1024_vs_oracle(hip):
+    """BASELINE configs[1] exactly as benchmarked (batch 1024, alg_param_hypelcnn.json): ONE full forward+backward
+    against the float64 numpy oracle -- 16-slab filter-gradient splits, channel parts, folded shortcut epilogues at
+    392-tile grids.  Batch norm couples all 1024 samples, so there is no cheaper decomposition."""
+    alg = _alg("alg_param_hypelcnn.json")
+    built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 7, 145, 15, alg, 1024, 77)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    assert "tap-split-reduce" in tags and "wgrad-reduce" in tags and "splitk-reduce" in tags
+    ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 15, alg,
+                                     tol_logit=1e-3, tol_grad=5e-4)
+    got = ct.value(built.y_conv).cpu().numpy()
+    assert (got.argmax(1) == ref["logits"].argmax(1)).all()
+    print(f"\nHYPELCNN nb=1024 vs fp64 oracle: logits {err:.2e}, worst grad {worst}")
+
+
+def test_avon_hypelcnn_hsi_only_two_classes_vs_oracle(hip):
+    """BASELINE configs[4] classifier shape: AVON has no LiDAR (loader/AVONDataLoader.py:32) -> HYPELCNN on 7x7x360
+    HSI-only patches, 2 classes (:95-110), full alg_param_hypelcnn.json, batch 64."""
+    alg = _alg("alg_param_hypelcnn.json")
+    built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 7, 360, 2, alg, 64, 360)
+    ct = U.run_train_step(built, x, onehot, masks)
+    ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 2, alg,
+                                     tol_logit=1e-3, tol_grad=5e-4)
+    got = ct.value(built.y_conv).cpu().numpy()
+    assert (got.argmax(1) == ref["logits"].argmax(1)).all()
+    li = U.run_eval(built, x)
+    p2 = {k: sess.get_variable("nn_core/" + k).astype(np.float64) for k in params}
+    ri = OT.forward_backward("HYPELCNNModel", p2, x.astype(np.float64), None, 2, alg, False)
+    assert np.abs(li - ri["logits"]).max() < 1e-3 * max(1.0, np.abs(ri["logits"]).max())
+    assert (li.argmax(1) == ri["logits"].argmax(1)).all()
+    print(f"\nAVON-shape HYPELCNN nb=64 vs fp64 oracle: logits {err:.2e}, worst grad {worst}")
+
+
+def test_three_adam_steps_track_oracle_trainer_on_gpu(hip):
+    """Three full train steps (forward, backward, TF1 Adam, staircase LR, moving statistics) against
+    oracle/train.py::ClassifierTrainer: every variable within 5e-5 after the third update."""
+    model_name, patch, ch, classes, nb = "HYPELCNNModel", 5, 11, 4, 6
+    alg = dict(SMALL_H)
+    built, sess, params, x, onehot, masks = _case(hip, model_name, patch, ch, classes, alg, nb, 5)
+    trainer = OT.ClassifierTrainer(model_name, {k: v.copy() for k, v in params.items()}, classes, alg)
+    for step in range(3):
+        U.run_train_step(built, x, onehot, masks)
+        sess.adam_step(built.lr.eval(sess.global_step))
+        trainer.train_step(x.astype(np.float64), onehot.astype(np.float64), masks)
+    worst = 0.0
+    for k, v in trainer.params.items():
+        got = sess.get_variable("nn_core/" + k)
+        e = np.abs(got - v).max() / max(1.0, np.abs(v).max())
+        worst = max(worst, e)
+        assert e < 5e-5, (k, e)
+    assert sess.global_step == 3
+    print(f"\n3 Adam steps on GPU vs oracle trainer: worst variable error {worst:.2e}")

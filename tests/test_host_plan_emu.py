@@ -86,3 +86,110 @@ def test_tap_split_forward_matches_oracle(monkeypatch):
     ct = U.run_train_step(built, x, onehot, masks)
     assert any(l.tag == "tap-split-reduce" for l in ct.plan.fwd)
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, ALG_H, tol_logit=2e-5, tol_grad=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Large-batch planner branches (plan.py: biased tap / channel-part split, data-gradient segment split, 64-row
+# filter-gradient ranges).  They are gated on nb >= 64 / a device-filling launch in production; here each one is
+# forced at a size the float64 oracle finishes in seconds, the tagged launch is asserted to be present, and the
+# whole training step is compared with the oracle.
+def _tags(ct):
+    return [l.tag for l in ct.plan.fwd + ct.plan.bwd]
+
+
+def test_biased_tap_and_channel_part_split_matches_oracle(monkeypatch):
+    """DUALCNN (biases, no BN): branches with > MAX_TAPS taps go into a bias-free launch whose partial copies are
+    summed (+ bias) by the reduce; the reduction dimension is additionally cut into channel parts."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TAP_SPLIT_MIN_BATCH", 1)
+    monkeypatch.setattr(plan, "MAX_TAPS_PER_TILE", 4)
+    monkeypatch.setattr(plan, "L2_CHUNK_BYTES", 4096)  # every multi-tap level input "exceeds the L2": channel parts
+    built, sess, params, x, onehot, masks = _case("DUALCNNModel", 5, 7, 3, ALG_D, 4, 31)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    assert any(t.endswith("/split") and t.startswith("fwd:") for t in tags), "biased split launch missing"
+    assert "tap-split-reduce" in tags
+    # channel parts: at least one forward launch carries groups with a non-zero sub-key (second channel part)
+    assert any(getattr(l, "kparts", 1) > 1 for l in ct.plan.fwd), "no level was cut into channel parts"
+    U.compare_step(built, ct, params, x, onehot, masks, "DUALCNNModel", 3, ALG_D, tol_logit=2e-5, tol_grad=2e-4)
+
+
+def test_channel_part_split_with_batch_norm_matches_oracle(monkeypatch):
+    """The same channel-part cut for the un-biased (batch-normed) levels of HYPELCNN."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TAP_SPLIT_MIN_BATCH", 1)
+    monkeypatch.setattr(plan, "MAX_TAPS_PER_TILE", 4)
+    monkeypatch.setattr(plan, "L2_CHUNK_BYTES", 4096)
+    alg = dict(ALG_H, filter_count=96)
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 5, 9, 4, alg, 5, 23)
+    ct = U.run_train_step(built, x, onehot, masks)
+    assert "tap-split-reduce" in _tags(ct)
+    assert any(getattr(l, "kparts", 1) > 1 for l in ct.plan.fwd)
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
+
+
+def test_dgrad_segment_split_matches_oracle(monkeypatch):
+    """Data gradient of an unfolded multi-kernel level: the per-pixel segment list is cut into chunks that write
+    partial copies of dX, summed by one reduce (DUALCNN levels; HYPELCNN levels fold their shortcut instead)."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TAP_SPLIT_MIN_BATCH", 1)
+    monkeypatch.setattr(plan, "DGRAD_MAX_SEGS", 5)
+    built, sess, params, x, onehot, masks = _case("DUALCNNModel", 5, 7, 3, ALG_D, 4, 37)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    assert "dgrad-split-reduce" in tags and any(t.startswith("dgrad:") and t.endswith("/split") for t in tags)
+    U.compare_step(built, ct, params, x, onehot, masks, "DUALCNNModel", 3, ALG_D, tol_logit=2e-5, tol_grad=2e-4)
+
+
+@pytest.mark.parametrize("model_name,patch,ch,classes,alg", [
+    ("DUALCNNModel", 5, 7, 3, ALG_D),
+    ("HYPELCNNModel", 5, 11, 4, ALG_H),
+])
+def test_wgrad_row_ranges_of_device_filling_launch_match_oracle(monkeypatch, model_name, patch, ch, classes, alg):
+    """Filter gradients of a launch that already fills the device are still cut into 64-row batch ranges
+    (split-major tile order); forced by declaring one block 'device filling' at batch 192 (3 ranges, the last
+    boundary not a multiple of the 128-row tile)."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TARGET_BLOCKS", 1)
+    built, sess, params, x, onehot, masks = _case(model_name, patch, ch, classes, alg, 192, 41)
+    ct = U.run_train_step(built, x, onehot, masks)
+    assert "wgrad-reduce" in _tags(ct)
+    n_split = [l.args[2] for l in ct.plan.bwd if l.tag == "wgrad-reduce"]
+    assert max(n_split) >= 3, n_split
+    U.compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg, tol_logit=2e-5, tol_grad=2e-4)
+
+
+def test_all_large_batch_branches_together_match_oracle(monkeypatch):
+    """Every split policy at once, at the batch size where production enables them (nb = 64) on a small DUALCNN."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "MAX_TAPS_PER_TILE", 4)
+    monkeypatch.setattr(plan, "DGRAD_MAX_SEGS", 5)
+    monkeypatch.setattr(plan, "L2_CHUNK_BYTES", 1 << 16)
+    monkeypatch.setattr(plan, "TARGET_BLOCKS", 4)
+    built, sess, params, x, onehot, masks = _case("DUALCNNModel", 5, 7, 3, ALG_D, 64, 43)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    for want in ("tap-split-reduce", "dgrad-split-reduce", "wgrad-reduce"):
+        assert want in tags, want
+    U.compare_step(built, ct, params, x, onehot, masks, "DUALCNNModel", 3, ALG_D, tol_logit=2e-5, tol_grad=2e-4)
+
+
+def test_nonfinite_loss_is_flagged_on_the_device_and_the_update_refused():
+    """NanTensorHook + check_numerics semantics (monitored_session_runner.py:151, common_nn_ops.py:232): a step
+    whose loss is NaN sets the flag behind the gradient buffer, the guarded optimiser leaves parameters and slots
+    untouched, and the session reports the step -- on the next poll without `sync`, immediately with it."""
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 5, 11, 4, ALG_H, 6, 3)
+    U.run_train_step(built, x, onehot, masks)
+    sess.adam_step(1e-3)
+    assert float(sess.grads[sess.n_train]) == 0.0 and sess.nonfinite_step(sync=True) is None
+    p1, m1 = sess.params.clone(), sess.slot_m.clone()
+    bad = x.copy()
+    bad[0, 0, 0, 0] = np.nan
+    U.run_train_step(built, bad, onehot, masks)
+    assert float(sess.grads[sess.n_train]) == 1.0
+    sess.adam_step(1e-3)
+    import torch
+    assert torch.equal(sess.params, p1) and torch.equal(sess.slot_m, m1), "a non-finite step must not update anything"
+    assert sess.nonfinite_step() is None, "the newest flag copy is not inspected without sync (pipelined loop)"
+    assert sess.nonfinite_step(sync=True) == 2
+    assert sess.nonfinite_step() == 2

@@ -110,8 +110,15 @@ def test_session_export_and_restore_through_tf_bundle(tmp_path):
         s1.adam_step(3e-3)
     prefix = M.export_tf_checkpoint(s1, str(tmp_path / "model.ckpt-3"))
     names = set(T.read_index(prefix + ".index"))
-    assert {b"", b"global_step", b"beta1_power", b"nn_core/conv_enc_0/weights", b"nn_core/conv_enc_0/weights/Adam",
-            b"nn_core/conv_enc_0/weights/Adam_1", b"nn_core/fc_final/BatchNorm/moving_variance"} <= names
+    # names of the reference's Saver: AdamOptimizer(name="nn_core/Adam") under name_scope("training_optimizer")
+    # (common/common_nn_ops.py:215-230; Saver include=["training_optimizer"], monitored_session_runner.py:164-168)
+    assert {b"", b"global_step", b"training_optimizer/beta1_power", b"training_optimizer/beta2_power",
+            b"nn_core/conv_enc_0/weights", b"nn_core/conv_enc_0/weights/nn_core/Adam",
+            b"nn_core/conv_enc_0/weights/nn_core/Adam_1", b"nn_core/fc_final/BatchNorm/moving_variance"} <= names
+    assert b"beta1_power" not in names and b"nn_core/conv_enc_0/weights/Adam" not in names
+    acc = T.read_checkpoint(prefix, names={"training_optimizer/beta1_power", "training_optimizer/beta2_power"})
+    assert abs(float(acc["training_optimizer/beta1_power"]) - 0.9 ** 4) < 1e-7
+    assert abs(float(acc["training_optimizer/beta2_power"]) - 0.999 ** 4) < 1e-7
     assert M.latest_checkpoint(str(tmp_path)) == prefix
     b2, s2 = fresh(2)
     assert not np.array_equal(s2.params.numpy(), s1.params.numpy())
@@ -126,6 +133,39 @@ def test_session_export_and_restore_through_tf_bundle(tmp_path):
         U.run_train_step(b, x, onehot, {})
         s.adam_step(3e-3)
     np.testing.assert_array_equal(s2.params.numpy(), s1.params.numpy())
+    # the default-named spelling (`<var>/Adam`, what a GAN session or an older export of this build wrote) restores
+    # too; a bundle without any slots warns
+    allv = T.read_checkpoint(prefix)
+    legacy = {k.replace("/nn_core/Adam", "/Adam"): v for k, v in allv.items()}
+    T.write_checkpoint(str(tmp_path / "legacy" / "model.ckpt-3"), legacy)
+    b3, s3 = fresh(3)
+    M.restore_checkpoint(s3, str(tmp_path / "legacy" / "model.ckpt-3"))
+    restored = T.read_checkpoint(prefix)
+    for v in s3.trainable:
+        np.testing.assert_array_equal(s3.slot_v.numpy()[v.offset:v.offset + v.size].reshape(v.shape),
+                                      restored[v.name + "/nn_core/Adam_1"])
+    T.write_checkpoint(str(tmp_path / "bare" / "model.ckpt-3"),
+                       {k: v for k, v in allv.items() if "Adam" not in k and "_power" not in k})
+    b4, s4 = fresh(4)
+    with pytest.warns(UserWarning, match="optimiser slots"):
+        M.restore_checkpoint(s4, str(tmp_path / "bare" / "model.ckpt-3"))
+    assert s4.global_step == 3 and float(s4.slot_m.abs().max()) == 0.0
+
+
+def test_gan_session_exports_default_adam_names_with_its_beta1(tmp_path):
+    """GAN optimisers keep TF's default name and beta1 = 0.5 (gan/wrappers/gan_common.py:264-265)."""
+    from tests import parity_util as U
+    from tests.emu_backend import EmuBackend
+    built = U.build("HYPELCNNModel", 3, 5, 3, {"drop_out_ratio": 0.3, "filter_count": 32, "learning_rate": 3e-3,
+                                               "learning_rate_decay_factor": 0.96, "learning_rate_decay_step": 350,
+                                               "lrelu_alpha": 0.18, "optimizer": "AdamOptimizer", "bn_decay": 0.9,
+                                               "l2regularizer_scale": 1e-5, "spectral_hierarchy_level": 1,
+                                               "spatial_hierarchy_level": 1, "degradation_coeff": 3,
+                                               "use_residual": True}, EmuBackend(), with_eval=False)
+    sess = built.ctx.session()
+    sess.global_step = 2
+    d = T.session_to_variables(sess, optimizer_name="Adam", accumulator_scope="", beta1=0.5)
+    assert "nn_core/conv_enc_0/weights/Adam_1" in d and abs(float(d["beta1_power"]) - 0.5 ** 3) < 1e-7
 
 
 # ------------------------------------------------------------------------------------------------ TFRecord files

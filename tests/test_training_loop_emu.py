@@ -73,7 +73,7 @@ def test_log_suffix_format(tmp_path):
 GAN_SCENE = "gulfport:h=24:w=30:bands=16:classes=3:samples=0.6"
 
 
-def _gan_params(tmp_path, gan_type, steps):
+def _gan_params(tmp_path, gan_type, steps, scene=None, batch=32):
     from hypelcnn_amd.gan import gan_train_for_shadow as GT
     import argparse
     from hypelcnn_amd.common import cmd_parser as cp
@@ -81,17 +81,22 @@ def _gan_params(tmp_path, gan_type, steps):
     for add in (cp.add_parse_cmds_for_loaders, cp.add_parse_cmds_for_loggers, cp.add_parse_cmds_for_trainers,
                 cp.add_parse_cmds_for_json_loader, GT.add_parse_cmds_for_app, cp.add_parse_cmds_for_opt):
         add(parser)
-    flags, _ = parser.parse_known_args(["--loader_name", "SyntheticDataLoader", "--path", GAN_SCENE, "--gan_type",
-                                        gan_type, "--batch_size", "32", "--step", str(steps), "--base_log_path",
+    flags, _ = parser.parse_known_args(["--loader_name", "SyntheticDataLoader", "--path", scene or GAN_SCENE,
+                                        "--gan_type", gan_type, "--batch_size", str(batch), "--step", str(steps),
+                                        "--base_log_path",
                                         str(tmp_path / "gan"), "--validation_steps", "1000",
                                         "--validation_sample_count", "64"])
     return GT, dict(vars(flags))
 
 
-def run_joint_loop(tmp_path, backend_factory, gan_steps=30, cls_steps=40):
+def run_joint_loop(tmp_path, backend_factory, gan_steps=30, cls_steps=40, scene=None, gan_type="cycle_gan",
+                   neighborhood=1, alg=None, batch=32, gan_batch=32):
     """SURVEY cfg5: train a shadow GAN on (lit, shadowed) spectra of the scene, then train the classifier with the
-    trained generator applied to every pixel of a patch with probability 0.5 (augment_data_with_shadow=cycle_gan)."""
-    GT, params = _gan_params(tmp_path, "cycle_gan", gan_steps)
+    trained generator applied to every pixel of a patch with probability 0.5 (augment_data_with_shadow=<gan_type>;
+    the loaders register cycle_gan / dcl_gan / dcl_cycle_gan generators, loader/AVONDataLoader.py:38-45)."""
+    scene = scene or GAN_SCENE
+    alg = alg or ALG
+    GT, params = _gan_params(tmp_path, gan_type, gan_steps, scene, gan_batch)
     div = GT.run_session(params, params["base_log_path"], backend=backend_factory())
     assert all(np.isfinite(d) for d in div)
     gan_dir = f"{params['base_log_path']}_{GT.get_log_suffix(type('F', (), params))}"
@@ -103,11 +108,11 @@ def run_joint_loop(tmp_path, backend_factory, gan_steps=30, cls_steps=40):
     assert any(n.startswith("Model/ModelX2Y/Generator/net1/weights") for n in names), sorted(names)[:6]
 
     p = tmp_path / "alg.json"
-    p.write_text(json.dumps(ALG))
-    argv = ["--loader_name", "SyntheticDataLoader", "--path", GAN_SCENE + f":gan_ckpt={ckpt}", "--neighborhood", "1",
-            "--model_name", "HYPELCNNModel", "--algorithm_param_path", str(p), "--batch_size", "32", "--step",
-            str(cls_steps), "--base_log_path", str(tmp_path / "log"), "--perform_validation", "false",
-            "--save_checkpoint_steps", "1000", "--augment_data_with_shadow", "cycle_gan",
+    p.write_text(json.dumps(alg))
+    argv = ["--loader_name", "SyntheticDataLoader", "--path", scene + f":gan_ckpt={ckpt}", "--neighborhood",
+            str(neighborhood), "--model_name", "HYPELCNNModel", "--algorithm_param_path", str(p), "--batch_size",
+            str(batch), "--step", str(cls_steps), "--base_log_path", str(tmp_path / "log"), "--perform_validation",
+            "false", "--save_checkpoint_steps", "1000", "--augment_data_with_shadow", gan_type,
             "--augment_data_with_rotation", "true", "--augmentation_random_threshold", "0.5"]
     flags, _ = T.build_parser().parse_known_args(argv)
     be = backend_factory()
@@ -115,7 +120,7 @@ def run_joint_loop(tmp_path, backend_factory, gan_steps=30, cls_steps=40):
     real_call = be.call
     be.call = lambda name, *a: (seen.append(name), real_call(name, *a))[1]
     log_dir = os.path.join(flags.base_log_path, T.get_log_suffix(flags))
-    res = T.perform_an_episode(flags, dict(ALG), T.get_model_from_name(flags.model_name), log_dir, backend=be)
+    res = T.perform_an_episode(flags, dict(alg), T.get_model_from_name(flags.model_name), log_dir, backend=be)
     assert np.isfinite(res.loss)
     assert "augment_patches_f32" in seen, "the fused augmentation kernel must carry the generator output"
     return res, seen
@@ -123,6 +128,14 @@ def run_joint_loop(tmp_path, backend_factory, gan_steps=30, cls_steps=40):
 
 def test_joint_gan_augmentation_and_classifier_loop(tmp_path):
     res, seen = run_joint_loop(tmp_path, EmuBackend)
+    assert res.test_accuracy > 0.5
+
+
+def test_joint_loop_with_cut_based_generator_on_hsi_only_scene(tmp_path):
+    """BASELINE configs[4] in miniature: AVON geometry (no LiDAR channel, 2 classes), the CUT-based DCL-GAN (two
+    cut models, NCE + feature discriminators) trains the shadow generator, which then augments the HYPELCNN input."""
+    res, seen = run_joint_loop(tmp_path, EmuBackend, gan_steps=12, cls_steps=40, gan_type="dcl_gan",
+                               scene="avon:h=24:w=30:bands=24:samples=0.6")
     assert res.test_accuracy > 0.5
 
 
@@ -134,3 +147,31 @@ def test_simple_shadow_struct_is_registered_by_the_loader():
     assert ratio.shape == (7,) and ratio[-1] == 1.0 and (ratio[:-1] > 1.0).all()   # lit / shadow > 1, LiDAR untouched
     ds2 = SyntheticDataLoader("avon:h=12:w=14:bands=8").load_data(0, True)
     assert ds2.shadow_creator_dict["simple"].ratio.shape == (8,)
+
+
+def test_session_loop_stops_on_nan_loss_without_poisoned_checkpoint(tmp_path, monkeypatch):
+    """A batch with a NaN input at step 7: the loop stops within two steps, no checkpoint is written after it and
+    the parameters are still finite (the device-side guard refused the update)."""
+    from hypelcnn_amd.common import common_nn_ops as cno
+    flags = _flags(tmp_path, 60, ["--save_checkpoint_steps", "5", "--perform_validation", "false"])
+    calls = {"n": 0}
+    real = cno.BatchIterator.next_batch
+
+    def poisoned(self):
+        b = real(self)
+        if b is not None and self.collective:
+            calls["n"] += 1
+            if calls["n"] == 7:
+                x = b[0].clone()
+                x[0, 0, 0, 0] = float("nan")
+                b = (x,) + tuple(b[1:])
+        return b
+
+    monkeypatch.setattr(cno.BatchIterator, "next_batch", poisoned)
+    model = T.get_model_from_name(flags.model_name)
+    log_dir = os.path.join(flags.base_log_path, T.get_log_suffix(flags))
+    T.perform_an_episode(flags, dict(ALG), model, log_dir, backend=EmuBackend())
+    ckpts = sorted(int(f.split("-")[1].split(".")[0]) for f in os.listdir(log_dir) if f.startswith("model.ckpt-"))
+    assert ckpts == [5], ckpts
+    with np.load(os.path.join(log_dir, "model.ckpt-5.npz")) as z:
+        assert all(np.isfinite(z[k]).all() for k in z.files)
