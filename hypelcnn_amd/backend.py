@@ -135,6 +135,7 @@ def load_library(path=LIB_PATH):
 class HipBackend:
     """Launches hand-written gfx950 kernels through the C-ABI on a torch CUDA(HIP) stream."""
     name = "hip"
+    _streams = {}  # device index -> (main stream, side stream), shared by every backend object of the process
 
     def __init__(self, device=None):
         if not torch.cuda.is_available():
@@ -146,12 +147,16 @@ class HipBackend:
             raise HypelError("libhypel_hip.so ABI version mismatch")
         # All hypel launches (and the torch plumbing ops around them) run on ONE dedicated non-default
         # stream: HIP cannot capture the legacy null stream into a graph, and a private stream keeps the
-        # step ordered without device-wide syncs.
-        self.stream = torch.cuda.Stream(self.device)
+        # step ordered without device-wide syncs.  The stream pair is per DEVICE, not per backend object: torch's
+        # "current stream" is process-global state, so a second HipBackend with streams of its own would silently
+        # move the first one's copies (set_input, .cpu()) onto a stream its kernels are not ordered with.
+        key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if key not in HipBackend._streams:
+            # side stream: independent kernels of the backward pass (filter gradients) run there and fill the grid
+            # tails of the data-gradient kernels on the main stream
+            HipBackend._streams[key] = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        self.stream, self.side_stream = HipBackend._streams[key]
         torch.cuda.set_stream(self.stream)
-        # side stream: independent kernels of the backward pass (filter gradients) run here and fill the grid
-        # tails of the data-gradient kernels on the main stream
-        self.side_stream = torch.cuda.Stream(self.device)
 
     # -- memory (PyTorch is the allocator: plumbing only) --
     def empty(self, n, dtype=torch.float32):

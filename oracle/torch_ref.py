@@ -93,11 +93,27 @@ def hypelcnn_loss(logits, img, x, onehot):
     return (ce + rec).mean()
 
 
-def dualcnn(P, x, class_count, alg, training, masks=None):
+def dualcnn(P, x, class_count, alg, training, masks=None, trace=None, kink_force=None):
+    """trace (dict): receives every layer's PRE-activation by scope.  kink_force {scope: bool tensor}: the branch
+    (pre > 0) each leaky-ReLU element takes, pinned by the caller (parity tests pin elements whose fp32
+    pre-activation lies within rounding of the kink to the product's own decision, see tests/parity_util.py)."""
     a = alg["lrelu_alpha"]
-    act = lambda t: F.leaky_relu(t, a)
-    cb = lambda t, sc, f=act: (lambda y: f(y) if f else y)(conv_same(t, P[sc + "/weights"], P[sc + "/biases"]))
-    fb = lambda t, sc, f=act: (lambda y: f(y) if f else y)(t @ P[sc + "/weights"] + P[sc + "/biases"])
+
+    def act(t, sc):
+        if trace is not None:
+            trace[sc] = t.detach()
+        if kink_force is not None and sc in kink_force:
+            pos = kink_force[sc]
+            return torch.where(pos, t, a * t)
+        return F.leaky_relu(t, a)
+
+    def cb(t, sc, f=act):
+        y = conv_same(t, P[sc + "/weights"], P[sc + "/biases"])
+        return f(y, sc) if f else y
+
+    def fb(t, sc, f=act):
+        y = t @ P[sc + "/weights"] + P[sc + "/biases"]
+        return f(y, sc) if f else y
     c = x.shape[3]
     hs, lidar = x[..., :c - 1], x[..., c - 1:]
     d = alg["hs_lidar_diff"]

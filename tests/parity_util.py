@@ -180,7 +180,7 @@ def run_eval(built, x):
     return ct.value(built.eval_out.y_conv).cpu().numpy()
 
 
-def torch_reference_step(model_name, params, x, onehot, masks, classes, alg, threads=None):
+def torch_reference_step(model_name, params, x, onehot, masks, classes, alg, threads=None, kink_force=None):
     """The float64 oracle through oracle/torch_ref.py (torch-CPU autograd composition; agrees with oracle/models.py
     to 1e-12, tests/test_oracle_selfcheck.py) -- used where the numpy tape is too slow (full-size DUALCNN: 81 GFLOP
     per patch).  Same result dict as oracle.train.forward_backward (no per-layer trace)."""
@@ -199,14 +199,20 @@ def torch_reference_step(model_name, params, x, onehot, masks, classes, alg, thr
             logits, img, nm = TR.hypelcnn(P, xt, classes, alg, True, mk)
             loss = TR.hypelcnn_loss(logits, img, xt, oh)
         else:
-            fwd = TR.dualcnn if model_name == "DUALCNNModel" else TR.concnn
-            logits = fwd(P, xt, classes, alg, True, mk)
+            trace = {}
+            if model_name == "DUALCNNModel":
+                logits = TR.dualcnn(P, xt, classes, alg, True, mk, trace=trace, kink_force=kink_force)
+            else:
+                logits = TR.concnn(P, xt, classes, alg, True, mk)
             loss = (-(oh * torch.log_softmax(logits, -1)).sum(-1)).mean()
         names = [k for k, v in P.items() if v.requires_grad]
         grads = torch.autograd.grad(loss, [P[k] for k in names])
-        return {"logits": logits.detach().numpy(), "loss": float(loss.detach()),
-                "grads": {k: g.numpy() for k, g in zip(names, grads)},
-                "new_moving": {k: v.detach().numpy() for k, v in nm.items()}}
+        out = {"logits": logits.detach().numpy(), "loss": float(loss.detach()),
+               "grads": {k: g.numpy() for k, g in zip(names, grads)},
+               "new_moving": {k: v.detach().numpy() for k, v in nm.items()}}
+        if model_name != "HYPELCNNModel":
+            out["pre"] = trace  # scope -> float64 pre-activation (torch tensors, NHWC / [N, C])
+        return out
     finally:
         torch.set_num_threads(old)
 
@@ -229,3 +235,34 @@ def compare_with_reference(built, ct, ref, tol_logit=1e-3, tol_grad=2e-3):
         got = sess.get_variable("nn_core/" + k)
         assert np.abs(got - v).max() < 1e-4 * max(1.0, np.abs(v).max()), k
     return err, worst, errs
+
+
+def product_kink_decisions_biased(built, ct, ref_pre, alpha_zone=1e-4):
+    """Leaky-ReLU layers WITHOUT batch norm (DUALCNN: conv/fc + bias -> lrelu): the product's pre-activation is its
+    Y buffer (bias already added by the GEMM epilogue or the split reduce).  Returns ({scope: bool tensor of the
+    product's branch decisions where they may legitimately differ, oracle's elsewhere}, n_ambiguous, n_flipped);
+    asserts that decisions differ only where the float64 pre-activation is within `alpha_zone` of the kink."""
+    from hypelcnn_amd import graph as G
+    plan = ct.plan
+    nb = plan.nb
+    force, n_amb, n_flip = {}, 0, 0
+    for idx, node in enumerate(built.train_tower.nodes):
+        if not isinstance(node, G.LinearNode) or node.act is None or node.act.kind != "lrelu" or node.has_bn:
+            continue
+        aux = plan.node_aux[idx]
+        c = node.cout
+        out = node.out
+        y = plan.buffers[aux["y"].buf][: out.npix * nb * c].reshape(out.npix, nb, c).permute(1, 0, 2).cpu()
+        off = 0
+        for b in node.branches:
+            got = y[:, :, off:off + b.cout]
+            pre64 = ref_pre[b.scope].reshape(nb, out.npix, b.cout)
+            amb = pre64.abs() < alpha_zone
+            differ = (got > 0) != (pre64 > 0)
+            assert not bool((differ & ~amb).any()), f"{b.scope}: branch decision differs outside the ambiguous zone"
+            n_amb += int(amb.sum())
+            if bool(differ.any()):
+                n_flip += int(differ.sum())
+                force[b.scope] = torch.where(differ, got > 0, pre64 > 0).reshape(ref_pre[b.scope].shape)
+            off += b.cout
+    return force, n_amb, n_flip
