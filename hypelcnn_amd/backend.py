@@ -19,12 +19,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HYPEL_LIB_PATH: an alternative build of the same ABI (A/B experiments on one GPU box)
 LIB_PATH = os.environ.get("HYPEL_LIB_PATH") or os.path.join(_HERE, "csrc", "libhypel_hip.so")
 
+MAX_SIDE_STREAMS = 4  # side streams a plan may fork filter gradients onto (plan.SIDE_STREAMS <= this)
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 GEMM_BM = 128
 
 SEG_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("k", "<i4"), ("reserved", "<i4")])
 GROUP_DTYPE = np.dtype([("c_off", "<i8"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("rows", "<i4"),
                         ("reserved", "<i4")])
+MTILE_DTYPE = np.dtype([("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8"), ("m0", "<i4"), ("rows", "<i4"),
+                        ("n0", "<i4"), ("n", "<i4"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("k0", "<i4"),
+                        ("flags", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"), ("reserved", "<i4")])
+REDUCE_ENTRY_DTYPE = np.dtype([("partial_off", "<i8"), ("out_off", "<i8"), ("stride", "<i8"), ("count", "<i8"),
+                               ("n_splits", "<i4"), ("flags", "<i4")])
 TILE_DTYPE = np.dtype([("group", "<i4"), ("m0", "<i4"), ("rows", "<i4"), ("seg_begin", "<i4"), ("seg_count", "<i4"),
                        ("k0", "<i4"), ("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8")])
 
@@ -61,6 +67,8 @@ SIGNATURES = {
     "seg_gemm_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32],
     "seg_gemm_res_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P],
     "reduce_splits_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I32, _I64],
+    "seg_gemm_multi_f32": [_P, _I32, _I32, _I32, _P, _P, _I32],
+    "reduce_splits_multi_f32": [_P, _P, _I32],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
     "bn_stats_f32": [_P, _I64, _I64, _I32, _I32, _P, _P, _F, _P, _P, _P, _P, _F],
     "bn_act_small_fwd": [_P, _I64, _I64, _I32, _F, _P, _I32, _F, _P, _I64, _P, _P, _P, _P, _F, _P, _I64],
@@ -154,8 +162,10 @@ class HipBackend:
         if key not in HipBackend._streams:
             # side stream: independent kernels of the backward pass (filter gradients) run there and fill the grid
             # tails of the data-gradient kernels on the main stream
-            HipBackend._streams[key] = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
-        self.stream, self.side_stream = HipBackend._streams[key]
+            HipBackend._streams[key] = (torch.cuda.Stream(self.device),
+                                        [torch.cuda.Stream(self.device) for _ in range(MAX_SIDE_STREAMS)])
+        self.stream, self.side_streams = HipBackend._streams[key]
+        self.side_stream = self.side_streams[0]
         torch.cuda.set_stream(self.stream)
 
     # -- memory (PyTorch is the allocator: plumbing only) --
@@ -186,17 +196,21 @@ class HipBackend:
     # -- launches --
     def bind(self, name, args, stream=None):
         if name == "_fork" or name == "_join":
+            # _fork (k,): side stream k waits for the main stream; _join (k1, k2, ..): the main stream waits for them
             fn = self.lib.hypel_stream_fork if name == "_fork" else self.lib.hypel_stream_join
-            main, side, lib = self.stream.cuda_stream, self.side_stream.cuda_stream, self.lib
+            main, lib = self.stream.cuda_stream, self.lib
+            ks = [int(k) for k in args] if args else [1]
+            sides = [self.side_streams[k - 1].cuda_stream for k in ks]
 
             def sync_call():
-                if fn(main, side) != 0:
-                    raise HypelError(lib.hypel_last_error().decode())
+                for side in sides:
+                    if fn(main, side) != 0:
+                        raise HypelError(lib.hypel_last_error().decode())
 
             return sync_call
         fn = getattr(self.lib, "hypel_" + name)
-        if stream == 1:
-            st = self.side_stream.cuda_stream
+        if isinstance(stream, int) and 1 <= stream <= MAX_SIDE_STREAMS:
+            st = self.side_streams[stream - 1].cuda_stream
         else:
             st = self.stream_handle() if stream is None or stream == 0 else stream
         cargs = []

@@ -313,7 +313,10 @@ class BatchIterator:
     def _reset(self):
         self._gen = torch.Generator(device="cpu")  # epoch permutations: identical on every rank (see next_batch)
         self._gen.manual_seed(self.seed)
-        self._aug_gen = torch.Generator(device="cpu")  # augmentation draws: a stream of their own, per rank
+        # augmentation draws: a stream of their own, per rank -- drawn ON THE DEVICE the batch lives on: on a 256-thread
+        # host a handful of tiny CPU torch.rand calls costs 10 ms per batch (measured), more than the whole train step
+        dev = getattr(getattr(self, "backend", None), "device", None)
+        self._aug_gen = torch.Generator(device=dev if dev is not None and dev.type == "cuda" else "cpu")
         self._aug_gen.manual_seed(self.seed + 7919 * (self._dp()[1] + 1))
         self._epoch = 0
         self._pos = 0
@@ -403,16 +406,17 @@ def draw_augmentations(b, c, info, gen):
     reference applies the maps -- rot90 by k in {0,1,2} (never 270 degrees, :402), shadow op with probability
     `augmentation_random_threshold`, left-right / up-down flips with p = 0.5, per-channel U(-s, 0) shift."""
     d = {}
+    dev = gen.device  # the draws are made where the generator lives (the batch's device in the product iterators)
     if info.perform_rotation_augmentation:
-        d["rot_k"] = torch.randint(0, 3, (b,), generator=gen).to(torch.int32)
+        d["rot_k"] = torch.randint(0, 3, (b,), generator=gen, device=dev).to(torch.int32)
     if info.perform_shadow_augmentation and info.shadow_struct is not None:
-        d["shadow_pick"] = (torch.rand(b, generator=gen) < info.augmentation_random_threshold).to(torch.uint8)
+        d["shadow_pick"] = (torch.rand(b, generator=gen, device=dev) < info.augmentation_random_threshold).to(torch.uint8)
     if info.perform_reflection_augmentation:
-        d["flip_lr"] = (torch.rand(b, generator=gen) < 0.5).to(torch.uint8)
-        d["flip_ud"] = (torch.rand(b, generator=gen) < 0.5).to(torch.uint8)
+        d["flip_lr"] = (torch.rand(b, generator=gen, device=dev) < 0.5).to(torch.uint8)
+        d["flip_ud"] = (torch.rand(b, generator=gen, device=dev) < 0.5).to(torch.uint8)
     if info.perform_spectral_augmentation:
         s = float(info.perform_spectral_augmentation)
-        d["delta"] = (torch.rand(b, c, generator=gen) * s - s).contiguous()
+        d["delta"] = (torch.rand(b, c, generator=gen, device=dev) * s - s).contiguous()
     return d
 
 

@@ -159,6 +159,39 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t 
     }
 }
 
+// Several reductions in one launch: blockIdx.y = entry, blockIdx.x strides over the entry's elements (float4 when
+// the entry's count / stride / addresses allow it).  Same summation order as reduce_splits_kernel.
+__global__ void reduce_splits_multi_kernel(const float* __restrict__ base,
+                                           const hypel_reduce_entry_t* __restrict__ entries) {
+    const hypel_reduce_entry_t e = entries[blockIdx.y];
+    const float* __restrict__ partial = base + e.partial_off;
+    float* __restrict__ out = const_cast<float*>(base) + e.out_off;
+    const bool acc = e.flags & 1;
+    const bool v4 = (e.count % 4 == 0) && (e.stride % 4 == 0) && ((((uintptr_t)partial) | ((uintptr_t)out)) & 15) == 0;
+    if (v4) {
+        const int64_t count4 = e.count / 4;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count4;
+             q += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t o = q * 4;
+            float4 s = acc ? *reinterpret_cast<const float4*>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int k = 0; k < e.n_splits; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)k * e.stride + o);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4*>(out + o) = s;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e.count;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            float s = acc ? out[i] : 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < e.n_splits; ++k) s += partial[(int64_t)k * e.stride + i];
+            out[i] = s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- BN statistics
 // grid = (n_chunks, ceil(c/64)); block = 64 x 4.  Shifted sums (shift = first row of the chunk) keep the
 // fp32 accumulation well conditioned; the chunk's (mean, M2) pair is then exact enough to Chan-merge in fp64.
@@ -1156,6 +1189,15 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
                            n_splits, out, count, accumulate, bias, n, ldc);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
+    return 0;
+}
+
+extern "C" int hypel_reduce_splits_multi_f32(const float* base, const hypel_reduce_entry_t* entries, int32_t n_entries,
+                                             hypel_stream_t stream) {
+    HYPEL_REQUIRE(base && entries && n_entries >= 0, "hypel_reduce_splits_multi_f32");
+    if (n_entries == 0) return 0;
+    hipLaunchKernelGGL(reduce_splits_multi_kernel, dim3(192, n_entries), dim3(256), 0, ST, base, entries);
+    HYPEL_CHECK_LAUNCH("hypel_reduce_splits_multi_f32");
     return 0;
 }
 

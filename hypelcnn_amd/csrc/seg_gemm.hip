@@ -22,6 +22,29 @@
 
 #include "common.h"
 
+// regs[i] -> LDS dword (image_base + tid + 256 * i), i < N: the staging layout of every UNPADDED image (thread t holds
+// element t + 256 i of the row-major tile).  ds_write_addtid_b32 takes its address from M0 + offset + 4 * lane, so a
+// wave stores 64 consecutive dwords without an address register.  m0 = byte address of the wave's first dword.
+template <int N, int I = 0>
+__device__ __forceinline__ void lds_store_addtid(unsigned m0, const float (&regs)[N]) {
+    if constexpr (I + 4 <= N) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %1 offset:%5\n\tds_write_addtid_b32 %2 offset:%6\n\t"
+                     "ds_write_addtid_b32 %3 offset:%7\n\tds_write_addtid_b32 %4 offset:%8"
+                     :
+                     : "s"(m0), "v"(regs[I]), "v"(regs[I + 1]), "v"(regs[I + 2]), "v"(regs[I + 3]), "i"(1024 * I),
+                       "i"(1024 * (I + 1)), "i"(1024 * (I + 2)), "i"(1024 * (I + 3))
+                     : "memory");
+        lds_store_addtid<N, I + 4>(m0, regs);
+    } else if constexpr (I < N) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%2"
+                     :
+                     : "s"(m0), "v"(regs[I]), "i"(1024 * I)
+                     : "memory");
+        lds_store_addtid<N, I + 1>(m0, regs);
+    }
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -40,6 +63,9 @@ constexpr int BK = HYPEL_GEMM_BK;
 #ifndef HYPEL_GEMM_CHUNK
 #define HYPEL_GEMM_CHUNK 8  // granularity (reduction columns) at which a short k-tile stops issuing MFMAs
 #endif
+#ifndef HYPEL_GEMM_ADDTID
+#define HYPEL_GEMM_ADDTID 0  // 1: unpadded LDS images are written with ds_write_addtid_b32 (no address VGPR: 2 cycles
+#endif                       // per wave-store instead of 4, MI355X_MICROARCH.md LDS table)
 constexpr int CHUNK = HYPEL_GEMM_CHUNK;
 static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
 #ifndef HYPEL_OCC_BN32
@@ -49,13 +75,17 @@ static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
 // NARROW: 128x16 blocks on v_mfma_f32_16x16x4_f32 for n <= 16 (the Cout = 15 level of HYPELCNN, fc_final): each wave
 // owns 32 rows x 16 columns as two 16x16 accumulators, so a 15-column output wastes 1/16 of the MFMA work instead of
 // the 17/32 it wastes on a 32-wide tile.
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false>
+// MULTI: one launch covers the tiles of SEVERAL products (the filter gradients of many layers): `tiles` is then an
+// array of hypel_mtile_t, one record per BLOCK, that carries the block's column tile, its product's n / lda / ldb /
+// ldc and accumulate flag; operand offsets (records and segments) are relative to the one base pointer passed as
+// A = B = C.
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false>
 __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
                                                         const hypel_group_t* __restrict__ groups,
                                                         const hypel_seg_t* __restrict__ segs,
-                                                        const hypel_tile_t* __restrict__ tiles, int n_tiles,
+                                                        const void* __restrict__ tiles_v, int n_tiles,
                                                         int n_ntiles, const float* __restrict__ bias,
                                                         int accumulate, const float* __restrict__ res, int64_t ldr,
                                                         const int32_t* __restrict__ res_start) {
@@ -88,14 +118,32 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     const int xcd = bid & 7, loc = bid >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int tile_id = lid / n_ntiles;
-    const int n0 = (lid - tile_id * n_ntiles) * BN;
-    if (tile_id >= n_tiles) return;
-    // one record per tile: the group's fields and its first segment travel with it (no tiles -> groups -> segs chain
-    // in front of the first operand loads)
-    const hypel_tile_t tile = tiles[tile_id];
-    struct { int64_t c_off; int seg_begin, seg_count, rows; } grp = {tile.c_off, tile.seg_begin, tile.seg_count, tile.rows};
-    const int m0 = tile.m0;
+    struct { int64_t c_off; int seg_begin, seg_count, rows; } grp;
+    struct { int64_t a_off0, b_off0; int k0; } tile;
+    int m0, n0;
+    if constexpr (MULTI) {
+        if (lid >= n_tiles) return;
+        const hypel_mtile_t rec = reinterpret_cast<const hypel_mtile_t*>(tiles_v)[lid];
+        grp = {rec.c_off, rec.seg_begin, rec.seg_count, rec.rows};
+        tile = {rec.a_off0, rec.b_off0, rec.k0};
+        m0 = rec.m0;
+        n0 = rec.n0;
+        n = rec.n;
+        lda = rec.lda;
+        ldb = rec.ldb;
+        ldc = rec.ldc;
+        accumulate = rec.flags & 1;
+    } else {
+        const int tile_id = lid / n_ntiles;
+        n0 = (lid - tile_id * n_ntiles) * BN;
+        if (tile_id >= n_tiles) return;
+        // one record per tile: the group's fields and its first segment travel with it (no tiles -> groups -> segs
+        // chain in front of the first operand loads)
+        const hypel_tile_t t = reinterpret_cast<const hypel_tile_t*>(tiles_v)[tile_id];
+        grp = {t.c_off, t.seg_begin, t.seg_count, t.rows};
+        tile = {t.a_off0, t.b_off0, t.k0};
+        m0 = t.m0;
+    }
     const int rows_left = grp.rows - m0;  // valid rows in this tile (may exceed BM)
     const int cols_left = n - n0;
 
@@ -159,6 +207,8 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     constexpr int B_TILE = TB ? 32 * B_PITCH : 32;
 
     float ra[A_PER_THREAD], rb[B_PER_THREAD];
+    // byte address of this wave's first dword inside an unpadded LDS image (dword index tid = 64 * wave + lane)
+    const unsigned lds_m0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + 256u * (unsigned)wave;
 
     int ls = grp.seg_begin;
     const int s_end = grp.seg_begin + grp.seg_count;
@@ -223,10 +273,21 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     while (have) {
         const int kvalid = min(BK, seg.k - lk);
         __syncthreads();  // previous tile's MFMAs are done reading LDS
+        constexpr bool A_TID = HYPEL_GEMM_ADDTID && A_PITCH == A_COLS;
+        constexpr bool B_TID = HYPEL_GEMM_ADDTID && B_PITCH == B_COLS;
+        if constexpr (A_TID) {
+            lds_store_addtid<A_PER_THREAD>(lds_m0, ra);
+        } else {
 #pragma unroll
-        for (int i = 0; i < A_PER_THREAD; ++i) As[(a_row0 + i * A_RSTEP) * A_PITCH + a_col] = ra[i];
+            for (int i = 0; i < A_PER_THREAD; ++i) As[(a_row0 + i * A_RSTEP) * A_PITCH + a_col] = ra[i];
+        }
+        if constexpr (B_TID) {
+            lds_store_addtid<B_PER_THREAD>(lds_m0 + 4u * A_ROWS * A_PITCH, rb);
+        } else {
 #pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) Bs[(b_row0 + i * B_RSTEP) * B_PITCH + b_col] = rb[i];
+            for (int i = 0; i < B_PER_THREAD; ++i) Bs[(b_row0 + i * B_RSTEP) * B_PITCH + b_col] = rb[i];
+        }
+        if constexpr (A_TID || B_TID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // invisible to hipcc's counter
         __syncthreads();
 
         // advance the (segment, k) cursor and put the next tile's loads in flight
@@ -357,24 +418,28 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool NARROW = false>
+template <int WM, int WN, int TM, int TN, bool NARROW = false, bool MULTI = false>
 int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb, int tb, float* c, int64_t ldc,
-               int n, const hypel_group_t* groups, const hypel_seg_t* segs, const hypel_tile_t* tiles, int n_tiles,
+               int n, const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
                const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
                hipStream_t st) {
     constexpr int BN = NARROW ? 16 : WN * TN * 32;
-    const int n_nt = (n + BN - 1) / BN;
+    const int n_nt = MULTI ? 1 : (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
     // diagnostic: unused dynamic LDS lowers the number of resident blocks per CU (occupancy experiments)
     static const int lds_pad = getenv("HYPEL_GEMM_LDS_PAD") ? atoi(getenv("HYPEL_GEMM_LDS_PAD")) : 0;
 #define HYPEL_GO(TA_, TB_)                                                                                         \
-    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW>), dim3(grid), dim3(256), lds_pad, st, a, \
+    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW, MULTI>), dim3(grid), dim3(256), lds_pad, st, a, \
                        lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,     \
                        res_start)
-    if (!ta && !tb) HYPEL_GO(false, false);
-    else if (!ta && tb) HYPEL_GO(false, true);
-    else if (ta && !tb) HYPEL_GO(true, false);
-    else HYPEL_GO(true, true);
+    if constexpr (MULTI) {  // filter gradients only: A transposed, B as stored
+        HYPEL_GO(true, false);
+    } else {
+        if (!ta && !tb) HYPEL_GO(false, false);
+        else if (!ta && tb) HYPEL_GO(false, true);
+        else if (ta && !tb) HYPEL_GO(true, false);
+        else HYPEL_GO(true, true);
+    }
 #undef HYPEL_GO
     return 0;
 }
@@ -436,4 +501,26 @@ extern "C" int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans
     HYPEL_REQUIRE(res && ldr > 0, "hypel_seg_gemm_res_f32");
     return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                              accumulate, res, ldr, res_start, stream);
+}
+
+extern "C" int hypel_seg_gemm_multi_f32(const float* base, int32_t trans_a, int32_t trans_b, int32_t tile_width,
+                                        const hypel_seg_t* segs, const hypel_mtile_t* blocks, int32_t n_blocks,
+                                        hypel_stream_t stream) {
+    HYPEL_REQUIRE(base && segs && blocks && n_blocks >= 0, "hypel_seg_gemm_multi_f32");
+    HYPEL_REQUIRE(trans_a == 1 && trans_b == 0, "hypel_seg_gemm_multi_f32: only A^T B products (filter gradients)");
+    HYPEL_REQUIRE(tile_width == 16 || tile_width == 32 || tile_width == 64, "hypel_seg_gemm_multi_f32");
+    if (n_blocks == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    float* c = const_cast<float*>(base);
+    if (tile_width == 16)
+        launch_cfg<4, 1, 1, 1, true, true>(base, 0, 1, base, 0, 0, c, 0, 16, nullptr, segs, blocks, n_blocks, nullptr, 0,
+                                           nullptr, 0, nullptr, st);
+    else if (tile_width == 32)
+        launch_cfg<4, 1, 1, 1, false, true>(base, 0, 1, base, 0, 0, c, 0, 32, nullptr, segs, blocks, n_blocks, nullptr, 0,
+                                            nullptr, 0, nullptr, st);
+    else
+        launch_cfg<4, 1, 1, 2, false, true>(base, 0, 1, base, 0, 0, c, 0, 64, nullptr, segs, blocks, n_blocks, nullptr, 0,
+                                            nullptr, 0, nullptr, st);
+    HYPEL_CHECK_LAUNCH("hypel_seg_gemm_multi_f32");
+    return 0;
 }

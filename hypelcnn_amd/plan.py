@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 from . import graph as G
-from .backend import GEMM_BM, GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
+from .backend import GEMM_BM, GROUP_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
 
 STAT_CHUNK_ROWS = 256  # upper bound; see stat_chunk_rows()
 
@@ -42,7 +42,7 @@ TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitt
 
 
 class Launch:
-    __slots__ = ("name", "args", "flops", "bytes", "tag", "stream", "kparts")
+    __slots__ = ("name", "args", "flops", "bytes", "tag", "stream", "kparts", "meta")
 
     def __init__(self, name, args, flops=0, nbytes=0, tag="", stream=0):
         self.name = name
@@ -52,9 +52,16 @@ class Launch:
         self.tag = tag
         self.stream = stream  # 0 = main, 1 = side (concurrent filter gradients)
         self.kparts = 1  # channel parts the reduction dimension of a level forward was cut into (diagnostic)
+        self.meta = {}  # diagnostics (e.g. the products a merged filter-gradient launch contains)
 
 
-USE_SIDE_STREAM = True
+# Side streams for work that only READS a layer's finished dY / X (un-merged filter gradients, HYPEL_MERGE_WGRAD=0).
+# Default 0 = everything on the main stream: measured on MI355X (round 2, same box A/B, 100 steps each) the forked
+# step is 2 % SLOWER (7.49 vs 7.35 ms; 2, 3, 4 side streams: 7.58 / 7.53 / 7.30) -- kernels of two HIP streams
+# hardly ever run side by side here (rocprofv3 timeline: two GEMMs concurrently active for < 2 % of a step), so the
+# fork/join edges cost more than the overlap returns.
+USE_SIDE_STREAM = os.environ.get("HYPEL_SIDE_STREAMS", "0") != "0"
+SIDE_STREAMS = max(1, int(os.environ.get("HYPEL_SIDE_STREAMS", "0") or 0))
 # Statistics kernels that finalise themselves (last block of a channel stripe, ticket counter): correct and tested,
 # but measured SLOWER on MI355X (8.65 vs 7.88 ms/step): every block pays the round trip of a device-scope atomic
 # through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
@@ -63,6 +70,10 @@ TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
 SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
 SMALL_BN_ROWS = 1024  # hypel_bn_act_small_*: rows kept in registers (32 row lanes x 32 rows)
 FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
+# Filter gradients have no consumer before the optimiser: instead of one launch (+ one reduce) per layer they are
+# collected and go out as ONE hypel_seg_gemm_multi_f32 per tile width (+ ONE hypel_reduce_splits_multi_f32) at the end
+# of the backward pass (and at every data-parallel sync point).  A step's twenty ~25 us launch ramps/drains become three.
+MERGE_WGRAD = os.environ.get("HYPEL_MERGE_WGRAD", "1") != "0"
 
 
 class Storage:
@@ -452,12 +463,13 @@ class TowerPlan:
                 if sync_at is not None and idx == sync_at[0]:
                     # every weight gradient at flat offsets >= sync_at[1] is final once the side stream is joined:
                     # the session starts their all-reduce here, under the rest of the backward pass
+                    self._flush_wgrads()
                     if getattr(self, "_side_open", False):
-                        self.bwd.append(Launch("_join", (), tag="join"))
-                        self._side_open = False
+                        self.bwd.append(self._join_sides())
                     self.sync_points.append((len(self.bwd), sync_at[1], sync_at[2]))
+            self._flush_wgrads()
             if getattr(self, "_side_open", False):
-                self.bwd.append(Launch("_join", (), tag="join"))
+                self.bwd.append(self._join_sides())
             if tw.n_dropout and not self.external_masks:
                 self.bwd.append(Launch("step_inc", (self._ref("step_ctr"),), tag="rng"))
         # shared scratch (stream order makes reuse safe)
@@ -1020,14 +1032,25 @@ class TowerPlan:
         new = self.bwd[start:]
         if not new:
             return
+        k = 1 + getattr(self, "_side_rr", 0) % SIDE_STREAMS
+        self._side_rr = getattr(self, "_side_rr", 0) + 1
+        suffix = f"_s{k}"
         for l in new:
-            l.stream = 1
+            l.stream = k
         for i, (launch, pos, name) in enumerate(self._pending_scratch):
-            if launch in new and not name.endswith("_s1"):
-                self.scratch_sizes[name + "_s1"] = max(self.scratch_sizes.get(name + "_s1", 1), self.scratch_sizes[name])
-                self._pending_scratch[i] = (launch, pos, name + "_s1")
-        self.bwd[start:start] = [Launch("_fork", (), tag="fork")]
+            if launch in new and not name.endswith(suffix):
+                self.scratch_sizes[name + suffix] = max(self.scratch_sizes.get(name + suffix, 1), self.scratch_sizes[name])
+                self._pending_scratch[i] = (launch, pos, name + suffix)
+        self.bwd[start:start] = [Launch("_fork", (k,), tag="fork")]
         self._side_open = True
+        self._side_used = getattr(self, "_side_used", set()) | {k}
+
+    def _join_sides(self):
+        """The main stream waits for every side stream forked since the last join."""
+        used = tuple(sorted(getattr(self, "_side_used", {1})))
+        self._side_used = set()
+        self._side_open = False
+        return Launch("_join", used, tag="join")
 
     def _wgrad_splits(self, base_blocks, n_pairs):
         """Filter-gradient reduction = S_pix x S_row splits: the pixel-pair list is cut into S_pix contiguous chunks
@@ -1066,6 +1089,15 @@ class TowerPlan:
         s_pix, s_row = self._wgrad_splits(n_groups_blocks, max_segs)
         S = s_pix * s_row
         tb = tables_by_split_builder((s_pix, s_row))
+        if MERGE_WGRAD:
+            pend = self.__dict__.setdefault("_pending_wgrads", [])
+            if acc and pend:
+                # a second application of shared weights adds to what an earlier pending product writes: keep the order
+                self._flush_wgrads()
+                pend = self._pending_wgrads
+            pend.append(dict(tb=tb, S=S, slab=int(slab), w0=int(w0_offset), n=int(n), a_ref=a_ref, lda=int(lda),
+                             b_ref=b_ref, ldb=int(ldb), tag=tag, acc=int(acc)))
+            return
         if S == 1:
             self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None,
                             acc, tag, allow_split=False)
@@ -1079,6 +1111,108 @@ class TowerPlan:
                     nbytes=4 * slab * (S + 1), tag="wgrad-reduce")
         self._scratch(l2, 0, "scratch_wgrad", S * slab)
         self.bwd.append(l2)
+
+    def _flush_wgrads(self):
+        """Emit the collected filter gradients: one hypel_seg_gemm_multi_f32 per tile width over the blocks of every
+        pending product, then one hypel_reduce_splits_multi_f32 that sums the split slabs into the gradient buffer.
+
+        Block order: the blocks of one (product, split) pair -- all taps and column tiles that read the same batch-row
+        range of X and dY -- form a locality group; groups are dealt to the 8 XCDs heaviest first onto the least
+        loaded XCD (each XCD's L2 then streams a row range once for all its taps, and the XCDs finish together), and
+        the record array is laid out so that the kernel's XCD remap (block b runs on XCD b % 8 and takes record
+        (b % 8) * L + b / 8) hands XCD x exactly its list; short lists are padded with empty records."""
+        pend = self.__dict__.get("_pending_wgrads") or []
+        self._pending_wgrads = []
+        if not pend:
+            return
+        base = Ref(self.sess.params)
+        base_ptr = base.ptr()
+
+        def rel(ref):
+            d = ref.ptr() - base_ptr
+            assert d % 4 == 0
+            return d // 4
+
+        # scratch for the split slabs of this flush
+        need = sum(e["S"] * e["slab"] for e in pend if e["S"] > 1)
+        fid = self.__dict__.setdefault("_wgrad_flushes", 0)
+        self._wgrad_flushes = fid + 1
+        sname = f"wgrad_partials:{fid}"
+        self._alloc(sname, max(need, 1))
+        spos = 0
+        grads0 = rel(Ref(self.sess.grads))
+        by_width = {}
+        entries = []
+        for e in pend:
+            n = e["n"]
+            width = 16 if n <= 16 else (32 if n <= 32 else 64)
+            if e["S"] > 1:
+                c_base = rel(self._ref(sname, spos))
+                entries.append((c_base, grads0 + e["w0"], e["slab"], e["slab"], e["S"], e["acc"]))
+                spos += e["S"] * e["slab"]
+                flags = 0
+            else:
+                c_base = grads0 + e["w0"]
+                flags = e["acc"]
+            e.update(width=width, c_base=c_base, flags=flags, a0=rel(e["a_ref"]), b0=rel(e["b_ref"]))
+            by_width.setdefault(width, []).append(e)
+        for width in sorted(by_width, reverse=True):
+            segs, lists, macs_total, nbytes, tags = [], [], 0, 0, []
+            for e in by_width[width]:
+                n, tb = e["n"], e["tb"]
+                tags.append(e["tag"])
+                nbytes += tb.compulsory_bytes(n, e["lda"], 1, e["ldb"], 0)
+                groups = {}
+                for gi, (c_off, gs, rows) in enumerate(tb.groups):
+                    if not gs:
+                        # a split with no reduction rows still owns its slab: the reduce reads it, so it must be zero
+                        seg_begin, ksum = len(segs), 0
+                    else:
+                        seg_begin = len(segs)
+                        ksum = 0
+                        for (a_off, b_off, k) in gs:
+                            segs.append((e["a0"] + int(a_off), e["b0"] + int(b_off), int(k), 0))
+                            ksum += k
+                    macs_total += rows * ksum * n
+                    first = segs[seg_begin] if gs else (0, 0, 0, 0)
+                    key = tb.keys[gi] if tb.keys[gi] is not None else 0
+                    recs = groups.setdefault(key, [0, []])
+                    for m0 in range(0, rows, GEMM_BM):
+                        work = ksum * min(GEMM_BM, rows - m0)
+                        for n0 in range(0, n, width):
+                            recs[1].append((work, (e["c_base"] + int(c_off), first[0], first[1], m0, rows, n0, n,
+                                                   seg_begin, len(gs), first[2], e["flags"], e["lda"], e["ldb"], n, 0)))
+                            recs[0] += work
+                for w, r in groups.values():  # inside a locality group: heavy blocks (taps with many pixel pairs) first
+                    r.sort(key=lambda t: -t[0])
+                    lists.append((w, [rec for _, rec in r]))
+            lists.sort(key=lambda t: -t[0])
+            xcd_work, xcd_recs = [0] * 8, [[] for _ in range(8)]
+            for w, r in lists:
+                x = min(range(8), key=lambda i: (xcd_work[i], i))
+                xcd_work[x] += w
+                xcd_recs[x] += r
+            L = max(len(r) for r in xcd_recs)
+            arr = np.zeros(8 * L, MTILE_DTYPE)  # zero record = empty block (rows 0, no segments)
+            for x in range(8):
+                if xcd_recs[x]:
+                    arr[x * L:x * L + len(xcd_recs[x])] = np.array(xcd_recs[x], MTILE_DTYPE)
+            sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
+            s_t, r_t = self.be.upload(sarr), self.be.upload(arr)
+            self.tables += [s_t, r_t]
+            l = Launch("seg_gemm_multi_f32", (base, 1, 0, width, Ref(s_t), Ref(r_t), int(len(arr))),
+                       flops=2 * macs_total, nbytes=nbytes, tag=f"wgrad-merged/{width}")
+            l.meta = {"products": tags, "blocks": int(sum(len(r) for r in xcd_recs)),
+                      "xcd_work": [int(w) for w in xcd_work]}
+            self.bwd.append(l)
+        if entries:
+            earr = np.array([(p, o, st, cnt, S, acc) for (p, o, st, cnt, S, acc) in entries], REDUCE_ENTRY_DTYPE)
+            e_t = self.be.upload(earr)
+            self.tables.append(e_t)
+            l = Launch("reduce_splits_multi_f32", (base, Ref(e_t), int(len(earr))),
+                       nbytes=4 * sum(cnt * (S + 1) for (_, _, _, cnt, S, _) in entries), tag="wgrad-reduce")
+            l.meta = {"splits": [int(S) for (_, _, _, _, S, _) in entries]}
+            self.bwd.append(l)
 
     @staticmethod
     def _split_even(segs, S):
@@ -1342,8 +1476,9 @@ class PhasePlan(TowerPlan):
                     self._bwd_featstack(idx, node)
                 elif isinstance(node, G.PostNode):
                     self._bwd_post(idx, node)
+            self._flush_wgrads()
             if getattr(self, "_side_open", False):
-                self.bwd.append(Launch("_join", (), tag="join"))
+                self.bwd.append(self._join_sides())
             self._emit_regularisers()
         for name, size in self.scratch_sizes.items():
             self._alloc(name, size)

@@ -95,6 +95,33 @@ int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans_a, const f
                            const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
                            const float* res, int64_t ldr, const int32_t* res_start, hypel_stream_t stream);
 
+/* SEVERAL products C_p = A_p^T B_p in ONE launch -- the filter gradients of many layers (tf.gradients w.r.t. the
+ * `weights` of every tf_slim.conv2d / fully_connected, common/common_nn_ops.py:232), which are mutually independent
+ * and individually too small to fill 256 CUs: every launch pays ~25 us of ramp-up and drain, a step has twenty of
+ * them.  `blocks` holds one record per 128 x tile_width output BLOCK: its group (rows, segment range, output offset,
+ * first segment, as in hypel_tile_t) plus what used to be per-launch arguments -- column tile n0, the product's n,
+ * lda, ldb, ldc -- and flags (bit 0 = accumulate into C).  Every offset (records and `segs`) is in elements relative
+ * to `base`, one pointer for A, B and C (the operands live in different allocations; differences of device
+ * addresses are exact in int64).  tile_width in {16, 32, 64}; trans_a = 1, trans_b = 0 only. */
+typedef struct {
+    int64_t c_off; int64_t a_off0; int64_t b_off0;      /* output offset of the group; segs[seg_begin] copy */
+    int32_t m0; int32_t rows; int32_t n0; int32_t n;      /* output rows [m0, m0+128) x columns [n0, n0+tile_width) */
+    int32_t seg_begin; int32_t seg_count; int32_t k0; int32_t flags;
+    int32_t lda; int32_t ldb; int32_t ldc; int32_t reserved;
+} hypel_mtile_t;
+int hypel_seg_gemm_multi_f32(const float* base, int32_t trans_a, int32_t trans_b, int32_t tile_width,
+                             const hypel_seg_t* segs, const hypel_mtile_t* blocks, int32_t n_blocks,
+                             hypel_stream_t stream);
+
+/* Several hypel_reduce_splits_f32 in one launch (the second stage of the merged filter-gradient launch):
+ * entry e: out_e[i] = (flags_e & 1 ? out_e[i] : 0) + sum_{s < n_splits_e} partial_e[s*stride_e + i], i < count_e;
+ * partial_off / out_off in elements relative to `base`. */
+typedef struct {
+    int64_t partial_off; int64_t out_off; int64_t stride; int64_t count; int32_t n_splits; int32_t flags;
+} hypel_reduce_entry_t;
+int hypel_reduce_splits_multi_f32(const float* base, const hypel_reduce_entry_t* entries, int32_t n_entries,
+                                  hypel_stream_t stream);
+
 /* out[o(i)] = (accumulate ? out[o(i)] : 0) + (bias ? bias[i mod n] : 0) + sum_s partial[s*stride + o(i)], s ascending
  * (deterministic second stage of every split launch: filter gradients, FC-shaped products whose output has too
  * few tiles to fill 256 CUs, and the tap-split heavy branches of a multi-kernel level).

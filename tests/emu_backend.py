@@ -8,7 +8,9 @@ real HIP kernels against the oracle.  Never imported by the hypelcnn_amd package
 import numpy as np
 import torch
 
-from hypelcnn_amd.backend import GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
+import ctypes
+
+from hypelcnn_amd.backend import GROUP_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
 
 
 def _arr(ref, dtype=np.float32):
@@ -19,6 +21,13 @@ def _arr(ref, dtype=np.float32):
     if a.dtype != dtype:
         a = a.view(dtype) if a.dtype.itemsize == np.dtype(dtype).itemsize else a
     return a[ref.off:]
+
+
+def _at(base_ref, off, count):
+    """float32 view of `count` elements at element offset `off` (any sign) from a base Ref: the multi-product kernels
+    address every operand relative to ONE base pointer, across allocations."""
+    addr = base_ref.ptr() + int(off) * 4
+    return np.ctypeslib.as_array((ctypes.c_float * int(count)).from_address(addr))
 
 
 def _mat(ref, ld, rows, cols, dtype=np.float32):
@@ -227,6 +236,59 @@ class EmuBackend:
                 cm += acc.astype(np.float32)
             else:
                 cm[...] = acc.astype(np.float32)
+
+    def k_seg_gemm_multi_f32(self, base, ta, tb, tile_width, segs, blocks, n_blocks):
+        """Specification of the merged filter-gradient launch: every block record is one 128 x tile_width output
+        block of its own product C = A^T B (+ C when flagged), all offsets relative to `base`."""
+        assert ta == 1 and tb == 0 and tile_width in (16, 32, 64)
+        s = segs.t.numpy()[segs.off:].view(SEG_DTYPE)
+        recs = blocks.t.numpy()[blocks.off:].view(MTILE_DTYPE)[:n_blocks]
+        seen = set()
+        for r in recs:
+            rows, n, m0, n0 = int(r["rows"]), int(r["n"]), int(r["m0"]), int(r["n0"])
+            if rows == 0:  # padding record (the XCD lists of the launch are padded to equal length)
+                assert int(r["seg_count"]) == 0
+                continue
+            assert m0 % 128 == 0 and n0 % tile_width == 0 and m0 < rows and n0 < n
+            key = (int(r["c_off"]), m0, n0)
+            assert key not in seen, "two blocks write the same output tile"
+            seen.add(key)
+            mr, nc = min(128, rows - m0), min(tile_width, n - n0)
+            lda, ldb, ldc = int(r["lda"]), int(r["ldb"]), int(r["ldc"])
+            acc = np.zeros((mr, nc), np.float64)
+            sb, sc = int(r["seg_begin"]), int(r["seg_count"])
+            if sc:
+                assert (int(r["a_off0"]), int(r["b_off0"]), int(r["k0"])) == \
+                    (int(s[sb]["a_off"]), int(s[sb]["b_off"]), int(s[sb]["k"]))
+            for sg in s[sb:sb + sc]:
+                k = int(sg["k"])
+                if k == 0:
+                    continue
+                a = _at(base, int(sg["a_off"]) + m0, (k - 1) * lda + mr)
+                am = np.lib.stride_tricks.as_strided(a, (k, mr), (lda * 4, 4)).T
+                b = _at(base, int(sg["b_off"]) + n0, (k - 1) * ldb + nc)
+                bm = np.lib.stride_tricks.as_strided(b, (k, nc), (ldb * 4, 4))
+                acc += am.astype(np.float64) @ bm.astype(np.float64)
+            c = _at(base, int(r["c_off"]) + m0 * ldc + n0, (mr - 1) * ldc + nc)
+            cm = np.lib.stride_tricks.as_strided(c, (mr, nc), (ldc * 4, 4))
+            if int(r["flags"]) & 1:
+                cm += acc.astype(np.float32)
+            else:
+                cm[...] = acc.astype(np.float32)
+
+    def k_reduce_splits_multi_f32(self, base, entries, n_entries):
+        ents = entries.t.numpy()[entries.off:].view(REDUCE_ENTRY_DTYPE)[:n_entries]
+        for e in ents:
+            count, stride, S = int(e["count"]), int(e["stride"]), int(e["n_splits"])
+            p = _at(base, int(e["partial_off"]), (S - 1) * stride + count)
+            o = _at(base, int(e["out_off"]), count)
+            tot = np.zeros(count, np.float64)
+            for k in range(S):
+                tot += p[k * stride:k * stride + count]
+            if int(e["flags"]) & 1:
+                o += tot.astype(np.float32)
+            else:
+                o[...] = tot.astype(np.float32)
 
     def k_reduce_splits_f32(self, partial, stride, n_splits, out, count, accumulate, bias=None, n=0, ldc=0):
         p = _arr(partial)

@@ -154,7 +154,7 @@ def test_wgrad_row_ranges_of_device_filling_launch_match_oracle(monkeypatch, mod
     built, sess, params, x, onehot, masks = _case(model_name, patch, ch, classes, alg, 192, 41)
     ct = U.run_train_step(built, x, onehot, masks)
     assert "wgrad-reduce" in _tags(ct)
-    n_split = [l.args[2] for l in ct.plan.bwd if l.tag == "wgrad-reduce"]
+    n_split = [S for l in ct.plan.bwd if l.tag == "wgrad-reduce" for S in (l.meta.get("splits") or [l.args[2]])]
     assert max(n_split) >= 3, n_split
     U.compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg, tol_logit=2e-5, tol_grad=2e-4)
 
@@ -193,3 +193,30 @@ def test_nonfinite_loss_is_flagged_on_the_device_and_the_update_refused():
     assert sess.nonfinite_step() is None, "the newest flag copy is not inspected without sync (pipelined loop)"
     assert sess.nonfinite_step(sync=True) == 2
     assert sess.nonfinite_step() == 2
+
+
+def test_filter_gradients_go_out_as_merged_launches(monkeypatch):
+    """All filter gradients of a step leave as ONE multi-product launch per tile width plus ONE merged reduce; the
+    un-merged plan (HYPEL_MERGE_WGRAD=0) gives the same gradients."""
+    from hypelcnn_amd import plan
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 7, 9, 4, dict(ALG_H, filter_count=96), 5, 21)
+    ct = U.run_train_step(built, x, onehot, masks)
+    names = [l.name for l in ct.plan.bwd]
+    n_multi = names.count("seg_gemm_multi_f32")
+    assert 1 <= n_multi <= 3 and names.count("reduce_splits_multi_f32") == 1
+    assert not any(l.tag.startswith("wgrad:") for l in ct.plan.bwd), "a filter gradient was launched on its own"
+    merged = [l for l in ct.plan.bwd if l.name == "seg_gemm_multi_f32"]
+    n_layers = sum(1 for n in built.train_tower.nodes if hasattr(n, "branches"))
+    assert sum(len(l.meta["products"]) for l in merged) >= n_layers
+    for l in merged:  # XCD work lists are balanced (heaviest-first dealing)
+        w = l.meta["xcd_work"]
+        assert max(w) <= 1.5 * (sum(w) / 8) + max(w) / max(1, l.meta["blocks"] // 8)
+    g_merged = sess.grads.clone()
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, dict(ALG_H, filter_count=96),
+                   tol_logit=2e-5, tol_grad=2e-4)
+    monkeypatch.setattr(plan, "MERGE_WGRAD", False)
+    built2, sess2, _, _, _, _ = _case("HYPELCNNModel", 7, 9, 4, dict(ALG_H, filter_count=96), 5, 21)
+    ct2 = U.run_train_step(built2, x, onehot, masks)
+    assert any(l.tag.startswith("wgrad:") for l in ct2.plan.bwd)
+    import torch
+    torch.testing.assert_close(sess2.grads, g_merged, rtol=1e-5, atol=1e-7)
