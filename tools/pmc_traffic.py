@@ -39,6 +39,9 @@ def main():
     ap.add_argument("write")
     ap.add_argument("--known-bytes", type=float, default=1024 * 49 * 145 * 4, help="bytes nhwc_to_pnc moves one way")
     ap.add_argument("--json")
+    ap.add_argument("--workload", default="hypelcnn")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--source", default="")
     args = ap.parse_args()
     f = load(args.fetch, "FETCH_SIZE")
     w = load(args.write, "WRITE_SIZE")
@@ -63,7 +66,18 @@ def main():
             print(f"{k:34s} {n:8d} {rd/1e6:15.2f} {wr/1e6:16.2f} {(rd+wr)*n/1e6:10.1f}")
     print(f"sum over the run: {tot/1e9:.2f} GB")
     if args.json:
-        json.dump({"fetch_factor": cal_f, "write_factor": cal_w, "kernels": out}, open(args.json, "w"), indent=1)
+        # summary of the dominant kernel family for bench.py's roofline.traffic: one nhwc_to_pnc launch per step
+        steps = out.get("nhwc_to_pnc_kernel", {}).get("launches", 0)
+        gemm = {k: v for k, v in out.items() if k.startswith("seg_gemm")}
+        g_launches = sum(v["launches"] for v in gemm.values())
+        g_bytes = sum(v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in gemm.values())
+        summary = {"workload": args.workload, "batch": args.batch, "source": args.source, "fetch_factor": cal_f,
+                   "write_factor": cal_w, "steps_profiled": steps, "seg_gemm_launches": g_launches,
+                   "seg_gemm_launches_per_step": (g_launches // steps) if steps else None,
+                   "seg_gemm_bytes_per_launch": g_bytes / max(1, g_launches),
+                   "seg_gemm_bytes_per_step": (g_bytes / steps) if steps else None,
+                   "all_kernels_bytes_per_step": (tot / steps) if steps else None, "kernels": out}
+        json.dump(summary, open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
