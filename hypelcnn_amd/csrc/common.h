@@ -42,6 +42,21 @@ __device__ __forceinline__ float hypel_act(float v, int act, float alpha) {
     }
 }
 
+// Batch-norm pre-activation with separately rounded steps -- xhat = (y - mean) * rstd, pre = xhat + beta -- in EVERY
+// kernel that evaluates it.  Forward and backward must take the same leaky-ReLU branch for an element that lands
+// within rounding of the kink (and the parity harness must be able to recompute that decision from the buffers);
+// left to itself hipcc contracts the expression into an fma in some kernels and not in others.
+// (__fmul_rn / __fadd_rn do not stop it: in HIP-Clang they are plain operators; the fp-contract pragma does.)
+__device__ __forceinline__ float hypel_bn_xhat(float y, float mean, float rstd) {
+#pragma clang fp contract(off)
+    const float d = y - mean;
+    return d * rstd;
+}
+__device__ __forceinline__ float hypel_bn_pre(float xhat, float beta) {
+#pragma clang fp contract(off)
+    return xhat + beta;
+}
+
 // derivative of the activation evaluated from its INPUT v
 __device__ __forceinline__ float hypel_act_grad(float v, int act, float alpha) {
     switch (act) {

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
             Vec<VEC> m, r, b;
             m.load_param(mean + col); r.load_param(rstd + col); b.load_param(beta + col);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) v.v[k] = (v.v[k] - m.v[k]) * r.v[k] + b.v[k];
+            for (int k = 0; k < VEC; ++k) v.v[k] = hypel_bn_pre(hypel_bn_xhat(v.v[k], m.v[k], r.v[k]), b.v[k]);
         }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) v.v[k] = hypel_act(v.v[k], act, alpha);
@@ -499,8 +499,8 @@ __device__ __forceinline__ void bwd_elem(const float* __restrict__ dz, int64_t l
     float v = y[row * ldy + col];
     float pre = v;
     if (mean) {
-        xhat = (v - mean[col]) * rstd[col];
-        pre = xhat + beta[col];
+        xhat = hypel_bn_xhat(v, mean[col], rstd[col]);
+        pre = hypel_bn_pre(xhat, beta[col]);
     } else {
         xhat = v;
     }
@@ -643,8 +643,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
             for (int q = 0; q < 4; ++q) {
                 float xhat = yv[q], pre = yv[q];
                 if (mean) {
-                    xhat = (yv[q] - mu[q]) * rs[q];
-                    pre = xhat + be[q];
+                    xhat = hypel_bn_xhat(yv[q], mu[q], rs[q]);
+                    pre = hypel_bn_pre(xhat, be[q]);
                 }
                 float g = gv[q];
                 if (mask) g *= mv[q];
@@ -702,8 +702,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
             s0.load_param(sums + col); s1.load_param(sums + c + col);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float xhat = (yv.v[k] - m.v[k]) * r.v[k];
-                const float dyh = g.v[k] * hypel_act_grad(xhat + b.v[k], act, alpha);
+                const float xhat = hypel_bn_xhat(yv.v[k], m.v[k], r.v[k]);
+                const float dyh = g.v[k] * hypel_act_grad(hypel_bn_pre(xhat, b.v[k]), act, alpha);
                 g.v[k] = r.v[k] * (dyh - s0.v[k] * inv_m - xhat * (s1.v[k] * inv_m));
             }
         } else {
@@ -987,12 +987,12 @@ __device__ __forceinline__ void bn_act_small_fwd_body(
     if (act == HYPEL_ACT_LRELU) {  // the common case without the per-element activation switch
 #pragma unroll
         for (int i = 0; i < SMALL_R; ++i) {
-            const float p = (v[i] - mu) * rs + be;
+            const float p = hypel_bn_pre(hypel_bn_xhat(v[i], mu, rs), be);
             v[i] = (p > 0.0f ? p : p * alpha) * mk[i];
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < SMALL_R; ++i) v[i] = hypel_act((v[i] - mu) * rs + be, act, alpha) * mk[i];
+        for (int i = 0; i < SMALL_R; ++i) v[i] = hypel_act(hypel_bn_pre(hypel_bn_xhat(v[i], mu, rs), be), act, alpha) * mk[i];
     }
 #pragma unroll
     for (int i = 0; i < SMALL_R; ++i) {
@@ -1045,8 +1045,8 @@ __device__ __forceinline__ void bn_act_small_bwd_body(
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int i = 0; i < SMALL_R; ++i) {
-        xh[i] = (xh[i] - mu) * rs;
-        const float p = xh[i] + be;
+        xh[i] = hypel_bn_xhat(xh[i], mu, rs);
+        const float p = hypel_bn_pre(xh[i], be);
         const float slope = act == HYPEL_ACT_LRELU ? (p > 0.0f ? 1.0f : alpha) : hypel_act_grad(p, act, alpha);
         g[i] = (FULL || ty + i * SMALL_TY < rows) ? g[i] * slope : 0.0f;
         s0 += g[i];

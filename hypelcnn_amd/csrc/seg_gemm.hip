@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
                                                         const void* __restrict__ tiles_v, int n_tiles,
                                                         int n_ntiles, const float* __restrict__ bias,
                                                         int accumulate, const float* __restrict__ res, int64_t ldr,
-                                                        const int32_t* __restrict__ res_start) {
+                                                        const int32_t* __restrict__ res_start,
+                                                        float* __restrict__ stats) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = NARROW ? 16 : WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
@@ -382,6 +383,64 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
             *p = v;
         }
     };
+    // Batch-norm statistics in the epilogue (tf_slim.batch_norm's batch moments, HYPELCNNModel.py:37,43-44): the tile's
+    // per-column (mean, sum of squared deviations) over its valid rows, straight from the accumulators -- the
+    // statistics pass that re-read the whole GEMM output (hypel_col_stats_partial) is gone.  Two passes over the
+    // registers per 32-row slab, Chan's merge of the block's slabs through LDS in slab order; one (mean, M2) pair per
+    // 128-row tile = exactly the chunk format hypel_bn_finalize merges (chunk_rows = 128).  Single-group launches
+    // only (chunk = m0 / 128), no accumulate.
+    if constexpr (!NARROW && !MULTI) {
+        if (stats) {
+            constexpr int SLABS = WM * TM;
+            float* red = lds;  // [SLABS][BN][2], after the last MFMA phase
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int slab = wm * TM + i;
+                    const int nw = min(32, max(0, rows_left - slab * 32));
+                    float s1 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi < rows_left) s1 += acc[i][j][e];
+                    s1 += __shfl_xor(s1, 32, 64);
+                    const float mean = nw > 0 ? s1 / (float)nw : 0.0f;
+                    float m2 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi < rows_left) {
+                            const float d = acc[i][j][e] - mean;
+                            m2 += d * d;
+                        }
+                    m2 += __shfl_xor(m2, 32, 64);
+                    if (lhi == 0) {
+                        const int cl = (wn * TN + j) * 32 + l31;
+                        red[(slab * BN + cl) * 2 + 0] = mean;
+                        red[(slab * BN + cl) * 2 + 1] = m2;
+                    }
+                }
+            __syncthreads();
+            if (tid < BN && tid < cols_left) {
+                float na = 0.0f, mean_a = 0.0f, m2_a = 0.0f;
+#pragma unroll
+                for (int sl = 0; sl < SLABS; ++sl) {
+                    const float nb_ = (float)min(32, max(0, rows_left - sl * 32));
+                    if (nb_ > 0.0f) {
+                        const float mb = red[(sl * BN + tid) * 2 + 0], m2b = red[(sl * BN + tid) * 2 + 1];
+                        const float d = mb - mean_a, nab = na + nb_;
+                        mean_a += d * nb_ / nab;
+                        m2_a += m2b + d * d * na * nb_ / nab;
+                        na = nab;
+                    }
+                }
+                if (bias) mean_a += bias[bias_col0 + tid];
+                const int64_t chunk = m0 / BM;
+                stats[(chunk * 2 + 0) * n + n0 + tid] = mean_a;
+                stats[(chunk * 2 + 1) * n + n0 + tid] = m2_a;
+            }
+        }
+    }
     if constexpr (NARROW) {
         // C/D layout of 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
         const int col = l15;
@@ -422,7 +481,7 @@ template <int WM, int WN, int TM, int TN, bool NARROW = false, bool MULTI = fals
 int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb, int tb, float* c, int64_t ldc,
                int n, const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
                const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
-               hipStream_t st) {
+               hipStream_t st, float* stats = nullptr) {
     constexpr int BN = NARROW ? 16 : WN * TN * 32;
     const int n_nt = MULTI ? 1 : (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
@@ -431,7 +490,7 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
 #define HYPEL_GO(TA_, TB_)                                                                                         \
     hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW, MULTI>), dim3(grid), dim3(256), lds_pad, st, a, \
                        lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,     \
-                       res_start)
+                       res_start, stats)
     if constexpr (MULTI) {  // filter gradients only: A transposed, B as stored
         HYPEL_GO(true, false);
     } else {
@@ -450,7 +509,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
                              int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
                              const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles, const float* bias,
                              int32_t accumulate, const float* res, int64_t ldr, const int32_t* res_start,
-                             hypel_stream_t stream) {
+                             hypel_stream_t stream, float* stats = nullptr) {
     HYPEL_REQUIRE(a && b && c && groups && segs && tiles, "hypel_seg_gemm_f32");
     HYPEL_REQUIRE(n > 0 && n_tiles >= 0, "hypel_seg_gemm_f32");
     if (n_tiles == 0) return 0;
@@ -469,18 +528,18 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
     // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (HYPEL_GEMM_MFMA16=0: 128x32)
     static const int mfma16 = getenv("HYPEL_GEMM_MFMA16") ? atoi(getenv("HYPEL_GEMM_MFMA16")) : 1;
-    if (n <= 16 && mfma16)
+    if (n <= 16 && mfma16 && !stats)  // the 16-wide variant has no statistics epilogue
         launch_cfg<4, 1, 1, 1, true>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st);
     else if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, res, ldr, res_start, st);
+                               accumulate, res, ldr, res_start, st, stats);
     else if (n <= 64 || !bn128)
         launch_cfg<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, res, ldr, res_start, st);
+                               accumulate, res, ldr, res_start, st, stats);
     else
         launch_cfg<2, 2, 2, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, res, ldr, res_start, st);
+                               accumulate, res, ldr, res_start, st, stats);
     HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
     return 0;
 }
@@ -491,6 +550,16 @@ extern "C" int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, 
                                   const float* bias, int32_t accumulate, hypel_stream_t stream) {
     return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                              accumulate, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int hypel_seg_gemm_stats_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
+                                        int32_t trans_b, float* c, int64_t ldc, int32_t n,
+                                        const hypel_group_t* groups, const hypel_seg_t* segs, const hypel_tile_t* tiles,
+                                        int32_t n_tiles, const float* bias, int32_t accumulate, float* stats_partial,
+                                        hypel_stream_t stream) {
+    HYPEL_REQUIRE(stats_partial && (accumulate & 1) == 0, "hypel_seg_gemm_stats_f32");
+    return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                             accumulate, nullptr, 0, nullptr, stream, stats_partial);
 }
 
 extern "C" int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,

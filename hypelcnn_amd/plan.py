@@ -74,6 +74,9 @@ FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 # collected and go out as ONE hypel_seg_gemm_multi_f32 per tile width (+ ONE hypel_reduce_splits_multi_f32) at the end
 # of the backward pass (and at every data-parallel sync point).  A step's twenty ~25 us launch ramps/drains become three.
 MERGE_WGRAD = os.environ.get("HYPEL_MERGE_WGRAD", "1") != "0"
+# Batch-norm statistics of a 1x1 convolution's output in the GEMM epilogue (hypel_seg_gemm_stats_f32) instead of a
+# separate pass over Y (hypel_col_stats_partial)
+STATS_EPILOGUE = os.environ.get("HYPEL_STATS_EPILOGUE", "1") != "0"
 
 
 class Storage:
@@ -370,8 +373,9 @@ class TowerPlan:
         return 1 if blocks64 < 768 else 2
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
-                   allow_split=True, res=None):
-        """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32)."""
+                   allow_split=True, res=None, stats=None):
+        """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32).
+        stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate)."""
         split = self._split_k(tables, n, lda, ta, ldb, tb, ldc) if allow_split and res is None else None
         if split is not None:
             stab, S, c_min, count = split
@@ -396,7 +400,14 @@ class TowerPlan:
         if res is not None:
             name = "seg_gemm_res_f32"
             args = args + (res[0], int(res[1]), res[2])
-        lst.append(Launch(name, args, flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag))
+        elif stats is not None:
+            assert len(tables.groups) == 1 and not (int(accumulate) & 1) and int(ldc) == int(n)
+            name = "seg_gemm_stats_f32"
+            args = args + (None,)
+        l = Launch(name, args, flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag)
+        if stats is not None:
+            self._scratch(l, len(args) - 1, "scratch_partial", stats)
+        lst.append(l)
 
     def _dp_sync_node(self):
         """Data-parallel overlap: the node index (walking backward) after which >= 60 % of the weight-gradient
@@ -555,6 +566,11 @@ class TowerPlan:
                 key = (b.cout, bias_ref is not None and splits.get(id(b), 1) > 1)
                 by_cout.setdefault(key, []).append((b, choff))
                 choff += b.cout
+            # batch-norm statistics in the epilogue: a lone 1x1 branch on contiguous input writes ONE [rows x c] matrix
+            fuse_stats = (STATS_EPILOGUE and node.has_bn and node.training and len(node.branches) == 1
+                          and node.branches[0].k == 1 and s_st.contiguous and s_max == 1 and c > 16
+                          and not self._small_bn(node, rows_all))
+            aux["stats_in_gemm"] = fuse_stats
             for (cout, split_launch), items in by_cout.items():
                 biased_launch = not split_launch
                 tb = GemmTables()
@@ -582,7 +598,8 @@ class TowerPlan:
                 self._emit_gemm(self.fwd, tb, cout, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), cout, 0,
                                 self._ref(ybuf), c, bias_ref if biased_launch else None, 0,
                                 f"fwd:{items[0][0].scope}" + ("/split" if not biased_launch and bias_ref is not None else ""),
-                                allow_split=False)
+                                allow_split=False,
+                                stats=((rows_all + GEMM_BM - 1) // GEMM_BM) * 2 * c if fuse_stats else None)
                 if len(self.fwd) > pos:
                     self.fwd[pos].kparts = kp_used
                 for b, off in items:
@@ -626,6 +643,15 @@ class TowerPlan:
             if node.training and self._small_bn(node, rows):
                 # short matrix (rows = batch): statistics + finaliser + activation in ONE launch (_emit_post_fwd)
                 aux["small_bn"] = True
+                aux["mean"] = self._ref(f"mean:{idx}")
+            elif node.training and aux.get("stats_in_gemm"):
+                # the GEMM left one (mean, M2) pair per 128-row tile: only the finaliser remains
+                n_chunks = (rows + GEMM_BM - 1) // GEMM_BM
+                l2 = Launch("bn_finalize", (None, n_chunks, GEMM_BM, rows, c, float(node.bn_eps),
+                                            self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"), self._s(aux["mm"]),
+                                            self._s(aux["mv"]), float(node.bn_decay)), tag="bn-finalize")
+                self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+                self.fwd.append(l2)
                 aux["mean"] = self._ref(f"mean:{idx}")
             elif node.training:
                 chunk = stat_chunk_rows(rows)

@@ -85,6 +85,17 @@ int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
                        hypel_stream_t stream);
 
+/* hypel_seg_gemm_f32 that also leaves the batch-norm statistics of its output (tf_slim.batch_norm under the conv /
+ * fully_connected arg_scope, nnmodel/HYPELCNNModel.py:37,40-45): for a launch with ONE group (a 1x1 convolution or
+ * a dense layer: C is one [rows x n] matrix, ldc == n) every 128-row tile t writes
+ * stats_partial[(2t) * n + col] = mean of the tile's valid rows, stats_partial[(2t+1) * n + col] = their sum of
+ * squared deviations -- the chunk format of hypel_col_stats_partial with chunk_rows = 128, ready for
+ * hypel_bn_finalize(n_chunks = ceil(rows / 128), chunk_rows = 128).  No accumulate. */
+int hypel_seg_gemm_stats_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
+                             int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
+                             const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles, const float* bias,
+                             int32_t accumulate, float* stats_partial, hypel_stream_t stream);
+
 /* hypel_seg_gemm_f32 with the shortcut gradient folded into the epilogue.  For `net = f(conv(net)) + scale_in_to_out(
  * net)` (nnmodel/HYPELCNNModel.py:160-163,176-183) the gradient of `net` is conv-data-gradient + transpose of the
  * channel map applied to dZ; instead of a separate gather pass plus a read-modify-write of the result, output

@@ -186,6 +186,19 @@ class EmuBackend:
                     rm = np.lib.stride_tricks.as_strided(R[r0 * ldr + o0:], (rows, o1 - o0), (ldr * 4, 4))
                     cm[:, col] += rm.astype(np.float64).sum(1).astype(np.float32)
 
+    def k_seg_gemm_stats_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate,
+                             stats):
+        """The product, then per 128-row tile of its single group the (mean, sum of squared deviations) of every
+        column -- the chunk format of k_col_stats_partial with chunk_rows = 128."""
+        assert (accumulate & 1) == 0 and ldc == n
+        self.k_seg_gemm_f32(a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate)
+        g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
+        t = tiles.t.numpy()[tiles.off:].view(TILE_DTYPE)[:n_tiles]
+        gis = {int(tt["group"]) for tt in t}
+        assert len(gis) == 1, "statistics epilogue: single-group launches only"
+        grp = g[gis.pop()]
+        self.k_col_stats_partial(c + int(grp["c_off"]), ldc, int(grp["rows"]), n, 128, stats)
+
     def k_seg_gemm_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate):
         accumulate &= 1  # bits 8-9 carry a tile-width hint that must not change the result
         A, B, C = _arr(a), _arr(b), _arr(c)

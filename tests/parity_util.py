@@ -118,14 +118,26 @@ def compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg, 
         # changes the gradient by a discrete amount.  For elements the ORACLE itself flags as ambiguous
         # (|pre-activation| < 1e-4) the product's own branch decision is read back from its device buffers and
         # pinned in the oracle; everywhere else the decisions must already agree.  Then gradients must match.
-        force, n_amb, n_flip = product_kink_decisions(built, ct, ref, alg)
-        assert n_flip > 0, f"gradient {worst[0]} rel err {worst[1]} vs fp64 oracle and no kink flip explains it"
-        alt = OT.forward_backward(model_name, {k: v.copy() for k, v in params.items()}, x.astype(np.float64),
-                                  onehot.astype(np.float64), classes, alg, True, masks, kink_force=force)
-        errs2 = grad_errors(alt)
+        # Pinning a decision shifts everything downstream by a rounding-sized amount, which can move another
+        # near-zero pre-activation across the kink: repeat against the re-run oracle until the decisions agree
+        force_all, cur, history = {}, ref, []
+        for _ in range(4):
+            force, n_amb, n_flip = product_kink_decisions(built, ct, cur, alg)
+            # (an element that is already pinned is reported again: its float64 pre-activation is reconstructed from
+            # the oracle's activation output, whose sign the pin has changed -- only NEW elements count)
+            new = sum(1 for sc, d in force.items() for i in d if i not in force_all.get(sc, {}))
+            history.append(new)
+            if new == 0:
+                break
+            for sc, d in force.items():
+                force_all.setdefault(sc, {}).update(d)
+            cur = OT.forward_backward(model_name, {k: v.copy() for k, v in params.items()}, x.astype(np.float64),
+                                      onehot.astype(np.float64), classes, alg, True, masks, kink_force=force_all)
+        assert history[0] > 0, f"gradient {worst[0]} rel err {worst[1]} vs fp64 oracle and no kink flip explains it"
+        errs2 = grad_errors(cur)
         best = max(((k, e) for k, e in errs2.items()), key=lambda t: t[1])
-        assert best[1] < tol_grad, (f"gradient {worst[0]} rel err {worst[1]} vs fp64 oracle; after pinning {n_flip} "
-                                    f"kink flips (of {n_amb} ambiguous): {best}")
+        assert best[1] < tol_grad, (f"gradient {worst[0]} rel err {worst[1]} vs fp64 oracle; after pinning kink flips "
+                                    f"{history} (of {n_amb} ambiguous): {best}")
         worst = best
     for k, v in ref["new_moving"].items():
         got = sess.get_variable("nn_core/" + k)

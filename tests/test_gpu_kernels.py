@@ -163,6 +163,78 @@ def test_seg_gemm_res_epilogue(hip, cin, cout, mapped, acc):
     np.testing.assert_array_equal(got[:, :2], dx[:, :2])
 
 
+@pytest.mark.parametrize("rows,k,n,hint", [(50176 // 8, 120, 240, 2), (300, 145, 120, 0), (1000, 480, 480, 1),
+                                          (129, 33, 60, 2), (128 * 5, 64, 33, 0)])
+def test_seg_gemm_stats_epilogue(hip, rows, k, n, hint):
+    """1x1 convolution forward with the batch-norm statistics in the epilogue: the product itself, and per 128-row
+    tile the (mean, sum of squared deviations) of every column in the chunk format hypel_bn_finalize merges; then the
+    finaliser on those partials against the plain statistics of Y (both tile widths, ragged rows / columns)."""
+    rng = np.random.default_rng(rows + n)
+    b = Both(hip)
+    a = (rng.standard_normal((rows, k)) + 0.5).astype(np.float32)
+    w = rng.standard_normal((k, n)).astype(np.float32)
+    garr, sarr, tarr, _ = _tables(b, [(0, [(0, 0, k)], rows)]).finalize(n)
+    n_chunks = (rows + 127) // 128
+    for nm, arr in (("a", a), ("w", w), ("y", np.zeros(rows * n, np.float32)), ("g", garr), ("s", sarr), ("t", tarr),
+                    ("part", np.zeros(n_chunks * 2 * n, np.float32)), ("mean", np.zeros(n, np.float32)),
+                    ("rstd", np.zeros(n, np.float32)), ("mm", np.zeros(n, np.float32)), ("mv", np.ones(n, np.float32))):
+        b.arr(nm, arr)
+    b.run("seg_gemm_stats_f32", "a", k, 0, "w", n, 0, "y", n, n, "g", "s", "t", len(tarr), None, hint << 8, "part")
+    b.check("y", rtol=2e-4, atol=2e-5)
+    b.check("part", rtol=1e-3, atol=2e-4)
+    b.run("bn_finalize", "part", n_chunks, 128, rows, n, 1e-3, "mean", "rstd", "mm", "mv", 0.95)
+    y = a.astype(np.float64) @ w.astype(np.float64)
+    got_mean, got_rstd = b.h["mean"].cpu().numpy(), b.h["rstd"].cpu().numpy()
+    np.testing.assert_allclose(got_mean, y.mean(0), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got_rstd, 1.0 / np.sqrt(y.var(0) + 1e-3), rtol=1e-4)
+    np.testing.assert_allclose(b.h["mv"].cpu().numpy(), 0.95 + 0.05 * y.var(0, ddof=1), rtol=1e-4)
+
+
+def test_seg_gemm_multi_products(hip):
+    """Three filter-gradient-shaped products (C_p = A_p^T B_p) of different n / ld / split structure in ONE launch per
+    tile width, addressed relative to one base pointer across separate allocations, then the merged reduce."""
+    from hypelcnn_amd.backend import MTILE_DTYPE, REDUCE_ENTRY_DTYPE
+    rng = np.random.default_rng(17)
+    prods = [dict(m=145, n=120, k=600, S=3, acc=0), dict(m=60, n=60, k=200, S=1, acc=1), dict(m=130, n=70, k=333, S=2, acc=0)]
+    for be in (hip, EmuBackend()):
+        rng = np.random.default_rng(17)
+        base = be.zeros(16)
+        bp = Ref(base).ptr()
+        rel = lambda t, off=0: (Ref(t, off).ptr() - bp) // 4
+        segs, recs, ents, outs, wants = [], [], [], [], []
+        for p in prods:
+            m, n, k, S = p["m"], p["n"], p["k"], p["S"]
+            x = rng.standard_normal((k, m + 3)).astype(np.float32)       # A stored [k, m], lda = m + 3
+            dy = rng.standard_normal((k, n + 1)).astype(np.float32)      # B stored [k, n], ldb = n + 1
+            out0 = rng.standard_normal(m * n).astype(np.float32)
+            xt, dt, ot = be.upload(x), be.upload(dy), be.upload(out0)
+            part = be.zeros(S * m * n) if S > 1 else None
+            cuts = [k * s // S for s in range(S + 1)]
+            for s_ in range(S):
+                k0, k1 = cuts[s_], cuts[s_ + 1]
+                sb = len(segs)
+                segs.append((rel(xt, k0 * (m + 3)), rel(dt, k0 * (n + 1)), k1 - k0, 0))
+                c_off = rel(part, s_ * m * n) if S > 1 else rel(ot)
+                for m0 in range(0, m, 128):
+                    for n0 in range(0, n, 64):
+                        recs.append((c_off, segs[sb][0], segs[sb][1], m0, m, n0, n, sb, 1, k1 - k0,
+                                     p["acc"] if S == 1 else 0, m + 3, n + 1, n, 0))
+            if S > 1:
+                ents.append((rel(part), rel(ot), m * n, m * n, S, p["acc"]))
+            outs.append((ot, xt, dt, part))
+            wants.append((out0.reshape(m, n) if p["acc"] else 0) + x[:, :m].astype(np.float64).T @ dy[:, :n].astype(np.float64))
+        pad = [tuple([0] * 15)] * 5  # empty records (rows = 0) anywhere in the array are legal
+        rarr = np.array(recs[:4] + pad + recs[4:], MTILE_DTYPE)
+        s_t, r_t = be.upload(np.array(segs, SEG_DTYPE)), be.upload(rarr)
+        be.call("seg_gemm_multi_f32", Ref(base), 1, 0, 64, Ref(s_t), Ref(r_t), len(rarr))
+        e_t = be.upload(np.array(ents, REDUCE_ENTRY_DTYPE))
+        be.call("reduce_splits_multi_f32", Ref(base), Ref(e_t), len(ents))
+        be.synchronize()
+        for (ot, _, _, _), want, p in zip(outs, wants, prods):
+            got = ot.cpu().numpy().reshape(p["m"], p["n"])
+            np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(want).max()), err_msg=be.name)
+
+
 def test_seg_gemm_empty_group_writes_zero(hip):
     b = Both(hip)
     garr, sarr, tarr, _ = _tables(b, [(0, [], 50)]).finalize(40)
