@@ -45,6 +45,19 @@ __device__ __forceinline__ void lds_store_addtid(unsigned m0, const float (&regs
     }
 }
 
+// Batch-norm backward reduction riding in a data-gradient epilogue (see the kernel's epilogue): the layer whose
+// output gradient dZ this launch finishes.  partial == nullptr: off.
+struct BnBwdEpi {
+    const float* y;  // that layer's pre-normalisation output Y, row-aligned with C
+    int64_t ldy;
+    const float* mean;
+    const float* rstd;
+    const float* beta;
+    int act;
+    float alpha;
+    float* partial;  // [n_tiles][2][n]: per tile sum(dyh), sum(dyh * xhat)
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -79,7 +92,9 @@ static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
 // array of hypel_mtile_t, one record per BLOCK, that carries the block's column tile, its product's n / lda / ldb /
 // ldc and accumulate flag; operand offsets (records and segments) are relative to the one base pointer passed as
 // A = B = C.
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false>
+// BNB: instantiate the batch-norm backward epilogue (16 more live registers at the end of the block: a separate
+// instantiation keeps the register allocation -- 6 waves per SIMD -- of every other launch).
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false>
 __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
                                                         int n_ntiles, const float* __restrict__ bias,
                                                         int accumulate, const float* __restrict__ res, int64_t ldr,
                                                         const int32_t* __restrict__ res_start,
-                                                        float* __restrict__ stats) {
+                                                        float* __restrict__ stats, BnBwdEpi bnb) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = NARROW ? 16 : WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
@@ -122,6 +137,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     struct { int64_t c_off; int seg_begin, seg_count, rows; } grp;
     struct { int64_t a_off0, b_off0; int k0; } tile;
     int m0, n0;
+    int tile_index = 0;  // position in the tile table (non-MULTI): the chunk index of the epilogue reductions
     if constexpr (MULTI) {
         if (lid >= n_tiles) return;
         const hypel_mtile_t rec = reinterpret_cast<const hypel_mtile_t*>(tiles_v)[lid];
@@ -140,6 +156,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
         if (tile_id >= n_tiles) return;
         // one record per tile: the group's fields and its first segment travel with it (no tiles -> groups -> segs
         // chain in front of the first operand loads)
+        tile_index = tile_id;
         const hypel_tile_t t = reinterpret_cast<const hypel_tile_t*>(tiles_v)[tile_id];
         grp = {t.c_off, t.seg_begin, t.seg_count, t.rows};
         tile = {t.a_off0, t.b_off0, t.k0};
@@ -371,10 +388,11 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     // monotone channel map of scale_in_to_out -- from the row-aligned matrix `res` (same pixel-major row order as C)
     const float* rbase = res ? res + (grp.c_off / ldc + m0) * ldr : nullptr;
     // one output element: bias, optional read-modify-write, optional shortcut-gradient gather
-    auto put = [&](int row, int col, float accv, float bv, int o0, int o1) {
+    auto put = [&](int row, int col, float accv, float bv, int o0, int o1) -> float {
+        float v = 0.0f;
         if (row < rows_left) {
             float* p = cbase + (int64_t)row * ldc + col;
-            float v = accv + bv;
+            v = accv + bv;
             if (accumulate) v += *p;
             if (res) {
                 const float* rr = rbase + (int64_t)row * ldr;
@@ -382,6 +400,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
             }
             *p = v;
         }
+        return v;
     };
     // Batch-norm statistics in the epilogue (tf_slim.batch_norm's batch moments, HYPELCNNModel.py:37,43-44): the tile's
     // per-column (mean, sum of squared deviations) over its valid rows, straight from the accumulators -- the
@@ -457,6 +476,9 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
                 for (int e = 0; e < 4; ++e) put(wm * 32 + t * 16 + 4 * lq + e, col, acc16[t][e], bv, o0, o1);
         }
     } else {
+        float bs0[TN], bs1[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bs0[j] = bs1[j] = 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -470,11 +492,81 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
                     o0 = res_start[n0 + col];
                     o1 = res_start[n0 + col + 1];
                 }
+                if (BNB && bnb.partial) {
+                    // The value just written IS the finished gradient dZ of the producing layer's output (this launch
+                    // is its last writer): feed the batch-norm / activation backward reduction of that layer from it
+                    // -- sum(dyh) and sum(dyh * xhat) per column, dyh = dZ * act'(pre) -- instead of a separate pass
+                    // over dZ and Y (hypel_bn_act_bwd_reduce).
+                    const int colabs = (int)(grp.c_off % ldc) + n0 + col;
+                    const float mu = bnb.mean[colabs], rs = bnb.rstd[colabs], be = bnb.beta[colabs];
+                    const float* yb = bnb.y + (grp.c_off / ldc + m0) * bnb.ldy + colabs;
+                    // all 16 loads of Y in flight before the first store (a load behind a store through another
+                    // pointer cannot be hoisted by the compiler: 16 serialised round trips otherwise)
+                    float yv[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    put((wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi, col, acc[i][j][e], bv, o0, o1);
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                        yv[e] = row < rows_left ? yb[(int64_t)row * bnb.ldy] : 0.0f;
+                    }
+                    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                        const float v = put(row, col, acc[i][j][e], bv, o0, o1);
+                        if (row < rows_left) {
+                            const float xhat = hypel_bn_xhat(yv[e], mu, rs);
+                            const float dyh = v * hypel_act_grad(hypel_bn_pre(xhat, be), bnb.act, bnb.alpha);
+                            s0 += dyh;
+                            s1 += dyh * xhat;
+                        }
+                    }
+                    bs0[j] += s0;
+                    bs1[j] += s1;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        put((wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi, col, acc[i][j][e], bv, o0, o1);
+                }
             }
+        if (BNB && bnb.partial) {
+            float* red = lds;  // [WM][BN][2]
+            __syncthreads();   // every wave has left its last MFMA phase: the operand tiles are dead
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float t0 = bs0[j] + __shfl_xor(bs0[j], 32, 64);
+                const float t1 = bs1[j] + __shfl_xor(bs1[j], 32, 64);
+                if (lhi == 0) {
+                    const int cl = (wn * TN + j) * 32 + l31;
+                    red[(wm * BN + cl) * 2 + 0] = t0;
+                    red[(wm * BN + cl) * 2 + 1] = t1;
+                }
+            }
+            __syncthreads();
+            if (tid < BN && tid < cols_left) {
+                float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    t0 += red[(w * BN + tid) * 2 + 0];
+                    t1 += red[(w * BN + tid) * 2 + 1];
+                }
+                bnb.partial[((int64_t)tile_index * 2 + 0) * n + n0 + tid] = t0;
+                bnb.partial[((int64_t)tile_index * 2 + 1) * n + n0 + tid] = t1;
+            }
+        }
     }
+}
+
+template <int WM, int WN, int TM, int TN, bool NARROW = false, bool MULTI = false>
+int launch_cfg_bnb(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int n,
+                   const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
+                   const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
+                   hipStream_t st, BnBwdEpi bnb) {
+    constexpr int BN = WN * TN * 32;
+    const int n_nt = (n + BN - 1) / BN;
+    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, false, true, false, false, true>), dim3(n_tiles * n_nt),
+                       dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate,
+                       res, ldr, res_start, (float*)nullptr, bnb);
+    return 0;
 }
 
 template <int WM, int WN, int TM, int TN, bool NARROW = false, bool MULTI = false>
@@ -490,7 +582,7 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
 #define HYPEL_GO(TA_, TB_)                                                                                         \
     hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW, MULTI>), dim3(grid), dim3(256), lds_pad, st, a, \
                        lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,     \
-                       res_start, stats)
+                       res_start, stats, BnBwdEpi{})
     if constexpr (MULTI) {  // filter gradients only: A transposed, B as stored
         HYPEL_GO(true, false);
     } else {
@@ -509,7 +601,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
                              int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
                              const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles, const float* bias,
                              int32_t accumulate, const float* res, int64_t ldr, const int32_t* res_start,
-                             hypel_stream_t stream, float* stats = nullptr) {
+                             hypel_stream_t stream, float* stats = nullptr, BnBwdEpi bnb = BnBwdEpi{}) {
     HYPEL_REQUIRE(a && b && c && groups && segs && tiles, "hypel_seg_gemm_f32");
     HYPEL_REQUIRE(n > 0 && n_tiles >= 0, "hypel_seg_gemm_f32");
     if (n_tiles == 0) return 0;
@@ -528,7 +620,18 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
     // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (HYPEL_GEMM_MFMA16=0: 128x32)
     static const int mfma16 = getenv("HYPEL_GEMM_MFMA16") ? atoi(getenv("HYPEL_GEMM_MFMA16")) : 1;
-    if (n <= 16 && mfma16 && !stats)  // the 16-wide variant has no statistics epilogue
+    if (bnb.partial) {  // data gradients only: A as stored, B transposed
+        HYPEL_REQUIRE(!trans_a && trans_b, "hypel_seg_gemm_bnbwd_f32: data-gradient operand layout only");
+        if (n <= 32 || narrow)
+            launch_cfg_bnb<4, 1, 1, 1>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
+                                       ldr, res_start, st, bnb);
+        else
+            launch_cfg_bnb<4, 1, 1, 2>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
+                                       ldr, res_start, st, bnb);
+        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_bnbwd_f32");
+        return 0;
+    }
+    if (n <= 16 && mfma16 && !stats)  // the 16-wide variant has no reduction epilogues
         launch_cfg<4, 1, 1, 1, true>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st);
     else if (n <= 32 || narrow)
@@ -560,6 +663,20 @@ extern "C" int hypel_seg_gemm_stats_f32(const float* a, int64_t lda, int32_t tra
     HYPEL_REQUIRE(stats_partial && (accumulate & 1) == 0, "hypel_seg_gemm_stats_f32");
     return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                              accumulate, nullptr, 0, nullptr, stream, stats_partial);
+}
+
+extern "C" int hypel_seg_gemm_bnbwd_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
+                                        int32_t trans_b, float* c, int64_t ldc, int32_t n,
+                                        const hypel_group_t* groups, const hypel_seg_t* segs, const hypel_tile_t* tiles,
+                                        int32_t n_tiles, const float* bias, int32_t accumulate, const float* res,
+                                        int64_t ldr, const int32_t* res_start, const float* y, int64_t ldy,
+                                        const float* mean, const float* rstd, const float* beta, int32_t act,
+                                        float alpha, float* partial, hypel_stream_t stream) {
+    HYPEL_REQUIRE(y && mean && rstd && beta && partial && ldy > 0 && n > 16, "hypel_seg_gemm_bnbwd_f32");
+    HYPEL_REQUIRE(res == nullptr || ldr > 0, "hypel_seg_gemm_bnbwd_f32");
+    return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                             accumulate, res, ldr, res_start, stream, nullptr,
+                             BnBwdEpi{y, ldy, mean, rstd, beta, act, alpha, partial});
 }
 
 extern "C" int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,

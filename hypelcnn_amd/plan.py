@@ -31,7 +31,7 @@ def stat_chunk_rows(rows):
     c = max(16, min(STAT_CHUNK_ROWS, c))
     return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
-TARGET_BLOCKS = 1024
+TARGET_BLOCKS = int(os.environ.get("HYPEL_WGRAD_TARGET_BLOCKS", "1024"))  # blocks a filter-gradient product is split towards
 WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
 WGRAD_MIN_SPLITS = int(os.environ.get("HYPEL_WGRAD_MIN_SPLITS", "0"))  # 0 = one split per 64 batch rows once a launch fills the device unsplit
 SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel-part splitting also for biased convs
@@ -77,6 +77,12 @@ MERGE_WGRAD = os.environ.get("HYPEL_MERGE_WGRAD", "1") != "0"
 # Batch-norm statistics of a 1x1 convolution's output in the GEMM epilogue (hypel_seg_gemm_stats_f32) instead of a
 # separate pass over Y (hypel_col_stats_partial)
 STATS_EPILOGUE = os.environ.get("HYPEL_STATS_EPILOGUE", "1") != "0"
+# First pass of the batch-norm backward (column sums of dyh and dyh * xhat) in the epilogue of the data-gradient GEMM
+# that finishes the layer's output gradient (hypel_seg_gemm_bnbwd_f32) instead of hypel_bn_act_bwd_reduce.  Correct
+# (emulation + GPU parity tests run it) but OFF by default: measured on MI355X (round 2, same-box A/B) the twelve
+# reduction passes it removes cost 0.21 ms at HBM speed, while the row-strided reads of Y at the end of every
+# data-gradient block cost the GEMMs 0.26 ms (step 7.12-7.14 vs 7.07-7.08 ms).
+BNBWD_EPILOGUE = os.environ.get("HYPEL_BNBWD_EPILOGUE", "0") != "0"
 
 
 class Storage:
@@ -373,10 +379,13 @@ class TowerPlan:
         return 1 if blocks64 < 768 else 2
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
-                   allow_split=True, res=None, stats=None):
+                   allow_split=True, res=None, stats=None, bnbwd=None):
         """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32).
-        stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate)."""
+        stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate).
+        bnbwd = producer node index whose batch-norm backward reduction rides in this data gradient's epilogue
+        (hypel_seg_gemm_bnbwd_f32); dropped (returns False) when the product is split along K."""
         split = self._split_k(tables, n, lda, ta, ldb, tb, ldc) if allow_split and res is None else None
+        fused_bnbwd = False
         if split is not None:
             stab, S, c_min, count = split
             pos = len(lst)
@@ -397,7 +406,19 @@ class TowerPlan:
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
                 Ref(t_t), int(len(tarr)), bias_ref, int(accumulate) | (hint << 8))
         name = "seg_gemm_f32"
-        if res is not None:
+        if bnbwd is not None:
+            paux = self.node_aux[bnbwd]
+            pnode = self.tower.nodes[bnbwd]
+            pname = f"bnbwd_partial:{bnbwd}"
+            self._alloc(pname, len(tarr) * 2 * int(n))
+            act = pnode.act
+            name = "seg_gemm_bnbwd_f32"
+            r = res if res is not None else (None, 0, None)
+            args = args + (r[0], int(r[1]), r[2], self._ref(paux["y"].buf), int(paux["y"].ld), paux["mean"], paux["rstd"],
+                           paux["beta_ref"], act.code if act else 0, float(act.alpha) if act else 0.0, self._ref(pname))
+            paux["bwd_partial"] = (pname, int(len(tarr)))
+            fused_bnbwd = True
+        elif res is not None:
             name = "seg_gemm_res_f32"
             args = args + (res[0], int(res[1]), res[2])
         elif stats is not None:
@@ -408,6 +429,7 @@ class TowerPlan:
         if stats is not None:
             self._scratch(l, len(args) - 1, "scratch_partial", stats)
         lst.append(l)
+        return fused_bnbwd
 
     def _dp_sync_node(self):
         """Data-parallel overlap: the node index (walking backward) after which >= 60 % of the weight-gradient
@@ -433,10 +455,49 @@ class TowerPlan:
                 return idx, tail_lo, hi_all
         return None
 
+    # ------------------------------------------------------------------ consumers / epilogue fusion
+    @staticmethod
+    def _inputs_of(node):
+        if isinstance(node, G.LinearNode):
+            return list(node.sources) + [r for r, _ in node.residuals]
+        if isinstance(node, G.PostNode):
+            return [node.src] + [r for r, _ in node.residuals]
+        if hasattr(node, "srcs"):
+            return list(node.srcs)
+        return [node.src]
+
+    def _index_consumers(self):
+        self._node_index = {id(n): i for i, n in enumerate(self.tower.nodes)}
+        self._first_consumer = {}
+        for i, n in enumerate(self.tower.nodes):
+            for t in self._inputs_of(n):
+                self._first_consumer.setdefault(id(t.owner), i)
+
+    def _bnbwd_producer(self, idx, src, gst, n_launches):
+        """Index of the layer whose batch-norm backward reduction can ride in the epilogue of the data gradient that
+        node `idx` is about to write into d(src): src is that layer's whole output, `idx` is its FIRST consumer in
+        forward order (= the last writer of the gradient in backward order), one launch writes it, plain storage."""
+        if not BNBWD_EPILOGUE or not self.training or n_launches != 1 or not hasattr(self, "_first_consumer"):
+            return None
+        own = src.owner
+        p = own.node
+        if p is None or not isinstance(p, G.LinearNode) or not (p.has_bn and p.has_post and p.training):
+            return None
+        if src.root is not None or self._first_consumer.get(id(own)) != idx:
+            return None
+        pidx = self._node_index[id(p)]
+        paux = self.node_aux.get(pidx, {})
+        if paux.get("small_bn") or paux.get("mask") is not None or "mean" not in paux:
+            return None
+        if not (gst.contiguous and gst.ch_off == 0 and gst.ld == src.c and src.c > 16):
+            return None
+        return pidx
+
     # ------------------------------------------------------------------ build
     def _build(self):
         tw = self.tower
         nb = self.nb
+        self._index_consumers()
         # inputs: the loader hands over NHWC batches; keep a persistent staging tensor and convert
         for name, t in tw.inputs.items():
             if t.hw is None:
@@ -957,7 +1018,7 @@ class TowerPlan:
                             tb.add_group(gst.pix_off(pin), segs, nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
                                     self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}",
-                                    res=fold_res)
+                                    res=fold_res, bnbwd=self._bnbwd_producer(idx, src, gst, len(by_cout)))
                     fold_res = None
                     acc = 1
             # ---- filter gradient ----
@@ -991,7 +1052,7 @@ class TowerPlan:
                     for p in range(src.npix):
                         tb.add_group(gst.pix_off(p), [(0, b.w.offset + (rowbase + p * src.c) * c, c)], nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), c, 1, self._ref(gst.buf),
-                                    gst.ld, None, acc, f"dgrad:{b.scope}")
+                                    gst.ld, None, acc, f"dgrad:{b.scope}", bnbwd=self._bnbwd_producer(idx, src, gst, 1))
                 rowbase += src.npix * src.c
             if trains:
                 self._on_side(lambda: self._wgrad_dense(idx, node, aux, dy, c))
@@ -1023,7 +1084,14 @@ class TowerPlan:
             pacc = 0
             if dparam is not None:
                 pacc = self._param_acc(aux["beta"] if has_bn else aux["bias"])
-            if FUSED_STATS:
+            if aux.get("bwd_partial") is not None and has_bn and mask is None:
+                # the data gradient that finished dZ already left sum(dyh), sum(dyh * xhat) per tile
+                pname, n_tiles = aux["bwd_partial"]
+                l2 = Launch("bwd_reduce_finalize", (self._ref(pname), n_tiles, c, None, dparam, pacc),
+                            tag="post-bwd-finalize")
+                self._scratch(l2, 3, "sums", 2 * c)
+                self.bwd.append(l2)
+            elif FUSED_STATS:
                 l1 = Launch("bn_act_bwd_sums", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
                                                 chunk, None, self._tickets(c), None, dparam, pacc),
                             nbytes=8 * rows * c, tag="post-bwd-reduce")

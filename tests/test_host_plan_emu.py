@@ -220,3 +220,27 @@ def test_filter_gradients_go_out_as_merged_launches(monkeypatch):
     assert any(l.tag.startswith("wgrad:") for l in ct2.plan.bwd)
     import torch
     torch.testing.assert_close(sess2.grads, g_merged, rtol=1e-5, atol=1e-7)
+
+
+def test_bn_backward_reduction_rides_in_the_data_gradient_epilogue(monkeypatch):
+    """Every batch-normed convolution's first backward pass (column sums of dyh, dyh * xhat) is produced by the data
+    gradient that finishes its output gradient: no stand-alone reduction launch is left for them, and the step equals
+    the oracle; switching the fusion off gives the same gradients through the separate pass."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "BNBWD_EPILOGUE", True)  # an option (measured slower on MI355X, see plan.py)
+    alg = dict(ALG_H, filter_count=96)
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 7, 9, 4, alg, 5, 31)
+    ct = U.run_train_step(built, x, onehot, masks)
+    names = [l.name for l in ct.plan.bwd]
+    assert "seg_gemm_bnbwd_f32" in names
+    n_conv_bn = sum(1 for n in built.train_tower.nodes if getattr(n, "kind", "") == "conv" and n.has_bn)
+    assert names.count("seg_gemm_bnbwd_f32") >= n_conv_bn - 1
+    assert names.count("bn_act_bwd_reduce") <= 1
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
+    g_fused = sess.grads.clone()
+    monkeypatch.setattr(plan, "BNBWD_EPILOGUE", False)
+    built2, sess2, _, _, _, _ = _case("HYPELCNNModel", 7, 9, 4, alg, 5, 31)
+    ct2 = U.run_train_step(built2, x, onehot, masks)
+    assert "seg_gemm_bnbwd_f32" not in [l.name for l in ct2.plan.bwd]
+    import torch
+    torch.testing.assert_close(sess2.grads, g_fused, rtol=1e-5, atol=1e-7)
