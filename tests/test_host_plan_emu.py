@@ -234,8 +234,9 @@ def test_bn_backward_reduction_rides_in_the_data_gradient_epilogue(monkeypatch):
     names = [l.name for l in ct.plan.bwd]
     assert "seg_gemm_bnbwd_f32" in names
     n_conv_bn = sum(1 for n in built.train_tower.nodes if getattr(n, "kind", "") == "conv" and n.has_bn)
-    assert names.count("seg_gemm_bnbwd_f32") >= n_conv_bn - 1
-    assert names.count("bn_act_bwd_reduce") <= 1
+    # (layers with <= 16 channels keep the separate pass: the 16-wide GEMM variant has no reduction epilogue)
+    assert names.count("seg_gemm_bnbwd_f32") >= n_conv_bn - 3
+    assert names.count("bn_act_bwd_reduce") <= 3
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
     g_fused = sess.grads.clone()
     monkeypatch.setattr(plan, "BNBWD_EPILOGUE", False)
