@@ -38,6 +38,8 @@ SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel
 DGRAD_MAX_SEGS = int(os.environ.get("HYPEL_DGRAD_MAX_SEGS", "18"))  # segments per data-gradient tile (0 = never split)
 MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
 L2_CHUNK_BYTES = int(float(os.environ.get("HYPEL_L2_CHUNK_MB", "3.5")) * (1 << 20))  # X working set an XCD's L2 keeps
+SPLITK_BELOW = int(os.environ.get("HYPEL_SPLITK_BELOW", "192"))    # FC-shaped products with fewer 128x64 blocks are cut along K
+SPLITK_TARGET = int(os.environ.get("HYPEL_SPLITK_TARGET", "384"))  # ... into slices that give about this many blocks
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
 
 
@@ -323,9 +325,9 @@ class TowerPlan:
         n_nt = (n + 63) // 64 if n > 32 else 1
         blocks = sum((rows + GEMM_BM - 1) // GEMM_BM for _, _, rows in groups) * n_nt
         kmax = max(sum(k for _, _, k in gs) for _, gs, _ in groups)
-        if blocks >= 192 or kmax < 512:
+        if blocks >= SPLITK_BELOW or kmax < 512:
             return None
-        S = min((384 + blocks - 1) // blocks, kmax // 128, 32)
+        S = min((SPLITK_TARGET + blocks - 1) // blocks, kmax // 128, 32)
         if S < 2:
             return None
         order = sorted(groups, key=lambda g: g[0])

@@ -23,5 +23,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_w -o w -- pytho
 cd $ROOT
 F=$(find $OUT/pmc_f -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_w -name "*counter_collection.csv" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W --json $OUT/hbm_traffic.json --source "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-input-pipeline (every step of the run incl. pre-warm and event replay), tools/pmc_traffic.py" > $OUT/hbm_traffic.txt 2>&1
+[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic_per_launch.py $F $W > $OUT/hbm_traffic_per_launch.txt 2>&1
 rm -rf $OUT/trace $OUT/pmc_f $OUT/pmc_w   # raw traces are large; the summaries above are what gets committed
 ls -la $OUT
