@@ -84,6 +84,10 @@ static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
+#ifndef HYPEL_OCC_BN96
+#define HYPEL_OCC_BN96 5  // ... and the 128x96 data-gradient variant (5 blocks per CU = 1280 resident: 392 x 3 row x column
+                          // tiles fit); the forward variant needs ~104 registers: 4 waves per SIMD, 1024 resident
+#endif
 
 // NARROW: 128x16 blocks on v_mfma_f32_16x16x4_f32 for n <= 16 (the Cout = 15 level of HYPELCNN, fc_final): each wave
 // owns 32 rows x 16 columns as two 16x16 accumulators, so a 15-column output wastes 1/16 of the MFMA work instead of
@@ -95,7 +99,7 @@ static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
 // BNB: instantiate the batch-norm backward epilogue (16 more live registers at the end of the block: a separate
 // instantiation keeps the register allocation -- 6 waves per SIMD -- of every other launch).
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false>
-__global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : 3))) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
                                                         const hypel_group_t* __restrict__ groups,
@@ -121,7 +125,10 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
     constexpr int B_COLS = TB ? BK : BN;
     constexpr int B_PITCH = TB ? (NARROW ? BK + 2 : BK + 1) : BN;
     constexpr int A_PER_THREAD = A_ROWS * A_COLS / 256;
-    constexpr int B_PER_THREAD = B_ROWS * B_COLS / 256;
+    // a 96-column B row does not divide the 256 threads: then only the first (256 / B_COLS) * B_COLS = 192 threads
+    // stage B (two rows of 96 per pass), the fourth wave sits that part out
+    constexpr int B_THREADS = (256 / B_COLS) * B_COLS;
+    constexpr int B_PER_THREAD = B_ROWS * B_COLS / B_THREADS;
     constexpr int A_RSTEP = 256 / A_COLS;
     constexpr int B_RSTEP = 256 / B_COLS;
     __shared__ float lds[A_ROWS * A_PITCH + B_ROWS * B_PITCH];
@@ -178,7 +185,8 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
 
     // per-thread staging coordinates
     const int a_col = tid % A_COLS, a_row0 = tid / A_COLS;
-    const int b_col = tid % B_COLS, b_row0 = tid / B_COLS;
+    const bool b_stager = B_THREADS == 256 || tid < B_THREADS;
+    const int b_col = b_stager ? tid % B_COLS : 0x3fffffff / 4, b_row0 = b_stager ? tid / B_COLS : 0;
 
     f32x16 acc[NARROW ? 1 : TM][NARROW ? 1 : TN];
     f32x4 acc16[2];  // NARROW: rows [0,16) and [16,32) of the wave's 32 x 16 tile
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
         const int kvalid = min(BK, seg.k - lk);
         __syncthreads();  // previous tile's MFMAs are done reading LDS
         constexpr bool A_TID = HYPEL_GEMM_ADDTID && A_PITCH == A_COLS;
-        constexpr bool B_TID = HYPEL_GEMM_ADDTID && B_PITCH == B_COLS;
+        constexpr bool B_TID = HYPEL_GEMM_ADDTID && B_PITCH == B_COLS && B_THREADS == 256;
         if constexpr (A_TID) {
             lds_store_addtid<A_PER_THREAD>(lds_m0, ra);
         } else {
@@ -303,7 +311,8 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : 3)) void seg_
             lds_store_addtid<B_PER_THREAD>(lds_m0 + 4u * A_ROWS * A_PITCH, rb);
         } else {
 #pragma unroll
-            for (int i = 0; i < B_PER_THREAD; ++i) Bs[(b_row0 + i * B_RSTEP) * B_PITCH + b_col] = rb[i];
+            for (int i = 0; i < B_PER_THREAD; ++i)
+                if (B_THREADS == 256 || b_stager) Bs[(b_row0 + i * B_RSTEP) * B_PITCH + b_col] = rb[i];
         }
         if constexpr (A_TID || B_TID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // invisible to hipcc's counter
         __syncthreads();
@@ -615,8 +624,22 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     // bits 8-9 of `accumulate`: tile-width hint of the caller (1 = 128x32, 2 = 128x64), measured per launch class
     // (profiles/r1_gemm_tile_choice.txt): data gradients with >= 48 reduction columns per segment and launches with
     // few blocks run faster on the narrow tile, wide filter gradients on the wide one
-    const int hint = (accumulate >> 8) & 3;
+    int hint = (accumulate >> 8) & 3;
     accumulate &= 1;
+    // hint 3 = 128x96 blocks (three 32x32 accumulators per wave, 5 resident blocks per CU): N = 240 / 480 tile without
+    // padding (5 x 96, 96 + 96 + 48) and a layer's 392 row tiles x 3 or 5 column tiles fit the resident capacity where
+    // 392 x 4 / x 8 of the 64-wide tiling overflow it by 2 %.  HYPEL_GEMM_FORCE_WIDTH=32|64|96: experiments.
+    static const int force_w = getenv("HYPEL_GEMM_FORCE_WIDTH") ? atoi(getenv("HYPEL_GEMM_FORCE_WIDTH")) : 0;
+    if (force_w == 32) hint = 1;
+    if (force_w == 64) hint = 2;
+    if (force_w == 96) hint = 3;
+    if (hint == 3 && n > 64 && !bnb.partial) {
+        launch_cfg<4, 1, 1, 3>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                               accumulate, res, ldr, res_start, st, stats);
+        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
+        return 0;
+    }
+    if (hint == 3) hint = 2;
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
     // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (HYPEL_GEMM_MFMA16=0: 128x32)
     static const int mfma16 = getenv("HYPEL_GEMM_MFMA16") ? atoi(getenv("HYPEL_GEMM_MFMA16")) : 1;

@@ -38,6 +38,7 @@ SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel
 DGRAD_MAX_SEGS = int(os.environ.get("HYPEL_DGRAD_MAX_SEGS", "18"))  # segments per data-gradient tile (0 = never split)
 MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
 L2_CHUNK_BYTES = int(float(os.environ.get("HYPEL_L2_CHUNK_MB", "3.5")) * (1 << 20))  # X working set an XCD's L2 keeps
+FWD_HINT_R2 = os.environ.get("HYPEL_FWD_HINT_R2", "1") != "0"  # round-2 forward tile-width rule (incl. 128x96 tiles)
 SPLITK_BELOW = int(os.environ.get("HYPEL_SPLITK_BELOW", "192"))    # FC-shaped products with fewer 128x64 blocks are cut along K
 SPLITK_TARGET = int(os.environ.get("HYPEL_SPLITK_TARGET", "384"))  # ... into slices that give about this many blocks
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
@@ -378,6 +379,15 @@ class TowerPlan:
             return 1 if blocks64 < 900 else 2
         if ta:
             return 1 if blocks64 < 900 else 2
+        # forward.  Round-2 per-launch A/B of the three tile widths (tools/gemm_microbench.py, HYPEL_GEMM_FORCE_WIDTH):
+        # single-segment products (1x1 convolutions, n <= 512) run fastest on 128x32 tiles -- except n = 480, which
+        # tiles 5 x 96 without padding and whose 392 x 5 blocks are just under two resident rounds of the 128x96
+        # variant (conv_dec_0 218 vs 227 (32) vs 244 (64) us; conv_enc_2 129 vs 134 vs 138) -- multi-segment levels
+        # and the very wide dense layers on 128x64.
+        if n <= 512 and FWD_HINT_R2 and all(len(segs) == 1 for _, segs, _ in tables.groups):
+            if n >= 480 and n % 96 == 0:
+                return 3
+            return 1
         return 1 if blocks64 < 768 else 2
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
