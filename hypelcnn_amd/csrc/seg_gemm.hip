@@ -98,8 +98,20 @@ static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
 // A = B = C.
 // BNB: instantiate the batch-norm backward epilogue (16 more live registers at the end of the block: a separate
 // instantiation keeps the register allocation -- 6 waves per SIMD -- of every other launch).
+#ifndef HYPEL_GEMM_SGPR_CAP
+#define HYPEL_GEMM_SGPR_CAP 0  // > 0: cap the scalar registers of every variant (experiments on blocks per CU)
+#endif
+#if HYPEL_GEMM_SGPR_CAP > 0
+// (r2 experiment, -DHYPEL_GEMM_SGPR_CAP=96: hipcc honours it for the 128x32 variants only -- 94 scalar registers, 7
+// instead of 6 blocks per CU -- the 1x1 data gradients gain 3 %, the multi-segment level gradients lose 3 % to the
+// extra scalar spills in the segment loop; step 7.03 vs 7.08 ms.  Not adopted: a template-dependent cap is not
+// accepted by the attribute.)
+#define HYPEL_SGPR_ATTR __attribute__((amdgpu_num_sgpr(HYPEL_GEMM_SGPR_CAP)))
+#else
+#define HYPEL_SGPR_ATTR
+#endif
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false>
-__global__ __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : 3))) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
+__global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : 3))) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
                                                         const hypel_group_t* __restrict__ groups,
