@@ -309,13 +309,21 @@ def main():
     # the shader clock needs 30-40 ms of uninterrupted work to ramp: pre-warm at least 50 ms of steps
     # whatever --warmup says (untimed, like the W warm-up steps)
     torch.cuda.synchronize()
+    # (every rank must run the SAME number of steps -- a step ends in collectives -- so the count is derived from
+    # three timed steps and, under data parallelism, agreed on by a MAX all-reduce)
     tw = time.perf_counter()
-    n_prewarm = 0
-    while (time.perf_counter() - tw < 0.05 or n_prewarm < 2) and n_prewarm < 10000:
+    for _ in range(3):
         one_step()
-        n_prewarm += 1
-        if n_prewarm % 4 == 0:
-            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - tw) / 3
+    n_prewarm = max(2, min(500, int(0.05 / max(est, 1e-6)) + 1))
+    if use_dist:
+        t = torch.tensor([n_prewarm], device="cuda", dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_prewarm = int(t[0])
+    for _ in range(n_prewarm):
+        one_step()
+    n_prewarm += 3
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
