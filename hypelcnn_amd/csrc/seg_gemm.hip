@@ -66,7 +66,11 @@ namespace {
 #ifndef HYPEL_GEMM_BK
 #define HYPEL_GEMM_BK 32  // reduction columns per LDS tile (a multiple of 16)
 #endif
-constexpr int BK = HYPEL_GEMM_BK;
+constexpr int BK_WIDE = HYPEL_GEMM_BK;
+#ifndef HYPEL_GEMM_BK_NARROW
+#define HYPEL_GEMM_BK_NARROW 32  // reduction columns per LDS tile of the 128x16 variant (experiments: 64)
+#endif
+constexpr int BK_NARROW = HYPEL_GEMM_BK_NARROW;
 #ifndef HYPEL_GEMM_SETPRIO
 #define HYPEL_GEMM_SETPRIO 1
 #endif
@@ -80,7 +84,7 @@ constexpr int BK = HYPEL_GEMM_BK;
 #define HYPEL_GEMM_ADDTID 0  // 1: unpadded LDS images are written with ds_write_addtid_b32 (no address VGPR: 2 cycles
 #endif                       // per wave-store instead of 4, MI355X_MICROARCH.md LDS table)
 constexpr int CHUNK = HYPEL_GEMM_CHUNK;
-static_assert(CHUNK % 4 == 0 && BK % CHUNK == 0, "chunk of k2 / k4 steps");
+static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, "chunk of k2 / k4 steps");
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
@@ -127,6 +131,7 @@ __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
     static_assert(!NARROW || (WM == 4 && TM == 1 && TN == 1), "narrow variant: 4 x 1 waves of 32 x 16");
     // LDS images (rows x pitch), global row order preserved
+    constexpr int BK = NARROW ? BK_NARROW : BK_WIDE;
     constexpr int A_ROWS = TA ? BK : BM;
     constexpr int A_COLS = TA ? BM : BK;
     // pitches: a fragment read must hit 32 distinct banks per half-wave.  32x32x2 fragments read 32 rows at one k
