@@ -197,7 +197,7 @@ def pmc_traffic(workload, nb, launches_per_step):
 
 def input_pipeline_iterator(be, nb, patch, chans, classes, rank, pool=8192):
     """The reference's tf.data stage (common/common_nn_ops.py:188-201,376-440) for the timed loop: a resident pool
-    of `pool` synthetic patches, per-epoch permutation, per-sample rot90 / flips / spectral shift drawn on the host
+    of `pool` synthetic patches, per-epoch permutation, per-sample rot90 / flips / spectral shift drawn on the device
     and applied by ONE hypel_augment_patches_f32 launch that also gathers the batch."""
     from hypelcnn_amd.common import common_nn_ops as cno
     gen = torch.Generator(device="cpu")
@@ -386,7 +386,7 @@ def main():
             dtp = float(t[0])
         pipeline = {"what": "same train step with the device input pipeline in the loop: epoch permutation over a "
                             "resident pool of 8192 patches, rot90 / flips / spectral shift drawn per sample on the "
-                            "host, one fused hypel_augment_patches_f32 gather+augment launch per step",
+                            "device, one fused hypel_augment_patches_f32 gather+augment launch per step",
                     "steps": n_p, "ms_per_step": dtp / n_p * 1e3, "value": nb * world * n_p / dtp, "unit": "patches/s"}
 
     roof = None
