@@ -114,7 +114,12 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 #else
 #define HYPEL_SGPR_ATTR
 #endif
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false>
+// PAIR (data gradients, !TA && TB): two consecutive segments of at most 16 reduction columns each share ONE k-tile
+// (columns 0-15 from the first, 16-31 from the second).  A data gradient through a convolution with 15 filters (the
+// narrowest HYPELCNN level, DUALCNN's last levels) otherwise stages, synchronises and walks a whole 32-column k-tile
+// for 15 useful columns.  A segment whose k has HYPEL_SEG_PAIR_FLAG set is paired with the next one of its group.
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
+          bool PAIR = false>
 __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : 3))) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
@@ -264,6 +269,12 @@ __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32
         seg.b_off = tile.b_off0;
         seg.k = tile.k0;
     }
+    hypel_seg_t seg2;  // PAIR: partner of `seg` while (seg.k & HYPEL_SEG_PAIR_FLAG)
+    seg2.a_off = 0; seg2.b_off = 0; seg2.k = 0; seg2.reserved = 0;
+    if constexpr (PAIR) {
+        static_assert(!TA && TB && !NARROW && !MULTI, "segment pairing: data-gradient operand layout only");
+        if (have && (seg.k & HYPEL_SEG_PAIR_FLAG)) seg2 = segs[ls + 1];
+    }
 
     // Staging loads are raw buffer loads: the tile base lives in a scalar descriptor, each thread keeps ONE
     // 32-bit offset per operand and the per-load row step is a scalar soffset.  An invalid element is fetched
@@ -293,7 +304,40 @@ __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32
         }
     };
 
+    // PAIR: the k columns [0, 16) of the tile come from (offX, kx), [16, 32) from (offY, ky): ONE descriptor based at
+    // the lower of the two addresses, the other one's distance goes into the per-lane offset (both operands of a data
+    // gradient live in one allocation each, < 2 GB apart); rows = the non-reduction dimension.
+    auto stage_pair = [&](const float* basep, int64_t offx, int64_t offy, int kx, int ky, int64_t ld, int row0, int col,
+                          int rows_valid, auto& regs, auto rstep_c, auto count_c) {
+        constexpr int RSTEP = decltype(rstep_c)::value;
+        constexpr int COUNT = decltype(count_c)::value;
+        const int ld4 = __builtin_amdgcn_readfirstlane((int)ld * 4);
+        const int64_t lo = offx < offy ? offx : offy;
+        const int dx = __builtin_amdgcn_readfirstlane((int)((offx - lo) * 4));
+        const int dy = __builtin_amdgcn_readfirstlane((int)((offy - lo) * 4));
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(basep + lo), 0, 0x7ffffff0, 0x00020000);
+        const int kOOB = 0x7fffffff;
+        const int c2 = col - 16;
+        const int voff = col < 16 ? (col < kx ? dx + (row0 * (int)ld + col) * 4 : kOOB)
+                                  : (c2 < ky ? dy + (row0 * (int)ld + c2) * 4 : kOOB);
+#pragma unroll
+        for (int i = 0; i < COUNT; ++i) {
+            const int v = (row0 + i * RSTEP) < rows_valid ? voff : kOOB;
+            regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, i * RSTEP * ld4, 0));
+        }
+    };
+
     auto load_tiles = [&](const hypel_seg_t& sg, int k0) {
+        if constexpr (PAIR) {
+            if (sg.k & HYPEL_SEG_PAIR_FLAG) {
+                const int kx = sg.k & ~HYPEL_SEG_PAIR_FLAG, ky = seg2.k;
+                stage_pair(A + (int64_t)m0 * lda, sg.a_off, seg2.a_off, kx, ky, lda, a_row0, a_col, min(BM, rows_left),
+                           ra, std::integral_constant<int, A_RSTEP>{}, std::integral_constant<int, A_PER_THREAD>{});
+                stage_pair(B + (int64_t)n0 * ldb, sg.b_off, seg2.b_off, kx, ky, ldb, b_row0, b_col, min(BN, cols_left),
+                           rb, std::integral_constant<int, B_RSTEP>{}, std::integral_constant<int, B_PER_THREAD>{});
+                return;
+            }
+        }
         const int k_left = min(BK, sg.k - k0);
         const int m_left = min(BM, rows_left);
         const int n_left = min(BN, cols_left);
@@ -314,7 +358,8 @@ __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32
     if (have) load_tiles(seg, lk);
 
     while (have) {
-        const int kvalid = min(BK, seg.k - lk);
+        const bool paired = PAIR && (seg.k & HYPEL_SEG_PAIR_FLAG);
+        const int kvalid = paired ? 16 + seg2.k : min(BK, seg.k - lk);
         __syncthreads();  // previous tile's MFMAs are done reading LDS
         constexpr bool A_TID = HYPEL_GEMM_ADDTID && A_PITCH == A_COLS;
         constexpr bool B_TID = HYPEL_GEMM_ADDTID && B_PITCH == B_COLS && B_THREADS == 256;
@@ -336,10 +381,14 @@ __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32
 
         // advance the (segment, k) cursor and put the next tile's loads in flight
         lk += BK;
-        if (lk >= seg.k) {
-            ++ls;
+        if (paired || lk >= seg.k) {
+            ls += paired ? 2 : 1;
             lk = 0;
-            if (ls < s_end) seg = segs[ls];
+            if (ls < s_end) {
+                seg = segs[ls];
+                if constexpr (PAIR)
+                    if (seg.k & HYPEL_SEG_PAIR_FLAG) seg2 = segs[ls + 1];
+            }
         }
         have = ls < s_end;
         if (have) load_tiles(seg, lk);
@@ -582,6 +631,19 @@ __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32
     }
 }
 
+template <int WM, int WN, int TM, int TN>
+int launch_cfg_pair(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int n,
+                    const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
+                    const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
+                    hipStream_t st) {
+    constexpr int BN = WN * TN * 32;
+    const int n_nt = (n + BN - 1) / BN;
+    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, false, true, false, false, false, true>), dim3(n_tiles * n_nt),
+                       dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate,
+                       res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
+    return 0;
+}
+
 template <int WM, int WN, int TM, int TN, bool NARROW = false, bool MULTI = false>
 int launch_cfg_bnb(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int n,
                    const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
@@ -642,6 +704,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     // (profiles/r1_gemm_tile_choice.txt): data gradients with >= 48 reduction columns per segment and launches with
     // few blocks run faster on the narrow tile, wide filter gradients on the wide one
     int hint = (accumulate >> 8) & 3;
+    const bool pairs = (accumulate & HYPEL_GEMM_PAIRED_SEGS) != 0;  // segments carry HYPEL_SEG_PAIR_FLAG
     accumulate &= 1;
     // hint 3 = 128x96 blocks (three 32x32 accumulators per wave, 5 resident blocks per CU): N = 240 / 480 tile without
     // padding (5 x 96, 96 + 96 + 48) and a layer's 392 row tiles x 3 or 5 column tiles fit the resident capacity where
@@ -660,6 +723,18 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
     // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (HYPEL_GEMM_MFMA16=0: 128x32)
     static const int mfma16 = getenv("HYPEL_GEMM_MFMA16") ? atoi(getenv("HYPEL_GEMM_MFMA16")) : 1;
+    if (pairs) {  // data gradients only: A as stored, B transposed; n > 16
+        HYPEL_REQUIRE(!trans_a && trans_b && n > 16 && !stats && !bnb.partial, "hypel_seg_gemm_f32: paired segments");
+        const bool narrow_p = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
+        if (n <= 32 || narrow_p)
+            launch_cfg_pair<4, 1, 1, 1>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
+                                        ldr, res_start, st);
+        else
+            launch_cfg_pair<4, 1, 1, 2>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
+                                        ldr, res_start, st);
+        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
+        return 0;
+    }
     if (bnb.partial) {  // data gradients only: A as stored, B transposed
         HYPEL_REQUIRE(!trans_a && trans_b, "hypel_seg_gemm_bnbwd_f32: data-gradient operand layout only");
         if (n <= 32 || narrow)

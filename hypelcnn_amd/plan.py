@@ -128,6 +128,11 @@ def valid_taps(h, w, k, oy, ox):
     return out
 
 
+SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
+GEMM_PAIRED_SEGS = 0x400    # ... HYPEL_GEMM_PAIRED_SEGS (bit of `accumulate`)
+PAIR_SEGS = os.environ.get("HYPEL_PAIR_SEGS", "1") != "0"  # short data-gradient segments (k <= 16) share k-tiles
+
+
 class GemmTables:
     """Host-side builder of the (groups, segments, tiles) tables of one hypel_seg_gemm_f32 launch."""
 
@@ -141,7 +146,10 @@ class GemmTables:
         self.keys.append(key)
         self.subkeys.append(subkey)
 
-    def finalize(self, n):
+    def finalize(self, n, pair=False):
+        """pair: consecutive segments of a group with k <= 16 each are marked to share one k-tile (SEG_PAIR_FLAG on
+        the first; the kernel's data-gradient variant for short segments).  self.paired = number of pairs made."""
+        self.paired = 0
         segs = []
         garr = np.zeros(len(self.groups), GROUP_DTYPE)
         tiles = []
@@ -149,9 +157,20 @@ class GemmTables:
         for gi, (c_off, gs, rows) in enumerate(self.groups):
             garr[gi] = (c_off, len(segs), len(gs), rows, 0)
             ksum = 0
+            first = len(segs)
             for (a_off, b_off, k) in gs:
                 segs.append((int(a_off), int(b_off), int(k), 0))
                 ksum += k
+            if pair:
+                i = first
+                while i + 1 < len(segs):
+                    (a0, b0, k0, _), (a1, b1, k1, _) = segs[i], segs[i + 1]
+                    if k0 <= 16 and k1 <= 16 and abs(a0 - a1) * 4 < (1 << 31) and abs(b0 - b1) * 4 < (1 << 31):
+                        segs[i] = (a0, b0, k0 | SEG_PAIR_FLAG, 0)
+                        self.paired += 1
+                        i += 2
+                    else:
+                        i += 1
             macs += rows * ksum * n
             for m0 in range(0, rows, GEMM_BM):
                 key = (self.keys[gi] if self.keys[gi] is not None else m0 // GEMM_BM, self.subkeys[gi])
@@ -166,6 +185,8 @@ class GemmTables:
         for i, (_, g, m0, _) in enumerate(tiles):  # each record repeats what a block needs to start its tile
             c_off, gs, rows = self.groups[g]
             a0, b0, k0 = gs[0] if gs else (0, 0, 0)
+            if gs:
+                a0, b0, k0 = segs[int(garr[g]["seg_begin"])][:3]  # incl. the pair flag
             tarr[i] = (g, m0, rows, garr[g]["seg_begin"], len(gs), k0, c_off, a0, b0)
         return garr, sarr, tarr, macs
 
@@ -391,7 +412,7 @@ class TowerPlan:
         return 1 if blocks64 < 768 else 2
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
-                   allow_split=True, res=None, stats=None, bnbwd=None):
+                   allow_split=True, res=None, stats=None, bnbwd=None, pair=False):
         """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32).
         stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate).
         bnbwd = producer node index whose batch-norm backward reduction rides in this data gradient's epilogue
@@ -409,9 +430,12 @@ class TowerPlan:
             self._scratch(l2, 0, "scratch_wgrad", S * count)
             lst.append(l2)
             return
-        garr, sarr, tarr, macs = tables.finalize(n)
+        pair = bool(pair and PAIR_SEGS and not ta and tb and n > 16 and bnbwd is None and stats is None)
+        garr, sarr, tarr, macs = tables.finalize(n, pair=pair)
         if len(tarr) == 0:
             return
+        if pair and tables.paired:
+            accumulate = int(accumulate) | GEMM_PAIRED_SEGS
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
         hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
@@ -1030,7 +1054,8 @@ class TowerPlan:
                             tb.add_group(gst.pix_off(pin), segs, nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
                                     self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}",
-                                    res=fold_res, bnbwd=self._bnbwd_producer(idx, src, gst, len(by_cout)))
+                                    res=fold_res, bnbwd=self._bnbwd_producer(idx, src, gst, len(by_cout)),
+                                    pair=cout <= 16)
                     fold_res = None
                     acc = 1
             # ---- filter gradient ----

@@ -77,9 +77,17 @@ typedef struct {
     int32_t k0; int64_t c_off; int64_t a_off0; int64_t b_off0; /* c_off copy; segs[seg_begin] copy (0 if none) */
 } hypel_tile_t;
 #define HYPEL_GEMM_BM 128
+/* Short segments (data gradients through convolutions with <= 16 filters: K = 15 in the narrowest HYPELCNN level):
+ * a segment whose `k` has HYPEL_SEG_PAIR_FLAG set (real k = k & ~flag, <= 16) shares ONE 32-column k-tile with the
+ * NEXT segment of its group (k <= 16, flag clear); the tile record's k0 copy carries the flag too.  Launches whose
+ * tables contain such pairs pass HYPEL_GEMM_PAIRED_SEGS in `accumulate` (trans_a = 0, trans_b = 1, n > 16 only; the
+ * two a_off / b_off of a pair must be less than 2 GB apart).  Results do not depend on pairing. */
+#define HYPEL_SEG_PAIR_FLAG 0x40000000
+#define HYPEL_GEMM_PAIRED_SEGS 0x400
 
 /* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint
- * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks) -- results do not depend on it. */
+ * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks, 3 = 128x96 blocks for n > 64) -- results do not
+ * depend on it; bit 10 = HYPEL_GEMM_PAIRED_SEGS. */
 int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb, int32_t trans_b,
                        float* c, int64_t ldc, int32_t n, const hypel_group_t* groups, const hypel_seg_t* segs,
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,

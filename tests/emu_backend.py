@@ -223,7 +223,8 @@ class EmuBackend:
         self.k_col_stats_partial(c + int(grp["c_off"]), ldc, int(grp["rows"]), n, 128, stats)
 
     def k_seg_gemm_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate):
-        accumulate &= 1  # bits 8-9 carry a tile-width hint that must not change the result
+        accumulate_raw = accumulate
+        accumulate &= 1  # bits 8-9 carry a tile-width hint, bit 10 the paired-segments marker: no effect on the result
         A, B, C = _arr(a), _arr(b), _arr(c)
         g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
         s = segs.t.numpy()[segs.off:].view(SEG_DTYPE)
@@ -248,9 +249,16 @@ class EmuBackend:
             grp = g[gi]
             rows = int(grp["rows"])
             acc = np.zeros((rows, n), np.float64)
-            for si in range(int(grp["seg_begin"]), int(grp["seg_begin"]) + int(grp["seg_count"])):
+            s_lo, s_hi = int(grp["seg_begin"]), int(grp["seg_begin"]) + int(grp["seg_count"])
+            for si in range(s_lo, s_hi):
                 sg = s[si]
                 k = int(sg["k"])
+                if k & 0x40000000:  # HYPEL_SEG_PAIR_FLAG: shares a k-tile with the next segment (no effect on the result)
+                    assert (accumulate_raw & 0x400) and not ta and tb and n > 16, "pair flag without HYPEL_GEMM_PAIRED_SEGS"
+                    k &= ~0x40000000
+                    assert k <= 16 and si + 1 < s_hi and 0 < int(s[si + 1]["k"]) <= 16, "malformed segment pair"
+                    assert abs(int(sg["a_off"]) - int(s[si + 1]["a_off"])) * 4 < 2 ** 31
+                    assert abs(int(sg["b_off"]) - int(s[si + 1]["b_off"])) * 4 < 2 ** 31
                 if k == 0:
                     continue
                 ao, bo = int(sg["a_off"]), int(sg["b_off"])

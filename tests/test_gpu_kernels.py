@@ -236,6 +236,50 @@ def test_seg_gemm_bnbwd_epilogue(hip, cin, cout, mapped, acc, act, hint):
     np.testing.assert_allclose(got[1], (dyh * xhat).sum(0), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout,hint,with_res,acc", [(120, 15, 2, True, 0), (120, 15, 1, False, 1), (60, 7, 0, False, 0),
+                                                          (33, 16, 2, True, 1), (240, 9, 1, False, 0)])
+def test_seg_gemm_paired_short_segments(hip, cin, cout, hint, with_res, acc):
+    """Data gradient of a level of four branches with `cout` <= 16 filters each: per input pixel many segments of
+    K = cout; consecutive ones share a k-tile (HYPEL_SEG_PAIR_FLAG).  Odd segment counts, both tile widths, with and
+    without the folded shortcut epilogue, accumulate -- against the specification, and bit-identical to the unpaired
+    launch of the same tables (the k columns are summed in the same order)."""
+    from hypelcnn_amd.plan import GEMM_PAIRED_SEGS
+    rng = np.random.default_rng(cin + cout)
+    nb, P, branches = 130, 5, 4
+    c_total = branches * cout
+    dy = rng.standard_normal(P * nb * c_total).astype(np.float32)
+    w = rng.standard_normal(branches * 3 * cin * cout).astype(np.float32)
+    dz = rng.standard_normal((P * nb, cin)).astype(np.float32)
+    dx0 = rng.standard_normal(P * nb * cin).astype(np.float32)
+    groups = []
+    for p in range(P):
+        segs = []
+        for b_ in range(branches):
+            for t in range(3):
+                q = (p + t + b_) % P
+                if (p + b_ + t) % 5 == 4:
+                    continue  # ragged: some groups get an odd number of segments
+                segs.append((q * nb * c_total + b_ * cout, (b_ * 3 + t) * cin * cout, cout))
+        groups.append((p * nb * cin, segs, nb))
+    outs = []
+    for pair in (True, False):
+        b = Both(hip)
+        tabs = _tables(b, groups)
+        garr, sarr, tarr, _ = tabs.finalize(cin, pair=pair)
+        assert (tabs.paired > 0) == pair
+        for nm, arr in (("dy", dy), ("w", w), ("dz", dz), ("dx", dx0.copy()), ("g", garr), ("s", sarr), ("t", tarr)):
+            b.arr(nm, arr)
+        flags = acc | (hint << 8) | (GEMM_PAIRED_SEGS if pair else 0)
+        if with_res:
+            b.run("seg_gemm_res_f32", "dy", c_total, 0, "w", cout, 1, "dx", cin, cin, "g", "s", "t", len(tarr), None,
+                  flags, "dz", cin, None)
+        else:
+            b.run("seg_gemm_f32", "dy", c_total, 0, "w", cout, 1, "dx", cin, cin, "g", "s", "t", len(tarr), None, flags)
+        b.check("dx", rtol=2e-4, atol=2e-5)
+        outs.append(b.h["dx"].cpu().numpy().copy())
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-5)
+
+
 def test_seg_gemm_multi_products(hip):
     """Three filter-gradient-shaped products (C_p = A_p^T B_p) of different n / ld / split structure in ONE launch per
     tile width, addressed relative to one base pointer across separate allocations, then the merged reduce."""
