@@ -393,8 +393,11 @@ class TowerPlan:
         blocks64 = n_tiles * ((n + 63) // 64)
         if tb and not ta:
             ks = [k for _, segs, _ in tables.groups for _, _, k in segs]
-            if ks and sum(ks) / len(ks) < 48:  # short segments: per-k-tile overhead dominates, keep the wide tile
-                return 2
+            if ks and sum(ks) / len(ks) < 48:
+                # short segments: per-k-tile overhead dominates, keep the wide tile -- unless that leaves the launch
+                # with under ~1000 blocks (the n = 120 data gradient of the 15-filter level: 142 us on 128x32 tiles,
+                # 154 on 128x64, round-2 A/B with paired segments)
+                return 2 if blocks64 >= 1000 else 1
             if folded and blocks64 < 4000:
                 return 1
             return 1 if blocks64 < 900 else 2
