@@ -719,3 +719,60 @@ def test_gan_losses_l2norm_nce(hip):
     b.arr("g0", np.zeros((n, p * e), np.float32))
     b.run("nce_loss", "g0", p * e, "r", p * e, n, p, e, 0.07, 1.0, "loss", 0, None, 0, 0, None, 0, 0, "ws")
     np.testing.assert_allclose(b.h["loss"].cpu().numpy()[0], p * np.log(p * p), rtol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_seg_gemm_random_tables_all_variants(hip, seed):
+    """Randomised tables through every epilogue / staging variant added in round 2 (statistics epilogue, 128x96 tiles,
+    paired short segments, multi-segment groups with ragged rows) against the specification."""
+    from hypelcnn_amd.plan import GEMM_PAIRED_SEGS
+    rng = np.random.default_rng(1000 + seed)
+    mode = ["fwd", "dgrad", "dgrad_pair", "stats"][seed % 4]
+    n = int(rng.choice([17, 30, 60, 96, 120, 145, 192, 240]))
+    hint = int(rng.integers(0, 4))
+    if mode == "stats":
+        rows, k = int(rng.integers(1, 700)), int(rng.integers(1, 300))
+        b = Both(hip)
+        a = rng.standard_normal((rows, k)).astype(np.float32)
+        w = rng.standard_normal((k, n)).astype(np.float32)
+        garr, sarr, tarr, _ = _tables(b, [(0, [(0, 0, k)], rows)]).finalize(n)
+        n_chunks = (rows + 127) // 128
+        for nm, arr in (("a", a), ("w", w), ("y", np.zeros(rows * n, np.float32)), ("g", garr), ("s", sarr), ("t", tarr),
+                        ("part", np.zeros(n_chunks * 2 * n, np.float32))):
+            b.arr(nm, arr)
+        b.run("seg_gemm_stats_f32", "a", k, 0, "w", n, 0, "y", n, n, "g", "s", "t", len(tarr), None, hint << 8, "part")
+        b.check("y", rtol=2e-4, atol=2e-5)
+        b.check("part", rtol=2e-3, atol=5e-4)
+        return
+    tb_ = 0 if mode == "fwd" else 1
+    kmax = 16 if mode == "dgrad_pair" else 200
+    n_groups = int(rng.integers(1, 6))
+    lda = 300
+    ldb = (kmax + 3) if tb_ else (n + 5)
+    ldc = n + int(rng.integers(0, 4))
+    a = rng.standard_normal(4000 * lda).astype(np.float32)
+    bm = rng.standard_normal(900 * ldb).astype(np.float32)
+    groups, c_pos = [], 0
+    for _ in range(n_groups):
+        rows = int(rng.integers(1, 400))
+        segs = []
+        for _ in range(int(rng.integers(0, 7))):
+            k = int(rng.integers(1, kmax + 1))
+            a_off = int(rng.integers(0, 4000 - rows)) * lda + int(rng.integers(0, lda - k))
+            b_off = int(rng.integers(0, 900 - (n if tb_ else k))) * ldb + (int(rng.integers(0, ldb - k)) if tb_ else 0)
+            segs.append((a_off, b_off, k))
+        groups.append((c_pos * ldc, segs, rows))
+        c_pos += rows
+    c0 = rng.standard_normal(c_pos * ldc).astype(np.float32)
+    bias = rng.standard_normal(ldc).astype(np.float32)
+    acc = int(rng.integers(0, 2))
+    b = Both(hip)
+    tabs = _tables(b, groups)
+    pair = mode == "dgrad_pair"
+    garr, sarr, tarr, _ = tabs.finalize(n, pair=pair)
+    for nm, arr in (("a", a), ("b", bm), ("c", c0), ("bias", bias), ("g", garr), ("s", sarr), ("t", tarr)):
+        b.arr(nm, arr)
+    flags = acc | (hint << 8) | (GEMM_PAIRED_SEGS if (pair and tabs.paired) else 0)
+    b.run("seg_gemm_f32", "a", lda, 0, "b", ldb, tb_, "c", ldc, n, "g", "s", "t", len(tarr),
+          "bias" if seed % 3 == 0 else None, flags)
+    b.check("c", rtol=3e-4, atol=3e-5)
