@@ -927,36 +927,54 @@ __device__ __forceinline__ float small_lane_sum(float v, float (*sh)[SMALL_TX + 
 
 // All loads of a thread's rows are issued back to back (one memory round trip instead of rows/TY dependent ones:
 // a single-block-per-stripe kernel is otherwise pure latency) and the values stay in registers for the second phase.
-// Loads are unconditional (clamped row / column, validity applied arithmetically) so that the compiler emits one
-// straight-line burst instead of a guarded branch per element.
+// Raw buffer accesses: the array base sits in a scalar descriptor, a thread holds ONE 32-bit offset per array and the
+// row step is a scalar offset, so the 64-96 loads in flight need no address registers (with 64-bit pointers the kernels
+// spilled 28 / 67 VGPRs to scratch at the 128-register budget of a 1024-thread block).  A column or row outside the
+// tensor is addressed beyond the descriptor's range: the load returns 0 and the store is dropped.
+constexpr uint32_t SMALL_OOB = 0x7fffffffu;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t small_rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7ffffff0, 0x00020000);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void small_load_rows(const float* p, int ld, int rows, int col, bool ok, float (&v)[SMALL_R]) {
+    const int ty = threadIdx.x / SMALL_TX;
+    const __amdgpu_buffer_rsrc_t rs = small_rsrc(p);
+    const uint32_t v0 = ok ? (uint32_t)(ty * ld + col) * 4u : SMALL_OOB;
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        const uint32_t vo = (FULL || ty + i * SMALL_TY < rows) ? v0 : SMALL_OOB;
+        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * SMALL_TY * ld * 4, 0));
+    }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void small_store_rows(float* p, int ld, int rows, int col, bool ok, const float (&v)[SMALL_R]) {
+    const int ty = threadIdx.x / SMALL_TX;
+    const __amdgpu_buffer_rsrc_t rs = small_rsrc(p);
+    const uint32_t v0 = ok ? (uint32_t)(ty * ld + col) * 4u : SMALL_OOB;
+#pragma unroll
+    for (int i = 0; i < SMALL_R; ++i) {
+        const uint32_t vo = (FULL || ty + i * SMALL_TY < rows) ? v0 : SMALL_OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs, vo, i * SMALL_TY * ld * 4, 0);
+    }
+}
+
 template <bool FULL>  // FULL: rows == SMALL_MAX_ROWS, no row guards at all
-__device__ __forceinline__ void bn_act_small_fwd_body(
-    const float* __restrict__ y, int64_t ldy, int rows, int c, float eps, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ mean_out,
+__global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
+    const float* __restrict__ y, int ldy, int rows, int c, float eps, const float* __restrict__ beta, int act,
+    float alpha, const float* __restrict__ mask, int ldm, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay,
-    float* __restrict__ z, int64_t ldz, float (*sh)[SMALL_TX + 1]) {
+    float* __restrict__ z, int ldz) {
+    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
     const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
     const int col = blockIdx.x * SMALL_TX + tx;
     const bool ok = col < c;
     const int colc = ok ? col : c - 1;
     float v[SMALL_R], mk[SMALL_R];
-#pragma unroll
-    for (int i = 0; i < SMALL_R; ++i) {
-        const int r = ty + i * SMALL_TY;
-        const int rc = FULL ? r : min(r, rows - 1);
-        v[i] = y[(int64_t)rc * ldy + colc];
-    }
-    if (mask) {
-#pragma unroll
-        for (int i = 0; i < SMALL_R; ++i) {
-            const int r = ty + i * SMALL_TY;
-            const int rc = FULL ? r : min(r, rows - 1);
-            mk[i] = mask[(int64_t)rc * ldm + colc];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < SMALL_R; ++i) mk[i] = 1.0f;
-    }
+    small_load_rows<FULL>(y, ldy, rows, col, ok, v);
+    if (mask) small_load_rows<FULL>(mask, ldm, rows, col, ok, mk);
     const float shift = y[colc];  // first row: keeps the fp32 sums well conditioned
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
@@ -982,65 +1000,44 @@ __device__ __forceinline__ void bn_act_small_fwd_body(
             moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
         }
     }
-    if (!ok) return;
-    const float be = beta[col];
+    const float be = beta[colc];
     if (act == HYPEL_ACT_LRELU) {  // the common case without the per-element activation switch
 #pragma unroll
         for (int i = 0; i < SMALL_R; ++i) {
             const float p = hypel_bn_pre(hypel_bn_xhat(v[i], mu, rs), be);
-            v[i] = (p > 0.0f ? p : p * alpha) * mk[i];
+            v[i] = p > 0.0f ? p : p * alpha;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < SMALL_R; ++i) v[i] = hypel_act(hypel_bn_pre(hypel_bn_xhat(v[i], mu, rs), be), act, alpha) * mk[i];
+        for (int i = 0; i < SMALL_R; ++i) v[i] = hypel_act(hypel_bn_pre(hypel_bn_xhat(v[i], mu, rs), be), act, alpha);
     }
+    if (mask) {
 #pragma unroll
-    for (int i = 0; i < SMALL_R; ++i) {
-        const int r = ty + i * SMALL_TY;
-        if (FULL || r < rows) z[(int64_t)r * ldz + col] = v[i];
+        for (int i = 0; i < SMALL_R; ++i) v[i] *= mk[i];
     }
-}
-
-__global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
-    const float* __restrict__ y, int64_t ldy, int rows, int c, float eps, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ mean_out,
-    float* __restrict__ rstd_out, float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay,
-    float* __restrict__ z, int64_t ldz) {
-    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
-    if (rows == SMALL_MAX_ROWS)
-        bn_act_small_fwd_body<true>(y, ldy, rows, c, eps, beta, act, alpha, mask, ldm, mean_out, rstd_out,
-                                    moving_mean, moving_var, decay, z, ldz, sh);
-    else
-        bn_act_small_fwd_body<false>(y, ldy, rows, c, eps, beta, act, alpha, mask, ldm, mean_out, rstd_out,
-                                     moving_mean, moving_var, decay, z, ldz, sh);
+    small_store_rows<FULL>(z, ldz, rows, col, ok, v);
 }
 
 template <bool FULL>
-__device__ __forceinline__ void bn_act_small_bwd_body(
-    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int rows, int c,
+__global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ y, int ldy, int rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ dy, int64_t lddy,
-    float* __restrict__ dparam, int accumulate, float (*sh)[SMALL_TX + 1]) {
+    float alpha, const float* __restrict__ mask, int ldm, float* __restrict__ dy, int lddy,
+    float* __restrict__ dparam, int accumulate) {
+    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
     const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
     const int col = blockIdx.x * SMALL_TX + tx;
     const bool ok = col < c;
     const int colc = ok ? col : c - 1;
     float g[SMALL_R], xh[SMALL_R];  // dyh and xhat of this thread's rows
     const float mu = mean[colc], rs = rstd[colc], be = beta[colc];
-#pragma unroll
-    for (int i = 0; i < SMALL_R; ++i) {
-        const int r = ty + i * SMALL_TY;
-        const int rc = FULL ? r : min(r, rows - 1);
-        xh[i] = y[(int64_t)rc * ldy + colc];
-        g[i] = dz[(int64_t)rc * lddz + colc];
-    }
+    small_load_rows<FULL>(y, ldy, rows, col, ok, xh);
+    small_load_rows<FULL>(dz, lddz, rows, col, ok, g);
     if (mask) {
+        float mk[SMALL_R];
+        small_load_rows<FULL>(mask, ldm, rows, col, ok, mk);
 #pragma unroll
-        for (int i = 0; i < SMALL_R; ++i) {
-            const int r = ty + i * SMALL_TY;
-            const int rc = FULL ? r : min(r, rows - 1);
-            g[i] *= mask[(int64_t)rc * ldm + colc];
-        }
+        for (int i = 0; i < SMALL_R; ++i) g[i] *= mk[i];
     }
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
@@ -1054,29 +1051,12 @@ __device__ __forceinline__ void bn_act_small_bwd_body(
     }
     const float t0 = small_lane_sum(s0, sh);
     const float t1 = small_lane_sum(s1, sh);
-    if (!ok) return;
-    if (ty == 0 && dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + t0;
+    if (ok && ty == 0 && dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + t0;
     const float inv_m = 1.0f / (float)rows;
     const float m0 = t0 * inv_m, m1 = t1 * inv_m;
 #pragma unroll
-    for (int i = 0; i < SMALL_R; ++i) {
-        const int r = ty + i * SMALL_TY;
-        if (FULL || r < rows) dy[(int64_t)r * lddy + col] = rs * (g[i] - m0 - xh[i] * m1);
-    }
-}
-
-__global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
-    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int rows, int c,
-    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int64_t ldm, float* __restrict__ dy, int64_t lddy,
-    float* __restrict__ dparam, int accumulate) {
-    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
-    if (rows == SMALL_MAX_ROWS)
-        bn_act_small_bwd_body<true>(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy,
-                                    dparam, accumulate, sh);
-    else
-        bn_act_small_bwd_body<false>(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy,
-                                     dparam, accumulate, sh);
+    for (int i = 0; i < SMALL_R; ++i) g[i] = rs * (g[i] - m0 - xh[i] * m1);
+    small_store_rows<FULL>(dy, lddy, rows, col, ok, g);
 }
 
 // ------------------------------------------------------------------------------------- metrics
@@ -1317,6 +1297,9 @@ extern "C" int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float*
     return 0;
 }
 
+// byte offsets of the small-rows kernels are 32-bit buffer offsets
+static inline bool small_span_ok(int64_t rows, int64_t ld) { return ld > 0 && rows * ld * 4 < 0x7ffffff0ll; }
+
 extern "C" int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, float eps,
                                       const float* beta, int32_t act, float alpha, const float* mask, int64_t ldm,
                                       float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
@@ -1324,9 +1307,15 @@ extern "C" int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows,
     HYPEL_REQUIRE(y && beta && mean && rstd && z && rows > 0 && rows <= SMALL_MAX_ROWS && c > 0,
                   "hypel_bn_act_small_fwd");
     HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_act_small_fwd");
-    hipLaunchKernelGGL(bn_act_small_fwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(1024), 0, ST, y, ldy,
-                       (int)rows, c, eps, beta, act, alpha, mask, ldm, mean, rstd, moving_mean, moving_var, decay, z,
-                       ldz);
+    HYPEL_REQUIRE(small_span_ok(rows, ldy) && small_span_ok(rows, ldz) && (!mask || small_span_ok(rows, ldm)),
+                  "hypel_bn_act_small_fwd");
+    const dim3 grid((c + SMALL_TX - 1) / SMALL_TX);
+    if (rows == SMALL_MAX_ROWS)
+        hipLaunchKernelGGL(bn_act_small_fwd_kernel<true>, grid, dim3(1024), 0, ST, y, (int)ldy, (int)rows, c, eps, beta,
+                           act, alpha, mask, (int)ldm, mean, rstd, moving_mean, moving_var, decay, z, (int)ldz);
+    else
+        hipLaunchKernelGGL(bn_act_small_fwd_kernel<false>, grid, dim3(1024), 0, ST, y, (int)ldy, (int)rows, c, eps, beta,
+                           act, alpha, mask, (int)ldm, mean, rstd, moving_mean, moving_var, decay, z, (int)ldz);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_small_fwd");
     return 0;
 }
@@ -1337,8 +1326,16 @@ extern "C" int hypel_bn_act_small_bwd(const float* dz, int64_t lddz, const float
                                       float* dparam, int32_t accumulate, hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && y && mean && rstd && beta && dy && rows > 0 && rows <= SMALL_MAX_ROWS && c > 0,
                   "hypel_bn_act_small_bwd");
-    hipLaunchKernelGGL(bn_act_small_bwd_kernel, dim3((c + SMALL_TX - 1) / SMALL_TX), dim3(1024), 0, ST, dz, lddz, y,
-                       ldy, (int)rows, c, mean, rstd, beta, act, alpha, mask, ldm, dy, lddy, dparam, accumulate);
+    HYPEL_REQUIRE(small_span_ok(rows, lddz) && small_span_ok(rows, ldy) && small_span_ok(rows, lddy) &&
+                      (!mask || small_span_ok(rows, ldm)),
+                  "hypel_bn_act_small_bwd");
+    const dim3 grid((c + SMALL_TX - 1) / SMALL_TX);
+    if (rows == SMALL_MAX_ROWS)
+        hipLaunchKernelGGL(bn_act_small_bwd_kernel<true>, grid, dim3(1024), 0, ST, dz, (int)lddz, y, (int)ldy, (int)rows,
+                           c, mean, rstd, beta, act, alpha, mask, (int)ldm, dy, (int)lddy, dparam, accumulate);
+    else
+        hipLaunchKernelGGL(bn_act_small_bwd_kernel<false>, grid, dim3(1024), 0, ST, dz, (int)lddz, y, (int)ldy,
+                           (int)rows, c, mean, rstd, beta, act, alpha, mask, (int)ldm, dy, (int)lddy, dparam, accumulate);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_small_bwd");
     return 0;
 }

@@ -37,7 +37,7 @@ tot = sum(o[3] for o in out)
 print("total kernel ns per step", tot, " gemm ns", sum(o[3] for o in out if o[0].startswith('seg_gemm')))
 print(f"{'name':18s} {'tag':34s} {'GFLOP':>8s} {'us':>8s} {'TF/s':>7s} grid")
 for o in out:
-    if o[3] > 20000:
+    if o[3] > 20000 or (len(sys.argv) > 2 and sys.argv[2] == 'all'):
         tf = o[2]/o[3]/1e3 if o[2] else 0
         print(f"{o[0]:18s} {o[1]:34s} {o[2]/1e9:8.2f} {o[3]/1e3:8.1f} {tf:7.1f} {o[4]}")
 bytag = {}
