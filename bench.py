@@ -250,9 +250,14 @@ def main():
                     help="hypelcnn = BASELINE.json headline (configs[1]); the others are extra evidence lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: batch-norm statistics over the global batch (one small RCCL collective per BN layer and "
+                         "direction; default: per-rank statistics)")
     ap.add_argument("--no-input-pipeline", action="store_true",
                     help="skip the second measurement (step fed by the device BatchIterator + augmentation kernel)")
     args = ap.parse_args()
+    if args.sync_bn:
+        os.environ["HYPEL_SYNC_BN"] = "1"  # read by Session.init_data_parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -431,6 +436,8 @@ def main():
                      "hip_graph": ctx.capture_graphs, "loss": loss}
             if in_sync is not None:
                 cfg_d["dp_weights_identical_across_ranks"] = in_sync
+            if world > 1:
+                cfg_d["batch_norm"] = "synchronised (global batch)" if args.sync_bn else "per rank"
             if mac:
                 cfg_d["mfma_ceiling_patches_per_s_per_gpu"] = PEAK_F32_MFMA_TFLOPS * 1e12 / (6 * mac)
             unit = "patches/s"

@@ -77,12 +77,15 @@ SIGNATURES = {
     "bn_act_small_fwd": [_P, _I64, _I64, _I32, _F, _P, _I32, _F, _P, _I64, _P, _P, _P, _P, _F, _P, _I64],
     "bn_act_small_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _I32],
     "bn_finalize": [_P, _I32, _I32, _I64, _I32, _F, _P, _P, _P, _P, _F],
+    "bn_merge_partials": [_P, _I32, _I32, _I64, _I32, _P],
+    "bn_finalize_ranks": [_P, _I32, _I32, _F, _P, _P, _P, _P, _F],
     "rstd_from_var": [_P, _I32, _F, _P],
     "bn_act_fwd": [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64],
     "bn_act_bwd_reduce": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P],
     "bn_act_bwd_sums": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P, _P, _P, _P, _I32],
     "bwd_reduce_finalize": [_P, _I32, _I32, _P, _P, _I32],
     "bn_act_bwd_apply": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _P, _I64],
+    "bn_act_bwd_apply_global": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _I64],
     "chanmap_bwd": [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _I32],
     "softmax_xent": [_P, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _F],
     "mse": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I64, _F, _P],
@@ -143,6 +146,32 @@ def load_library(path=LIB_PATH):
     return lib
 
 
+COLLECTIVES = ("_allreduce", "_allgather")
+
+
+def bind_collective(name, args):
+    """Host-side pseudo-launches of a plan (synchronised batch norm): `_allreduce (ref, count)` sums `count` floats in
+    place over the data-parallel ranks, `_allgather (src, count, dst)` writes every rank's `count` floats to
+    dst[rank * count ...].  torch.distributed orders them with the current stream (RCCL on the GPU box, gloo in the CPU
+    tests); they cannot be captured, so a compiled tower cuts its HIP graphs around them (`host` attribute)."""
+    import torch.distributed as dist
+    if name == "_allreduce":
+        ref, count = args
+
+        def call():
+            dist.all_reduce(ref.t[ref.off:ref.off + count], op=dist.ReduceOp.SUM)
+    else:
+        src, count, dst = args
+
+        def call():
+            world = dist.get_world_size()
+            out = dst.t[dst.off:dst.off + world * count].view(world, count)
+            dist.all_gather(list(out.unbind(0)), src.t[src.off:src.off + count])
+
+    call.host = True
+    return call
+
+
 class HipBackend:
     """Launches hand-written gfx950 kernels through the C-ABI on a torch CUDA(HIP) stream."""
     name = "hip"
@@ -198,6 +227,8 @@ class HipBackend:
 
     # -- launches --
     def bind(self, name, args, stream=None):
+        if name in COLLECTIVES:
+            return bind_collective(name, args)
         if name == "_fork" or name == "_join":
             # _fork (k,): side stream k waits for the main stream; _join (k1, k2, ..): the main stream waits for them
             fn = self.lib.hypel_stream_fork if name == "_fork" else self.lib.hypel_stream_join

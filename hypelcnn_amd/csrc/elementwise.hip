@@ -236,7 +236,7 @@ __device__ __forceinline__ double lanes16_sum(double v, double* sh) {
 // The chunk partials are read in bursts of 16 per lane with clamped (always valid) addresses, so the loads of a
 // burst are all in flight together; a plain `for k` loop made this kernel a chain of ~2 x n_chunks/16 dependent
 // memory round trips (14 us for 256 chunks).
-template <bool COHERENT>
+template <bool COHERENT, bool M2OUT = false>  // M2OUT: `rstd` receives the merged sum of squared deviations instead
 __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks,
                                                  int chunk_rows, int64_t rows, int c, float eps,
                                                  float* __restrict__ mean, float* __restrict__ rstd,
@@ -282,6 +282,13 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
         }
     }
     const double m2_a = lanes16_sum(m2, sh);
+    if (M2OUT) {
+        if (ok && lane == 0) {
+            mean[col] = (float)mean_a;
+            rstd[col] = (float)m2_a;
+        }
+        return;
+    }
     if (ok && lane == 0) {
         const double var = m2_a / n_total;  // biased: what the fused batch norm normalises with
         mean[col] = (float)mean_a;
@@ -302,6 +309,48 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __shared__ double sh[64];
     bn_finalize_body<false>(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, moving_mean,
                             moving_var, decay, sh);
+}
+
+// Synchronised batch norm (data parallel, optional: SURVEY 8e): a rank merges its chunk partials into ONE
+// (mean, M2, rows) record -- out[0..c) mean, out[c..2c) M2, out[2c] = rows -- the records of all ranks are
+// all-gathered and bn_finalize_ranks merges them in rank order, so every rank normalises with the statistics of the
+// GLOBAL batch and holds bit-identical mean / rstd / moving averages.
+__global__ __launch_bounds__(256) void bn_merge_partials_kernel(const float* __restrict__ partial, int n_chunks,
+                                                                 int chunk_rows, int64_t rows, int c,
+                                                                 float* __restrict__ out) {
+    __shared__ double sh[64];
+    bn_finalize_body<false, true>(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, 0.0f, out, out + c, nullptr,
+                                  nullptr, 0.0f, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * c] = (float)rows;
+}
+
+__global__ void bn_finalize_ranks_kernel(const float* __restrict__ gathered, int world, int c, float eps,
+                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                         float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    const int64_t rec = 2 * (int64_t)c + 1;
+    double n_total = 0.0, s = 0.0;
+    for (int k = 0; k < world; ++k) {
+        const double n_k = (double)gathered[k * rec + 2 * c];
+        n_total += n_k;
+        s += n_k * (double)gathered[k * rec + col];
+    }
+    const double mean_a = s / n_total;
+    double m2 = 0.0;
+    for (int k = 0; k < world; ++k) {
+        const double n_k = (double)gathered[k * rec + 2 * c];
+        const double d = (double)gathered[k * rec + col] - mean_a;
+        m2 += (double)gathered[k * rec + c + col] + n_k * d * d;
+    }
+    const double var = m2 / n_total;
+    mean[col] = (float)mean_a;
+    rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
+    if (moving_mean) {
+        const double unbiased = n_total > 1.0 ? m2 / (n_total - 1.0) : var;
+        moving_mean[col] = (float)((double)moving_mean[col] * decay + mean_a * (1.0 - (double)decay));
+        moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
+    }
 }
 
 // Fused statistics: the LAST block of a 64-channel stripe to publish its partials (ticket counter, self-resetting so
@@ -684,8 +733,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, const float* __restrict__ sums, float* __restrict__ dy,
-    int64_t lddy, int tx_log2) {
-    const float inv_m = 1.0f / (float)rows;
+    int64_t lddy, int tx_log2, int64_t stat_rows) {
+    const float inv_m = 1.0f / (float)stat_rows;  // rows the sums run over: `rows`, or the global batch (synchronised BN)
     ew_loop<VEC>(rows, c, tx_log2, [&](int64_t row, int col) {
         Vec<VEC> yv, g;
         yv.load(y + row * ldy + col);
@@ -1227,6 +1276,26 @@ extern "C" int hypel_bn_finalize(const float* partial, int32_t n_chunks, int32_t
     return 0;
 }
 
+extern "C" int hypel_bn_merge_partials(const float* partial, int32_t n_chunks, int32_t chunk_rows, int64_t rows,
+                                       int32_t c, float* out, hypel_stream_t stream) {
+    HYPEL_REQUIRE(partial && out && n_chunks > 0 && c > 0 && rows > 0, "hypel_bn_merge_partials");
+    hipLaunchKernelGGL(bn_merge_partials_kernel, dim3((c + 15) / 16), dim3(256), 0, ST, partial, n_chunks, chunk_rows,
+                       rows, c, out);
+    HYPEL_CHECK_LAUNCH("hypel_bn_merge_partials");
+    return 0;
+}
+
+extern "C" int hypel_bn_finalize_ranks(const float* gathered, int32_t world, int32_t c, float eps, float* mean,
+                                       float* rstd, float* moving_mean, float* moving_var, float decay,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(gathered && mean && rstd && world > 0 && c > 0, "hypel_bn_finalize_ranks");
+    HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_finalize_ranks");
+    hipLaunchKernelGGL(bn_finalize_ranks_kernel, dim3((c + 63) / 64), dim3(64), 0, ST, gathered, world, c, eps, mean,
+                       rstd, moving_mean, moving_var, decay);
+    HYPEL_CHECK_LAUNCH("hypel_bn_finalize_ranks");
+    return 0;
+}
+
 extern "C" int hypel_rstd_from_var(const float* var, int32_t c, float eps, float* rstd, hypel_stream_t stream) {
     HYPEL_REQUIRE(var && rstd && c > 0, "hypel_rstd_from_var");
     hipLaunchKernelGGL(rstd_from_var_kernel, dim3((c + 63) / 64), dim3(64), 0, ST, var, c, eps, rstd);
@@ -1349,23 +1418,40 @@ extern "C" int hypel_bwd_reduce_finalize(const float* partial, int32_t n_chunks,
     return 0;
 }
 
-extern "C" int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
-                                      int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
-                                      float alpha, const float* mask, int64_t ldm, const float* sums, float* dy,
-                                      int64_t lddy, hypel_stream_t stream) {
-    HYPEL_REQUIRE(dz && y && dy && rows > 0 && c > 0, "hypel_bn_act_bwd_apply");
-    HYPEL_REQUIRE(mean == nullptr || sums != nullptr, "hypel_bn_act_bwd_apply");
+static int bn_act_bwd_apply_launch(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                                   const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                                   const float* mask, int64_t ldm, const float* sums, int64_t stat_rows, float* dy,
+                                   int64_t lddy, hypel_stream_t stream, const char* what) {
+    HYPEL_REQUIRE(dz && y && dy && rows > 0 && c > 0 && stat_rows >= rows, what);
+    HYPEL_REQUIRE(mean == nullptr || sums != nullptr, what);
     const bool v4 = (c % 4 == 0) && aligned16(y) && aligned16(dz) && aligned16(dy) && aligned16(mask) &&
                     ldy % 4 == 0 && lddz % 4 == 0 && lddy % 4 == 0 && (!mask || ldm % 4 == 0);
     const EwShape sh = ew_shape(rows, v4 ? c / 4 : c);
     if (v4)
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(sh.grid), dim3(256), 0, ST, dz, lddz, y, ldy, rows, c, mean,
-                           rstd, beta, act, alpha, mask, ldm, sums, dy, lddy, sh.tx_log2);
+                           rstd, beta, act, alpha, mask, ldm, sums, dy, lddy, sh.tx_log2, stat_rows);
     else
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<1>, dim3(sh.grid), dim3(256), 0, ST, dz, lddz, y, ldy, rows, c, mean,
-                           rstd, beta, act, alpha, mask, ldm, sums, dy, lddy, sh.tx_log2);
-    HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_apply");
+                           rstd, beta, act, alpha, mask, ldm, sums, dy, lddy, sh.tx_log2, stat_rows);
+    HYPEL_CHECK_LAUNCH(what);
     return 0;
+}
+
+extern "C" int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                      int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
+                                      float alpha, const float* mask, int64_t ldm, const float* sums, float* dy,
+                                      int64_t lddy, hypel_stream_t stream) {
+    return bn_act_bwd_apply_launch(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, rows, dy,
+                                   lddy, stream, "hypel_bn_act_bwd_apply");
+}
+
+extern "C" int hypel_bn_act_bwd_apply_global(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                             int32_t c, const float* mean, const float* rstd, const float* beta,
+                                             int32_t act, float alpha, const float* mask, int64_t ldm,
+                                             const float* sums, int64_t stat_rows, float* dy, int64_t lddy,
+                                             hypel_stream_t stream) {
+    return bn_act_bwd_apply_launch(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, stat_rows,
+                                   dy, lddy, stream, "hypel_bn_act_bwd_apply_global");
 }
 
 extern "C" int hypel_chanmap_bwd(const float* dz, int64_t lddz, int64_t rows, int32_t c, float* dr, int64_t lddr,

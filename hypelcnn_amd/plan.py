@@ -224,11 +224,19 @@ class GemmTables:
 class TowerPlan:
     """Buffers + launch lists of one tower at one batch size."""
 
-    def __init__(self, tower, nb, session, loss=None, labels_c=None, external_masks=False, seed=1234, global_nb=None):
+    def __init__(self, tower, nb, session, loss=None, labels_c=None, external_masks=False, seed=1234, global_nb=None,
+                 sync_bn=False):
         self.tower = tower
         self.nb = int(nb)
         # data parallel: samples in the GLOBAL batch this rank's nb samples are a shard of (None = nb x world)
         self.global_nb = global_nb
+        # synchronised batch norm (optional, training towers of a data-parallel session): batch statistics and the
+        # two backward sums run over the global batch -- one small all-gather / all-reduce per BN layer and direction
+        dist_ = getattr(session, "dist", None)
+        self.sync_bn = bool(sync_bn) and dist_ is not None and tower.is_training
+        self.world = dist_[0] if dist_ is not None else 1
+        if self.sync_bn and FUSED_STATS:
+            raise RuntimeError("HYPEL_FUSED_STATS and synchronised batch norm exclude each other")
         self.sess = session
         self.be = session.backend
         self.training = tower.is_training
@@ -747,11 +755,7 @@ class TowerPlan:
             elif node.training and aux.get("stats_in_gemm"):
                 # the GEMM left one (mean, M2) pair per 128-row tile: only the finaliser remains
                 n_chunks = (rows + GEMM_BM - 1) // GEMM_BM
-                l2 = Launch("bn_finalize", (None, n_chunks, GEMM_BM, rows, c, float(node.bn_eps),
-                                            self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}"), self._s(aux["mm"]),
-                                            self._s(aux["mv"]), float(node.bn_decay)), tag="bn-finalize")
-                self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
-                self.fwd.append(l2)
+                self._emit_bn_finalize(idx, node, aux, n_chunks, GEMM_BM, rows, c)
                 aux["mean"] = self._ref(f"mean:{idx}")
             elif node.training:
                 chunk = stat_chunk_rows(rows)
@@ -768,11 +772,8 @@ class TowerPlan:
                     l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, chunk, None),
                                 nbytes=4 * rows * c, tag="bn-stats")
                     self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                    l2 = Launch("bn_finalize", (None, n_chunks, chunk, rows, c, float(node.bn_eps), mean_ref, rstd_ref,
-                                                self._s(aux["mm"]), self._s(aux["mv"]), float(node.bn_decay)),
-                                tag="bn-finalize")
-                    self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
-                    self.fwd += [l1, l2]
+                    self.fwd.append(l1)
+                    self._emit_bn_finalize(idx, node, aux, n_chunks, chunk, rows, c)
                 aux["mean"] = self._ref(f"mean:{idx}")
             else:
                 self.fwd.append(Launch("rstd_from_var", (self._s(aux["mv"]), c, float(node.bn_eps),
@@ -788,6 +789,28 @@ class TowerPlan:
             self._emit_post_fwd(idx, node, self._ref(ybuf), c, rows, c, aux, self._ref(zbuf))
         else:
             self.storage[id(out)] = y_st
+
+    def _emit_bn_finalize(self, idx, node, aux, n_chunks, chunk, rows, c):
+        """Chunk partials (in scratch_partial) -> mean / rstd / moving averages.  Synchronised batch norm: the rank's
+        partials are merged into one (mean, M2, rows) record, the records of all ranks are all-gathered (a host-side
+        collective between two graph segments) and merged in rank order."""
+        mean_ref, rstd_ref = self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}")
+        tail = (float(node.bn_eps), mean_ref, rstd_ref, self._s(aux["mm"]), self._s(aux["mv"]), float(node.bn_decay))
+        if not self.sync_bn:
+            l2 = Launch("bn_finalize", (None, n_chunks, chunk, rows, c) + tail, tag="bn-finalize")
+            self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+            self.fwd.append(l2)
+            return
+        rec = 2 * c + 1
+        l2 = Launch("bn_merge_partials", (None, n_chunks, chunk, rows, c, None), tag="bn-sync-merge")
+        self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+        self._scratch(l2, 5, "sbn_local", rec)
+        l3 = Launch("_allgather", (None, rec, None), tag="bn-sync-gather")
+        self._scratch(l3, 0, "sbn_local", rec)
+        self._scratch(l3, 2, "sbn_all", self.world * rec)
+        l4 = Launch("bn_finalize_ranks", (None, self.world, c) + tail, tag="bn-finalize")
+        self._scratch(l4, 0, "sbn_all", self.world * rec)
+        self.fwd += [l2, l3, l4]
 
     def _mask_ref(self, idx, node, rows, c):
         if node.dropout_keep is None:
@@ -821,7 +844,8 @@ class TowerPlan:
     def _small_bn(self, node, rows):
         """Batch norm over a short matrix (the fully-connected tail: rows = batch) with no shortcut to add: one block
         per channel stripe covers every row, so the whole BN + activation is one launch per direction."""
-        return SMALL_BN and rows <= SMALL_BN_ROWS and not node.residuals and node.has_post
+        return (SMALL_BN and rows <= SMALL_BN_ROWS and not node.residuals and node.has_post
+                and not (self.sync_bn and node.has_bn))
 
     def _emit_post_fwd(self, idx, node, y_ref, ldy, rows, c, aux, z_ref):
         has_bn = isinstance(node, G.LinearNode) and node.has_bn
@@ -1147,9 +1171,22 @@ class TowerPlan:
                 self._scratch(l2, 3, "sums", 2 * c)
                 self.bwd += [l1, l2]
             sums = "pending"
+        sync = self.sync_bn and has_bn and node.training and sums is not None
+        if sync:
+            # sum(dyh), sum(dyh * xhat) over the GLOBAL batch (the parameter gradient above stays the local sum: it
+            # travels in the flat gradient all-reduce)
+            lc = Launch("_allreduce", (None, 2 * c), tag="bn-sync-reduce")
+            self._scratch(lc, 0, "sums", 2 * c)
+            self.bwd.append(lc)
         if dy is not None and (has_bn or code != 0 or mask is not None):
-            l3 = Launch("bn_act_bwd_apply", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c, None, dy,
-                                             c), nbytes=12 * rows * c, tag="post-bwd-apply")
+            if sync:
+                stat_rows = rows // self.nb * (self.global_nb if self.global_nb is not None else self.nb * self.world)
+                l3 = Launch("bn_act_bwd_apply_global", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
+                                                        None, int(stat_rows), dy, c), nbytes=12 * rows * c,
+                            tag="post-bwd-apply")
+            else:
+                l3 = Launch("bn_act_bwd_apply", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c, None,
+                                                 dy, c), nbytes=12 * rows * c, tag="post-bwd-apply")
             if sums is not None:
                 self._scratch(l3, 13, "sums", 2 * c)
             self.bwd.append(l3)

@@ -32,7 +32,7 @@ class CompiledTower:
         """The same step with every launch on the main stream (no fork/join): per-kernel timing needs kernels that
         do not overlap."""
         return [(l, self.be.bind(l.name, l.args, 0)) for l in self.plan.fwd + self.plan.bwd
-                if l.name not in ("_fork", "_join")]
+                if not l.name.startswith("_")]
 
     # ---- inputs / outputs ----
     def input(self, name):
@@ -70,54 +70,82 @@ class CompiledTower:
         return self.plan.buffers[self.plan.mask_bufs[index]]
 
     # ---- execution ----
+    def _items(self, with_bwd):
+        """The step as a list of ("run", [launches]) | ("host", call) | ("hook", k): runs are what a HIP graph can hold;
+        host calls (collectives of synchronised batch norm) and the data-parallel sync points sit between them."""
+        cuts = {i: k for k, (i, _, _) in enumerate(self.sync_points)} if with_bwd else {}
+        items, cur = [], []
+
+        def flush():
+            if cur:
+                items.append(("run", list(cur)))
+                cur.clear()
+
+        def add(f):
+            if getattr(f, "host", False):
+                flush()
+                items.append(("host", f))
+            else:
+                cur.append(f)
+
+        for f in self.fwd:
+            add(f)
+        if with_bwd:
+            for j, f in enumerate(self.bwd):
+                if j in cuts:
+                    flush()
+                    items.append(("hook", cuts[j]))
+                add(f)
+        flush()
+        return items
+
+    @staticmethod
+    def _run_items(items, hook=None):
+        for kind, v in items:
+            if kind == "run":
+                if callable(v):
+                    v()
+                else:
+                    for f in v:
+                        f()
+            elif kind == "host":
+                v()
+            elif hook is not None:
+                hook(v)
+
     def forward(self):
         if self._graph_fwd is not None:
             self._graph_fwd()
         else:
-            for f in self.fwd:
-                f()
-
-    def _segment_lists(self):
-        cuts = [i for i, _, _ in self.sync_points] + [len(self.bwd)]
-        out, start = [], 0
-        for k, c in enumerate(cuts):
-            out.append((self.fwd if k == 0 else []) + self.bwd[start:c])
-            start = c
-        return out
+            self._run_items(self._items(False))
 
     def forward_backward(self, hook=None):
         """hook(k): called on the host right after the launches up to sync point k were issued (data-parallel
         overlap: the session starts the all-reduce of the gradient range that is final at that point)."""
-        if not self.sync_points:
-            if self._graph_all is not None:
-                self._graph_all()
-            else:
-                for f in self.fwd:
-                    f()
-                for f in self.bwd:
-                    f()
-            return
-        segs = self._segments if self._segments is not None else self._segment_lists()
-        for k, seg in enumerate(segs):
-            if callable(seg):
-                seg()
-            else:
-                for f in seg:
-                    f()
-            if hook is not None and k < len(self.sync_points):
-                hook(k)
+        if self._segments is not None:
+            self._run_items(self._segments, hook)
+        elif self._graph_all is not None:
+            self._graph_all()
+        else:
+            self._run_items(self._items(True), hook)
 
     def capture(self):
-        """Capture forward (+ backward) into HIP graphs: one host call per step instead of ~300."""
+        """Capture forward (+ backward) into HIP graphs: one host call per step instead of ~300.  A step with sync
+        points or host-side collectives becomes a chain of graphs with those calls in between."""
         self.forward_backward() if self.bwd else self.forward()  # warm: first-use allocations / lazy module loads
         self.be.synchronize()
-        if self.bwd and self.sync_points:
-            self._segments = [self.be.capture(seg) for seg in self._segment_lists()]
-            self._graph_all = self._segments[0]  # "captured" marker for callers
+        items = self._items(bool(self.bwd))
+        graphs = [(kind, self.be.capture(v) if kind == "run" else v) for kind, v in items]
+        if len(graphs) == 1 and graphs[0][0] == "run":
+            if self.bwd:
+                self._graph_all = graphs[0][1]
+            else:
+                self._graph_fwd = graphs[0][1]
         elif self.bwd:
-            self._graph_all = self.be.capture(self.fwd + self.bwd)
+            self._segments = graphs
+            self._graph_all = graphs[0][1]  # "captured" marker for callers
         else:
-            self._graph_fwd = self.be.capture(self.fwd)
+            self._graph_fwd = lambda: self._run_items(graphs)
 
     def loss_value(self):
         b = self.plan.buffers
@@ -145,6 +173,7 @@ class Session:
         self._compiled = {}
         self.shared_inputs = {}  # (name, rows, c) -> device buffer shared by every GAN phase plan
         self.dist = None  # (world_size, rank) once init_data_parallel() ran
+        self.sync_bn = False
 
     # ---- variables ----
     def finalize_variables(self, rng=None):
@@ -244,15 +273,17 @@ class Session:
             self.slot_v.copy_(torch.from_numpy(np.asarray(d["training_optimizer/v"], np.float32)))
 
     # ---- towers ----
-    def compile(self, tower, nb, loss=None, external_masks=False, global_nb=None):
-        """global_nb: size of the global batch `nb` is this rank's shard of (data parallel; None = nb x world)."""
+    def compile(self, tower, nb, loss=None, external_masks=False, global_nb=None, sync_bn=None):
+        """global_nb: size of the global batch `nb` is this rank's shard of (data parallel; None = nb x world).
+        sync_bn: batch-norm statistics over the global batch (None = the session's `sync_bn`, see init_data_parallel)."""
         if self.dist is None or (global_nb is not None and int(global_nb) == int(nb) * self.dist[0]):
             global_nb = None
-        key = (id(tower), int(nb), id(loss), external_masks, global_nb)
+        sync_bn = bool(self.sync_bn if sync_bn is None else sync_bn) and self.dist is not None
+        key = (id(tower), int(nb), id(loss), external_masks, global_nb, sync_bn)
         ct = self._compiled.get(key)
         if ct is None:
             plan = TowerPlan(tower, nb, self, loss=loss, external_masks=external_masks, seed=self._rank_seed(),
-                             global_nb=global_nb)
+                             global_nb=global_nb, sync_bn=sync_bn)
             ct = CompiledTower(plan, self.backend)
             self._compiled[key] = ct
         return ct
@@ -348,9 +379,13 @@ class Session:
         return None
 
     # ---- data parallel (new vs the reference: SURVEY §2.3 / §8e) ----
-    def init_data_parallel(self, broadcast=True):
+    def init_data_parallel(self, broadcast=True, sync_bn=None):
+        """sync_bn (None = environment HYPEL_SYNC_BN=1): training towers compiled from now on normalise with the
+        statistics of the GLOBAL batch, which makes N ranks x nb samples equal one device at N x nb samples (the
+        reference's single-device semantics); costs one small collective per BN layer and direction."""
         import torch.distributed as dist
         import os
+        self.sync_bn = (os.environ.get("HYPEL_SYNC_BN") == "1") if sync_bn is None else bool(sync_bn)
         selftest = os.environ.get("HYPEL_DP_SELFTEST") == "1"  # keep the collectives on a 1-rank communicator
         if not dist.is_initialized() or (dist.get_world_size() == 1 and not selftest):
             self.dist = None

@@ -173,6 +173,15 @@ int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows, int32_t c,
 int hypel_bn_finalize(const float* partial, int32_t n_chunks, int32_t chunk_rows, int64_t rows, int32_t c, float eps,
                       float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
                       hypel_stream_t stream);
+/* Synchronised batch norm across data-parallel ranks (optional; the reference is single-device, so this is what makes
+ * N ranks x nb equal the reference's one device at batch N x nb -- tf_slim.batch_norm, HYPELCNNModel.py:37,43):
+ * a rank merges its chunk partials into one record out[0..c) = mean, out[c..2c) = sum of squared deviations,
+ * out[2c] = rows; the host all-gathers the records (RCCL); hypel_bn_finalize_ranks merges `world` records
+ * ([world][2c+1], rank order, fp64) into mean / rstd / moving averages -- identical on every rank. */
+int hypel_bn_merge_partials(const float* partial, int32_t n_chunks, int32_t chunk_rows, int64_t rows, int32_t c,
+                            float* out, hypel_stream_t stream);
+int hypel_bn_finalize_ranks(const float* gathered, int32_t world, int32_t c, float eps, float* mean, float* rstd,
+                            float* moving_mean, float* moving_var, float decay, hypel_stream_t stream);
 /* hypel_col_stats_partial + hypel_bn_finalize in ONE launch: the last block of each 64-channel stripe to publish
  * its partials (ticket in counters[ceil(c/64)], int32, zero before the first call; the finishing block resets it,
  * so a HIP-graph replay needs no memset) merges that stripe's partials in the same fixed chunk order. */
@@ -222,6 +231,12 @@ int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float* y, int64_
                            const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
                            const float* mask, int64_t ldm, const float* sums, float* dy, int64_t lddy,
                            hypel_stream_t stream);
+/* the same with M = stat_rows >= rows: the sums were all-reduced over the data-parallel ranks and run over the global
+ * batch (synchronised batch norm, see hypel_bn_merge_partials). */
+int hypel_bn_act_bwd_apply_global(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                                  const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                                  const float* mask, int64_t ldm, const float* sums, int64_t stat_rows, float* dy,
+                                  int64_t lddy, hypel_stream_t stream);
 /* gradient of the channel map: dr[row][ci] (+)= sum_{c in [start[ci], start[ci+1])} dz[row][c];
  * start NULL -> identity (cin == c). */
 int hypel_chanmap_bwd(const float* dz, int64_t lddz, int64_t rows, int32_t c, float* dr, int64_t lddr, int32_t cin,

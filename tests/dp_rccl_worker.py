@@ -42,7 +42,8 @@ def main():
     assert torch.equal(sess.grads, g_plain), "eager exchange changed the gradients"
     U.inject(sess, params)
     ct.capture()  # one HIP graph per segment
-    assert ct._segments is not None and len(ct._segments) == len(ct.sync_points) + 1
+    assert ct._segments is not None
+    assert sum(1 for kind, _ in ct._segments if kind == "run") == len(ct.sync_points) + 1
     U.inject(sess, params)
     calls = []
     orig = dist.all_reduce
@@ -56,7 +57,27 @@ def main():
     sess.adam_step(3e-4)
     torch.cuda.synchronize()
     assert not torch.equal(sess.params, p0) and sess.nonfinite_step(sync=True) is None
-    print(f"DP_RCCL_SELFTEST_OK buckets={calls}")
+    # synchronised batch norm: the statistics travel through RCCL (all-gather of the per-rank records in the forward
+    # pass, all-reduce of the two backward sums) between the graph segments; on one rank the global batch IS the local
+    # one, so the step must reproduce the plain gradients up to the different merge arithmetic
+    U.inject(sess, params)
+    ct_s = sess.compile(built.train_tower, nb, loss=built.train_step.loss, external_masks=True, sync_bn=True)
+    assert ct_s is not ct and ct_s.plan.sync_bn
+    n_coll = sum(1 for l in ct_s.plan.fwd + ct_s.plan.bwd if l.name in ("_allgather", "_allreduce"))
+    assert n_coll >= 2
+    U.feed(ct_s, x, onehot, masks)
+    sess.train_step_exchange(ct_s)
+    torch.cuda.synchronize()
+    g_eager = sess.grads.clone()
+    # against the float64 oracle (the plain step is no yardstick here: the two paths round the statistics differently,
+    # and one leaky-ReLU kink decision of 250 000 flipping moves a dense-layer gradient by percents)
+    U.compare_step(built, ct_s, params, x, onehot, masks, "HYPELCNNModel", classes, alg, tol_logit=1e-4, tol_grad=5e-4)
+    ct_s.capture()
+    assert sum(1 for kind, _ in ct_s._segments if kind == "host") == n_coll
+    sess.train_step_exchange(ct_s)
+    torch.cuda.synchronize()
+    assert torch.equal(sess.grads, g_eager), "graph segments around the BN collectives changed the gradients"
+    print(f"DP_RCCL_SELFTEST_OK buckets={calls} sync_bn_collectives={n_coll}")
     dist.destroy_process_group()
 
 

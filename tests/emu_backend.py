@@ -10,7 +10,8 @@ import torch
 
 import ctypes
 
-from hypelcnn_amd.backend import GROUP_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
+from hypelcnn_amd.backend import (COLLECTIVES, GROUP_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref,
+                                  bind_collective)
 
 
 def _arr(ref, dtype=np.float32):
@@ -86,6 +87,8 @@ class EmuBackend:
     def bind(self, name, args, stream=None):
         if name in ("_fork", "_join"):
             return lambda: None
+        if name in COLLECTIVES:
+            return bind_collective(name, args)
         fn = getattr(self, "k_" + name)
         return lambda: fn(*args)
 
@@ -414,6 +417,29 @@ class EmuBackend:
             mmv[...] = mmv * np.float64(decay) + mean_a * (1 - np.float64(decay))
             mvv[...] = mvv * np.float64(decay) + unb * (1 - np.float64(decay))
 
+    def k_bn_merge_partials(self, partial, n_chunks, chunk_rows, rows, c, out):
+        po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c).astype(np.float64)
+        n_k = np.array([min(rows, (k + 1) * chunk_rows) - k * chunk_rows for k in range(n_chunks)], np.float64)
+        mean_a = (n_k[:, None] * po[:, 0]).sum(0) / rows
+        m2_a = (po[:, 1] + n_k[:, None] * (po[:, 0] - mean_a) ** 2).sum(0)
+        o = _arr(out)
+        o[:c], o[c:2 * c], o[2 * c] = mean_a, m2_a, rows
+
+    def k_bn_finalize_ranks(self, gathered, world, c, eps, mean, rstd, mm, mv, decay):
+        g = _arr(gathered)[: world * (2 * c + 1)].reshape(world, 2 * c + 1).astype(np.float64)
+        n_k = g[:, 2 * c]
+        n_a = n_k.sum()
+        mean_a = (n_k[:, None] * g[:, :c]).sum(0) / n_a
+        m2_a = (g[:, c:2 * c] + n_k[:, None] * (g[:, :c] - mean_a) ** 2).sum(0)
+        var = m2_a / n_a
+        _arr(mean)[:c] = mean_a
+        _arr(rstd)[:c] = 1.0 / np.sqrt(var + eps)
+        if mm is not None:
+            unb = m2_a / (n_a - 1) if n_a > 1 else var
+            mmv, mvv = _arr(mm)[:c], _arr(mv)[:c]
+            mmv[...] = mmv * np.float64(decay) + mean_a * (1 - np.float64(decay))
+            mvv[...] = mvv * np.float64(decay) + unb * (1 - np.float64(decay))
+
     def k_rstd_from_var(self, var, c, eps, rstd):
         _arr(rstd)[:c] = 1.0 / np.sqrt(_arr(var)[:c].astype(np.float64) + eps)
 
@@ -466,11 +492,17 @@ class EmuBackend:
             d[...] = (d if accumulate else 0) + s[0]
 
     def k_bn_act_bwd_apply(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, dy, lddy):
+        self.k_bn_act_bwd_apply_global(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, rows,
+                                       dy, lddy)
+
+    def k_bn_act_bwd_apply_global(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums,
+                                  stat_rows, dy, lddy):
+        assert stat_rows >= rows
         dyh, xhat = self._dyh(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm)
         g = dyh
         if mean is not None:
             s = _arr(sums)[: 2 * c].astype(np.float64).reshape(2, c)
-            g = _arr(rstd)[:c] * (dyh - s[0] / rows - xhat * s[1] / rows)
+            g = _arr(rstd)[:c] * (dyh - s[0] / stat_rows - xhat * s[1] / stat_rows)
         _mat(dy, lddy, rows, c)[...] = g.astype(np.float32)
 
     def k_chanmap_bwd(self, dz, lddz, rows, c, dr, lddr, cin, start, accumulate):

@@ -79,9 +79,15 @@ def make_masks(built, nb, rng):
 
 
 def run_train_step(built, x, onehot, masks):
-    sess = built.ctx.session()
-    nb = x.shape[0]
-    ct = built.train_step.compiled(nb)
+    built.ctx.session()
+    ct = built.train_step.compiled(x.shape[0])
+    feed(ct, x, onehot, masks)
+    ct.forward_backward()
+    return ct
+
+
+def feed(ct, x, onehot, masks):
+    """Inputs and external dropout masks of one step into a compiled training tower."""
     dev = ct.input("x").device
     ct.set_input("x", torch.as_tensor(x, dtype=torch.float32).to(dev))
     ct.set_input("labels", torch.as_tensor(onehot, dtype=torch.float32).to(dev))
@@ -89,8 +95,6 @@ def run_train_step(built, x, onehot, masks):
         idx = int(key.split("_")[1])
         buf = ct.dropout_mask(idx)
         buf.copy_(torch.as_tensor(np.ascontiguousarray(to_pixel_major(m)).reshape(-1), dtype=torch.float32).to(dev))
-    ct.forward_backward()
-    return ct
 
 
 def compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg, tol_logit=1e-3, tol_grad=2e-3,

@@ -174,3 +174,76 @@ def test_two_rank_iterator_shards_are_disjoint_and_complete(tmp_path):
     assert torch.equal(r0["conf"], r1["conf"]) and int(r0["conf"].sum()) == 23
     assert r0["tails"][17] == r1["tails"][17] == [(4, 8), (4, 8)], "a 1-sample tail is dropped on both ranks"
     assert r0["tails"][19] == [(4, 8), (4, 8), (2, 3)] and r1["tails"][19] == [(4, 8), (4, 8), (1, 3)]
+
+
+def _syncbn_case():
+    """Global batch of 8 (HYPELCNN toy), fixed parameters and dropout masks: what one device computes."""
+    from tests import parity_util as U
+    rng = np.random.default_rng(2024)
+    params = U.make_params("HYPELCNNModel", 5, 9, 4, ALG, rng)
+    x = rng.random((8, 5, 5, 9)).astype(np.float32)
+    onehot = np.eye(4, dtype=np.float32)[rng.integers(0, 4, 8)]
+    return params, x, onehot, rng
+
+
+def _syncbn_worker(rank, world, port, outdir, split):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import parity_util as U
+    from tests.emu_backend import EmuBackend
+    built = U.build("HYPELCNNModel", 5, 9, 4, ALG, EmuBackend(), with_eval=False)
+    sess = built.ctx.session()
+    params, x, onehot, rng = _syncbn_case()
+    U.inject(sess, params)
+    masks = U.make_masks(built, 8, rng)
+    lo, hi = (0, split) if rank == 0 else (split, 8)
+    ct = sess.compile(built.train_tower, hi - lo, loss=built.train_step.loss, external_masks=True, global_nb=8,
+                      sync_bn=True)
+    assert ct.plan.sync_bn and not any(l.name.startswith("bn_act_small") for l in ct.plan.fwd + ct.plan.bwd)
+    U.feed(ct, x[lo:hi], onehot[lo:hi], {k: m[lo:hi] for k, m in masks.items()})
+    state0 = sess.state.clone()
+    sess.train_step_exchange(ct)
+    out = {"grads": sess.grads.clone(), "state": sess.state.clone(), "logits": ct.value(built.y_conv).clone(),
+           "loss": ct.loss_value()}
+    # the same shard WITHOUT synchronisation normalises with local statistics: a different result
+    sess.state.copy_(state0)
+    ct_l = sess.compile(built.train_tower, hi - lo, loss=built.train_step.loss, external_masks=True, global_nb=8,
+                        sync_bn=False)
+    assert ct_l is not ct
+    U.feed(ct_l, x[lo:hi], onehot[lo:hi], {k: m[lo:hi] for k, m in masks.items()})
+    sess.train_step_exchange(ct_l)
+    out["grads_local_bn"] = sess.grads.clone()
+    torch.save(out, os.path.join(outdir, f"sbn{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("split", [4, 5])   # equal shards, ragged shards (5 + 3)
+def test_two_rank_sync_batch_norm_equals_one_device_at_the_global_batch(tmp_path, split):
+    """SURVEY 8e (optional row): with synchronised batch norm two ranks holding 4+4 (or 5+3) samples compute what the
+    reference's single device computes on all 8 -- logits, loss, gradients and the moving averages."""
+    port = _free_port()
+    mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path), split), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "sbn0.pt"), torch.load(tmp_path / "sbn1.pt")
+    sys.path.insert(0, ROOT)
+    from tests import parity_util as U
+    from tests.emu_backend import EmuBackend
+    built = U.build("HYPELCNNModel", 5, 9, 4, ALG, EmuBackend(), with_eval=False)
+    sess = built.ctx.session()
+    assert sess.dist is None
+    params, x, onehot, rng = _syncbn_case()
+    U.inject(sess, params)
+    masks = U.make_masks(built, 8, rng)
+    ct = U.run_train_step(built, x, onehot, masks)
+    g = sess.grads[:sess.n_train]
+    scale = float(g.abs().max())
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["state"], r1["state"])
+    torch.testing.assert_close(r0["grads"][:sess.n_train], g, rtol=1e-4, atol=2e-6 * scale)
+    torch.testing.assert_close(r0["state"], sess.state, rtol=1e-5, atol=1e-6)
+    logits = ct.value(built.y_conv)
+    torch.testing.assert_close(torch.cat([r0["logits"], r1["logits"]]), logits, rtol=1e-4, atol=1e-5)
+    assert abs((r0["loss"] * split + r1["loss"] * (8 - split)) / 8 - ct.loss_value()) < 1e-5
+    # local statistics on 3-5 samples are a different model: the check above is not vacuous
+    assert float((r0["grads_local_bn"][:sess.n_train] - g).abs().max()) > 1e-2 * scale

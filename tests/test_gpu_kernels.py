@@ -776,3 +776,45 @@ def test_seg_gemm_random_tables_all_variants(hip, seed):
     b.run("seg_gemm_f32", "a", lda, 0, "b", ldb, tb_, "c", ldc, n, "g", "s", "t", len(tarr),
           "bias" if seed % 3 == 0 else None, flags)
     b.check("c", rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("rows,c,world", [(1000, 120, 1), (777, 45, 3), (128, 480, 8)])
+def test_sync_bn_kernels_match_the_global_statistics(hip, rows, c, world):
+    """hypel_bn_merge_partials (a rank's chunk partials -> one (mean, M2, rows) record) and hypel_bn_finalize_ranks
+    (records of all ranks -> mean / rstd / moving averages) against the emulation and the definition on the
+    concatenated rows; hypel_bn_act_bwd_apply_global against the emulation."""
+    rng = np.random.default_rng(rows + world)
+    chunk = 128
+    nch = (rows + chunk - 1) // chunk
+    xs = [(rng.standard_normal((rows - 7 * r, c)) * (rng.random(c) * 3 + 0.1) + rng.standard_normal(c) * 5 + r).astype(np.float32)
+          for r in range(world)]
+    b = Both(hip)
+    rec = 2 * c + 1
+    b.arr("all", np.zeros(world * rec, np.float32))
+    for r, x in enumerate(xs):
+        rr = x.shape[0]
+        nch_r = (rr + chunk - 1) // chunk
+        b.arr(f"x{r}", x)
+        b.arr(f"part{r}", np.zeros(nch * 2 * c, np.float32))
+        b.run("col_stats_partial", f"x{r}", c, rr, c, chunk, f"part{r}")
+        b.run("bn_merge_partials", f"part{r}", nch_r, chunk, rr, c, ("all", r * rec))
+    b.check("all", rtol=1e-4, atol=1e-4)
+    for nm in ("mean", "rstd"):
+        b.arr(nm, np.zeros(c, np.float32))
+    b.arr("mm", rng.standard_normal(c).astype(np.float32))
+    b.arr("mv", (rng.random(c) + 0.5).astype(np.float32))
+    b.run("bn_finalize_ranks", "all", world, c, 1e-3, "mean", "rstd", "mm", "mv", 0.95)
+    for nm in ("mean", "rstd", "mm", "mv"):
+        b.check(nm, rtol=1e-5, atol=1e-6)
+    x64 = np.concatenate(xs).astype(np.float64)
+    np.testing.assert_allclose(b.h["mean"].cpu().numpy(), x64.mean(0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b.h["rstd"].cpu().numpy(), 1 / np.sqrt(x64.var(0) + 1e-3), rtol=1e-5)
+    # backward apply with the statistic row count of the global batch
+    r0 = xs[0].shape[0]
+    b.arr("dz", rng.standard_normal((r0, c)).astype(np.float32))
+    b.arr("beta", rng.standard_normal(c).astype(np.float32) * 0.1)
+    b.arr("sums", rng.standard_normal(2 * c).astype(np.float32) * 10)
+    b.arr("dy", np.zeros(r0 * c, np.float32))
+    b.run("bn_act_bwd_apply_global", "dz", c, "x0", c, r0, c, "mean", "rstd", "beta", 1, 0.18, None, c, "sums",
+          int(x64.shape[0]), "dy", c)
+    b.check("dy", rtol=1e-4, atol=1e-5)
