@@ -222,3 +222,106 @@ def test_feature_discriminator_ragged_slices():
     assert ps == 10 and len(sl) == 7 and sl[-1] == (60, 64)
     t = M.feature_discriminator_layer_table(64, 6, 2)
     assert sum(ci * co + co for _, ci, co in t) == 1053
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Third-party pins.  TensorFlow cannot run here, so the three TF conventions that SURVEY Appendix A states in prose are
+# additionally checked against PyTorch's OWN operators (not the torch restatement in oracle/torch_ref.py): an
+# independent implementation of the same published semantics.
+
+@pytest.mark.parametrize("k", [2, 4, 6, 3])
+def test_even_kernel_same_padding_matches_torch_conv2d_same(k):
+    """TF SAME, stride 1: pad_before = (k-1)//2, the extra pixel of an even kernel goes to the bottom / right.  PyTorch's
+    conv2d(padding='same') documents the same rule (total = k-1, left = total//2, the remainder right)."""
+    rng = np.random.RandomState(10 + k)
+    x = rng.randn(2, 6, 7, 3)
+    w = rng.randn(k, k, 3, 4)
+    b = rng.randn(4)
+    xv, wv, bv = O.Var(x), O.Var(w), O.Var(b)
+    y = O.conv2d_same(xv, wv, bv)
+    xt = torch.tensor(x).permute(0, 3, 1, 2).requires_grad_()
+    wt = torch.tensor(w).permute(3, 2, 0, 1).requires_grad_()
+    bt = torch.tensor(b, requires_grad=True)
+    yt = torch.nn.functional.conv2d(xt, wt, bt, padding="same")
+    np.testing.assert_allclose(y.v, yt.permute(0, 2, 3, 1).detach().numpy(), rtol=1e-12, atol=1e-12)
+    seed = rng.randn(*y.v.shape)
+    O.backward(y, seed)
+    yt.backward(torch.tensor(seed).permute(0, 3, 1, 2))
+    np.testing.assert_allclose(xv.g, xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(wv.g, wt.grad.permute(2, 3, 1, 0).numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(bv.g, bt.grad.numpy(), rtol=1e-11, atol=1e-11)
+
+
+def test_batch_norm_moments_and_bessel_correction_match_torch_batch_norm():
+    """Fused batch norm: normalise with the BIASED batch variance, feed the moving variance the UNBIASED one
+    (N/(N-1)), moving <- moving*decay + batch*(1-decay).  torch.nn.functional.batch_norm(training=True) implements the
+    same three conventions with momentum = 1 - decay."""
+    rng = np.random.RandomState(3)
+    x = rng.randn(5, 3, 3, 6) * 2 + 1
+    beta = rng.randn(6)
+    decay, eps = 0.95, 1e-3
+    mm0, mv0 = rng.randn(6), rng.rand(6) + 0.5
+    xv, bv = O.Var(x), O.Var(beta)
+    y, mean, var, m = O.batch_norm_train(xv, bv, eps=eps)
+    mm1 = O.moving_average_update(mm0, mean, decay)
+    mv1 = O.moving_average_update(mv0, var * m / (m - 1), decay)
+    xt = torch.tensor(x).permute(0, 3, 1, 2).requires_grad_()
+    bt = torch.tensor(beta, requires_grad=True)
+    rm, rv = torch.tensor(mm0.copy()), torch.tensor(mv0.copy())
+    yt = torch.nn.functional.batch_norm(xt, rm, rv, weight=None, bias=bt, training=True, momentum=1 - decay, eps=eps)
+    np.testing.assert_allclose(y.v, yt.permute(0, 2, 3, 1).detach().numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(mm1, rm.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mv1, rv.numpy(), rtol=1e-12, atol=1e-12)
+    seed = rng.randn(*x.shape)
+    O.backward(y, seed)
+    yt.backward(torch.tensor(seed).permute(0, 3, 1, 2))
+    np.testing.assert_allclose(xv.g, xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(bv.g, bt.grad.numpy(), rtol=1e-11, atol=1e-11)
+    # inference mode uses the moving statistics as they are
+    yi = O.batch_norm_infer(O.Var(x), O.Var(beta), mm1, mv1, eps=eps)
+    yti = torch.nn.functional.batch_norm(torch.tensor(x).permute(0, 3, 1, 2), rm, rv, None, torch.tensor(beta), False,
+                                         0.0, eps)
+    np.testing.assert_allclose(yi.v, yti.permute(0, 2, 3, 1).numpy(), rtol=1e-11, atol=1e-11)
+
+
+def test_tf1_adam_epsilon_placement_against_torch_adam():
+    """TF1 Adam (Kingma & Ba section 2's "epsilon hat" form, the docstring of tf.compat.v1.train.AdamOptimizer):
+    theta -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps).  torch.optim.Adam puts eps next to the bias-CORRECTED
+    sqrt: theta -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps') -- the same update iff eps' = eps / sqrt(1-b2^t).
+    Driving torch's own optimiser with that per-step eps must reproduce the oracle's trajectory; with the constant
+    eps (the naive port) it must not, for gradients as small as eps."""
+    rng = np.random.RandomState(8)
+    g_seq = [rng.randn(7) * 10.0 ** rng.uniform(-9, 0, 7) for _ in range(6)]
+    lr, b1, b2, eps = 3e-4, 0.9, 0.999, 1e-8
+    p, m, v = rng.randn(7), np.zeros(7), np.zeros(7)
+    pt = torch.tensor(p.copy(), requires_grad=True)
+    pn = torch.tensor(p.copy(), requires_grad=True)
+    opt = torch.optim.Adam([pt], lr=lr, betas=(b1, b2), eps=eps)
+    naive = torch.optim.Adam([pn], lr=lr, betas=(b1, b2), eps=eps)
+    for t, g in enumerate(g_seq, start=1):
+        T.adam_tf1_step(p, g, m, v, lr, t, b1, b2, eps)
+        opt.param_groups[0]["eps"] = eps / math.sqrt(1 - b2 ** t)
+        pt.grad = torch.tensor(g.copy())
+        opt.step()
+        pn.grad = torch.tensor(g.copy())
+        naive.step()
+    np.testing.assert_allclose(p, pt.detach().numpy(), rtol=1e-12, atol=1e-15)
+    assert np.abs(p - pn.detach().numpy()).max() > 1e-6  # the placement is observable
+
+
+def test_softmax_xent_and_lrelu_match_torch_operators():
+    rng = np.random.RandomState(4)
+    z = rng.randn(9, 15) * 3
+    lab = np.eye(15)[rng.randint(0, 15, 9)]
+    zv = O.Var(z)
+    loss = O.softmax_xent(zv, lab)
+    zt = torch.tensor(z, requires_grad=True)
+    lt = torch.nn.functional.cross_entropy(zt, torch.tensor(lab), reduction="none")
+    np.testing.assert_allclose(loss.v, lt.detach().numpy(), rtol=1e-12, atol=1e-12)
+    O.backward(O.reduce_mean(loss))
+    lt.mean().backward()
+    np.testing.assert_allclose(zv.g, zt.grad.numpy(), rtol=1e-11, atol=1e-13)
+    x = rng.randn(50)
+    xv = O.Var(x)
+    y = O.leaky_relu(xv, 0.18)
+    np.testing.assert_allclose(y.v, torch.nn.functional.leaky_relu(torch.tensor(x), 0.18).numpy(), rtol=0, atol=0)
