@@ -248,23 +248,15 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
     const int colc = ok ? col : c - 1;
     const double n_total = (double)rows;
     const int64_t last_rows = rows - (int64_t)(n_chunks - 1) * chunk_rows;
-    double s = 0.0;
-    for (int k0 = 0; k0 < n_chunks; k0 += 256) {
-        float m[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = min(k0 + lane + 16 * j, n_chunks - 1);
-            m[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + colc);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = k0 + lane + 16 * j;
-            const double n_k = k < n_chunks - 1 ? (double)chunk_rows : (k == n_chunks - 1 ? (double)last_rows : 0.0);
-            s += n_k * (double)m[j];
-        }
-    }
-    const double mean_a = lanes16_sum(s, sh) / n_total;
-    double m2 = 0.0;
+    // ONE pass over the partials (round 2: the two-pass form -- mean first, then deviations from it -- was two chains of
+    // dependent load bursts): deviations are taken from the first chunk's mean instead, which every lane loads along
+    // with its burst; sum n_k d_k and sum (M2_k + n_k d_k^2) then give mean and M2 without cancellation (fp64, and the
+    // chunk means of one channel lie within a few batch standard deviations of each other).
+    const double shift = (double)ld_partial<COHERENT>(partial + colc);
+    // requested up front: behind the reductions' barriers these would be one more memory round trip
+    const float mm0 = (!M2OUT && moving_mean) ? moving_mean[colc] : 0.0f;
+    const float mv0 = (!M2OUT && moving_mean) ? moving_var[colc] : 0.0f;
+    double s = 0.0, m2 = 0.0;
     for (int k0 = 0; k0 < n_chunks; k0 += 256) {
         float m[16], q[16];
 #pragma unroll
@@ -277,11 +269,15 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
         for (int j = 0; j < 16; ++j) {
             const int k = k0 + lane + 16 * j;
             const double n_k = k < n_chunks - 1 ? (double)chunk_rows : (k == n_chunks - 1 ? (double)last_rows : 0.0);
-            const double d = (double)m[j] - mean_a;
+            const double d = (double)m[j] - shift;
+            s += n_k * d;
             m2 += k < n_chunks ? (double)q[j] + n_k * d * d : 0.0;
         }
     }
-    const double m2_a = lanes16_sum(m2, sh);
+    const double s_a = lanes16_sum(s, sh);
+    const double mean_a = shift + s_a / n_total;
+    double m2_a = lanes16_sum(m2, sh) - s_a * s_a / n_total;
+    if (m2_a < 0.0) m2_a = 0.0;
     if (M2OUT) {
         if (ok && lane == 0) {
             mean[col] = (float)mean_a;
@@ -295,8 +291,8 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
         rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
         if (moving_mean) {
             const double unbiased = n_total > 1.0 ? m2_a / (n_total - 1.0) : var;  // Bessel-corrected
-            moving_mean[col] = (float)((double)moving_mean[col] * decay + mean_a * (1.0 - (double)decay));
-            moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
+            moving_mean[col] = (float)((double)mm0 * decay + mean_a * (1.0 - (double)decay));
+            moving_var[col] = (float)((double)mv0 * decay + unbiased * (1.0 - (double)decay));
         }
     }
 }
@@ -569,6 +565,7 @@ __device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __rest
     const int col = blk16 * 16 + ch;
     const bool ok = col < c;
     const int colc = ok ? col : c - 1;
+    const float dp0 = (dparam && accumulate) ? dparam[colc] : 0.0f;  // requested before the reductions' barriers
     double a = 0.0, b = 0.0;
     for (int k0 = 0; k0 < n_chunks; k0 += 256) {  // bursts of 16 independent loads per lane (see bn_finalize_body)
         float pa[16], pb[16];
@@ -590,7 +587,7 @@ __device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __rest
     if (ok && lane == 0) {
         sums[col] = (float)a;
         sums[c + col] = (float)b;
-        if (dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + (float)a;
+        if (dparam) dparam[col] = dp0 + (float)a;
     }
 }
 
@@ -1025,6 +1022,10 @@ __global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
     small_load_rows<FULL>(y, ldy, rows, col, ok, v);
     if (mask) small_load_rows<FULL>(mask, ldm, rows, col, ok, mk);
     const float shift = y[colc];  // first row: keeps the fp32 sums well conditioned
+    // everything the tail needs is requested now: a load behind the block barriers below would be one more memory
+    // round trip in a kernel that is nothing but latency
+    const float be = beta[colc];
+    const float mm0 = moving_mean ? moving_mean[colc] : 0.0f, mv0 = moving_mean ? moving_var[colc] : 0.0f;
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
     for (int i = 0; i < SMALL_R; ++i) {
@@ -1045,11 +1046,10 @@ __global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
         rstd_out[col] = rs;
         if (moving_mean) {
             const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-            moving_mean[col] = (float)((double)moving_mean[col] * decay + mean * (1.0 - (double)decay));
-            moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
+            moving_mean[col] = (float)((double)mm0 * decay + mean * (1.0 - (double)decay));
+            moving_var[col] = (float)((double)mv0 * decay + unbiased * (1.0 - (double)decay));
         }
     }
-    const float be = beta[colc];
     if (act == HYPEL_ACT_LRELU) {  // the common case without the per-element activation switch
 #pragma unroll
         for (int i = 0; i < SMALL_R; ++i) {
@@ -1080,6 +1080,7 @@ __global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
     const int colc = ok ? col : c - 1;
     float g[SMALL_R], xh[SMALL_R];  // dyh and xhat of this thread's rows
     const float mu = mean[colc], rs = rstd[colc], be = beta[colc];
+    const float dp0 = (dparam && accumulate) ? dparam[colc] : 0.0f;  // requested before the barriers (see forward)
     small_load_rows<FULL>(y, ldy, rows, col, ok, xh);
     small_load_rows<FULL>(dz, lddz, rows, col, ok, g);
     if (mask) {
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
     }
     const float t0 = small_lane_sum(s0, sh);
     const float t1 = small_lane_sum(s1, sh);
-    if (ok && ty == 0 && dparam) dparam[col] = (accumulate ? dparam[col] : 0.0f) + t0;
+    if (ok && ty == 0 && dparam) dparam[col] = dp0 + t0;
     const float inv_m = 1.0f / (float)rows;
     const float m0 = t0 * inv_m, m1 = t1 * inv_m;
 #pragma unroll
