@@ -247,3 +247,67 @@ def test_two_rank_sync_batch_norm_equals_one_device_at_the_global_batch(tmp_path
     assert abs((r0["loss"] * split + r1["loss"] * (8 - split)) / 8 - ct.loss_value()) < 1e-5
     # local statistics on 3-5 samples are a different model: the check above is not vacuous
     assert float((r0["grads_local_bn"][:sess.n_train] - g).abs().max()) > 1e-2 * scale
+
+
+def _episode_worker(rank, world, port, outdir, sync_bn):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if sync_bn:
+        os.environ["HYPEL_SYNC_BN"] = "1"
+    import json
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hypelcnn_amd.classify import train_for_classification as T
+    from tests.emu_backend import EmuBackend
+    alg = {"batch_size": 25, "drop_out_ratio": 0.3, "filter_count": 32, "learning_rate": 3e-3,
+           "learning_rate_decay_factor": 0.96, "learning_rate_decay_step": 350, "lrelu_alpha": 0.18,
+           "optimizer": "AdamOptimizer", "bn_decay": 0.9, "l2regularizer_scale": 1e-5, "spectral_hierarchy_level": 1,
+           "spatial_hierarchy_level": 1, "degradation_coeff": 3, "use_residual": True}
+    p = os.path.join(outdir, f"alg{rank}.json")
+    with open(p, "w") as f:
+        json.dump(alg, f)
+    # epoch-limited run (11 epochs of 320 samples, global batch 2 x 25): the last batch of the run is short (40 samples,
+    # 20 per rank), so a second training plan is compiled mid-run and its collectives must line up as well (uneven
+    # shards: test_two_rank_sync_batch_norm_equals_one_device_at_the_global_batch, _worker)
+    argv = ["--loader_name", "SyntheticDataLoader", "--path", "grss2013:h=23:w=29:bands=10:classes=3:samples=0.6",
+            "--neighborhood", "1", "--model_name", "HYPELCNNModel", "--algorithm_param_path", p,
+            "--batch_size", "25", "--epoch", "11", "--base_log_path", os.path.join(outdir, f"log{rank}"),
+            "--perform_validation", "true", "--validation_steps", "30", "--save_checkpoint_steps", "50"]
+    flags, _ = T.build_parser().parse_known_args(argv)
+    model = T.get_model_from_name(flags.model_name)
+    log_dir = os.path.join(flags.base_log_path, "dp")
+    import hypelcnn_amd.plan as P
+    plans = []
+    init = P.TowerPlan.__init__
+
+    def recording_init(self, *a, **kw):
+        init(self, *a, **kw)
+        plans.append((self.training, self.nb, self.global_nb, self.sync_bn, self.world))
+
+    P.TowerPlan.__init__ = recording_init
+    res = T.perform_an_episode(flags, alg, model, log_dir, backend=EmuBackend())
+    import torch
+    torch.save({"loss": float(res.loss), "test": float(res.test_accuracy), "val": float(res.validation_accuracy),
+                "plans": plans,
+                "files": sorted(os.listdir(log_dir)) if os.path.isdir(log_dir) else []},
+               os.path.join(outdir, f"ep{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_two_rank_training_episode_runs_in_lock_step(tmp_path, sync_bn):
+    """The reference-shaped entry point (flags -> loader -> importer -> graph -> monitored session with validation and
+    checkpoints) under two gloo ranks: every collective of the loop -- iterator tail decisions, gradient buckets with
+    the non-finite flag, confusion-matrix sums, and with HYPEL_SYNC_BN=1 one all-gather / all-reduce per batch-norm
+    layer and direction -- has to line up on both ranks or the run dead-locks (the timeout fails the test)."""
+    port = _free_port()
+    mp.spawn(_episode_worker, args=(2, port, str(tmp_path), sync_bn), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "ep0.pt"), torch.load(tmp_path / "ep1.pt")
+    assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"])
+    # the evaluation confusion matrices are summed over the ranks: both report the same accuracies
+    assert r0["test"] == r1["test"] and r0["val"] == r1["val"]
+    assert r0["test"] > 0.8 and r0["val"] > 0.8, r0
+    train0 = [p for p in r0["plans"] if p[0]]
+    assert train0 and all(p[4] == 2 and p[3] == sync_bn for p in train0), r0["plans"]
+    assert sorted(p[1] for p in train0) == [20, 25], train0  # the full batch and the short last one
