@@ -960,15 +960,25 @@ constexpr int SMALL_TY = 32;    // row lanes (block = 1024 threads)
 constexpr int SMALL_R = 32;     // rows per thread, kept in registers between the reduction and the apply pass
 constexpr int SMALL_MAX_ROWS = SMALL_TY * SMALL_R;
 
-__device__ __forceinline__ float small_lane_sum(float v, float (*sh)[SMALL_TX + 1]) {
-    const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
+// Both column sums of a kernel in ONE exchange: a wave holds two row lanes of its 32 columns, which one cross-lane add
+// combines (fixed order); the 16 wave partials go through LDS as float2 and every thread adds them up in wave order
+// -- one barrier and 16 ds_read_b64 per thread instead of four barriers and 64 ds_read_b32 (the two separate
+// 32-deep exchanges were 3.7 of the 7 us such a kernel spends, phase-stamped copy in tools/exp/probe).
+__device__ __forceinline__ void small_lane_sum2(float& a, float& b, float2 (*sh)[SMALL_TX]) {
+    const int tx = threadIdx.x & (SMALL_TX - 1), wave = threadIdx.x >> 6;
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if ((threadIdx.x & 63) < SMALL_TX) sh[wave][tx] = make_float2(a, b);
     __syncthreads();
-    sh[ty][tx] = v;
-    __syncthreads();
-    float t = 0.0f;
+    float ta = 0.0f, tb = 0.0f;
 #pragma unroll
-    for (int k = 0; k < SMALL_TY; ++k) t += sh[k][tx];
-    return t;
+    for (int k = 0; k < SMALL_TY / 2; ++k) {
+        const float2 t = sh[k][tx];
+        ta += t.x;
+        tb += t.y;
+    }
+    a = ta;
+    b = tb;
 }
 
 // All loads of a thread's rows are issued back to back (one memory round trip instead of rows/TY dependent ones:
@@ -1013,7 +1023,7 @@ __global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
     float alpha, const float* __restrict__ mask, int ldm, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, float* __restrict__ moving_mean, float* __restrict__ moving_var, float decay,
     float* __restrict__ z, int ldz) {
-    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
+    __shared__ float2 sh[SMALL_TY / 2][SMALL_TX];
     const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
     const int col = blockIdx.x * SMALL_TX + tx;
     const bool ok = col < c;
@@ -1033,8 +1043,8 @@ __global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
         s += d;
         ss += d * d;
     }
-    const double ts = (double)small_lane_sum(s, sh);
-    const double tss = (double)small_lane_sum(ss, sh);
+    small_lane_sum2(s, ss, sh);
+    const double ts = (double)s, tss = (double)ss;
     const double n = (double)rows;
     const double mean = (double)shift + ts / n;
     double m2 = tss - ts * ts / n;
@@ -1073,7 +1083,7 @@ __global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int ldm, float* __restrict__ dy, int lddy,
     float* __restrict__ dparam, int accumulate) {
-    __shared__ float sh[SMALL_TY][SMALL_TX + 1];
+    __shared__ float2 sh[SMALL_TY / 2][SMALL_TX];
     const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;
     const int col = blockIdx.x * SMALL_TX + tx;
     const bool ok = col < c;
@@ -1099,8 +1109,8 @@ __global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
         s0 += g[i];
         s1 += g[i] * xh[i];
     }
-    const float t0 = small_lane_sum(s0, sh);
-    const float t1 = small_lane_sum(s1, sh);
+    small_lane_sum2(s0, s1, sh);
+    const float t0 = s0, t1 = s1;
     if (ok && ty == 0 && dparam) dparam[col] = dp0 + t0;
     const float inv_m = 1.0f / (float)rows;
     const float m0 = t0 * inv_m, m1 = t1 * inv_m;
