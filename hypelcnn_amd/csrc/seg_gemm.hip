@@ -120,7 +120,7 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // for 15 useful columns.  A segment whose k has HYPEL_SEG_PAIR_FLAG set is paired with the next one of its group.
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
           bool PAIR = false>
-__global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : 3))) void seg_gemm_kernel(const float* __restrict__ A, int64_t lda,
+__device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
                                                         const hypel_group_t* __restrict__ groups,
@@ -631,6 +631,34 @@ __global__ HYPEL_SGPR_ATTR __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32
     }
 }
 
+#define HYPEL_GEMM_PARAMS                                                                                          \
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, float *__restrict__ C,       \
+        int64_t ldc, int n, const hypel_group_t *__restrict__ groups, const hypel_seg_t *__restrict__ segs,           \
+        const void *__restrict__ tiles_v, int n_tiles, int n_ntiles, const float *__restrict__ bias, int accumulate, \
+        const float *__restrict__ res, int64_t ldr, const int32_t *__restrict__ res_start, float *__restrict__ stats, \
+        BnBwdEpi bnb
+#define HYPEL_GEMM_ARGS \
+    A, lda, B, ldb, C, ldc, n, groups, segs, tiles_v, n_tiles, n_ntiles, bias, accumulate, res, ldr, res_start, stats, bnb
+#define HYPEL_GEMM_BOUNDS \
+    __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : 3)))
+
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
+          bool PAIR = false>
+__global__ HYPEL_SGPR_ATTR HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PARAMS) {
+    seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, BNB, PAIR>(HYPEL_GEMM_ARGS);
+}
+
+// The same code under a cap of 96 scalar registers: 7 instead of 6 resident 128x32 blocks per CU (hipcc uses all 106
+// otherwise; LDS and vector registers allow 7).  For launches whose groups have ONE segment (1x1 convolutions and
+// their data gradients): 392 row tiles x 4 column tiles = 1568 blocks of an n = 120 layer -- 3136 for n = 240 -- are
+// 2 % over the 1536 blocks that 6 per CU hold, so every such launch ends in a round of 32 - 64 blocks; with 7 per CU
+// they are resident at once.  The multi-segment launches lose to the extra scalar spills in their segment loop
+// (round-2 A/B), and the attribute cannot depend on a template parameter: hence a second kernel symbol.
+template <int WM, int WN, int TM, int TN, bool TA, bool TB>
+__global__ __attribute__((amdgpu_num_sgpr(96))) HYPEL_GEMM_BOUNDS void seg_gemm_kernel_s96(HYPEL_GEMM_PARAMS) {
+    seg_gemm_body<WM, WN, TM, TN, TA, TB, false, false, false, false>(HYPEL_GEMM_ARGS);
+}
+
 template <int WM, int WN, int TM, int TN>
 int launch_cfg_pair(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int n,
                     const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
@@ -661,10 +689,23 @@ template <int WM, int WN, int TM, int TN, bool NARROW = false, bool MULTI = fals
 int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb, int tb, float* c, int64_t ldc,
                int n, const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
                const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
-               hipStream_t st, float* stats = nullptr) {
+               hipStream_t st, float* stats = nullptr, bool cap96 = false) {
     constexpr int BN = NARROW ? 16 : WN * TN * 32;
     const int n_nt = MULTI ? 1 : (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
+    if constexpr (TM * TN == 1 && !NARROW && !MULTI) {
+        if (cap96 && !ta) {  // single-segment launches on the 7-blocks-per-CU build of the 128x32 kernel
+            if (tb)
+                hipLaunchKernelGGL((seg_gemm_kernel_s96<WM, WN, TM, TN, false, true>), dim3(grid), dim3(256), 0, st, a, lda,
+                                   b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,
+                                   res_start, stats, BnBwdEpi{});
+            else
+                hipLaunchKernelGGL((seg_gemm_kernel_s96<WM, WN, TM, TN, false, false>), dim3(grid), dim3(256), 0, st, a, lda,
+                                   b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,
+                                   res_start, stats, BnBwdEpi{});
+            return 0;
+        }
+    }
     // diagnostic: unused dynamic LDS lowers the number of resident blocks per CU (occupancy experiments)
     static const int lds_pad = getenv("HYPEL_GEMM_LDS_PAD") ? atoi(getenv("HYPEL_GEMM_LDS_PAD")) : 0;
 #define HYPEL_GO(TA_, TB_)                                                                                         \
@@ -705,6 +746,8 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     // few blocks run faster on the narrow tile, wide filter gradients on the wide one
     int hint = (accumulate >> 8) & 3;
     const bool pairs = (accumulate & HYPEL_GEMM_PAIRED_SEGS) != 0;  // segments carry HYPEL_SEG_PAIR_FLAG
+    static const int cap_on = getenv("HYPEL_GEMM_S96") ? atoi(getenv("HYPEL_GEMM_S96")) : 1;
+    const bool cap96 = cap_on && (accumulate & HYPEL_GEMM_SINGLE_SEG) != 0;  // every group has one segment
     accumulate &= 1;
     // hint 3 = 128x96 blocks (three 32x32 accumulators per wave, 5 resident blocks per CU): N = 240 / 480 tile without
     // padding (5 x 96, 96 + 96 + 48) and a layer's 392 row tiles x 3 or 5 column tiles fit the resident capacity where
@@ -751,7 +794,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
                                      accumulate, res, ldr, res_start, st);
     else if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, res, ldr, res_start, st, stats);
+                               accumulate, res, ldr, res_start, st, stats, cap96);
     else if (n <= 64 || !bn128)
         launch_cfg<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats);

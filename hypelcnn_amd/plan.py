@@ -129,6 +129,8 @@ def valid_taps(h, w, k, oy, ox):
 
 
 SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
+GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
+SINGLE_SEG_HINT = os.environ.get("HYPEL_SINGLE_SEG_HINT", "1") != "0"
 GEMM_PAIRED_SEGS = 0x400    # ... HYPEL_GEMM_PAIRED_SEGS (bit of `accumulate`)
 PAIR_SEGS = os.environ.get("HYPEL_PAIR_SEGS", "1") != "0"  # short data-gradient segments (k <= 16) share k-tiles
 
@@ -450,6 +452,8 @@ class TowerPlan:
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
         hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
+        if SINGLE_SEG_HINT and not ta and bnbwd is None and all(len(segs) == 1 for _, segs, _ in tables.groups):
+            accumulate = int(accumulate) | GEMM_SINGLE_SEG
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
                 Ref(t_t), int(len(tarr)), bias_ref, int(accumulate) | (hint << 8))
         name = "seg_gemm_f32"

@@ -84,6 +84,10 @@ typedef struct {
  * two a_off / b_off of a pair must be less than 2 GB apart).  Results do not depend on pairing. */
 #define HYPEL_SEG_PAIR_FLAG 0x40000000
 #define HYPEL_GEMM_PAIRED_SEGS 0x400
+/* Hint: every group of the launch has exactly ONE segment (a 1x1 convolution or its data gradient).  With 128x32 blocks
+ * such launches run on a build of the kernel that keeps 7 instead of 6 blocks resident per CU.  Results do not depend
+ * on the hint. */
+#define HYPEL_GEMM_SINGLE_SEG 0x800
 
 /* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint
  * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks, 3 = 128x96 blocks for n > 64) -- results do not

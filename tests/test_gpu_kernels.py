@@ -818,3 +818,43 @@ def test_sync_bn_kernels_match_the_global_statistics(hip, rows, c, world):
     b.run("bn_act_bwd_apply_global", "dz", c, "x0", c, r0, c, "mean", "rstd", "beta", 1, 0.18, None, c, "sums",
           int(x64.shape[0]), "dy", c)
     b.check("dy", rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,k,n,tb_,kind", [
+    (1000, 145, 120, 0, "plain"), (777, 120, 240, 0, "stats"), (300, 240, 120, 1, "plain"), (515, 480, 240, 1, "res"),
+    (129, 33, 17, 0, "plain"), (64, 60, 30, 1, "res"),
+])
+def test_seg_gemm_single_segment_hint(hip, rows, k, n, tb_, kind):
+    """HYPEL_GEMM_SINGLE_SEG: single-segment launches (1x1 convolutions and their data gradients) run on the build of
+    the 128x32 kernel that is capped at 96 scalar registers; same results as the specification and as the uncapped
+    kernel, for the plain, statistics and shortcut-gradient entry points."""
+    from hypelcnn_amd.plan import GEMM_SINGLE_SEG
+    rng = np.random.default_rng(rows + n)
+    a = rng.standard_normal((rows, k)).astype(np.float32)
+    w = rng.standard_normal((n, k) if tb_ else (k, n)).astype(np.float32)
+    outs = []
+    for flag in (GEMM_SINGLE_SEG, 0):
+        b = Both(hip)
+        # three groups of ragged rows, one segment each
+        cuts = [0, rows // 3, rows // 3 + 1, rows]
+        groups = [(cuts[i] * n, [(cuts[i] * k, 0, k)], cuts[i + 1] - cuts[i]) for i in range(3)]
+        if kind == "stats":
+            groups = [(0, [(0, 0, k)], rows)]
+        garr, sarr, tarr, _ = _tables(b, groups).finalize(n)
+        for nm, arr in (("a", a), ("w", w), ("y", np.zeros(rows * n, np.float32)), ("g", garr), ("s", sarr), ("t", tarr)):
+            b.arr(nm, arr)
+        acc = (1 << 8) | flag   # 128x32 tiles
+        if kind == "stats":
+            b.arr("part", np.zeros(((rows + 127) // 128) * 2 * n, np.float32))
+            b.run("seg_gemm_stats_f32", "a", k, 0, "w", n, 0, "y", n, n, "g", "s", "t", len(tarr), None, acc, "part")
+            b.check("part", rtol=1e-3, atol=2e-4)
+        elif kind == "res":
+            b.arr("dz", rng.standard_normal((rows, n)).astype(np.float32))
+            b.run("seg_gemm_res_f32", "a", k, 0, "w", k, 1, "y", n, n, "g", "s", "t", len(tarr), None, acc, "dz", n, None)
+        else:
+            b.run("seg_gemm_f32", "a", k, 0, "w", k if tb_ else n, tb_, "y", n, n, "g", "s", "t", len(tarr), None, acc)
+        b.check("y", rtol=2e-4, atol=2e-5)
+        outs.append(b.h["y"].cpu().numpy().copy())
+        rng = np.random.default_rng(rows + n + 1)  # same dz for both passes
+    if kind != "res":
+        np.testing.assert_array_equal(outs[0], outs[1])
