@@ -848,6 +848,24 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
     if (threadIdx.x == 0) ws[blockIdx.x] = t;
 }
 
+// contiguous operands (lda == ldb == ldda == c, 16-byte aligned, count % 4 == 0): three flat float4 streams instead of
+// a 64-bit division per element
+__global__ __launch_bounds__(256) void mse_partial_flat4_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                                 int64_t count4, float4* __restrict__ da, float gcoef,
+                                                                 float* __restrict__ ws) {
+    __shared__ float sh[4];
+    float s = 0.0f;
+#pragma unroll 2
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = a[i], y = b[i];
+        const float4 d = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+        s += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        if (da) da[i] = make_float4(gcoef * d.x, gcoef * d.y, gcoef * d.z, gcoef * d.w);
+    }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
 __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x, int64_t count,
                                                            float* __restrict__ ws) {
     __shared__ float sh[4];
@@ -1497,7 +1515,13 @@ extern "C" int hypel_mse(const float* a, int64_t lda, const float* b, int64_t ld
     const int64_t total = rows * c;
     const int grid = hypel_grid_1d(total, 256, RED_BLOCKS);
     const float gcoef = gscale * 2.0f / (float)total;
-    hipLaunchKernelGGL(mse_partial_kernel, dim3(grid), dim3(256), 0, ST, a, lda, b, ldb, rows, c, da, ldda, gcoef, ws);
+    const bool flat = lda == c && ldb == c && (!da || ldda == c) && total % 4 == 0 && aligned16(a) && aligned16(b) &&
+                      aligned16(da);
+    if (flat)
+        hipLaunchKernelGGL(mse_partial_flat4_kernel, dim3(grid), dim3(256), 0, ST, reinterpret_cast<const float4*>(a),
+                           reinterpret_cast<const float4*>(b), total / 4, reinterpret_cast<float4*>(da), gcoef, ws);
+    else
+        hipLaunchKernelGGL(mse_partial_kernel, dim3(grid), dim3(256), 0, ST, a, lda, b, ldb, rows, c, da, ldda, gcoef, ws);
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, grid, 1.0 / (double)total, out);
     HYPEL_CHECK_LAUNCH("hypel_mse");
     return 0;

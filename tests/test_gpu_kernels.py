@@ -530,6 +530,11 @@ def test_losses(hip):
     b.run("mse", "a", f, "bb", f, rows, f, "out", "da", f, 1.0, "ws")
     b.check("out", rtol=1e-5)
     b.check("da", rtol=1e-5, atol=1e-9)
+    # strided operands (a window of a wider buffer) and a count that is no multiple of 4: the general kernel
+    b.arr("da", np.zeros(rows * f, np.float32))
+    b.run("mse", "a", f, "bb", f, rows - 1, f - 3, "out", "da", f, 0.5, "ws")
+    b.check("out", rtol=1e-5)
+    b.check("da", rtol=1e-5, atol=1e-9)
     b.run("sum_f32", "loss", n, 1.0 / n, "out", "ws")
     b.check("out", rtol=1e-5)
 
