@@ -73,15 +73,17 @@ __device__ __forceinline__ void ew_loop(int64_t rows, int c, int tx_log2, F body
 }
 
 // ------------------------------------------------------------------------------------- layout
-__global__ void nhwc_to_pnc_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int p, int c,
-                                   int64_t ld) {
-    const int64_t total = (int64_t)p * n * ld;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % ld);
-        const int64_t rn = i / ld;
-        const int64_t nn = rn % n;
-        const int pp = (int)(rn / n);
-        out[i] = cc < c ? x[(nn * p + pp) * c + cc] : 0.0f;
+// One wavefront per output row (pixel pp, sample nn): the row's c floats are contiguous on both sides, and the index
+// arithmetic (two divisions) is paid once per row instead of four 64-bit divisions per element.
+__global__ __launch_bounds__(256) void nhwc_to_pnc_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                                          int p, int c, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_rows = (int64_t)p * n;
+    for (int64_t rn = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); rn < n_rows; rn += (int64_t)gridDim.x * 4) {
+        const int64_t pp = rn / n, nn = rn - pp * n;
+        const float* __restrict__ src = x + (nn * p + pp) * c;
+        float* __restrict__ dst = out + rn * ld;
+        for (int cc = lane; cc < (int)ld; cc += 64) dst[cc] = cc < c ? src[cc] : 0.0f;
     }
 }
 
@@ -1207,8 +1209,9 @@ __global__ void lrn_bwd_kernel(const float* __restrict__ x, int64_t ldx, const f
 extern "C" int hypel_nhwc_to_pnc(const float* x, float* out, int64_t n, int32_t p, int32_t c, int64_t ld,
                                  hypel_stream_t stream) {
     HYPEL_REQUIRE(x && out && n > 0 && p > 0 && c > 0 && ld >= c, "hypel_nhwc_to_pnc");
-    hipLaunchKernelGGL(nhwc_to_pnc_kernel, dim3(hypel_grid_1d((int64_t)p * n * ld, 256)), dim3(256), 0, ST, x, out, n,
-                       p, c, ld);
+    const int64_t row_blocks = ((int64_t)p * n + 3) / 4;  // 4 rows (one per wave) per block
+    hipLaunchKernelGGL(nhwc_to_pnc_kernel, dim3((unsigned)(row_blocks < 65536 * 4 ? row_blocks : 65536 * 4)), dim3(256), 0,
+                       ST, x, out, n, p, c, ld);
     HYPEL_CHECK_LAUNCH("hypel_nhwc_to_pnc");
     return 0;
 }
