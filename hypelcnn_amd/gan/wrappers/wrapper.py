@@ -1,4 +1,7 @@
-"""GAN method plugin contracts (reference gan/wrappers/wrapper.py:4-38)."""
+"""GAN method plugin contracts (reference gan/wrappers/wrapper.py:4-38).
+
+Interface file: the abstract method names and signatures below ARE the reference's plugin surface (upstream is MIT-licensed); they are
+reproduced on purpose -- a plugin written for the reference must subclass exactly this -- and contain no behaviour."""
 from abc import ABC, abstractmethod
 
 

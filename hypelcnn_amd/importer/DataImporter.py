@@ -1,4 +1,7 @@
-"""Importer plugin contract (reference importer/DataImporter.py:4-20)."""
+"""Importer plugin contract (reference importer/DataImporter.py:4-20).
+
+Interface file: the abstract method names and signatures below ARE the reference's plugin surface (upstream is MIT-licensed); they are
+reproduced on purpose -- a plugin written for the reference must subclass exactly this -- and contain no behaviour."""
 from abc import ABC, abstractmethod
 
 

@@ -1,4 +1,7 @@
-"""Dataset plugin contract (reference loader/DataLoader.py:5-47)."""
+"""Dataset plugin contract (reference loader/DataLoader.py:5-47).
+
+Interface file: the abstract method names and signatures below ARE the reference's plugin surface (upstream is MIT-licensed); they are
+reproduced on purpose -- a plugin written for the reference must subclass exactly this -- and contain no behaviour."""
 from abc import ABC, abstractmethod
 from enum import Enum
 

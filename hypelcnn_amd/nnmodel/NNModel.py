@@ -1,4 +1,7 @@
-"""Model plugin contract -- same two methods as the reference (nnmodel/NNModel.py:4-12)."""
+"""Model plugin contract -- same two methods as the reference (nnmodel/NNModel.py:4-12).
+
+Interface file: the abstract method names and signatures below ARE the reference's plugin surface (upstream is MIT-licensed); they are
+reproduced on purpose -- a plugin written for the reference must subclass exactly this -- and contain no behaviour."""
 from abc import ABC, abstractmethod
 
 
