@@ -39,8 +39,8 @@ DGRAD_MAX_SEGS = int(os.environ.get("HYPEL_DGRAD_MAX_SEGS", "18"))  # segments p
 MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
 L2_CHUNK_BYTES = int(float(os.environ.get("HYPEL_L2_CHUNK_MB", "3.5")) * (1 << 20))  # X working set an XCD's L2 keeps
 FWD_HINT_R2 = os.environ.get("HYPEL_FWD_HINT_R2", "1") != "0"  # round-2 forward tile-width rule (incl. 128x96 tiles)
-SPLITK_BELOW = int(os.environ.get("HYPEL_SPLITK_BELOW", "192"))    # FC-shaped products with fewer 128x64 blocks are cut along K
-SPLITK_TARGET = int(os.environ.get("HYPEL_SPLITK_TARGET", "384"))  # ... into slices that give about this many blocks
+SPLITK_BELOW = int(os.environ.get("HYPEL_SPLITK_BELOW", "400"))    # FC-shaped products with fewer 128x64 blocks are cut along K
+SPLITK_TARGET = int(os.environ.get("HYPEL_SPLITK_TARGET", "768"))  # ... into slices that give about this many blocks
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
 
 
