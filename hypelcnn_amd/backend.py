@@ -58,6 +58,7 @@ def build_library(verbose=False):
 
 
 _P, _I64, _I32, _F, _U64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_uint64
+_F64 = ctypes.c_double
 
 # name -> argument ctypes (stream appended automatically); mirrors include/hypel.h one to one
 SIGNATURES = {
@@ -95,6 +96,8 @@ SIGNATURES = {
     "adam_tf1_guarded": [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P],
     "momentum_tf1_guarded": [_P, _P, _P, _I64, _F, _F, _P],
     "loss_guard_f32": [_P, _P, _P],
+    "mse_partial_f32": [_P, _I64, _P, _I64, _I64, _I32, _P, _I64, _F, _P],
+    "loss_finalize_f32": [_P, _I32, _P, _F64, _P, _P, _P, _P],
     "dropout_mask": [_P, _I64, _F, _U64, _P],
     "step_inc": [_P],
     "argmax_confusion": [_P, _I64, _I64, _I32, _P, _P, _P],

@@ -892,6 +892,40 @@ __global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restri
     if (threadIdx.x == 0) out[0] = (float)(sh[0] * scale);
 }
 
+// The tail of the classifier loss in ONE launch (it was five: two-stage sum of the per-row cross entropies, second stage
+// of the reconstruction MSE, the non-finite guard, the dropout step counter): mean of loss_rows[n_rows] -> out_ce,
+// sum of mse_ws[n_mse] x mse_scale -> out_mse (nullable), flag = either non-finite (nullable), step += 1 (nullable).
+// fp64, fixed association (thread-strided, then a tree over the 256 threads).
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ loss_rows, int n_rows,
+                                                             const float* __restrict__ mse_ws, int n_mse,
+                                                             double mse_scale, float* __restrict__ out_ce,
+                                                             float* __restrict__ out_mse, float* __restrict__ flag,
+                                                             uint64_t* __restrict__ step) {
+    __shared__ double sh[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n_rows; i += 256) a += (double)loss_rows[i];
+    if (mse_ws)
+        for (int i = threadIdx.x; i < n_mse; i += 256) b += (double)mse_ws[i];
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ce = (float)(sh[0][0] / (double)n_rows);
+        const float mse = (float)(sh[1][0] * mse_scale);
+        out_ce[0] = ce;
+        if (out_mse) out_mse[0] = mse;
+        if (flag) flag[0] = (isfinite(ce) && (!mse_ws || isfinite(mse))) ? 0.0f : 1.0f;
+        if (step) step[0] += 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------- optimisers
 // `skip` (nullable): a device flag written by hypel_loss_guard_f32 (non-zero = the step's loss was not finite).  The
 // optimiser then leaves parameters and slots untouched -- create_train_op's check_numerics refuses the update the
@@ -1512,11 +1546,23 @@ extern "C" int hypel_softmax_xent(const float* logits, int64_t ld, int64_t n, in
     return 0;
 }
 
+static void mse_partial_launch(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c,
+                               float* da, int64_t ldda, float gscale, float* ws, int grid, hypel_stream_t stream);
+
 extern "C" int hypel_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c, float* out,
                          float* da, int64_t ldda, float gscale, float* ws, hypel_stream_t stream) {
     HYPEL_REQUIRE(a && b && out && ws && rows > 0 && c > 0, "hypel_mse");
     const int64_t total = rows * c;
     const int grid = hypel_grid_1d(total, 256, RED_BLOCKS);
+    mse_partial_launch(a, lda, b, ldb, rows, c, da, ldda, gscale, ws, grid, stream);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, grid, 1.0 / (double)total, out);
+    HYPEL_CHECK_LAUNCH("hypel_mse");
+    return 0;
+}
+
+static void mse_partial_launch(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c,
+                               float* da, int64_t ldda, float gscale, float* ws, int grid, hypel_stream_t stream) {
+    const int64_t total = rows * c;
     const float gcoef = gscale * 2.0f / (float)total;
     const bool flat = lda == c && ldb == c && (!da || ldda == c) && total % 4 == 0 && aligned16(a) && aligned16(b) &&
                       aligned16(da);
@@ -1525,8 +1571,25 @@ extern "C" int hypel_mse(const float* a, int64_t lda, const float* b, int64_t ld
                            reinterpret_cast<const float4*>(b), total / 4, reinterpret_cast<float4*>(da), gcoef, ws);
     else
         hipLaunchKernelGGL(mse_partial_kernel, dim3(grid), dim3(256), 0, ST, a, lda, b, ldb, rows, c, da, ldda, gcoef, ws);
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, grid, 1.0 / (double)total, out);
-    HYPEL_CHECK_LAUNCH("hypel_mse");
+}
+
+extern "C" int hypel_mse_partial_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c,
+                                     float* da, int64_t ldda, float gscale, float* ws, hypel_stream_t stream) {
+    HYPEL_REQUIRE(a && b && ws && rows > 0 && c > 0, "hypel_mse_partial_f32");
+    // always HYPEL_MSE_PARTIALS blocks (a block without elements publishes 0): the finaliser's count is a constant
+    mse_partial_launch(a, lda, b, ldb, rows, c, da, ldda, gscale, ws, HYPEL_MSE_PARTIALS, stream);
+    HYPEL_CHECK_LAUNCH("hypel_mse_partial_f32");
+    return 0;
+}
+
+extern "C" int hypel_loss_finalize_f32(const float* loss_rows, int32_t n_rows, const float* mse_ws, double mse_scale,
+                                       float* out_ce, float* out_mse, float* flag, uint64_t* step,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(loss_rows && n_rows > 0 && out_ce && ((mse_ws == nullptr) == (out_mse == nullptr)),
+                  "hypel_loss_finalize_f32");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, loss_rows, n_rows, mse_ws, HYPEL_MSE_PARTIALS,
+                       mse_scale, out_ce, out_mse, flag, step);
+    HYPEL_CHECK_LAUNCH("hypel_loss_finalize_f32");
     return 0;
 }
 

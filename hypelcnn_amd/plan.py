@@ -129,6 +129,8 @@ def valid_taps(h, w, k, oy, ox):
 
 
 SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
+LOSS_TAIL = os.environ.get("HYPEL_LOSS_TAIL", "1") != "0"  # xent / MSE sums, non-finite flag, step counter: one finaliser
+MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
 SINGLE_SEG_HINT = os.environ.get("HYPEL_SINGLE_SEG_HINT", "1") != "0"
 GEMM_PAIRED_SEGS = 0x400    # ... HYPEL_GEMM_PAIRED_SEGS (bit of `accumulate`)
@@ -593,7 +595,7 @@ class TowerPlan:
             self._flush_wgrads()
             if getattr(self, "_side_open", False):
                 self.bwd.append(self._join_sides())
-            if tw.n_dropout and not self.external_masks:
+            if tw.n_dropout and not self.external_masks and not getattr(self, "_step_in_loss", False):
                 self.bwd.append(Launch("step_inc", (self._ref("step_ctr"),), tag="rng"))
         # shared scratch (stream order makes reuse safe)
         for name, size in self.scratch_sizes.items():
@@ -917,9 +919,14 @@ class TowerPlan:
         self.fwd.append(Launch("softmax_xent", (self._ref(l_st.buf, l_st.ch_off), l_st.ld, nb, logits.c,
                                                 self._ref(lab_st.buf), lab_st.ld, self._ref("loss_ps"), dl, lddl,
                                                 gworld / nb), tag="loss"))
-        l2 = Launch("sum_f32", (self._ref("loss_ps"), nb, 1.0 / nb, self._ref("loss_ce"), None), tag="loss")
-        self._scratch(l2, 4, "scratch_red")
-        self.fwd.append(l2)
+        guard = self.sess.guard_ref() if self.training and hasattr(self.sess, "guard_ref") else None
+        # the dropout step counter advances once per training step, after the last mask of the step was drawn (masks
+        # are drawn in the forward pass): it rides in the loss finaliser
+        step = None
+        if LOSS_TAIL and self.training and self.tower.n_dropout and not self.external_masks:
+            step = self._ref("step_ctr")
+            self._step_in_loss = True
+        mse_args = None
         if ps.extra_mse is not None:
             m = ps.extra_mse
             a_st = self.storage_of(m.a)
@@ -932,15 +939,32 @@ class TowerPlan:
                 gst, acc = self._grad_target(m.a)
                 assert acc == 0
                 da, ldda = self._ref(gst.buf), gst.ld
-            l3 = Launch("mse", (self._ref(a_st.buf), a_st.ld, self._ref("in:" + src.name), feat, nb, feat,
-                                self._ref("loss_mse"), da, ldda, gworld, None), nbytes=12 * nb * feat, tag="loss")
+            mse_args = (self._ref(a_st.buf), a_st.ld, self._ref("in:" + src.name), feat, nb, feat)
+        if LOSS_TAIL:
+            # xent rows + MSE block partials -> ONE finaliser (means, non-finite flag, step counter)
+            ws = None
+            if mse_args is not None:
+                self._alloc("mse_ws", MSE_PARTIALS)
+                ws = self._ref("mse_ws")
+                self.fwd.append(Launch("mse_partial_f32", mse_args + (da, ldda, gworld, ws), nbytes=12 * nb * feat,
+                                       tag="loss"))
+            self.fwd.append(Launch("loss_finalize_f32", (
+                self._ref("loss_ps"), nb, ws, 1.0 / (nb * feat) if mse_args is not None else 0.0, self._ref("loss_ce"),
+                self._ref("loss_mse") if mse_args is not None else None, guard, step), tag="loss"))
+            return
+        l2 = Launch("sum_f32", (self._ref("loss_ps"), nb, 1.0 / nb, self._ref("loss_ce"), None), tag="loss")
+        self._scratch(l2, 4, "scratch_red")
+        self.fwd.append(l2)
+        if mse_args is not None:
+            l3 = Launch("mse", mse_args + (self._ref("loss_mse"), da, ldda, gworld, None), nbytes=12 * nb * feat,
+                        tag="loss")
             self._scratch(l3, 10, "scratch_red")
             self.fwd.append(l3)
-        if self.training and hasattr(self.sess, "guard_ref"):
+        if guard is not None:
             # NanTensorHook / check_numerics on the device: flag behind the gradient buffer, read by the optimiser
             self.fwd.append(Launch("loss_guard_f32", (self._ref("loss_ce"),
                                                       self._ref("loss_mse") if ps.extra_mse is not None else None,
-                                                      self.sess.guard_ref()), tag="loss-guard"))
+                                                      guard), tag="loss-guard"))
 
     # ------------------------------------------------------------------ backward
     @staticmethod

@@ -256,6 +256,18 @@ int hypel_softmax_xent(const float* logits, int64_t ld, int64_t n, int32_t c, co
  * da = gscale*2*(a-b)/(rows*c) (da NULL -> skipped).  ws: >= 1024 floats. */
 int hypel_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c, float* out, float* da,
               int64_t ldda, float gscale, float* ws, hypel_stream_t stream);
+/* The classifier's loss tail in two launches instead of six (HYPELCNNModel.py:101-112: softmax cross entropy + weighted
+ * reconstruction MSE; NanTensorHook, monitored_session_runner.py:151):
+ * hypel_mse_partial_f32 = first stage of hypel_mse -- da as there, ws[HYPEL_MSE_PARTIALS] = per-block sums of squares;
+ * hypel_loss_finalize_f32: out_ce = mean(loss_rows[n_rows]) (the per-row values hypel_softmax_xent wrote),
+ * out_mse = sum(mse_ws) * mse_scale (both NULL = no reconstruction term), flag = 1.0f if either is not finite else 0
+ * (NULL = no guard; same flag as hypel_loss_guard_f32), *step += 1 (NULL = leave; same as hypel_step_inc). */
+#define HYPEL_MSE_PARTIALS 1024
+int hypel_mse_partial_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c, float* da,
+                          int64_t ldda, float gscale, float* ws, hypel_stream_t stream);
+int hypel_loss_finalize_f32(const float* loss_rows, int32_t n_rows, const float* mse_ws, double mse_scale, float* out_ce,
+                            float* out_mse, float* flag, uint64_t* step, hypel_stream_t stream);
+
 /* out[0] = sum(x[0..count)) * scale, deterministic two-stage.  ws >= 1024 floats. */
 int hypel_sum_f32(const float* x, int64_t count, float scale, float* out, float* ws, hypel_stream_t stream);
 

@@ -537,6 +537,30 @@ class EmuBackend:
         if da is not None:
             _mat(da, ldda, rows, c)[...] = gscale * 2.0 * d / (rows * c)
 
+    MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
+
+    def k_mse_partial_f32(self, a, lda, b, ldb, rows, c, da, ldda, gscale, ws):
+        d = _mat(a, lda, rows, c).astype(np.float64) - _mat(b, ldb, rows, c)
+        w = _arr(ws)[: self.MSE_PARTIALS]
+        w[...] = 0.0
+        w[0] = (d * d).sum()   # any split over the partials: only their sum is specified
+        if da is not None:
+            _mat(da, ldda, rows, c)[...] = gscale * 2.0 * d / (rows * c)
+
+    def k_loss_finalize_f32(self, loss_rows, n_rows, mse_ws, mse_scale, out_ce, out_mse, flag, step):
+        ce = np.float32(_arr(loss_rows)[:n_rows].astype(np.float64).mean())
+        _arr(out_ce)[0] = ce
+        ok = np.isfinite(ce)
+        assert (mse_ws is None) == (out_mse is None)
+        if mse_ws is not None:
+            mse = np.float32(_arr(mse_ws)[: self.MSE_PARTIALS].astype(np.float64).sum() * mse_scale)
+            _arr(out_mse)[0] = mse
+            ok = ok and np.isfinite(mse)
+        if flag is not None:
+            _arr(flag)[0] = 0.0 if ok else 1.0
+        if step is not None:
+            step.t[step.off] += 1
+
     def k_sum_f32(self, x, count, scale, out, ws):
         _arr(out)[0] = _arr(x)[:count].astype(np.float64).sum() * scale
 

@@ -537,6 +537,25 @@ def test_losses(hip):
     b.check("da", rtol=1e-5, atol=1e-9)
     b.run("sum_f32", "loss", n, 1.0 / n, "out", "ws")
     b.check("out", rtol=1e-5)
+    # the fused loss tail: MSE block partials + one finaliser (means, non-finite flag, step counter)
+    b.arr("da2", np.zeros(rows * f, np.float32))
+    b.arr("ws2", np.full(1024, 7.0, np.float32))
+    b.run("mse_partial_f32", "a", f, "bb", f, rows, f, "da2", f, 1.0, "ws2")
+    b.check("da2", rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(b.h["ws2"].cpu().numpy().astype(np.float64).sum(), b.e["ws2"].numpy().astype(np.float64).sum(),
+                               rtol=1e-5)
+    for nm in ("ce", "mse", "flag"):
+        b.arr(nm, np.full(1, -1.0, np.float32))
+    b.arr("step", np.array([41], np.int64))
+    b.run("loss_finalize_f32", "loss", n, "ws2", 1.0 / (rows * f), "ce", "mse", "flag", "step")
+    b.check("ce", rtol=1e-5)
+    b.check("mse", rtol=1e-5)
+    a64, b64 = b.e["a"].numpy().astype(np.float64), b.e["bb"].numpy().astype(np.float64)
+    np.testing.assert_allclose(b.h["mse"].cpu().numpy()[0], ((a64 - b64) ** 2).mean(), rtol=1e-5)
+    assert float(b.h["flag"].cpu()[0]) == 0.0 and int(b.h["step"].cpu()[0]) == 42 and int(b.e["step"][0]) == 42
+    b.arr("bad", np.array([np.inf] + [0.0] * (n - 1), np.float32))
+    b.run("loss_finalize_f32", "bad", n, None, 0.0, "ce", None, "flag", None)
+    assert float(b.h["flag"].cpu()[0]) == 1.0 and float(b.e["flag"][0]) == 1.0 and int(b.h["step"].cpu()[0]) == 42
 
 
 def test_optimizers_and_reduce(hip):
