@@ -36,7 +36,7 @@ WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
 WGRAD_MIN_SPLITS = int(os.environ.get("HYPEL_WGRAD_MIN_SPLITS", "0"))  # 0 = one split per 64 batch rows once a launch fills the device unsplit
 SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel-part splitting also for biased convs
 DGRAD_MAX_SEGS = int(os.environ.get("HYPEL_DGRAD_MAX_SEGS", "18"))  # segments per data-gradient tile (0 = never split)
-MAX_TAPS_PER_TILE = int(__import__('os').environ.get('HYPEL_MAX_TAPS', '9'))
+MAX_TAPS_PER_TILE = int(os.environ.get("HYPEL_MAX_TAPS", "9"))  # taps per forward tile of a multi-kernel level
 L2_CHUNK_BYTES = int(float(os.environ.get("HYPEL_L2_CHUNK_MB", "3.5")) * (1 << 20))  # X working set an XCD's L2 keeps
 FWD_HINT_R2 = os.environ.get("HYPEL_FWD_HINT_R2", "1") != "0"  # round-2 forward tile-width rule (incl. 128x96 tiles)
 SPLITK_BELOW = int(os.environ.get("HYPEL_SPLITK_BELOW", "400"))    # FC-shaped products with fewer 128x64 blocks are cut along K
