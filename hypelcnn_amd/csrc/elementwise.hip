@@ -1291,7 +1291,10 @@ extern "C" int hypel_reduce_splits_multi_f32(const float* base, const hypel_redu
                                              hypel_stream_t stream) {
     HYPEL_REQUIRE(base && entries && n_entries >= 0, "hypel_reduce_splits_multi_f32");
     if (n_entries == 0) return 0;
-    hipLaunchKernelGGL(reduce_splits_multi_kernel, dim3(192, n_entries), dim3(256), 0, ST, base, entries);
+    // blocks per entry: the big entries (FC weights: 3 M elements x 2-3 slabs) want many, the many-slab entries of the
+    // 1x1 convolutions few; 768 measured best on the H13 step (192: +35 us, 1536: +8, 3072: +20; HYPEL_RED_GX)
+    static const int gx = getenv("HYPEL_RED_GX") ? atoi(getenv("HYPEL_RED_GX")) : 768;
+    hipLaunchKernelGGL(reduce_splits_multi_kernel, dim3(gx, n_entries), dim3(256), 0, ST, base, entries);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_multi_f32");
     return 0;
 }
