@@ -77,13 +77,35 @@ __device__ __forceinline__ void ew_loop(int64_t rows, int c, int tx_log2, F body
 // arithmetic (two divisions) is paid once per row instead of four 64-bit divisions per element.
 __global__ __launch_bounds__(256) void nhwc_to_pnc_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
                                                           int p, int c, int64_t ld) {
+    constexpr int ROWS = 4;  // rows a wave moves per pass: all their loads are in flight before the first store
     const int lane = threadIdx.x & 63;
     const int64_t n_rows = (int64_t)p * n;
-    for (int64_t rn = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); rn < n_rows; rn += (int64_t)gridDim.x * 4) {
-        const int64_t pp = rn / n, nn = rn - pp * n;
-        const float* __restrict__ src = x + (nn * p + pp) * c;
-        float* __restrict__ dst = out + rn * ld;
-        for (int cc = lane; cc < (int)ld; cc += 64) dst[cc] = cc < c ? src[cc] : 0.0f;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r0 = wave * ROWS; r0 < n_rows; r0 += n_waves * ROWS) {
+        for (int c0 = 0; c0 < (int)ld; c0 += 64 * 3) {
+            float v[ROWS][3];
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                const int64_t rn = min(r0 + k, n_rows - 1);
+                const int64_t pp = rn / n, nn = rn - pp * n;
+                const float* __restrict__ src = x + (nn * p + pp) * c;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int cc = c0 + lane + 64 * j;
+                    v[k][j] = cc < c ? src[cc] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                if (r0 + k >= n_rows) break;
+                float* __restrict__ dst = out + (r0 + k) * ld;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int cc = c0 + lane + 64 * j;
+                    if (cc < (int)ld) dst[cc] = v[k][j];
+                }
+            }
+        }
     }
 }
 
@@ -1243,7 +1265,7 @@ __global__ void lrn_bwd_kernel(const float* __restrict__ x, int64_t ldx, const f
 extern "C" int hypel_nhwc_to_pnc(const float* x, float* out, int64_t n, int32_t p, int32_t c, int64_t ld,
                                  hypel_stream_t stream) {
     HYPEL_REQUIRE(x && out && n > 0 && p > 0 && c > 0 && ld >= c, "hypel_nhwc_to_pnc");
-    const int64_t row_blocks = ((int64_t)p * n + 3) / 4;  // 4 rows (one per wave) per block
+    const int64_t row_blocks = ((int64_t)p * n + 15) / 16;  // 4 waves x 4 rows per block and pass
     hipLaunchKernelGGL(nhwc_to_pnc_kernel, dim3((unsigned)(row_blocks < 65536 * 4 ? row_blocks : 65536 * 4)), dim3(256), 0,
                        ST, x, out, n, p, c, ld);
     HYPEL_CHECK_LAUNCH("hypel_nhwc_to_pnc");
@@ -1266,6 +1288,11 @@ extern "C" int hypel_fill_f32(float* dst, int64_t count, float value, hypel_stre
     return 0;
 }
 
+static int red_max_blocks() {
+    static const int v = getenv("HYPEL_RED_MAX_BLOCKS") ? atoi(getenv("HYPEL_RED_MAX_BLOCKS")) : 8192;
+    return v;
+}
+
 extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_splits, float* out,
                                        int64_t count, int32_t accumulate, const float* bias, int32_t n,
                                        int64_t ldc, hypel_stream_t stream) {
@@ -1278,11 +1305,11 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
     else if (!(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0) && (count % 4 == 0) &&
              (stride % 4 == 0) && aligned16(partial) && aligned16(out) &&
              ((ldc <= 0 && (!bias || n % 4 == 0)) || (ldc > 0 && ldc % 4 == 0 && n % 4 == 0)))
-        hipLaunchKernelGGL(reduce_splits_v4_kernel, dim3(hypel_grid_1d(count / 4, 256, 8192)), dim3(256), 0, ST,
+        hipLaunchKernelGGL(reduce_splits_v4_kernel, dim3(hypel_grid_1d(count / 4, 256, red_max_blocks())), dim3(256), 0, ST,
                            partial, stride, n_splits, out, count / 4, accumulate, bias, n, ldc);
     else
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256)), dim3(256), 0, ST, partial, stride,
-                           n_splits, out, count, accumulate, bias, n, ldc);
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256, red_max_blocks())), dim3(256), 0, ST,
+                           partial, stride, n_splits, out, count, accumulate, bias, n, ldc);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
     return 0;
 }
