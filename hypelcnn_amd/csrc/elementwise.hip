@@ -29,7 +29,8 @@ static inline EwShape ew_shape(int64_t rows, int cvec) {
     const int ty = 256 >> l;
     int64_t g = (rows + ty - 1) / ty;
     if (g < 1) g = 1;
-    if (g > 8192) g = 8192;
+    static const int cap = getenv("HYPEL_EW_MAX_BLOCKS") ? atoi(getenv("HYPEL_EW_MAX_BLOCKS")) : 8192;
+    if (g > cap) g = cap;
     return EwShape{l, (int)g};
 }
 static inline bool aligned16(const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }

@@ -21,13 +21,14 @@ import numpy as np
 from . import graph as G
 from .backend import GEMM_BM, GROUP_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
 
-STAT_CHUNK_ROWS = 256  # upper bound; see stat_chunk_rows()
+STAT_CHUNK_ROWS = int(os.environ.get("HYPEL_STAT_CHUNK_ROWS", "256"))  # upper bound; see stat_chunk_rows()
+STAT_BLOCKS = int(os.environ.get("HYPEL_STAT_BLOCKS", "256"))            # blocks per 64-column stripe aimed at
 
 
 def stat_chunk_rows(rows):
     """Rows per partial-reduction block: ~256 blocks per 64-column stripe, between 16 and 256 rows each
     (a thread walks chunk/4 rows serially, so short matrices get short chunks)."""
-    c = (rows + 255) // 256
+    c = (rows + STAT_BLOCKS - 1) // STAT_BLOCKS
     c = max(16, min(STAT_CHUNK_ROWS, c))
     return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
