@@ -132,6 +132,7 @@ def valid_taps(h, w, k, oy, ox):
 SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
 LOSS_TAIL = os.environ.get("HYPEL_LOSS_TAIL", "1") != "0"  # xent / MSE sums, non-finite flag, step counter: one finaliser
 MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
+RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the device holds at once
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
 SINGLE_SEG_HINT = os.environ.get("HYPEL_SINGLE_SEG_HINT", "1") != "0"
 GEMM_PAIRED_SEGS = 0x400    # ... HYPEL_GEMM_PAIRED_SEGS (bit of `accumulate`)
@@ -410,7 +411,13 @@ class TowerPlan:
                 # short segments: per-k-tile overhead dominates, keep the wide tile -- unless that leaves the launch
                 # with under ~1000 blocks (the n = 120 data gradient of the 15-filter level: 142 us on 128x32 tiles,
                 # 154 on 128x64, round-2 A/B with paired segments)
-                return 2 if blocks64 >= 1000 else 1
+                if blocks64 < 1000:
+                    return 1
+                # ... and unless the 64-wide tiling overflows the resident capacity (6 blocks per CU) by a few blocks: the
+                # level-1 data gradient of H13 (392 x 4 = 1568 on 1536) then ends in a round of 32 lone blocks, and the
+                # 32-wide tiling (3136 blocks, two even rounds) is 46 us faster per step
+                over = blocks64 % RESIDENT_BLOCKS_64
+                return 1 if blocks64 < 2 * RESIDENT_BLOCKS_64 and 0 < over <= RESIDENT_BLOCKS_64 // 10 else 2
             if folded and blocks64 < 4000:
                 return 1
             return 1 if blocks64 < 900 else 2
