@@ -10,6 +10,7 @@ zero-argument callable, so a planned step is replayed as a flat list of pre-boun
 """
 import ctypes
 import os
+import time
 import subprocess
 
 import numpy as np
@@ -167,9 +168,12 @@ def bind_collective(name, args):
         src, count, dst = args
 
         def call():
+            # into ONE long-lived tensor: the list form of all_gather stages through a temporary whose release (by the
+            # process group's watchdog thread, whenever it reaps the finished work) makes the caching allocator record
+            # and poll an event -- which invalidates a HIP-graph capture that happens to be under way on the compute
+            # stream ("operation not permitted on an event last recorded in a capturing stream", 1 run in 8)
             world = dist.get_world_size()
-            out = dst.t[dst.off:dst.off + world * count].view(world, count)
-            dist.all_gather(list(out.unbind(0)), src.t[src.off:src.off + count])
+            dist.all_gather_into_tensor(dst.t[dst.off:dst.off + world * count], src.t[src.off:src.off + count])
 
     call.host = True
     return call
@@ -273,8 +277,25 @@ class HipBackend:
         self.bind(name, args)()
 
     # -- HIP graph capture --
-    def capture(self, launches):
-        """Capture a list of bound launches into a hipGraphExec; returns a replay callable."""
+    def settle_before_capture(self):
+        """A HIP-graph capture on the compute stream must not overlap the RCCL process group's watchdog thread while
+        that thread still polls / reaps finished collectives: HIP then fails the capture AND the watchdog's event query
+        ("operation not permitted on an event last recorded in a capturing stream", which terminates the process).
+        torch.cuda.graph() coordinates with the watchdog internally; a capture started through the C-ABI cannot, so it
+        waits until the device is idle and the watchdog (100 ms period) has nothing left to look at.  Reproduced and
+        cured in tools/exp/capture_vs_watchdog.py: 8 of 9 runs of 60 capture bursts die without the pause, 0 of 6 with
+        it.  No-op without an initialised NCCL process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+            return
+        torch.cuda.synchronize(self.device)
+        time.sleep(float(os.environ.get("HYPEL_CAPTURE_SETTLE_S", "0.3")))
+
+    def capture(self, launches, settled=False):
+        """Capture a list of bound launches into a hipGraphExec; returns a replay callable.
+        settled: the caller already called settle_before_capture() and issued no collective since."""
+        if not settled:
+            self.settle_before_capture()
         st = self.stream_handle()
         lib = self.lib
         if lib.hypel_graph_begin_capture(st) != 0:

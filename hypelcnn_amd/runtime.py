@@ -135,7 +135,10 @@ class CompiledTower:
         self.forward_backward() if self.bwd else self.forward()  # warm: first-use allocations / lazy module loads
         self.be.synchronize()
         items = self._items(bool(self.bwd))
-        graphs = [(kind, self.be.capture(v) if kind == "run" else v) for kind, v in items]
+        settle = getattr(self.be, "settle_before_capture", None)
+        if settle is not None:
+            settle()  # once for the whole chain of segments: no collective is issued between their captures
+        graphs = [(kind, self.be.capture(v, True) if kind == "run" else v) for kind, v in items]
         if len(graphs) == 1 and graphs[0][0] == "run":
             if self.bwd:
                 self._graph_all = graphs[0][1]

@@ -95,7 +95,7 @@ class EmuBackend:
     def call(self, name, *args):
         getattr(self, "k_" + name)(*args)
 
-    def capture(self, launches):
+    def capture(self, launches, settled=False):
         def replay():
             for f in launches:
                 f()
