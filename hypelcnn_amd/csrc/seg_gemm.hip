@@ -102,6 +102,9 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // A = B = C.
 // BNB: instantiate the batch-norm backward epilogue (16 more live registers at the end of the block: a separate
 // instantiation keeps the register allocation -- 6 waves per SIMD -- of every other launch).
+#ifndef HYPEL_GEMM_RUNNING_SOFFSET
+#define HYPEL_GEMM_RUNNING_SOFFSET 1  // row step of the staging loads as one running scalar (see stage()); 0 = precomputed
+#endif
 #ifndef HYPEL_GEMM_SGPR_CAP
 #define HYPEL_GEMM_SGPR_CAP 0  // > 0: cap the scalar registers of every variant (experiments on blocks per CU)
 #endif
@@ -291,6 +294,27 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
         const int kOOB = 0x7fffffff;
         const int voff = col < cols_valid ? (row0 * (int)ld + col) * 4 : kOOB;
+#if HYPEL_GEMM_RUNNING_SOFFSET
+        // the row step as ONE running scalar (an opaque s_add between the loads) instead of COUNT precomputed soffsets
+        // that stay live across the whole staging burst: up to 20 scalar registers less, the scalar spills of the
+        // 128x32 data-gradient variant drop from 11 to 2 (step 6.87 -> 6.81 ms, same-box A/B)
+        const int step = RSTEP * ld4;
+        int so = 0;
+        if (rows_valid >= COUNT * RSTEP) {
+#pragma unroll
+            for (int i = 0; i < COUNT; ++i) {
+                regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
+                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < COUNT; ++i) {
+                const int v = (row0 + i * RSTEP) < rows_valid ? voff : kOOB;
+                regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, so, 0));
+                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+            }
+        }
+#else
         if (rows_valid >= COUNT * RSTEP) {  // uniform: every staged row exists
 #pragma unroll
             for (int i = 0; i < COUNT; ++i)
@@ -302,6 +326,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                 regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, i * RSTEP * ld4, 0));
             }
         }
+#endif
     };
 
     // PAIR: the k columns [0, 16) of the tile come from (offX, kx), [16, 32) from (offY, ky): ONE descriptor based at
@@ -320,11 +345,22 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         const int c2 = col - 16;
         const int voff = col < 16 ? (col < kx ? dx + (row0 * (int)ld + col) * 4 : kOOB)
                                   : (c2 < ky ? dy + (row0 * (int)ld + c2) * 4 : kOOB);
+#if HYPEL_GEMM_RUNNING_SOFFSET
+        const int step = RSTEP * ld4;
+        int so = 0;
+#pragma unroll
+        for (int i = 0; i < COUNT; ++i) {
+            const int v = (row0 + i * RSTEP) < rows_valid ? voff : kOOB;
+            regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, so, 0));
+            asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+        }
+#else
 #pragma unroll
         for (int i = 0; i < COUNT; ++i) {
             const int v = (row0 + i * RSTEP) < rows_valid ? voff : kOOB;
             regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, i * RSTEP * ld4, 0));
         }
+#endif
     };
 
     auto load_tiles = [&](const hypel_seg_t& sg, int k0) {
