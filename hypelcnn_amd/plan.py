@@ -32,7 +32,7 @@ def stat_chunk_rows(rows):
     c = max(16, min(STAT_CHUNK_ROWS, c))
     return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
-TARGET_BLOCKS = int(os.environ.get("HYPEL_WGRAD_TARGET_BLOCKS", "1024"))  # blocks a filter-gradient product is split towards
+TARGET_BLOCKS = int(os.environ.get("HYPEL_WGRAD_TARGET_BLOCKS", "1536"))  # blocks a filter-gradient product is split towards
 WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
 WGRAD_MIN_SPLITS = int(os.environ.get("HYPEL_WGRAD_MIN_SPLITS", "0"))  # 0 = one split per 64 batch rows once a launch fills the device unsplit
 SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel-part splitting also for biased convs
