@@ -132,6 +132,7 @@ def valid_taps(h, w, k, oy, ox):
 SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
 LOSS_TAIL = os.environ.get("HYPEL_LOSS_TAIL", "1") != "0"  # xent / MSE sums, non-finite flag, step counter: one finaliser
 MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
+HINT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_HINT_OVERRIDE", "").split(",") if kv)}
 RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the device holds at once
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
 SINGLE_SEG_HINT = os.environ.get("HYPEL_SINGLE_SEG_HINT", "1") != "0"
@@ -462,6 +463,8 @@ class TowerPlan:
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
         hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
+        if HINT_OVERRIDE and tag in HINT_OVERRIDE:  # per-launch A/B: HYPEL_HINT_OVERRIDE="fwd:conv_enc_2=1,dgrad:fc_0=2"
+            hint = HINT_OVERRIDE[tag]
         if SINGLE_SEG_HINT and not ta and bnbwd is None and all(len(segs) == 1 for _, segs, _ in tables.groups):
             accumulate = int(accumulate) | GEMM_SINGLE_SEG
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
