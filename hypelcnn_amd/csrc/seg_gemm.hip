@@ -88,6 +88,9 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
+#ifndef HYPEL_OCC_BN64_TA
+#define HYPEL_OCC_BN64_TA 3  // waves per SIMD the 128x64 filter-gradient (A transposed) variants are compiled for
+#endif
 #ifndef HYPEL_OCC_BN96
 #define HYPEL_OCC_BN96 5  // ... and the 128x96 data-gradient variant (5 blocks per CU = 1280 resident: 392 x 3 row x column
                           // tiles fit); the forward variant needs ~104 registers: 4 waves per SIMD, 1024 resident
@@ -676,7 +679,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 #define HYPEL_GEMM_ARGS \
     A, lda, B, ldb, C, ldc, n, groups, segs, tiles_v, n_tiles, n_ntiles, bias, accumulate, res, ldr, res_start, stats, bnb
 #define HYPEL_GEMM_BOUNDS \
-    __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : 3)))
+    __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : (TA ? HYPEL_OCC_BN64_TA : 3))))
 
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
           bool PAIR = false>
