@@ -132,6 +132,7 @@ def valid_taps(h, w, k, oy, ox):
 SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
 LOSS_TAIL = os.environ.get("HYPEL_LOSS_TAIL", "1") != "0"  # xent / MSE sums, non-finite flag, step counter: one finaliser
 MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
+DP_SYNC_WORK = float(os.environ.get("HYPEL_DP_SYNC_WORK", "0.5"))  # share of the filter-gradient work before the sync point
 HINT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_HINT_OVERRIDE", "").split(",") if kv)}
 RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the device holds at once
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
@@ -498,26 +499,41 @@ class TowerPlan:
     def _dp_sync_node(self):
         """Data-parallel overlap: the node index (walking backward) after which >= 60 % of the weight-gradient
         bytes are final, with the flat range [lo, hi) they occupy.  Weights are laid out in creation order
-        (Session.finalize_variables), i.e. in node order, so that range is one contiguous tail."""
+        (Session.finalize_variables), i.e. in node order, so that range is one contiguous tail.
+        The merged filter-gradient launch is flushed at this point, so the point also has to cut the filter-gradient
+        WORK into two useful halves: at the first node that satisfies the byte rule (H13: fc_0, 75 % of the bytes but 8 %
+        of the multiply-adds) the early launch held a handful of badly shaped products and cost 0.13 ms per step; the
+        walk therefore continues until >= DP_SYNC_WORK of the filter-gradient multiply-adds are behind it, as long as
+        >= 15 % of them -- backward time to hide the all-reduce under -- remain (H13: the first level, 66 % / 34 %)."""
         sized = []
         for idx, node in enumerate(self.tower.nodes):
             if isinstance(node, G.LinearNode):
                 ws = [b.w for b in node.branches]
                 if ws and all(w.trainable and w.offset is not None for w in ws):
-                    sized.append((idx, min(w.offset for w in ws), max(w.offset + w.size for w in ws)))
+                    macs = sum(w.size for w in ws) * max(1, node.out.npix)  # x batch: the same factor for every node
+                    sized.append((idx, min(w.offset for w in ws), max(w.offset + w.size for w in ws), macs))
         if len(sized) < 2:
             return None
-        total = sum(hi - lo for _, lo, hi in sized)
-        hi_all = max(hi for _, _, hi in sized)
-        acc = 0
+        total = sum(hi - lo for _, lo, hi, _ in sized)
+        total_macs = sum(m for _, _, _, m in sized)
+        hi_all = max(hi for _, _, hi, _ in sized)
+        acc = acc_macs = 0
+        best = None
         for k in range(len(sized) - 1, 0, -1):  # never the first layer: nothing would be left to overlap with
-            idx, lo, hi = sized[k]
+            idx, lo, hi, macs = sized[k]
             acc += hi - lo
-            tail_lo = min(l for _, l, _ in sized[k:])
-            contiguous = sum(h - l for _, l, h in sized[k:]) == hi_all - tail_lo
+            acc_macs += macs
+            tail_lo = min(l for _, l, _, _ in sized[k:])
+            contiguous = sum(h - l for _, l, h, _ in sized[k:]) == hi_all - tail_lo
             if acc >= 0.6 * total and contiguous:
-                return idx, tail_lo, hi_all
-        return None
+                if best is None:
+                    best = (idx, tail_lo, hi_all)
+                if acc_macs > 0.85 * total_macs:
+                    break  # too little backward left behind this point
+                best = (idx, tail_lo, hi_all)
+                if acc_macs >= DP_SYNC_WORK * total_macs:
+                    break
+        return best
 
     # ------------------------------------------------------------------ consumers / epilogue fusion
     @staticmethod
