@@ -1070,15 +1070,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t small_rsrc(const float* p) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7ffffff0, 0x00020000);
 }
 
+// Row validity without compare masks (32 of them cost the ragged variant 64 scalar registers and 52-76 spills): a row
+// past the matrix turns the offset into 0xffffffff arithmetically, which the descriptor rejects like SMALL_OOB; the
+// row step is one running scalar offset (see seg_gemm.hip stage()).
+__device__ __forceinline__ uint32_t small_row_off(uint32_t v0, int last_row_minus_ty, int i) {
+    return v0 | (uint32_t)((last_row_minus_ty - i * SMALL_TY) >> 31);
+}
+
 template <bool FULL>
 __device__ __forceinline__ void small_load_rows(const float* p, int ld, int rows, int col, bool ok, float (&v)[SMALL_R]) {
     const int ty = threadIdx.x / SMALL_TX;
     const __amdgpu_buffer_rsrc_t rs = small_rsrc(p);
     const uint32_t v0 = ok ? (uint32_t)(ty * ld + col) * 4u : SMALL_OOB;
+    const int last = rows - 1 - ty;
+    const int step = SMALL_TY * ld * 4;
+    int so = 0;
 #pragma unroll
     for (int i = 0; i < SMALL_R; ++i) {
-        const uint32_t vo = (FULL || ty + i * SMALL_TY < rows) ? v0 : SMALL_OOB;
-        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * SMALL_TY * ld * 4, 0));
+        const uint32_t vo = FULL ? v0 : small_row_off(v0, last, i);
+        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+        asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
     }
 }
 
@@ -1087,10 +1098,14 @@ __device__ __forceinline__ void small_store_rows(float* p, int ld, int rows, int
     const int ty = threadIdx.x / SMALL_TX;
     const __amdgpu_buffer_rsrc_t rs = small_rsrc(p);
     const uint32_t v0 = ok ? (uint32_t)(ty * ld + col) * 4u : SMALL_OOB;
+    const int last = rows - 1 - ty;
+    const int step = SMALL_TY * ld * 4;
+    int so = 0;
 #pragma unroll
     for (int i = 0; i < SMALL_R; ++i) {
-        const uint32_t vo = (FULL || ty + i * SMALL_TY < rows) ? v0 : SMALL_OOB;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs, vo, i * SMALL_TY * ld * 4, 0);
+        const uint32_t vo = FULL ? v0 : small_row_off(v0, last, i);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs, vo, so, 0);
+        asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
     }
 }
 
