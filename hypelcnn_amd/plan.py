@@ -505,6 +505,8 @@ class TowerPlan:
         of the multiply-adds) the early launch held a handful of badly shaped products and cost 0.13 ms per step; the
         walk therefore continues until >= DP_SYNC_WORK of the filter-gradient multiply-adds are behind it, as long as
         >= 15 % of them -- backward time to hide the all-reduce under -- remain (H13: the first level, 66 % / 34 %)."""
+        if os.environ.get("HYPEL_DP_NO_SYNC") == "1":  # diagnostic: one graph, one all-reduce after the backward pass
+            return None
         sized = []
         for idx, node in enumerate(self.tower.nodes):
             if isinstance(node, G.LinearNode):
