@@ -71,7 +71,10 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void gan_generator_fwd_kernel(const
                                                                             int only_encoder, float* __restrict__ out,
                                                                             int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const GenLayout g = gen_layout(bands, only_encoder);
+    __shared__ GenLayout g_lds;  // layer table in LDS, not in per-lane scratch memory (see the tiled kernels)
+    if (threadIdx.x == 0) g_lds = gen_layout(bands, only_encoder);
+    __syncthreads();
+    const GenLayout& g = g_lds;
     float* ws = smem;                 // [wtotal]
     float* bs = ws + g.wtotal;        // [8]
     float* wave_base = bs + 8;
@@ -101,7 +104,10 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void gan_generator_bwd_kernel(
     const float* __restrict__ w, const float* __restrict__ b, int only_encoder, float* __restrict__ dx, int64_t lddx,
     int accumulate_dx, float* __restrict__ pw, float* __restrict__ pb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const GenLayout g = gen_layout(bands, only_encoder);
+    __shared__ GenLayout g_lds;
+    if (threadIdx.x == 0) g_lds = gen_layout(bands, only_encoder);
+    __syncthreads();
+    const GenLayout& g = g_lds;
     float* ws = smem;
     float* bs = ws + g.wtotal;
     float* wave_base = bs + 8;
@@ -332,7 +338,12 @@ __global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_fwd_tiled_kernel(
     const float* __restrict__ x, int64_t ldx, int64_t n, int bands, const float* __restrict__ w,
     const float* __restrict__ b, int only_encoder, float* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const GenTiled g = gen_tiled(bands, only_encoder);
+    // the layer table lives in LDS: as a per-thread struct its dynamically indexed arrays went to scratch memory (284
+    // bytes per lane) and every layer of every sample started with a round of private-memory loads
+    __shared__ GenTiled g_lds;
+    if (threadIdx.x == 0) g_lds = gen_tiled(bands, only_encoder);
+    __syncthreads();
+    const GenTiled& g = g_lds;
     float* wp = smem;                 // [wptotal]
     float* bs = wp + g.wptotal;       // [8]
     float* wave_base = bs + 8;
@@ -361,7 +372,10 @@ __global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_bwd_tiled_kernel(
     const float* __restrict__ w, const float* __restrict__ b, int only_encoder, float* __restrict__ dx, int64_t lddx,
     int accumulate_dx, float* __restrict__ pw, float* __restrict__ pb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const GenTiled g = gen_tiled(bands, only_encoder);
+    __shared__ GenTiled g_lds;  // see the forward kernel
+    if (threadIdx.x == 0) g_lds = gen_tiled(bands, only_encoder);
+    __syncthreads();
+    const GenTiled& g = g_lds;
     const int H = g.H, W = g.W, B4 = g.B4;
     float* wp = smem;
     float* wf = wp + g.wptotal;
@@ -722,7 +736,7 @@ extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, i
                                        const float* b, int32_t only_encoder, float* out, int64_t ldo,
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(x && w && b && out && n > 0 && bands >= 8, "hypel_gan_generator_fwd");
-    if (bands > GEN_TILED_MIN && gt_fwd_lds(bands, only_encoder) <= 160 * 1024) {
+    if (bands > GEN_TILED_MIN && gt_fwd_lds(bands, only_encoder) <= 160 * 1024 - 512) {  // 512: the static layer table
         const size_t tl = gt_fwd_lds(bands, only_encoder);
         if (tl > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)gan_generator_fwd_tiled_kernel,
@@ -733,7 +747,7 @@ extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, i
         return 0;
     }
     const size_t lds = gen_fwd_lds(bands, only_encoder);
-    HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_gan_generator_fwd");
+    HYPEL_REQUIRE(lds <= 160 * 1024 - 512, "hypel_gan_generator_fwd");
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)gan_generator_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
@@ -748,7 +762,7 @@ extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float*
                                        int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && bands >= 8, "hypel_gan_generator_bwd");
-    if (bands > GEN_TILED_MIN && gt_bwd_lds(bands, only_encoder) <= 160 * 1024) {
+    if (bands > GEN_TILED_MIN && gt_bwd_lds(bands, only_encoder) <= 160 * 1024 - 512) {  // 512: the static layer table
         const size_t tl = gt_bwd_lds(bands, only_encoder);
         if (tl > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)gan_generator_bwd_tiled_kernel,
@@ -759,7 +773,7 @@ extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float*
         return 0;
     }
     const size_t lds = gen_bwd_lds(bands, only_encoder);
-    HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_gan_generator_bwd");
+    HYPEL_REQUIRE(lds <= 160 * 1024 - 512, "hypel_gan_generator_bwd");
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)gan_generator_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
