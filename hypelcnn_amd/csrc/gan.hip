@@ -214,7 +214,14 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void gan_generator_bwd_kernel(
 //     steps of 4: two aligned ds_read_b128 (an 8-float window) + one broadcast b128 feed 16 FMAs, i.e. 0.19 LDS
 //     reads per FMA instead of 2, and 4 independent accumulators instead of one dependent chain.
 constexpr int GEN_TILED_MIN = 128;
-constexpr int GT_WAVES = 4;
+constexpr int GT_WAVES = 4;  // samples a block works on at a time ("slots"; each has its own LDS region)
+// Wavefronts that share ONE sample (round 2).  The backward kernel needs ~35 KB of LDS per sample at 360 bands, so a CU
+// holds four samples: with one wavefront each that was one wave per SIMD, nothing to hide an LDS round trip or an
+// FMA chain behind, and 90 output quads on 64 lanes took two passes (64 + 26).  Two waves split the quads / taps of
+// every phase (ranges are disjoint, phases end in a block barrier instead of a wave barrier): 8 waves per CU.
+constexpr int GT_COOP = 2;
+constexpr int GT_SLOT_THREADS = 64 * GT_COOP;
+constexpr int GT_QSTEP = 4 * GT_SLOT_THREADS;  // outputs a slot's threads cover per pass (4 per thread)
 
 struct GenTiled {
     int k[7], pl[7], woff[7];
@@ -289,11 +296,12 @@ __device__ __forceinline__ void gt_quad(const float* __restrict__ in, int H, int
     }
 }
 
-// forward of one sample by one wave.  rows: padded activation rows, row(i) = rows + slot(i) * W.
-// FULL = keep all 7 rows (backward recompute, slot(i) = i), else 3 rolling rows (slot(i) = i % 3).
-// The last full-generator layer leaves the pre-tanh values in `pre` (padded row, element q at pre[H + q]).
+// forward of one sample by the GT_COOP waves of a slot (st = thread index inside the slot).  rows: padded activation
+// rows, row(i) = rows + slot(i) * W.  FULL = keep all 7 rows (backward recompute, slot(i) = i), else 3 rolling rows
+// (slot(i) = i % 3).  The last full-generator layer leaves the pre-tanh values in `pre` (padded row, element q at
+// pre[H + q]).  Every phase ends in a block barrier: all threads of the block must call this together.
 template <bool FULL>
-__device__ __forceinline__ void gt_forward_wave(const GenTiled& g, int bands, int lane, const float* __restrict__ wp,
+__device__ __forceinline__ void gt_forward_wave(const GenTiled& g, int bands, int st, const float* __restrict__ wp,
                                                 const float* __restrict__ bs, float* __restrict__ rows,
                                                 uint8_t* __restrict__ slope, float* __restrict__ pre) {
     const int hidden = g.layers == 7 ? 6 : 4;
@@ -303,7 +311,7 @@ __device__ __forceinline__ void gt_forward_wave(const GenTiled& g, int bands, in
         const float* in = row(i - 1);
         const float* in2 = i >= 2 ? row(i - 2) : nullptr;
         float* out = row(i);
-        for (int p0 = 4 * lane; p0 < bands; p0 += 256) {
+        for (int p0 = 4 * st; p0 < bands; p0 += GT_QSTEP) {
             float acc[4] = {bs[i - 1], bs[i - 1], bs[i - 1], bs[i - 1]};
             gt_quad(in, H, p0, wp + g.wpoff[i - 1], g.dmin[i - 1], g.nch[i - 1], acc);
 #pragma unroll
@@ -319,22 +327,22 @@ __device__ __forceinline__ void gt_forward_wave(const GenTiled& g, int bands, in
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
     if (g.layers == 7) {
         const float* in = row(6);
-        for (int p0 = 4 * lane; p0 < bands; p0 += 256) {
+        for (int p0 = 4 * st; p0 < bands; p0 += GT_QSTEP) {
             float acc[4] = {bs[6], bs[6], bs[6], bs[6]};
             gt_quad(in, H, p0, wp + g.wpoff[6], g.dmin[6], g.nch[6], acc);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 if (p0 + t < bands) pre[H + p0 + t] = acc[t];
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_fwd_tiled_kernel(
+__global__ __launch_bounds__(GT_SLOT_THREADS * GT_WAVES) void gan_generator_fwd_tiled_kernel(
     const float* __restrict__ x, int64_t ldx, int64_t n, int bands, const float* __restrict__ w,
     const float* __restrict__ b, int only_encoder, float* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -347,27 +355,32 @@ __global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_fwd_tiled_kernel(
     float* wp = smem;                 // [wptotal]
     float* bs = wp + g.wptotal;       // [8]
     float* wave_base = bs + 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int st = threadIdx.x % GT_SLOT_THREADS, slot = threadIdx.x / GT_SLOT_THREADS;
     gt_stage_weights(g, w, wp, nullptr);
     if (threadIdx.x < 7) bs[threadIdx.x] = b[threadIdx.x];
-    float* rows = wave_base + (size_t)wave * 4 * g.W;  // 3 rolling rows + the pre-tanh row
+    float* rows = wave_base + (size_t)slot * 4 * g.W;  // 3 rolling rows + the pre-tanh row
     float* pre = rows + 3 * g.W;
-    for (int i = lane; i < 4 * g.W; i += 64) rows[i] = 0.0f;  // margins stay zero for the whole kernel
+    for (int i = st; i < 4 * g.W; i += GT_SLOT_THREADS) rows[i] = 0.0f;  // margins stay zero for the whole kernel
     __syncthreads();
-    for (int64_t s = (int64_t)blockIdx.x * GT_WAVES + wave; s < n; s += (int64_t)gridDim.x * GT_WAVES) {
-        for (int p = lane; p < bands; p += 64) rows[g.H + p] = x[s * ldx + p];
-        __builtin_amdgcn_wave_barrier();
-        gt_forward_wave<false>(g, bands, lane, wp, bs, rows, nullptr, pre);
+    // block-uniform trip count (the phases end in block barriers); a slot past the end works on zeros and stores nothing
+    const int64_t first = (int64_t)blockIdx.x * GT_WAVES, stride = (int64_t)gridDim.x * GT_WAVES;
+    for (int64_t s0 = first; s0 < n; s0 += stride) {
+        const int64_t s = s0 + slot;
+        const bool active = s < n;
+        for (int p = st; p < bands; p += GT_SLOT_THREADS) rows[g.H + p] = active ? x[s * ldx + p] : 0.0f;
+        __syncthreads();
+        gt_forward_wave<false>(g, bands, st, wp, bs, rows, nullptr, pre);
         const float* a4 = rows + (4 % 3) * g.W;
-        for (int p = lane; p < bands; p += 64)
-            out[s * ldo + p] = only_encoder ? a4[g.H + p] : tanhf(pre[g.H + p]);
-        __builtin_amdgcn_wave_barrier();
+        if (active)
+            for (int p = st; p < bands; p += GT_SLOT_THREADS)
+                out[s * ldo + p] = only_encoder ? a4[g.H + p] : tanhf(pre[g.H + p]);
+        __syncthreads();
     }
 }
 
-// Backward (recompute + reverse walk), tiled.  Per wave in LDS: 7 padded activation rows, one padded dc row,
-// 3 rolling da rows, 6 x bands slope flags (bytes), the filter gradients in offset space.
-__global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_bwd_tiled_kernel(
+// Backward (recompute + reverse walk), tiled.  Per slot in LDS: 7 padded activation rows, one padded dc row,
+// 3 rolling da rows, 6 x bands slope flags (bytes), the filter gradients in offset space, bias gradients + 2 partials.
+__global__ __launch_bounds__(GT_SLOT_THREADS * GT_WAVES) void gan_generator_bwd_tiled_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
     const float* __restrict__ w, const float* __restrict__ b, int only_encoder, float* __restrict__ dx, int64_t lddx,
     int accumulate_dx, float* __restrict__ pw, float* __restrict__ pb) {
@@ -383,35 +396,43 @@ __global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_bwd_tiled_kernel(
     float* wave_base = bs + 8;
     const int slope_words = (6 * bands + 15) / 16 * 4;  // bytes rounded up to 16, in floats
     const size_t per_wave = (size_t)8 * W + 3 * B4 + slope_words + g.wptotal + 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int st = threadIdx.x % GT_SLOT_THREADS, slot = threadIdx.x / GT_SLOT_THREADS;
+    const int lane = threadIdx.x & 63, cw = st >> 6;  // lane, wave inside the slot
     gt_stage_weights(g, w, wp, wf);
     if (threadIdx.x < 7) bs[threadIdx.x] = b[threadIdx.x];
-    float* rows = wave_base + wave * per_wave;  // a[0..6]
+    float* rows = wave_base + slot * per_wave;  // a[0..6]
     float* dc = rows + 7 * W;                   // padded
     float* da = dc + W;                         // 3 rolling rows of B4
     uint8_t* slope = reinterpret_cast<uint8_t*>(da + 3 * B4);
     float* dwp = da + 3 * B4 + slope_words;     // [wptotal] offset-space filter gradients
-    float* db = dwp + g.wptotal;
-    for (int i = lane; i < 8 * W; i += 64) rows[i] = 0.0f;
-    for (int i = lane; i < g.wptotal; i += 64) dwp[i] = 0.0f;
-    if (lane < 8) db[lane] = 0.0f;
+    float* db = dwp + g.wptotal;                // [7] bias gradients
+    __shared__ float dbp_all[GT_WAVES][GT_COOP];  // per-wave partial of the bias-gradient sum of the current layer
+    float* dbp = dbp_all[slot];
+    for (int i = st; i < 8 * W; i += GT_SLOT_THREADS) rows[i] = 0.0f;
+    for (int i = st; i < g.wptotal; i += GT_SLOT_THREADS) dwp[i] = 0.0f;
+    if (st < 8) db[st] = 0.0f;
     __syncthreads();
     const int hidden = g.layers == 7 ? 6 : 4;
     auto da_row = [&](int i) { return da + (i % 3) * B4; };
 
-    for (int64_t s = (int64_t)blockIdx.x * GT_WAVES + wave; s < n; s += (int64_t)gridDim.x * GT_WAVES) {
-        for (int p = lane; p < bands; p += 64) rows[H + p] = x[s * ldx + p];
-        __builtin_amdgcn_wave_barrier();
-        gt_forward_wave<true>(g, bands, lane, wp, bs, rows, slope, dc);
+    // block-uniform trip count (every phase ends in a block barrier); a slot past the end works on zeros: its dc rows
+    // are zero, so it adds nothing to the filter / bias gradients, and it stores nothing
+    const int64_t first = (int64_t)blockIdx.x * GT_WAVES, stride = (int64_t)gridDim.x * GT_WAVES;
+    for (int64_t s0 = first; s0 < n; s0 += stride) {
+        const int64_t s = s0 + slot;
+        const bool active = s < n;
+        for (int p = st; p < bands; p += GT_SLOT_THREADS) rows[H + p] = active ? x[s * ldx + p] : 0.0f;
+        __syncthreads();
+        gt_forward_wave<true>(g, bands, st, wp, bs, rows, slope, dc);
 
         // given dc (padded row): db_li, dW_li (offset space), din[q] (+)= sum_e wf[e] dc[q + e]
         auto layer_bwd = [&](int li, const float* in, float* din, bool assign) {
             float sb = 0.0f;
-            for (int p = lane; p < bands; p += 64) sb += dc[H + p];
+            for (int p = st; p < bands; p += GT_SLOT_THREADS) sb += dc[H + p];
             for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
-            if (lane == 0) db[li] += sb;
-            // filter gradient: the lane owns the 4 taps c0..c0+3 of offset space and walks the positions
-            for (int c0 = 4 * lane; c0 < 4 * g.nch[li]; c0 += 256) {
+            if (lane == 0) dbp[cw] = sb;
+            // filter gradient: the thread owns the 4 taps c0..c0+3 of offset space and walks the positions
+            for (int c0 = 4 * st; c0 < 4 * g.nch[li]; c0 += GT_QSTEP) {
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 const float4* base = reinterpret_cast<const float4*>(in + H + g.dmin[li] + c0);
                 const float4* dc4 = reinterpret_cast<const float4*>(dc + H);
@@ -437,52 +458,58 @@ __global__ __launch_bounds__(64 * GT_WAVES) void gan_generator_bwd_tiled_kernel(
                 *o4 = cur;
             }
             // input gradient
-            for (int q0 = 4 * lane; q0 < bands; q0 += 256) {
+            for (int q0 = 4 * st; q0 < bands; q0 += GT_QSTEP) {
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 gt_quad(dc, H, q0, wf + g.wfoff[li], g.emin[li], g.nchf[li], acc);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (q0 + t < bands) din[q0 + t] = assign ? acc[t] : din[q0 + t] + acc[t];
             }
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
+            if (st == 0) {  // the slot's waves in fixed order (dbp is next written behind another barrier)
+                float t = dbp[0];
+#pragma unroll
+                for (int k = 1; k < GT_COOP; ++k) t += dbp[k];
+                db[li] += t;
+            }
         };
 
         if (g.layers == 7) {
-            for (int p = lane; p < bands; p += 64) {
+            for (int p = st; p < bands; p += GT_SLOT_THREADS) {
                 const float t = tanhf(dc[H + p]);
-                dc[H + p] = dout[s * lddo + p] * (1.0f - t * t);
+                dc[H + p] = (active ? dout[s * lddo + p] : 0.0f) * (1.0f - t * t);
             }
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
             layer_bwd(6, rows + 6 * W, da_row(6), true);
         } else {
             float* d4 = da_row(4);
-            for (int p = lane; p < bands; p += 64) d4[p] = dout[s * lddo + p];
-            __builtin_amdgcn_wave_barrier();
+            for (int p = st; p < bands; p += GT_SLOT_THREADS) d4[p] = active ? dout[s * lddo + p] : 0.0f;
+            __syncthreads();
         }
         for (int i = hidden; i >= 1; --i) {
             const float* gi_row = da_row(i);
             float* d1 = da_row(i - 1);
             float* d2 = i >= 2 ? da_row(i - 2) : nullptr;
-            for (int p = lane; p < bands; p += 64) {
+            for (int p = st; p < bands; p += GT_SLOT_THREADS) {
                 const float gi = gi_row[p];
                 d1[p] = (i == hidden) ? gi : d1[p] + gi;  // first touch of da[hidden-1]
                 if (d2) d2[p] = gi;                        // first touch of da[i-2]
                 dc[H + p] = slope[(i - 1) * bands + p] ? gi : gi * GEN_ALPHA;
             }
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
             layer_bwd(i - 1, rows + (i - 1) * W, d1, false);
         }
-        if (dx) {
+        if (dx && active) {
             const float* d0 = da_row(0);
-            for (int p = lane; p < bands; p += 64) {
+            for (int p = st; p < bands; p += GT_SLOT_THREADS) {
                 float* d = dx + s * lddx + p;
                 *d = accumulate_dx ? *d + d0[p] : d0[p];
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
     __syncthreads();
-    // combine the waves (fixed order), map offset space back to tap order, publish the block's partial sums
+    // combine the slots (fixed order), map offset space back to tap order, publish the block's partial sums
     float* pwb = pw + (size_t)blockIdx.x * g.wtotal;
     const size_t dw_at = (size_t)8 * W + 3 * B4 + slope_words;
     for (int li = 0; li < 7; ++li)
@@ -741,7 +768,7 @@ extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, i
         if (tl > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)gan_generator_fwd_tiled_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(gan_generator_fwd_tiled_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * GT_WAVES), tl,
+        hipLaunchKernelGGL(gan_generator_fwd_tiled_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(GT_SLOT_THREADS * GT_WAVES), tl,
                            ST, x, ldx, n, bands, w, b, only_encoder, out, ldo);
         HYPEL_CHECK_LAUNCH("hypel_gan_generator_fwd");
         return 0;
@@ -767,7 +794,7 @@ extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float*
         if (tl > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)gan_generator_bwd_tiled_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(gan_generator_bwd_tiled_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(64 * GT_WAVES), tl,
+        hipLaunchKernelGGL(gan_generator_bwd_tiled_kernel, dim3(hypel_gan_generator_blocks(n)), dim3(GT_SLOT_THREADS * GT_WAVES), tl,
                            ST, x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb);
         HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd");
         return 0;
