@@ -289,7 +289,7 @@ class HipBackend:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
             return
         torch.cuda.synchronize(self.device)
-        time.sleep(float(os.environ.get("HYPEL_CAPTURE_SETTLE_S", "0.3")))
+        time.sleep(float(os.environ.get("HYPEL_CAPTURE_SETTLE_S", "0.5")))
 
     def capture(self, launches, settled=False):
         """Capture a list of bound launches into a hipGraphExec; returns a replay callable.
