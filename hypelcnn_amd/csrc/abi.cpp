@@ -1,4 +1,5 @@
 // libhypel_hip.so: error channel, device query, HIP-graph capture helpers.
+#include <cstdlib>
 #include <stdarg.h>
 #include <string.h>
 
@@ -91,7 +92,12 @@ extern "C" int hypel_stream_join(hypel_stream_t main_stream, hypel_stream_t side
 }
 
 extern "C" int hypel_graph_begin_capture(hypel_stream_t stream) {
-    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+    // HYPEL_CAPTURE_MODE=relaxed|global: experiments (default thread-local)
+    static const char* mode_env = getenv("HYPEL_CAPTURE_MODE");
+    hipStreamCaptureMode mode = hipStreamCaptureModeThreadLocal;
+    if (mode_env && mode_env[0] == 'r') mode = hipStreamCaptureModeRelaxed;
+    if (mode_env && mode_env[0] == 'g') mode = hipStreamCaptureModeGlobal;
+    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, mode);
     if (e != hipSuccess) {
         hypel_set_error("hypel_graph_begin_capture: %s", hipGetErrorString(e));
         return -2;
