@@ -458,7 +458,13 @@ def main():
         if pipeline is not None:
             out["with_input_pipeline"] = pipeline
         try:
-            out["commit"] = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip() or None
+            commit = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()
+            if not commit:  # the GPU box gets a snapshot without .git: tools/gpu.sh leaves the hash in this file
+                try:
+                    commit = open(os.path.join(ROOT, ".head_commit")).read().strip()
+                except OSError:
+                    commit = ""
+            out["commit"] = commit or None
         except OSError:
             pass
         print(json.dumps(out))
