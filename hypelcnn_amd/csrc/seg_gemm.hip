@@ -80,6 +80,11 @@ constexpr int BK_NARROW = HYPEL_GEMM_BK_NARROW;
 #ifndef HYPEL_GEMM_CHUNK
 #define HYPEL_GEMM_CHUNK 8  // granularity (reduction columns) at which a short k-tile stops issuing MFMAs
 #endif
+#ifndef HYPEL_GEMM_RD64
+#define HYPEL_GEMM_RD64 51  // operand fragments of two consecutive MFMA k-steps from ONE ds_read_b64 (see RD64 below); bits:
+                           // 1 = A B products, 2 = A B^T, 4 = A^T B, 8 = A^T B^T; 16 = also the 128x32 variants;
+                           // 32 = k-contiguous operands are transposed into the pair-interleaved image as well
+#endif
 #ifndef HYPEL_GEMM_ADDTID
 #define HYPEL_GEMM_ADDTID 0  // 1: unpadded LDS images are written with ds_write_addtid_b32 (no address VGPR: 2 cycles
 #endif                       // per wave-store instead of 4, MI355X_MICROARCH.md LDS table)
@@ -90,6 +95,9 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 #endif
 #ifndef HYPEL_OCC_BN64_TA
 #define HYPEL_OCC_BN64_TA 3  // waves per SIMD the 128x64 filter-gradient (A transposed) variants are compiled for
+#endif
+#ifndef HYPEL_OCC_BN32_TA
+#define HYPEL_OCC_BN32_TA 3  // ... the 128x32 filter-gradient variants
 #endif
 #ifndef HYPEL_OCC_BN96
 #define HYPEL_OCC_BN96 5  // ... and the 128x96 data-gradient variant (5 blocks per CU = 1280 resident: 392 x 3 row x column
@@ -148,10 +156,25 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     // pitches: a fragment read must hit 32 distinct banks per half-wave.  32x32x2 fragments read 32 rows at one k
     // (odd pitch 33 for the k-contiguous image); 16x16x4 fragments read 16 rows x 2 k per half-wave (pitch 34 resp.
     // 16 extra floats per k row of the transposed image)
-    constexpr int A_PITCH = TA ? (NARROW ? BM + 16 : BM) : (NARROW ? BK + 2 : BK + 1);
+    // RD64 (32x32x2 variants): the k-step PAIR t of a k-tile multiplies the reduction columns {4t, 4t+2} (first MFMA:
+    // lane half h supplies column 4t + 2h) and {4t+1, 4t+3} (second MFMA), so that a lane needs the two ADJACENT
+    // columns 4t + 2h, 4t + 2h + 1: one ds_read_b64 per operand tile per step pair instead of two ds_read_b32 (the b64
+    // form moves 256 B per LDS clock, the b32 form 128; MI355X_MICROARCH.md LDS table).  k-contiguous images ([m][k],
+    // [n][k]) keep their natural order with an even pitch of BK + 2 = 34 floats (32 rows x 8 bytes then cover the 64
+    // banks exactly once; the 2-way conflict of the staging stores is hidden under their register transfer); the
+    // k-strided images ([k][m], [k][n]) interleave the rows of a column pair: (k, x) -> ((k >> 1) * W + x) * 2 + (k & 1).
+    // The order of the products inside a k-tile changes (0,2,1,3,4,6,...), the result stays one fixed fmaf chain.
+    constexpr bool RD64 = !NARROW && ((HYPEL_GEMM_RD64 >> ((TA ? 2 : 0) + (TB ? 1 : 0))) & 1) &&
+                          (TM * TN > 1 || (HYPEL_GEMM_RD64 & 16));
+    // LIN: a k-contiguous operand is transposed on its way into LDS, into the same pair-interleaved image the
+    // k-strided operands use -- (x, k) -> (k >> 1) * PP + 2 x + (k & 1), pair pitch PP = 2 W + 2 (the 32 lanes that
+    // store one row's 32 columns then hit 32 banks) -- so that its fragment reads are 32 consecutive 8-byte words too
+    constexpr bool LIN = RD64 && (HYPEL_GEMM_RD64 & 32);
+    constexpr int PPA = 2 * BM + 2, PPB = 2 * BN + 2;
+    constexpr int A_PITCH = TA ? (NARROW ? BM + 16 : BM) : (NARROW || RD64 ? BK + 2 : BK + 1);
     constexpr int B_ROWS = TB ? BN : BK;
     constexpr int B_COLS = TB ? BK : BN;
-    constexpr int B_PITCH = TB ? (NARROW ? BK + 2 : BK + 1) : BN;
+    constexpr int B_PITCH = TB ? (NARROW || RD64 ? BK + 2 : BK + 1) : BN;
     constexpr int A_PER_THREAD = A_ROWS * A_COLS / 256;
     // a 96-column B row does not divide the 256 threads: then only the first (256 / B_COLS) * B_COLS = 192 threads
     // stage B (two rows of 96 per pass), the fourth wave sits that part out
@@ -159,7 +182,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int B_PER_THREAD = B_ROWS * B_COLS / B_THREADS;
     constexpr int A_RSTEP = 256 / A_COLS;
     constexpr int B_RSTEP = 256 / B_COLS;
-    __shared__ float lds[A_ROWS * A_PITCH + B_ROWS * B_PITCH];
+    static_assert(!RD64 || (A_RSTEP % 2 == 0 && B_RSTEP % 2 == 0 && (A_ROWS * A_PITCH) % 2 == 0), "RD64 staging layout");
+    __shared__ __attribute__((aligned(16))) float lds[A_ROWS * A_PITCH + B_ROWS * B_PITCH];
     float* As = lds;
     float* Bs = lds + A_ROWS * A_PITCH;
 
@@ -249,9 +273,18 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     // per-lane LDS read bases (k advances by immediate offsets in the unrolled loop)
     const int l15 = lane & 15, lq = lane >> 4;  // 16x16x4 fragments: row / column = lane & 15, k = lane >> 4
     const int a_rd = NARROW ? (TA ? (lq * A_PITCH + wm * 32 + l15) : ((wm * 32 + l15) * A_PITCH + lq))
+                     : RD64 ? (TA ? (lhi * BM + wm * TM * 32 + l31) * 2
+                                  : LIN ? lhi * PPA + 2 * (wm * TM * 32 + l31) : ((wm * TM * 32 + l31) * A_PITCH + 2 * lhi))
                             : (TA ? (lhi * A_PITCH + wm * TM * 32 + l31) : ((wm * TM * 32 + l31) * A_PITCH + lhi));
     const int b_rd = NARROW ? (TB ? (l15 * B_PITCH + lq) : (lq * B_PITCH + l15))
+                     : RD64 ? (!TB ? (lhi * BN + wn * TN * 32 + l31) * 2
+                                   : LIN ? lhi * PPB + 2 * (wn * TN * 32 + l31) : ((wn * TN * 32 + l31) * B_PITCH + 2 * lhi))
                             : (TB ? ((wn * TN * 32 + l31) * B_PITCH + lhi) : (lhi * B_PITCH + wn * TN * 32 + l31));
+    // RD64: LDS distance of one k-step pair (4 reduction columns) / between the wave's 32-row (column) tiles
+    constexpr int A_PSTEP = TA ? 4 * BM : (LIN ? 2 * PPA : 4);
+    constexpr int A_PTILE = TA || LIN ? 64 : 32 * A_PITCH;
+    constexpr int B_PSTEP = TB ? (LIN ? 2 * PPB : 4) : 4 * BN;
+    constexpr int B_PTILE = TB && !LIN ? 32 * B_PITCH : 64;
     constexpr int A_K4STEP = TA ? 4 * A_PITCH : 4;     // NARROW: LDS distance of one k4 step / of the second 16 rows
     constexpr int A_TILE16 = TA ? 16 : 16 * A_PITCH;
     constexpr int B_K4STEP = TB ? 4 : 4 * B_PITCH;
@@ -400,16 +433,33 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         const bool paired = PAIR && (seg.k & HYPEL_SEG_PAIR_FLAG);
         const int kvalid = paired ? 16 + seg2.k : min(BK, seg.k - lk);
         __syncthreads();  // previous tile's MFMAs are done reading LDS
-        constexpr bool A_TID = HYPEL_GEMM_ADDTID && A_PITCH == A_COLS;
-        constexpr bool B_TID = HYPEL_GEMM_ADDTID && B_PITCH == B_COLS && B_THREADS == 256;
+        constexpr bool A_TID = HYPEL_GEMM_ADDTID && !RD64 && A_PITCH == A_COLS;
+        constexpr bool B_TID = HYPEL_GEMM_ADDTID && !RD64 && B_PITCH == B_COLS && B_THREADS == 256;
         if constexpr (A_TID) {
             lds_store_addtid<A_PER_THREAD>(lds_m0, ra);
+        } else if constexpr (LIN && !TA) {  // [m][k] tile transposed into the pair-interleaved image
+#pragma unroll
+            for (int i = 0; i < A_PER_THREAD; ++i)
+                As[(a_col >> 1) * PPA + 2 * (a_row0 + i * A_RSTEP) + (a_col & 1)] = ra[i];
+        } else if constexpr (RD64 && TA) {  // [k][m] image, column pairs interleaved; the row step is even
+#pragma unroll
+            for (int i = 0; i < A_PER_THREAD; ++i)
+                As[(((a_row0 >> 1) + i * (A_RSTEP / 2)) * BM + a_col) * 2 + (a_row0 & 1)] = ra[i];
         } else {
 #pragma unroll
             for (int i = 0; i < A_PER_THREAD; ++i) As[(a_row0 + i * A_RSTEP) * A_PITCH + a_col] = ra[i];
         }
         if constexpr (B_TID) {
             lds_store_addtid<B_PER_THREAD>(lds_m0 + 4u * A_ROWS * A_PITCH, rb);
+        } else if constexpr (LIN && TB) {
+#pragma unroll
+            for (int i = 0; i < B_PER_THREAD; ++i)
+                Bs[(b_col >> 1) * PPB + 2 * (b_row0 + i * B_RSTEP) + (b_col & 1)] = rb[i];
+        } else if constexpr (RD64 && !TB) {  // [k][n] image, column pairs interleaved
+#pragma unroll
+            for (int i = 0; i < B_PER_THREAD; ++i)
+                if (B_THREADS == 256 || b_stager)
+                    Bs[(((b_row0 >> 1) + i * (B_RSTEP / 2)) * BN + b_col) * 2 + (b_row0 & 1)] = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_PER_THREAD; ++i)
@@ -451,6 +501,32 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                         const float a1 = As[a_rd + A_TILE16 + k4 * A_K4STEP];
                         acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc16[0], 0, 0, 0);
                         acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc16[1], 0, 0, 0);
+                    }
+                }
+            } else if constexpr (RD64) {
+                // CHUNK reduction columns (CHUNK / 4 step pairs) at a time, skipped beyond kvalid as below
+#pragma unroll
+                for (int q = 0; q < BK / CHUNK; ++q) {
+                    if (q > 0 && kvalid <= q * CHUNK) break;
+#pragma unroll
+                    for (int t = q * (CHUNK / 4); t < (q + 1) * (CHUNK / 4); ++t) {
+                        float2 a[TM], b[TN];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            a[i] = *reinterpret_cast<const float2*>(&As[a_rd + i * A_PTILE + t * A_PSTEP]);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            b[j] = *reinterpret_cast<const float2*>(&Bs[b_rd + j * B_PTILE + t * B_PSTEP]);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                     }
                 }
             } else {
@@ -679,7 +755,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 #define HYPEL_GEMM_ARGS \
     A, lda, B, ldb, C, ldc, n, groups, segs, tiles_v, n_tiles, n_ntiles, bias, accumulate, res, ldr, res_start, stats, bnb
 #define HYPEL_GEMM_BOUNDS \
-    __launch_bounds__(256, (TM * TN == 1 ? HYPEL_OCC_BN32 : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : (TA ? HYPEL_OCC_BN64_TA : 3))))
+    __launch_bounds__(256, (TM * TN == 1 ? (TA ? HYPEL_OCC_BN32_TA : HYPEL_OCC_BN32)       \
+                                         : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : (TA && TM * TN == 2 ? HYPEL_OCC_BN64_TA : 3))))
 
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
           bool PAIR = false>

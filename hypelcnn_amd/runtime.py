@@ -345,22 +345,46 @@ class Session:
         self._post_guard()
 
     # ---- non-finite loss guard (NanTensorHook, monitored_session_runner.py:151; check_numerics, common_nn_ops.py:232)
+    _GUARD_SLOTS = 4  # ring of pinned flag copies: the host looks at most this many optimiser steps behind the device
+
     def _post_guard(self):
         """After every optimiser launch: copy the step's flag into pinned host memory, asynchronously, and remember
         an event.  `nonfinite_step()` later looks at copies that are at least one step old, so the loop never drains
         the device queue to learn about a NaN -- and it does not have to: the guarded optimiser has already refused
-        the update on the device."""
+        the update on the device.  The copies live in a fixed ring of pinned slots and events (allocated once): a
+        caller that never polls (bench.py, library users of adam_step) pays O(1) per step -- the oldest copy is folded
+        into the verdict when the ring is full -- instead of one hipHostMalloc per step."""
         if not hasattr(self, "_guard_q"):
             self._guard_q = []
             self._guard_bad = None
+            self._guard_free = None
         if self.grads.device.type != "cuda":
             self._guard_q.append((self.global_step, float(self.grads[self.n_train]), None))
+            if len(self._guard_q) > self._GUARD_SLOTS:
+                self._guard_fold(self._guard_q.pop(0))
             return
-        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        if self._guard_free is None:
+            pinned = torch.empty(self._GUARD_SLOTS, dtype=torch.float32, pin_memory=True)
+            self._guard_free = [(pinned[i:i + 1], torch.cuda.Event()) for i in range(self._GUARD_SLOTS)]
+        if not self._guard_free:  # ring full: the oldest copy is several steps old, its event long since signalled
+            self._guard_fold(self._guard_q.pop(0))
+        host, ev = self._guard_free.pop()
         host.copy_(self.grads[self.n_train:self.n_train + 1], non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record()
         self._guard_q.append((self.global_step, host, ev))
+
+    def _guard_fold(self, entry):
+        """Read one queued flag copy (waiting for its event), return its slot to the ring, record a bad step."""
+        step, host, ev = entry
+        if ev is not None:
+            ev.synchronize()
+            value = float(host[0])
+            self._guard_free.append((host, ev))
+        else:
+            value = host
+        if value != 0.0 and self._guard_bad is None:
+            self._guard_bad = step
+        return value != 0.0
 
     def nonfinite_step(self, sync=False):
         """global_step value after the first step whose loss was NaN/Inf, or None.  Without `sync` only flag copies
@@ -371,14 +395,10 @@ class Session:
         q = getattr(self, "_guard_q", [])
         keep = 0 if sync else 1
         while len(q) > keep:
-            step, host, ev = q.pop(0)
-            if ev is not None:
-                ev.synchronize()
-                host = float(host[0])
-            if host != 0.0:
-                self._guard_bad = step
-                q.clear()
-                return step
+            if self._guard_fold(q.pop(0)):
+                while q:  # later copies are moot: hand their slots back
+                    self._guard_fold(q.pop(0))
+                return self._guard_bad
         return None
 
     # ---- data parallel (new vs the reference: SURVEY §2.3 / §8e) ----
