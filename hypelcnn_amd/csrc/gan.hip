@@ -752,6 +752,19 @@ static size_t gt_bwd_lds(int bands, int only_encoder) {
                             (size_t)GT_WAVES * ((size_t)8 * g.W + 3 * g.B4 + slope_words + g.wptotal + 8));
 }
 
+// gan_mfma.hip: the generator on the matrix cores for wide spectra (bands > 128).  HYPEL_GAN_MFMA=0 keeps the
+// register-tiled VALU kernels below (experiments, parity cross-checks).
+bool hypel_gm_supported(int bands);
+int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
+                 float* out, int64_t ldo, int blocks, hipStream_t st);
+int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
+                 const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
+                 int blocks, hipStream_t st);
+static bool gan_use_mfma(int bands) {
+    static const int on = getenv("HYPEL_GAN_MFMA") ? atoi(getenv("HYPEL_GAN_MFMA")) : 1;
+    return on && hypel_gm_supported(bands);
+}
+
 extern "C" int hypel_gan_generator_blocks(int64_t n) {
     int64_t b = (n + GEN_WAVES - 1) / GEN_WAVES;
     if (b < 1) b = 1;
@@ -763,6 +776,11 @@ extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, i
                                        const float* b, int32_t only_encoder, float* out, int64_t ldo,
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(x && w && b && out && n > 0 && bands >= 8, "hypel_gan_generator_fwd");
+    if (gan_use_mfma(bands)) {
+        hypel_gm_fwd(x, ldx, n, bands, w, b, only_encoder, out, ldo, 2 * hypel_gan_generator_blocks(n), ST);
+        HYPEL_CHECK_LAUNCH("hypel_gan_generator_fwd");
+        return 0;
+    }
     if (bands > GEN_TILED_MIN && gt_fwd_lds(bands, only_encoder) <= 160 * 1024 - 512) {  // 512: the static layer table
         const size_t tl = gt_fwd_lds(bands, only_encoder);
         if (tl > 64 * 1024)
@@ -789,6 +807,12 @@ extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float*
                                        int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && bands >= 8, "hypel_gan_generator_bwd");
+    if (gan_use_mfma(bands)) {
+        hypel_gm_bwd(x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb,
+                     hypel_gan_generator_blocks(n), ST);
+        HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd");
+        return 0;
+    }
     if (bands > GEN_TILED_MIN && gt_bwd_lds(bands, only_encoder) <= 160 * 1024 - 512) {  // 512: the static layer table
         const size_t tl = gt_bwd_lds(bands, only_encoder);
         if (tl > 64 * 1024)

@@ -1,0 +1,422 @@
+// Shadow-GAN generator for WIDE spectra (bands > 128; AVON: 360 bands) on the CDNA4 matrix cores.
+//
+// shadowdata_generator_model (gan/shadow_data_models.py:43-90): seven 1-channel SAME 1-D convolutions over the band axis
+// (kernel sizes B, B/2, B/4, B/8, B/4, B/2, B), leaky-ReLU(0.1), skip sums n_l = c_l + n_{l-1} + n_{l-2}, tanh on the
+// last layer.  At B = 360 that is 384 k multiply-adds per sample: a 1-in / 1-out channel convolution of N samples is
+//     Y[N x B] = X[N x B] . T[B x B],    T[i][j] = w[i - j + pad]   (banded Toeplitz),
+// i.e. matrix-core work.  One block = 16 samples (one v_mfma_f32_16x16x4_f32 row tile) x all bands, 8 wavefronts:
+//  * the activations of the 16 samples never leave the CU: three rotating [16 x B] LDS images (n_{l-2}, n_{l-1}, n_l);
+//  * T is never materialised: the B operand of lane (column jj, k-slot kq) is ONE LDS word of a zero-margined copy of
+//    the layer's taps, wz[B' + k - j + pad] -- the lanes of a fragment read 17 consecutive words (broadcasts);
+//  * a column tile only walks the 16-row chunks its band touches (exact taps rounded to chunks of 16);
+//  * backward: forward recompute with every layer's output kept in REGISTERS (MFMA C layout: 12 floats per lane and
+//    layer), then per layer l = L..1: dz_l = dn_l * act'(.), filter gradient, data gradient dn_{l-1} += dz_l . T^T
+//    (the same tap table, index mirrored).  The filter gradient dw[t] = sum_{n,j} dz[n][j] x[n][j + t - pad] is the
+//    sum of one diagonal of G = X^T dZ; tiles of G with the same tile offset I - J = 16 a are ACCUMULATED over J in one
+//    16x16 accumulator (K = 16 samples x 23 column tiles), so a layer needs only (k / 16 + 3) accumulators and one
+//    small diagonal reduction per block, in a fixed order (no float atomics).
+// fp32 MFMA is a k-ordered fmaf chain: same arithmetic class as the VALU kernels in gan.hip, which stay in charge
+// of bands <= 128 (12 k multiply-adds per sample at B = 64: launch latency, not arithmetic).
+#include "common.h"
+
+typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int GM_ROWS = 16;     // samples per row tile
+constexpr int GM_WAVES = 8;     // wavefronts per block (two per SIMD)
+constexpr int GM_THREADS = 64 * GM_WAVES;
+constexpr int GM_MAXT = 3;      // column tiles per wave: bands <= 16 * 8 * 3
+constexpr int GM_MAX_BANDS = 16 * GM_WAVES * GM_MAXT;
+constexpr int GM_GP = 17;       // pitch of a 16 x 16 filter-gradient tile in LDS (diagonal reads hit distinct banks)
+
+struct GmGeo {
+    int bands, bp, pitch, nt;  // bp = bands rounded up to 16; nt = column tiles; pitch = 18 mod 32 (see a_frag)
+};
+
+__host__ __device__ inline GmGeo gm_geo(int bands) {
+    GmGeo g;
+    g.bands = bands;
+    g.bp = (bands + 15) / 16 * 16;
+    g.nt = g.bp / 16;
+    g.pitch = g.bp + ((18 - g.bp % 32) + 32) % 32;
+    return g;
+}
+__host__ __device__ inline int gm_ksz(int bands, int l) {  // kernel size of layer l = 0..6
+    const int sh = l < 4 ? l : 6 - l;
+    return bands >> sh;
+}
+__host__ __device__ inline int gm_woff(int bands, int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += gm_ksz(bands, i);
+    return o;
+}
+// dynamic LDS: forward = 3 activation images + 2 tap tables; backward = 5 images + 2 tap tables + G tiles
+__host__ __device__ inline size_t gm_fwd_lds(int bands) {
+    const GmGeo g = gm_geo(bands);
+    return sizeof(float) * (3 * (size_t)GM_ROWS * g.pitch + 2 * 3 * (size_t)g.bp);
+}
+__host__ __device__ inline int gm_atiles(int bands) { return (bands + 30) / 16 + 2; }  // upper bound of the tile offsets a
+__host__ __device__ inline size_t gm_bwd_lds(int bands) {
+    const GmGeo g = gm_geo(bands);
+    return sizeof(float) * (5 * (size_t)GM_ROWS * g.pitch + 6 * (size_t)g.bp + (size_t)gm_atiles(bands) * 16 * GM_GP + 64);
+}
+
+// ---- one 16 x 16 output tile of  src[16 x B] . T  (MIRROR = false)  or  src . T^T  (MIRROR = true) -----------------
+// A fragment of v_mfma_f32_16x16x4_f32: lane (r = lane & 15, kq = lane >> 4) supplies src[r][k], k = kc + 4 s + kq: with
+// pitch = 18 mod 32 the 32 lanes of a ds_read_b32 group (16 rows x 2 k-slots) hit 32 banks.  B fragment: lane
+// (c = lane & 15, kq) supplies T[k][j0 + c] = w[k - (j0 + c) + pad] (mirrored: w[(j0 + c) - k + pad]) from the
+// zero-margined tap table wz (taps at [bp, bp + ksz)).
+template <bool MIRROR>
+__device__ __forceinline__ gm_f32x4 gm_conv_tile(const float* __restrict__ src, const float* __restrict__ wz, const GmGeo g,
+                                                 int j0, int ksz, int pad, int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+    // reduction range of the tile: forward i in [j0 - pad, j0 + 15 + ksz - 1 - pad]; mirrored j in
+    // [i0 - (ksz - 1 - pad), i0 + 15 + pad]; clipped to the real bands
+    const int lo = max(0, MIRROR ? j0 - (ksz - 1 - pad) : j0 - pad);
+    const int hi = min(g.bands - 1, MIRROR ? j0 + 15 + pad : j0 + 15 + ksz - 1 - pad);
+    gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* ap = src + r * g.pitch + kq;
+    const float* tp = MIRROR ? wz + g.bp + (j0 + r) + pad - kq : wz + g.bp - (j0 + r) + pad + kq;
+    for (int kc = lo & ~15; kc <= hi; kc += 16) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = kc + 4 * s;
+            const float a = ap[k];
+            const float b = MIRROR ? tp[-k] : tp[k];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void gm_fill_taps(float* wz, const GmGeo g, const float* __restrict__ w, int ksz, int tid) {
+    // only [bp, bp + bands) can ever hold taps; the margins were zeroed once
+    for (int i = tid; i < g.bands; i += GM_THREADS) wz[g.bp + i] = i < ksz ? w[i] : 0.0f;
+}
+
+// Forward of the whole stack for one row tile.  bufs: three [16 x pitch] images, the input in bufs[0] (zero beyond
+// `bands` and for rows without a sample).  KEEP: every lane keeps the layers' outputs (its 12 elements per layer, MFMA
+// C layout: column = lane & 15, row = 4 (lane >> 4) + e) and the leaky-ReLU branch bits for the backward pass.
+// Returns the image index that holds the result (n4 or tanh output); with out != nullptr the result also goes to global.
+template <bool ENC, bool KEEP>
+__device__ __forceinline__ int gm_forward(float* const (&bufs)[3], float* wz0, float* wz1, const GmGeo g,
+                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                          float* __restrict__ out, int64_t ldo, int rows_valid, int tid,
+                                          float (&keep)[6][GM_MAXT][4], unsigned (&mask)[7]) {
+    constexpr int L = ENC ? 4 : 7;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, rg = lane >> 4;
+    int woff = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int ksz = gm_ksz(g.bands, l), pad = (ksz - 1) / 2;
+        float* wz = (l & 1) ? wz1 : wz0;
+        gm_fill_taps(wz, g, w + woff, ksz, tid);
+        woff += ksz;
+        __syncthreads();  // taps of layer l and the outputs of layer l - 1 are in LDS
+        const float* src = bufs[l % 3];                          // n_{l}   (input of layer l + 1 in 1-based counting)
+        const float* skip2 = l >= 1 ? bufs[(l + 2) % 3] : nullptr;  // n_{l-1}
+        float* dst = bufs[(l + 1) % 3];
+        const float bl = bias[l];
+        const bool last_tanh = !ENC && l == 6;
+        unsigned mk = 0;
+#pragma unroll
+        for (int m = 0; m < GM_MAXT; ++m) {
+            const int jt = wave + GM_WAVES * m;
+            if (jt >= g.nt) break;
+            const int j0 = 16 * jt;
+            const gm_f32x4 acc = gm_conv_tile<false>(src, wz, g, j0, ksz, pad, lane);
+            const int c = j0 + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 4 * rg + e;
+                const float v = acc[e] + bl;
+                float y;
+                if (last_tanh) {
+                    y = tanhf(v);
+                } else {
+                    if (v > 0.0f) mk |= 1u << (4 * m + e);
+                    y = v > 0.0f ? v : 0.1f * v;
+                    y += src[row * g.pitch + c];             // + n_{l-1}
+                    if (l >= 1) y += skip2[row * g.pitch + c];  // + n_{l-2}
+                }
+                if (c < g.bands) {
+                    dst[row * g.pitch + c] = y;
+                    if (out != nullptr && l == L - 1 && row < rows_valid) out[(int64_t)row * ldo + c] = y;
+                } else {
+                    y = 0.0f;
+                }
+                if constexpr (KEEP)
+                    if (l < L - 1) keep[l][m][e] = y;
+            }
+        }
+        if constexpr (KEEP) mask[l] = mk;
+    }
+    return L % 3;
+}
+
+__device__ __forceinline__ void gm_zero(float* p, int n, int tid) {
+    for (int i = tid; i < n; i += GM_THREADS) p[i] = 0.0f;
+}
+
+__device__ __forceinline__ void gm_load_rows(float* img, const GmGeo g, const float* __restrict__ x, int64_t ldx,
+                                             int rows_valid, int tid) {
+    for (int i = tid; i < GM_ROWS * g.bp; i += GM_THREADS) {
+        const int row = i / g.bp, c = i - row * g.bp;
+        img[row * g.pitch + c] = (row < rows_valid && c < g.bands) ? x[(int64_t)row * ldx + c] : 0.0f;
+    }
+}
+
+template <bool ENC>
+__global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                            int64_t n, int bands,
+                                                                            const float* __restrict__ w,
+                                                                            const float* __restrict__ bias,
+                                                                            float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float gm_lds[];
+    const GmGeo g = gm_geo(bands);
+    const int tid = threadIdx.x;
+    float* const bufs[3] = {gm_lds, gm_lds + GM_ROWS * g.pitch, gm_lds + 2 * GM_ROWS * g.pitch};
+    float* wz0 = gm_lds + 3 * GM_ROWS * g.pitch;
+    float* wz1 = wz0 + 3 * g.bp;
+    gm_zero(gm_lds, 3 * GM_ROWS * g.pitch + 6 * g.bp, tid);  // image padding and tap margins stay zero
+    __syncthreads();
+    float keep[6][GM_MAXT][4];
+    unsigned mask[7];
+    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t r0 = t * GM_ROWS;
+        const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
+        gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
+        gm_forward<ENC, false>(bufs, wz0, wz1, g, w, bias, out + r0 * ldo, ldo, rows_valid, tid, keep, mask);
+        __syncthreads();  // the next row tile overwrites bufs[0]
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// pw[blocks][sum k], pb[blocks][8]: this block's partial filter / bias gradients (summed over its row tiles).
+template <bool ENC>
+__global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
+    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dx, int64_t lddx, int accumulate_dx,
+    float* __restrict__ pw, float* __restrict__ pb, int wtotal, int slabs) {
+    constexpr int L = ENC ? 4 : 7;
+    extern __shared__ __attribute__((aligned(16))) float gm_lds[];
+    const GmGeo g = gm_geo(bands);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, rg = lane >> 4;
+    const int img = GM_ROWS * g.pitch;
+    float* const bufs[3] = {gm_lds, gm_lds + img, gm_lds + 2 * img};  // forward images, then the gradient ring
+    float* Z = gm_lds + 3 * img;   // dz_l
+    float* X = gm_lds + 4 * img;   // n_{l-1}
+    float* wz = gm_lds + 5 * img;
+    float* wz2 = wz + 3 * g.bp;    // second tap table of the forward recompute
+    float* G = wz2 + 3 * g.bp;     // [a][16][GM_GP]
+    float* red = G + gm_atiles(bands) * 16 * GM_GP;  // [GM_WAVES] bias-gradient partials
+    gm_zero(gm_lds, 5 * img + 6 * g.bp, tid);
+    __syncthreads();
+
+    float dwacc[7], dbacc[7];  // thread t owns tap t of every layer; thread 0 the bias gradients
+#pragma unroll
+    for (int l = 0; l < 7; ++l) dwacc[l] = dbacc[l] = 0.0f;
+
+    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t r0 = t * GM_ROWS;
+        const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
+        float keep[6][GM_MAXT][4];
+        unsigned mask[7];
+        gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
+        const int res = gm_forward<ENC, true>(bufs, wz, wz2, g, w, bias, nullptr, 0, rows_valid, tid, keep, mask);
+        __syncthreads();
+        // gradient ring: Da = dn_l (complete), Db = partial dn_{l-1}, Dc = dn_{l-2} being initialised
+        float* Da = bufs[(res + 1) % 3];
+        float* Db = bufs[(res + 2) % 3];
+        float* Dc = bufs[res];  // still holds the forward result until the top layer has read it
+        const float* fwd_out = bufs[res];
+        gm_load_rows(Da, g, dout + r0 * lddo, lddo, rows_valid, tid);
+        __syncthreads();
+        int woff = gm_woff(bands, L);
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            const int ksz = gm_ksz(bands, l), pad = (ksz - 1) / 2;
+            woff -= ksz;
+            const bool top_tanh = !ENC && l == 6;
+            // ---- step A: dz_l, skip gradients, bias gradient; n_{l-1} from the registers (or x) into X ----
+            gm_fill_taps(wz, g, w + woff, ksz, tid);
+            float dbl = 0.0f;
+#pragma unroll
+            for (int m = 0; m < GM_MAXT; ++m) {
+                const int jt = wave + GM_WAVES * m;
+                if (jt >= g.nt) break;
+                const int c = 16 * jt + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = (4 * rg + e) * g.pitch + c;
+                    if (c < g.bands) {
+                        const float gd = Da[o];
+                        float f;
+                        if (top_tanh) {
+                            const float y = fwd_out[o];
+                            f = 1.0f - y * y;
+                        } else {
+                            f = ((mask[l] >> (4 * m + e)) & 1u) ? 1.0f : 0.1f;
+                        }
+                        const float z = gd * f;
+                        Z[o] = z;
+                        dbl += z;
+                        if (top_tanh) {
+                            Db[o] = 0.0f;  // n6 only feeds the last convolution
+                        } else {
+                            // n_l = c_l + n_{l-1} (+ n_{l-2}): the top skip layer initialises, the others accumulate
+                            Db[o] = (l == L - 1 || (!ENC && l == 5)) ? gd : Db[o] + gd;
+                            if (l >= 1) Dc[o] = gd;
+                        }
+                        if (l >= 1) X[o] = keep[l - 1][m][e];
+                    }
+                }
+            }
+            if (l == 0) gm_load_rows(X, g, x + r0 * ldx, ldx, rows_valid, tid);
+            // bias gradient: lanes -> wave -> block, fixed order
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dbl += __shfl_xor(dbl, off, 64);
+            if (lane == 0) red[wave] = dbl;
+            __syncthreads();
+            if (tid == 0) {
+                float s = 0.0f;
+#pragma unroll
+                for (int wv = 0; wv < GM_WAVES; ++wv) s += red[wv];
+                dbacc[l] += s;
+            }
+            // ---- step B: filter gradient.  Tile offset a: diagonals d = i - j in [16 a - 15, 16 a + 15] ----
+            const int a_lo = -((pad + 15) / 16), a_hi = (ksz - 1 - pad + 15) / 16;
+            for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
+                gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int j_lo = max(0, -a), j_hi = min(g.nt - 1, g.nt - 1 - a);
+                for (int jt = j_lo; jt <= j_hi; ++jt) {
+                    // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; n = 4 s + kq
+                    const float* ap = X + rg * g.pitch + 16 * (jt + a) + col;
+                    const float* bp = Z + rg * g.pitch + 16 * jt + col;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * g.pitch], bp[4 * s * g.pitch], acc, 0, 0, 0);
+                }
+                float* gt = G + (a - a_lo) * 16 * GM_GP;  // [i_local = 4 rg + e][j_local = col]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gt[(4 * rg + e) * GM_GP + col] = acc[e];
+            }
+            __syncthreads();
+            if (tid < ksz) {  // tap t = d + pad: sum the diagonal d of G, tiles ascending, rows ascending
+                const int d = tid - pad;
+                float s = 0.0f;
+                const int a0 = (d + 15 >= 0 ? (d + 15) / 16 : -((-(d + 15) + 15) / 16));  // floor((d + 15) / 16)
+                for (int a = a0 - 1; a <= a0; ++a) {
+                    if (a < a_lo || a > a_hi) continue;
+                    const int dl = d - 16 * a;  // i_local - j_local
+                    if (dl < -15 || dl > 15) continue;
+                    const float* gt = G + (a - a_lo) * 16 * GM_GP;
+                    for (int il = max(0, dl); il <= min(15, 15 + dl); ++il) s += gt[il * GM_GP + (il - dl)];
+                }
+                dwacc[l] += s;
+            }
+            // ---- step C: data gradient dn_{l-1} += dz_l . T^T ----
+            if (l > 0 || dx != nullptr) {
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m) {
+                    const int jt = wave + GM_WAVES * m;
+                    if (jt >= g.nt) break;
+                    const gm_f32x4 acc = gm_conv_tile<true>(Z, wz, g, 16 * jt, ksz, pad, lane);
+                    const int c = 16 * jt + col;
+                    if (c < g.bands) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Db[(4 * rg + e) * g.pitch + c] += acc[e];
+                    }
+                }
+            }
+            __syncthreads();
+            float* old = Da;
+            Da = Db;
+            Db = Dc;
+            Dc = old;
+        }
+        if (dx != nullptr) {
+            for (int i = tid; i < GM_ROWS * g.bp; i += GM_THREADS) {
+                const int row = i / g.bp, c = i - row * g.bp;
+                if (row < rows_valid && c < g.bands) {
+                    float* p = dx + (r0 + row) * lddx + c;
+                    const float v = Da[row * g.pitch + c];
+                    *p = accumulate_dx ? *p + v : v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // this block's partials; the slabs of the blocks beyond the grid (the planner's reduce sums `slabs` of them) are zeros
+    for (int sb = blockIdx.x + gridDim.x; sb < slabs; sb += gridDim.x) {
+        for (int i = tid; i < wtotal; i += GM_THREADS) pw[(size_t)sb * wtotal + i] = 0.0f;
+        if (tid < 8) pb[(size_t)sb * 8 + tid] = 0.0f;
+    }
+    float* pwb = pw + (size_t)blockIdx.x * wtotal;
+    int woff = 0;
+#pragma unroll
+    for (int l = 0; l < 7; ++l) {
+        const int ksz = gm_ksz(bands, l);
+        if (tid < ksz) pwb[woff + tid] = l < L ? dwacc[l] : 0.0f;
+        woff += ksz;
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int l = 0; l < 7; ++l) pb[(size_t)blockIdx.x * 8 + l] = l < L ? dbacc[l] : 0.0f;
+        pb[(size_t)blockIdx.x * 8 + 7] = 0.0f;
+    }
+}
+
+}  // namespace
+
+// Entry points used by gan.hip's dispatch (same contracts as the VALU kernels there).
+bool hypel_gm_supported(int bands) {
+    return bands > 128 && bands <= GM_MAX_BANDS && gm_bwd_lds(bands) <= 160 * 1024;
+}
+
+int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
+                 float* out, int64_t ldo, int blocks, hipStream_t st) {
+    const size_t lds = gm_fwd_lds(bands);
+    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
+    const int grid = (int)(tiles < blocks ? tiles : blocks);
+    if (only_encoder) {
+        (void)hipFuncSetAttribute((const void*)gan_generator_fwd_mfma_kernel<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gan_generator_fwd_mfma_kernel<true>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, n, bands, w, b,
+                           out, ldo);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gan_generator_fwd_mfma_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gan_generator_fwd_mfma_kernel<false>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, n, bands, w,
+                           b, out, ldo);
+    }
+    return 0;
+}
+
+int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
+                 const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
+                 int blocks, hipStream_t st) {
+    const size_t lds = gm_bwd_lds(bands);
+    int wtotal = 0;
+    for (int l = 0; l < 7; ++l) wtotal += gm_ksz(bands, l);
+    // every one of the `blocks` partial slabs is written (the planner's reduce sums all of them)
+    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
+    const int grid = (int)(tiles < blocks ? tiles : blocks);
+    if (only_encoder) {
+        (void)hipFuncSetAttribute((const void*)gan_generator_bwd_mfma_kernel<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gan_generator_bwd_mfma_kernel<true>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, dout, lddo, n,
+                           bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gan_generator_bwd_mfma_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gan_generator_bwd_mfma_kernel<false>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, dout, lddo,
+                           n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks);
+    }
+    return 0;
+}
