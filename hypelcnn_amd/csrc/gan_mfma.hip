@@ -28,6 +28,14 @@ constexpr int GM_WAVES = 8;     // wavefronts per block (two per SIMD)
 constexpr int GM_THREADS = 64 * GM_WAVES;
 constexpr int GM_MAXT = 3;      // column tiles per wave: bands <= 16 * 8 * 3
 constexpr int GM_MAX_BANDS = 16 * GM_WAVES * GM_MAXT;
+#ifndef GM_PIPE
+#define GM_PIPE 0  // 1: fragments of the next 16-column chunk requested by hand ahead of the current chunk's MFMAs
+                   // (measured slower than hipcc's own schedule: forward 62 vs 51 us, backward 177 vs 167 us at N = 4096)
+#endif
+#ifndef GM_FWD_ROLLED
+#define GM_FWD_ROLLED 0  // forward kernel: 1 = rolled layer loop (54 vs 51 us); the backward kernel's recompute is always
+                         // rolled (unrolled it spills > 200 registers)
+#endif
 constexpr int GM_GP = 17;       // pitch of a 16 x 16 filter-gradient tile in LDS (diagonal reads hit distinct banks)
 
 struct GmGeo {
@@ -78,15 +86,41 @@ __device__ __forceinline__ gm_f32x4 gm_conv_tile(const float* __restrict__ src, 
     gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const float* ap = src + r * g.pitch + kq;
     const float* tp = MIRROR ? wz + g.bp + (j0 + r) + pad - kq : wz + g.bp - (j0 + r) + pad + kq;
-    for (int kc = lo & ~15; kc <= hi; kc += 16) {
+    // the fragments of chunk kc + 16 are requested before the MFMAs of chunk kc issue (a wave has one partner on its
+    // SIMD: without this every chunk exposes an LDS round trip)
+    int kc = lo & ~15;
+    if (kc > hi) return acc;
+    float a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s] = ap[kc + 4 * s];
+        b[s] = MIRROR ? tp[-(kc + 4 * s)] : tp[kc + 4 * s];
+    }
+#if !GM_PIPE
+    for (; kc <= hi; kc += 16) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kc + 4 * s], MIRROR ? tp[-(kc + 4 * s)] : tp[kc + 4 * s], acc, 0, 0, 0);
+    }
+    return acc;
+#endif
+    for (; kc + 16 <= hi; kc += 16) {
+        float an[4], bn[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = kc + 4 * s;
-            const float a = ap[k];
-            const float b = MIRROR ? tp[-k] : tp[k];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            an[s] = ap[kc + 16 + 4 * s];
+            bn[s] = MIRROR ? tp[-(kc + 16 + 4 * s)] : tp[kc + 16 + 4 * s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a[s] = an[s];
+            b[s] = bn[s];
         }
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
     return acc;
 }
 
@@ -99,25 +133,36 @@ __device__ __forceinline__ void gm_fill_taps(float* wz, const GmGeo g, const flo
 // `bands` and for rows without a sample).  KEEP: every lane keeps the layers' outputs (its 12 elements per layer, MFMA
 // C layout: column = lane & 15, row = 4 (lane >> 4) + e) and the leaky-ReLU branch bits for the backward pass.
 // Returns the image index that holds the result (n4 or tanh output); with out != nullptr the result also goes to global.
-template <bool ENC, bool KEEP>
-__device__ __forceinline__ int gm_forward(float* const (&bufs)[3], float* wz0, float* wz1, const GmGeo g,
+template <bool ENC, bool KEEP, bool ROLLED = true>
+__device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, const GmGeo g,
                                           const float* __restrict__ w, const float* __restrict__ bias,
                                           float* __restrict__ out, int64_t ldo, int rows_valid, int tid,
                                           float (&keep)[6][GM_MAXT][4], unsigned (&mask)[7]) {
     constexpr int L = ENC ? 4 : 7;
     const int lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, rg = lane >> 4;
+    const int img = GM_ROWS * g.pitch;
     int woff = 0;
+    if constexpr (KEEP) {
 #pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < GM_MAXT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) keep[q][m][e] = 0.0f;
+    }
+    // one rolled loop over the layers (kept values go to their slot through wave-uniform selects): the unrolled form
+    // spent > 180 vector registers on seven copies of the addressing
+#pragma unroll ROLLED ? 1 : 7
     for (int l = 0; l < L; ++l) {
         const int ksz = gm_ksz(g.bands, l), pad = (ksz - 1) / 2;
         float* wz = (l & 1) ? wz1 : wz0;
         gm_fill_taps(wz, g, w + woff, ksz, tid);
         woff += ksz;
         __syncthreads();  // taps of layer l and the outputs of layer l - 1 are in LDS
-        const float* src = bufs[l % 3];                          // n_{l}   (input of layer l + 1 in 1-based counting)
-        const float* skip2 = l >= 1 ? bufs[(l + 2) % 3] : nullptr;  // n_{l-1}
-        float* dst = bufs[(l + 1) % 3];
+        const float* src = lds0 + (l % 3) * img;          // n_l (x for l = 0)
+        const float* skip2 = lds0 + ((l + 2) % 3) * img;  // n_{l-1}
+        float* dst = lds0 + ((l + 1) % 3) * img;
         const float bl = bias[l];
         const bool last_tanh = !ENC && l == 6;
         unsigned mk = 0;
@@ -138,7 +183,7 @@ __device__ __forceinline__ int gm_forward(float* const (&bufs)[3], float* wz0, f
                 } else {
                     if (v > 0.0f) mk |= 1u << (4 * m + e);
                     y = v > 0.0f ? v : 0.1f * v;
-                    y += src[row * g.pitch + c];             // + n_{l-1}
+                    y += src[row * g.pitch + c];                // + n_{l-1}
                     if (l >= 1) y += skip2[row * g.pitch + c];  // + n_{l-2}
                 }
                 if (c < g.bands) {
@@ -147,11 +192,16 @@ __device__ __forceinline__ int gm_forward(float* const (&bufs)[3], float* wz0, f
                 } else {
                     y = 0.0f;
                 }
-                if constexpr (KEEP)
-                    if (l < L - 1) keep[l][m][e] = y;
+                if constexpr (KEEP) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) keep[q][m][e] = q == l ? y : keep[q][m][e];
+                }
             }
         }
-        if constexpr (KEEP) mask[l] = mk;
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) mask[q] = q == l ? mk : mask[q];
+        }
     }
     return L % 3;
 }
@@ -189,7 +239,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
         const int64_t r0 = t * GM_ROWS;
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
-        gm_forward<ENC, false>(bufs, wz0, wz1, g, w, bias, out + r0 * ldo, ldo, rows_valid, tid, keep, mask);
+        gm_forward<ENC, false, GM_FWD_ROLLED != 0>(gm_lds, wz0, wz1, g, w, bias, out + r0 * ldo, ldo, rows_valid, tid, keep, mask);
         __syncthreads();  // the next row tile overwrites bufs[0]
     }
 }
@@ -217,9 +267,10 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     gm_zero(gm_lds, 5 * img + 6 * g.bp, tid);
     __syncthreads();
 
-    float dwacc[7], dbacc[7];  // thread t owns tap t of every layer; thread 0 the bias gradients
+    float dwacc[7];  // thread t owns tap t of every layer; red[GM_WAVES + l] collects the bias gradients
 #pragma unroll
-    for (int l = 0; l < 7; ++l) dwacc[l] = dbacc[l] = 0.0f;
+    for (int l = 0; l < 7; ++l) dwacc[l] = 0.0f;
+    if (tid < 7) red[GM_WAVES + tid] = 0.0f;
 
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
@@ -228,7 +279,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         float keep[6][GM_MAXT][4];
         unsigned mask[7];
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
-        const int res = gm_forward<ENC, true>(bufs, wz, wz2, g, w, bias, nullptr, 0, rows_valid, tid, keep, mask);
+        const int res = gm_forward<ENC, true>(gm_lds, wz, wz2, g, w, bias, nullptr, 0, rows_valid, tid, keep, mask);
         __syncthreads();
         // gradient ring: Da = dn_l (complete), Db = partial dn_{l-1}, Dc = dn_{l-2} being initialised
         float* Da = bufs[(res + 1) % 3];
@@ -238,11 +289,17 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         gm_load_rows(Da, g, dout + r0 * lddo, lddo, rows_valid, tid);
         __syncthreads();
         int woff = gm_woff(bands, L);
-#pragma unroll
+        // One rolled loop over the layers (the kept activations / branch bits of layer l are picked by wave-uniform
+        // selects): unrolled, the seven bodies needed > 200 scalar and > 200 vector spill slots.
+#pragma unroll 1
         for (int l = L - 1; l >= 0; --l) {
             const int ksz = gm_ksz(bands, l), pad = (ksz - 1) / 2;
             woff -= ksz;
             const bool top_tanh = !ENC && l == 6;
+            const bool init_b = l == L - 1 || (!ENC && l == 5);  // the top skip layer initialises dn_{l-1}
+            unsigned mk = 0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) mk = q == l ? mask[q] : mk;
             // ---- step A: dz_l, skip gradients, bias gradient; n_{l-1} from the registers (or x) into X ----
             gm_fill_taps(wz, g, w + woff, ksz, tid);
             float dbl = 0.0f;
@@ -254,6 +311,9 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int o = (4 * rg + e) * g.pitch + c;
+                    float xin = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) xin = q == l - 1 ? keep[q][m][e] : xin;
                     if (c < g.bands) {
                         const float gd = Da[o];
                         float f;
@@ -261,7 +321,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                             const float y = fwd_out[o];
                             f = 1.0f - y * y;
                         } else {
-                            f = ((mask[l] >> (4 * m + e)) & 1u) ? 1.0f : 0.1f;
+                            f = ((mk >> (4 * m + e)) & 1u) ? 1.0f : 0.1f;
                         }
                         const float z = gd * f;
                         Z[o] = z;
@@ -269,11 +329,11 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                         if (top_tanh) {
                             Db[o] = 0.0f;  // n6 only feeds the last convolution
                         } else {
-                            // n_l = c_l + n_{l-1} (+ n_{l-2}): the top skip layer initialises, the others accumulate
-                            Db[o] = (l == L - 1 || (!ENC && l == 5)) ? gd : Db[o] + gd;
+                            // n_l = c_l + n_{l-1} (+ n_{l-2})
+                            Db[o] = init_b ? gd : Db[o] + gd;
                             if (l >= 1) Dc[o] = gd;
                         }
-                        if (l >= 1) X[o] = keep[l - 1][m][e];
+                        if (l >= 1) X[o] = xin;
                     }
                 }
             }
@@ -287,20 +347,42 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                 float s = 0.0f;
 #pragma unroll
                 for (int wv = 0; wv < GM_WAVES; ++wv) s += red[wv];
-                dbacc[l] += s;
+                red[GM_WAVES + l] += s;
             }
             // ---- step B: filter gradient.  Tile offset a: diagonals d = i - j in [16 a - 15, 16 a + 15] ----
             const int a_lo = -((pad + 15) / 16), a_hi = (ksz - 1 - pad + 15) / 16;
             for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
                 gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int j_lo = max(0, -a), j_hi = min(g.nt - 1, g.nt - 1 - a);
-                for (int jt = j_lo; jt <= j_hi; ++jt) {
-                    // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; n = 4 s + kq
-                    const float* ap = X + rg * g.pitch + 16 * (jt + a) + col;
-                    const float* bp = Z + rg * g.pitch + 16 * jt + col;
+                // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; n = 4 s + kq
+                const float* ap = X + rg * g.pitch + 16 * a + col;
+                const float* bp = Z + rg * g.pitch + col;
+                // the next tile pair's fragments are requested ahead of this pair's MFMAs (here the hand-written prefetch
+                // pays: backward 167 vs 190 us at N = 4096 -- unlike in gm_conv_tile, GM_PIPE)
+                float fa[4], fb[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * g.pitch], bp[4 * s * g.pitch], acc, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    fa[s] = ap[16 * j_lo + 4 * s * g.pitch];
+                    fb[s] = bp[16 * j_lo + 4 * s * g.pitch];
+                }
+                for (int jt = j_lo; jt < j_hi; ++jt) {
+                    float na[4], nb[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        na[s] = ap[16 * (jt + 1) + 4 * s * g.pitch];
+                        nb[s] = bp[16 * (jt + 1) + 4 * s * g.pitch];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        fa[s] = na[s];
+                        fb[s] = nb[s];
+                    }
+                }
+                if (j_lo <= j_hi) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], acc, 0, 0, 0);
                 }
                 float* gt = G + (a - a_lo) * 16 * GM_GP;  // [i_local = 4 rg + e][j_local = col]
 #pragma unroll
@@ -318,7 +400,9 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                     const float* gt = G + (a - a_lo) * 16 * GM_GP;
                     for (int il = max(0, dl); il <= min(15, 15 + dl); ++il) s += gt[il * GM_GP + (il - dl)];
                 }
-                dwacc[l] += s;
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q == l) dwacc[q] += s;
             }
             // ---- step C: data gradient dn_{l-1} += dz_l . T^T ----
             if (l > 0 || dx != nullptr) {
@@ -365,11 +449,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         if (tid < ksz) pwb[woff + tid] = l < L ? dwacc[l] : 0.0f;
         woff += ksz;
     }
-    if (tid == 0) {
-#pragma unroll
-        for (int l = 0; l < 7; ++l) pb[(size_t)blockIdx.x * 8 + l] = l < L ? dbacc[l] : 0.0f;
-        pb[(size_t)blockIdx.x * 8 + 7] = 0.0f;
-    }
+    if (tid < 8) pb[(size_t)blockIdx.x * 8 + tid] = tid < L ? red[GM_WAVES + tid] : 0.0f;
 }
 
 }  // namespace
