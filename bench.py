@@ -172,7 +172,107 @@ def baseline_metric():
         return "HSI+LiDAR patches/sec fwd+bwd (GRSS2013 7\u00d77\u00d7145) at 1/2/4/8 GPU"
 
 
-TRAFFIC_SUMMARIES = ("r2_hbm_traffic.json", "r1_hbm_traffic.json")
+def source_fingerprint():
+    """sha256 over the tracked source files of the product path (relative path + content).  tools/gpu.sh stores it next
+    to the commit hash in .head_commit (the GPU snapshot has no .git); a .head_commit whose fingerprint does not match
+    the files this process runs from is stale and is NOT printed."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "include", "hypel.h")]
+    for base, _, names in os.walk(os.path.join(ROOT, "hypelcnn_amd")):
+        if "build" in base.split(os.sep) or "alt" in base.split(os.sep) or "__pycache__" in base:
+            continue
+        files += [os.path.join(base, n) for n in names if n.endswith((".py", ".hip", ".h", ".cpp", ".json")) or n == "Makefile"]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(hashlib.sha256(fh.read()).digest())
+    return h.hexdigest()[:16]
+
+
+def commit_label():
+    """Short hash of the code this process runs: from git when the tree has a .git (suffix +dirty when tracked files
+    differ), else from .head_commit -- only when its fingerprint matches the files on disk."""
+    commit = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()
+    if commit:
+        dirty = os.popen(f"git -C {ROOT} status --porcelain --untracked-files=no 2>/dev/null").read().strip()
+        return commit + ("+dirty" if dirty else ""), None
+    try:
+        parts = open(os.path.join(ROOT, ".head_commit")).read().split()
+    except OSError:
+        return None, "no .git and no .head_commit"
+    if len(parts) >= 2 and parts[1] == source_fingerprint():
+        return parts[0], None
+    return None, "stale .head_commit (source fingerprint differs): not printed"
+
+
+def generator_exact_macs(bands, only_encoder):
+    """Exact-tap multiply-adds of one generator application per sample (384 244 at B = 360)."""
+    tot = 0
+    for sh in (0, 1, 2, 3, 2, 1, 0)[: 4 if only_encoder else 7]:
+        k = bands >> sh
+        p = (k - 1) // 2
+        tot += sum(min(bands - 1, j + k - 1 - p) - max(0, j - p) + 1 for j in range(bands))
+    return tot
+
+
+def measure_gan_events(ops, nb, bands, steps):
+    """Eager replay of every phase of the GAN step with a HIP event pair around each generator launch (forward:
+    2 * MAC FLOP per sample; backward = recompute + data gradient + filter gradient: 6 * MAC).  Also counts the
+    launches of a step (kernel boundaries are what bounds the B = 64 stacks)."""
+    sess = ops.ctx.session()
+    towers = list(sess._compiled.values())
+    lists = [ct.serial_launches() for ct in towers]
+    n_launch = sum(len(l) for l in lists) + sum(len(ph.train_groups) for ph in ops.loss.phases)
+    ms, flops, n_gen = 0.0, 0.0, 0
+    for _ in range(steps):
+        evs = []
+        for launches in lists:
+            for l, f in launches:
+                if l.name.startswith("gan_generator"):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    f()
+                    b.record()
+                    bwd = l.name.endswith("bwd")
+                    enc = bool(l.args[8] if bwd else l.args[6])
+                    evs.append((a, b, (6 if bwd else 2) * generator_exact_macs(bands, enc) * nb))
+                else:
+                    f()
+        torch.cuda.synchronize()
+        ms += sum(a.elapsed_time(b) for a, b, _ in evs)
+        flops += sum(fl for _, _, fl in evs)
+        n_gen += len(evs)
+    return ms / steps, flops / steps, n_gen // steps, n_launch
+
+
+def gan_cpu_baseline(kind, bands, seconds_budget=12.0):
+    """oracle/gan.py::GanTrainer (numpy restatement of the wrapper's sequential train ops + TF1 Adam) on a bounded
+    sample: as many steps of a small batch as fit the budget."""
+    from oracle import gan as OG
+    rng = np.random.default_rng(1234)
+    nb = 256 if bands <= 64 else 32
+    cfg = OG.GanConfig(kind, bands)
+    params = OG.init_gan_params(kind, bands, rng)
+    tr = OG.GanTrainer(cfg, params)
+    x = rng.random((nb, 1, 1, bands), dtype=np.float32)
+    y = (x / (1.0 + rng.random((1, 1, 1, bands), dtype=np.float32))).astype(np.float32)
+    tr.step(x, y)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        tr.step(x, y)
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": nb * n / dt, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} full {kind} steps (all sequential train ops + TF1 Adam) of {nb} pairs x {bands} bands with the "
+                      f"numpy restatement oracle/gan.py::GanTrainer (numpy/OpenBLAS threads: host has {os.cpu_count()} "
+                      f"logical cores); not a TensorFlow number"}
+
+
+TRAFFIC_SUMMARIES = ("r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
 
 
 def pmc_traffic(workload, nb, launches_per_step):
@@ -237,7 +337,7 @@ def run_gan_workload(args, be, world, rank):
     gen.manual_seed(1234 + rank)
     x = torch.rand((nb, bands), generator=gen).cuda()
     y = (x / (1.0 + torch.rand((1, bands), generator=gen).cuda())).contiguous()
-    return nb, bands, kind, (lambda: ops.run_step(x, y)), (lambda: float(sum(ops.losses().values())))
+    return nb, bands, kind, (lambda: ops.run_step(x, y)), (lambda: float(sum(ops.losses().values()))), ops
 
 
 def main():
@@ -307,7 +407,7 @@ def main():
 
         loss_fn = ct.loss_value
     else:
-        nb, bands, kind, one_step, loss_fn = run_gan_workload(args, be, world, rank)
+        nb, bands, kind, one_step, loss_fn, gan_ops = run_gan_workload(args, be, world, rank)
 
     for _ in range(args.warmup):
         one_step()
@@ -412,13 +512,37 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "hypelcnn":
             cpu = cpu_baseline()
     if rank == 0 and not classifier:
-        # algorithmic HBM bytes per step: x and y read once (2*4*B*N); the achieved rate says how far
-        # from the HBM roofline a latency-bound stack of tiny kernels sits
-        alg_bytes = 2 * 4 * bands * nb
-        achieved = alg_bytes / (dt / args.steps) / 1e9
-        roof = {"bound": "hbm", "kernel": "gan phases (fused generator / discriminator GEMMs / losses)",
-                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                "note": "launch-latency bound: whole-step rate, not a single kernel"}
+        step_ms_mean = dt / args.steps * 1e3
+        gen_ms, gen_flops, n_gen, n_launch = measure_gan_events(gan_ops, nb, bands, max(2, min(5, args.steps)))
+        boundary_us = 1.7  # MI355X_MICROARCH.md price list, "boundary": 1.45-1.9 us per dependent kernel boundary
+        launch_floor_ms = n_launch * boundary_us * 1e-3
+        if bands > 128:
+            # GAN half of cfg5 (B = 360): the generator is fp32 matrix-core work (gan_mfma.hip) -- its exact-tap FLOP over
+            # its kernel time against the fp32 MFMA peak
+            achieved = gen_flops / (gen_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gan_generator_{fwd,bwd}_mfma_kernel (v_mfma_f32_16x16x4_f32)",
+                    "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "generator_launches_per_step": n_gen, "generator_ms_per_step": gen_ms,
+                    "generator_share_of_step": gen_ms / step_ms_mean,
+                    "algorithmic_gflop_per_step": gen_flops / 1e9,
+                    "flop_convention": "exact taps; forward 2 MAC, backward 6 MAC per sample (recompute + data + filter "
+                                       "gradient)",
+                    "launches_per_step": n_launch, "launch_floor_ms": launch_floor_ms}
+        else:
+            # cfg4 (B = 64): 12 k multiply-adds per sample and generator pass -- neither HBM nor the matrix cores bound
+            # the step, its kernel boundaries do.  HBM line for the record (algorithmic bytes: x and y read once,
+            # SURVEY 8d), and the launch floor = launches x the guide's per-boundary cost against the measured step.
+            alg_bytes = 2 * 4 * bands * nb
+            achieved = alg_bytes / (dt / args.steps) / 1e9
+            roof = {"bound": "hbm", "kernel": "gan phases (fused generator / discriminator GEMMs / losses)",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                    "note": "launch-latency bound: whole-step rate, not a single kernel; see launch_floor",
+                    "launches_per_step": n_launch, "boundary_us": boundary_us, "launch_floor_ms": launch_floor_ms,
+                    "launch_floor_frac": launch_floor_ms / step_ms_mean,
+                    "generator_launches_per_step": n_gen, "generator_ms_per_step": gen_ms}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = gan_cpu_baseline(kind, bands)
     if use_dist:
         dist.barrier()
     if rank == 0:
@@ -457,16 +581,9 @@ def main():
                "dtype": "f32", "data": "synthetic", "config": cfg_d, "roofline": roof, "cpu_baseline": cpu}
         if pipeline is not None:
             out["with_input_pipeline"] = pipeline
-        try:
-            commit = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()
-            if not commit:  # the GPU box gets a snapshot without .git: tools/gpu.sh leaves the hash in this file
-                try:
-                    commit = open(os.path.join(ROOT, ".head_commit")).read().strip()
-                except OSError:
-                    commit = ""
-            out["commit"] = commit or None
-        except OSError:
-            pass
+        out["commit"], note = commit_label()
+        if note:
+            out["commit_note"] = note
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -1,15 +1,25 @@
+"""Per-launch table of one training step from a rocprofv3 kernel trace of bench.py:
+  python profiles/analyze_trace.py <kernel_trace.csv> [all] [--workload hypelcnn|dualcnn]
+The launches of the LAST full step in the trace are matched, in order, with the planner's launch list (built here on
+the CPU emulation backend), so every kernel gets its layer tag and algorithmic FLOP."""
 import csv, json, sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+workload = "hypelcnn"
+if "--workload" in sys.argv:
+    i = sys.argv.index("--workload")
+    workload = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 trace = sys.argv[1]
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # plan
 from tests.emu_backend import EmuBackend
 import bench
-ctx, train_step, lr, alg = bench.build_model(1024, EmuBackend())
+nb = bench.CLASSIFIER_WORKLOADS[workload][5]
+ctx, train_step, lr, alg = bench.build_model(nb, EmuBackend(), workload)
 ctx.capture_graphs = False
-ct = train_step.compiled(1024)
+ct = train_step.compiled(nb)
 plan = ct.plan
 launches = [l for l in plan.fwd + plan.bwd if l.name not in ('_fork','_join')]
 names = []

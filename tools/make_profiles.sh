@@ -1,28 +1,44 @@
 #!/bin/bash
 # Regenerates the round's profile evidence on the GPU box (run through gpurun from the repo root):
-#   tools/make_profiles.sh <tag>      e.g. r2   -> gpurun_out/prof_<tag>/...; copy the summaries into profiles/
-# 1. bench line (driver contract)                      -> bench_n1.json
-# 2. rocprofv3 --kernel-trace --stats of the same cmd  -> kernel_stats.csv, per_launch.txt (profiles/analyze_trace.py)
-# 3. PMC passes FETCH_SIZE / WRITE_SIZE (separate)      -> hbm_traffic.{txt,json}
+#   tools/make_profiles.sh <tag> [workloads]     e.g. r3 "hypelcnn dualcnn cut cyclegan"  (default: all four)
+#   -> gpurun_out/prof_<tag>/<files>; copy the summaries into profiles/ (tools/collect_profiles.sh <tag>)
+# per workload:
+#   bench line (driver contract)                        -> bench_<wl>.json
+#   rocprofv3 --kernel-trace --stats of the same cmd    -> kernel_stats_<wl>.csv (+ per_launch_<wl>.txt for classifiers)
+#   classifiers: PMC passes FETCH_SIZE / WRITE_SIZE     -> hbm_traffic_<wl>.{txt,json}, hbm_traffic_per_launch_<wl>.txt
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
+WLS=${2:-"hypelcnn dualcnn cut cyclegan"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$(pwd)
-python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-input-pipeline > $ROOT/$OUT/trace_bench.json 2> $ROOT/$OUT/trace.err
-cd $ROOT
-S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/kernel_stats.csv
-T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
-[ -n "$T" ] && python profiles/analyze_trace.py $T > $OUT/per_launch.txt 2>&1
-cd /tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_f -o f -- python $ROOT/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-input-pipeline > /dev/null 2> $ROOT/$OUT/pmc_f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_w -o w -- python $ROOT/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-input-pipeline > /dev/null 2> $ROOT/$OUT/pmc_w.err
-cd $ROOT
-F=$(find $OUT/pmc_f -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_w -name "*counter_collection.csv" | head -1)
-[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W --json $OUT/hbm_traffic.json --source "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-input-pipeline (every step of the run incl. pre-warm and event replay), tools/pmc_traffic.py" > $OUT/hbm_traffic.txt 2>&1
-[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic_per_launch.py $F $W > $OUT/hbm_traffic_per_launch.txt 2>&1
-rm -rf $OUT/trace $OUT/pmc_f $OUT/pmc_w   # raw traces are large; the summaries above are what gets committed
+for WL in $WLS; do
+  case $WL in
+    hypelcnn) STEPS=100; TSTEPS=20; KNOWN=$((1024*49*145*4)); NB=1024;;
+    dualcnn)  STEPS=20;  TSTEPS=4;  KNOWN=$((512*121*49*4));  NB=512;;
+    *)        STEPS=100; TSTEPS=30; KNOWN=0; NB=0;;
+  esac
+  EXTRA=""; [ $WL = hypelcnn ] || EXTRA="--workload $WL"
+  python bench.py $EXTRA --steps $STEPS > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$WL -o t -- python $ROOT/bench.py $EXTRA --steps $TSTEPS --warmup 3 --no-cpu-baseline --no-input-pipeline > $ROOT/$OUT/trace_bench_$WL.json 2> $ROOT/$OUT/trace_$WL.err
+  cd $ROOT
+  S=$(find $OUT/trace_$WL -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/kernel_stats_$WL.csv
+  T=$(find $OUT/trace_$WL -name "*kernel_trace.csv" | head -1)
+  if [ $NB -gt 0 ]; then
+    [ -n "$T" ] && python profiles/analyze_trace.py $T --workload $WL > $OUT/per_launch_$WL.txt 2>&1
+    cd /tmp
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_f_$WL -o f -- python $ROOT/bench.py $EXTRA --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-input-pipeline > /dev/null 2> $ROOT/$OUT/pmc_f_$WL.err
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_w_$WL -o w -- python $ROOT/bench.py $EXTRA --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-input-pipeline > /dev/null 2> $ROOT/$OUT/pmc_w_$WL.err
+    cd $ROOT
+    F=$(find $OUT/pmc_f_$WL -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_w_$WL -name "*counter_collection.csv" | head -1)
+    [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W --workload $WL --batch $NB --known-bytes $KNOWN --json $OUT/hbm_traffic_$WL.json --source "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py $EXTRA --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-input-pipeline (every step of the run incl. pre-warm and event replay), tools/pmc_traffic.py" > $OUT/hbm_traffic_$WL.txt 2>&1
+    [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic_per_launch.py $F $W --workload $WL > $OUT/hbm_traffic_per_launch_$WL.txt 2>&1
+    rm -rf $OUT/pmc_f_$WL $OUT/pmc_w_$WL
+  else
+    [ -n "$S" ] && python tools/kstats.py $S 30 > $OUT/kernel_top_$WL.txt 2>&1
+  fi
+  rm -rf $OUT/trace_$WL   # raw traces are large; the summaries above are what gets committed
+done
 ls -la $OUT

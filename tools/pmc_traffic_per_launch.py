@@ -27,10 +27,16 @@ def last_step(lst):
 def main():
     from tests.emu_backend import EmuBackend
     import bench
+    workload = "hypelcnn"
+    if "--workload" in sys.argv:
+        i = sys.argv.index("--workload")
+        workload = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     fe, wr = last_step(load(sys.argv[1], "FETCH_SIZE")), last_step(load(sys.argv[2], "WRITE_SIZE"))
-    ctx, ts, lr, alg = bench.build_model(1024, EmuBackend())
+    nb = bench.CLASSIFIER_WORKLOADS[workload][5]
+    ctx, ts, lr, alg = bench.build_model(nb, EmuBackend(), workload)
     ctx.capture_graphs = False
-    plan = ts.compiled(1024).plan
+    plan = ts.compiled(nb).plan
     launches = [l for l in plan.fwd + plan.bwd if l.name not in ("_fork", "_join")]
     j = 0
     tot_alg = tot = 0.0
