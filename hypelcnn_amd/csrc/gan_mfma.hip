@@ -16,7 +16,9 @@
 //    16x16 accumulator (K = 16 samples x 23 column tiles), so a layer needs only (k / 16 + 3) accumulators and one
 //    small diagonal reduction per block, in a fixed order (no float atomics).
 // fp32 MFMA is a k-ordered fmaf chain: same arithmetic class as the VALU kernels in gan.hip, which stay in charge
-// of bands <= 128 (12 k multiply-adds per sample at B = 64: launch latency, not arithmetic).
+// of bands < 16 and bands > 384 (and of everything under HYPEL_GAN_MFMA=0).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
@@ -456,7 +458,10 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 
 // Entry points used by gan.hip's dispatch (same contracts as the VALU kernels there).
 bool hypel_gm_supported(int bands) {
-    return bands > 128 && bands <= GM_MAX_BANDS && gm_bwd_lds(bands) <= 160 * 1024;
+    // HYPEL_GAN_MFMA_MIN: smallest band count that runs here.  Default 16: also the narrow Gulfport stacks (B = 64:
+    // CycleGAN step 0.922 -> 0.887 ms, generator launches 31 -> 26 us) -- gan.hip's kernels keep B < 16 and B > 384
+    static const int min_bands = getenv("HYPEL_GAN_MFMA_MIN") ? atoi(getenv("HYPEL_GAN_MFMA_MIN")) : 16;
+    return bands >= min_bands && bands >= 16 && bands <= GM_MAX_BANDS && gm_bwd_lds(bands) <= 160 * 1024;
 }
 
 int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,

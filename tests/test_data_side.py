@@ -290,6 +290,37 @@ def test_gpu_full_scene_inference_matches_emulation(hip, tmp_path):
     assert n_tie <= 0.005 * margin.size
 
 
+@pytest.mark.gpu
+def test_gpu_full_scene_inference_matches_the_oracle_logits(hip, tmp_path):
+    """Row f1 against the ORACLE itself (not only the emulation): the label raster the HIP inference path writes for the
+    whole scene equals argmax of the float64 oracle's logits (oracle/train.py forward, inference mode, same checkpoint)
+    wherever the oracle's two best logits are more than 1e-4 apart; near-ties are counted."""
+    import glob
+    from hypelcnn_amd.loader.SyntheticDataLoader import SyntheticDataLoader
+    from oracle import train as OT
+    res, log_dir, alg_path = _train(tmp_path, "GeneratorImporter", hip, steps=60)
+    raster_gpu, _ = _infer(tmp_path, log_dir, alg_path, hip, "all", batch=128)
+    ckpt = sorted(glob.glob(os.path.join(log_dir, "model.ckpt-*.npz")))[-1]
+    with np.load(ckpt) as z:
+        state = {k.replace("|", "/"): z[k] for k in z.files}
+    params = {k[len("nn_core/"):]: v.astype(np.float64) for k, v in state.items() if k.startswith("nn_core/")
+              and "/Adam" not in k}
+    loader = SyntheticDataLoader(SCENE)
+    data_set = loader.load_data(1, True)
+    h, w = raster_gpu.shape
+    patches = np.stack([data_set.get_data_point(x, y) for y in range(h) for x in range(w)]).astype(np.float64)
+    cc = loader.get_class_count()
+    classes = len(cc) if hasattr(cc, "__len__") else int(cc)
+    ref = OT.forward_backward("HYPELCNNModel", params, patches, None, classes, ALG, False)["logits"]
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+    want = ref.argmax(1).astype(raster_gpu.dtype).reshape(h, w)
+    np.testing.assert_array_equal(raster_gpu[clear.reshape(h, w)], want[clear.reshape(h, w)])
+    n_tie = int((~clear).sum())
+    print(f"\nfull-scene labels vs fp64 oracle: {int(clear.sum())} pixels exact, {n_tie} near-ties")
+    assert n_tie <= 0.005 * clear.size
+
+
 # ------------------------------------------------------------------------------------------------ GRSS2018 (2x)
 @pytest.fixture(scope="module")
 def golden18():

@@ -35,7 +35,8 @@ def test_phase_gradients_match_oracle(hip, kind, bands, patches, n):
     wrapper, model, loss, ops = U.build(cfg, n, hip)
     sess = ops.ctx.session()
     U.inject(sess, params)
-    U.check_phase_gradients(cfg, ops, params, x, y, tol=2e-3)
+    worst = U.check_phase_gradients(cfg, ops, params, x, y, tol=5e-5)
+    print(f"\n{kind} B={bands}: worst phase-gradient error {worst:.2e} (relative to the tensor maximum)")
 
 
 def test_cyclegan_graph_replay_and_training_on_dummy_pairs(hip):
@@ -120,6 +121,24 @@ def test_cut_full_step_batch4096_eager_equals_graph(hip):
     torch.cuda.synchronize()
     assert torch.equal(sess.params, p_eager), "HIP-graph replay must equal the eager step"
     assert ops.losses() == l_eager
+
+
+def test_cfg5_joint_loop_at_the_per_gpu_batch_512(tmp_path):
+    """BASELINE configs[4] at its per-GPU size (batch 4096 over 8 GPUs = 512 each): the joint loop with
+    --batch_size 512 on 7x7x360 patches, the CUT-based (DCL-GAN) generator applied to all 49 pixels of a patch w.p. 0.5
+    (gan/gan_utilities.py:30-43, gan_common.py:282-304 -- 512 x 49 = 25 088 generator rows per augmented batch, through
+    the matrix-core generator kernel)."""
+    import json
+    import os
+    from hypelcnn_amd.backend import HipBackend
+    from tests.test_training_loop_emu import run_joint_loop
+    cfg_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hypelcnn_amd", "nnmodel", "modelconfigs")
+    alg = json.load(open(os.path.join(cfg_dir, "alg_param_hypelcnn.json")))
+    alg["learning_rate"] = 1e-3
+    res, seen = run_joint_loop(tmp_path, HipBackend, gan_steps=10, cls_steps=12, gan_type="dcl_gan",
+                               scene="avon:h=60:w=80:bands=360:samples=0.6", neighborhood=3, alg=alg, batch=512,
+                               gan_batch=512)
+    assert np.isfinite(res.loss), res.loss
 
 
 def test_cfg5_joint_loop_at_avon_shape_on_gpu(tmp_path):

@@ -680,6 +680,21 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.check("db", rtol=2e-4, atol=2e-5)
 
 
+def test_gan_generator_valu_kernels_in_a_subprocess():
+    """The generator runs on the matrix cores (gan_mfma.hip) from 16 bands on; gan.hip's wave-per-sample and register-tiled
+    kernels remain the path for B < 16 / B > 384 and under HYPEL_GAN_MFMA=0 (the library reads the switch once per
+    process): the same parity cases once more on them."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HYPEL_GAN_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_gan_generator_fwd_bwd", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "12 passed" in r.stdout, r.stdout[-500:]
+
+
 def test_l2norm_parts(hip):
     rng = np.random.default_rng(5)
     rows, e, parts = 4096, 2, 6

@@ -321,6 +321,22 @@ def test_avon_hypelcnn_hsi_only_two_classes_vs_oracle(hip):
     print(f"\nAVON-shape HYPELCNN nb=64 vs fp64 oracle: logits {err:.2e}, worst grad {worst}")
 
 
+def test_avon_hypelcnn_per_gpu_batch512_vs_oracle(hip):
+    """BASELINE configs[4] classifier at its PER-GPU batch (4096 over 8 GPUs = 512): HYPELCNN on 7x7x360 HSI-only
+    patches, 2 classes, full alg_param_hypelcnn.json -- K = 360 first-layer segments and other tile-width hints / split
+    counts than the 145-channel model at batch 1024.  One forward + backward against the float64 numpy oracle."""
+    alg = _alg("alg_param_hypelcnn.json")
+    built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 7, 360, 2, alg, 512, 512)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    assert "tap-split-reduce" in tags and "wgrad-reduce" in tags and "splitk-reduce" in tags, sorted(set(tags))
+    ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 2, alg,
+                                     tol_logit=1e-3, tol_grad=5e-4)
+    got = ct.value(built.y_conv).cpu().numpy()
+    assert (got.argmax(1) == ref["logits"].argmax(1)).all()
+    print(f"\nAVON-shape HYPELCNN nb=512 vs fp64 oracle: logits {err:.2e}, worst grad {worst}")
+
+
 def test_three_adam_steps_track_oracle_trainer_on_gpu(hip):
     """Three full train steps (forward, backward, TF1 Adam, staircase LR, moving statistics) against
     oracle/train.py::ClassifierTrainer: every variable within 5e-5 after the third update."""
