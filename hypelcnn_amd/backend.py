@@ -23,6 +23,7 @@ LIB_PATH = os.environ.get("HYPEL_LIB_PATH") or os.path.join(_HERE, "csrc", "libh
 MAX_SIDE_STREAMS = 4  # side streams a plan may fork filter gradients onto (plan.SIDE_STREAMS <= this)
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 GEMM_BM = 128
+ABI_VERSION = 2  # include/hypel.h HYPEL_ABI_VERSION: a library built from other headers is refused at load time
 
 SEG_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("k", "<i4"), ("reserved", "<i4")])
 GROUP_DTYPE = np.dtype([("c_off", "<i8"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("rows", "<i4"),
@@ -190,8 +191,8 @@ class HipBackend:
                              "(there is no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.lib = load_library()
-        if self.lib.hypel_version() != 1:
-            raise HypelError("libhypel_hip.so ABI version mismatch")
+        if self.lib.hypel_version() != ABI_VERSION:
+            raise HypelError(f"libhypel_hip.so ABI version {self.lib.hypel_version()} != {ABI_VERSION} (stale build or HYPEL_LIB_PATH)")
         # All hypel launches (and the torch plumbing ops around them) run on ONE dedicated non-default
         # stream: HIP cannot capture the legacy null stream into a graph, and a private stream keeps the
         # step ordered without device-wide syncs.  The stream pair is per DEVICE, not per backend object: torch's

@@ -115,7 +115,10 @@ def export_tf_checkpoint(sess, prefix):
     sess.average_state()
     if not is_chief():
         return prefix
-    tf_checkpoint.write_checkpoint(prefix, tf_checkpoint.session_to_variables(sess))
+    # a MomentumOptimizer session is exported under <var>/nn_core/Momentum (one slot, no beta powers): the names the
+    # reference's Saver restores for alg_param_concnn.json
+    tf_checkpoint.write_checkpoint(prefix, tf_checkpoint.session_to_variables(
+        sess, momentum=getattr(sess, "optimizer_kind", "adam") == "momentum"))
     with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"), "w") as f:
         base = os.path.basename(prefix)
         f.write(f'model_checkpoint_path: "{base}"\nall_model_checkpoint_paths: "{base}"\n')
@@ -207,8 +210,13 @@ def run_monitored_session(cross_entropy, log_dir, class_range, save_checkpoint_s
         evaluated = test_hook.after_run(sess, iteration) or evaluated
         if evaluated or iteration % TEST_ITERATION_COUNT == 0:
             loss = cross_entropy.eval()
-            if not numpy.isfinite(loss):  # NanTensorHook(fail_on_nan_loss=False): stop, do not raise
-                print(f"NaN loss at step {iteration}: stopping")
+            # NanTensorHook(fail_on_nan_loss=False): stop, do not raise.  The verdict is the step's ALL-REDUCED flag
+            # (sync=True also reads the newest copy), never this rank's local loss: under data parallelism only the
+            # rank whose shard produced the NaN would leave the loop, and its test_hook.end / average_state
+            # collectives would meet the other ranks' gradient all-reduce.
+            bad = sess.nonfinite_step(sync=True)
+            if bad is not None or (sess.dist is None and not numpy.isfinite(loss)):
+                print(f"NaN loss at step {bad if bad is not None else iteration}: stopping")
                 break
             if summary_fn is not None:
                 writer.add(summary_fn(sess, iteration))

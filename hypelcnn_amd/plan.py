@@ -245,6 +245,10 @@ class TowerPlan:
         self.world = dist_[0] if dist_ is not None else 1
         if self.sync_bn and FUSED_STATS:
             raise RuntimeError("HYPEL_FUSED_STATS and synchronised batch norm exclude each other")
+        if self.sync_bn and USE_SIDE_STREAM:
+            # the host collectives cut the HIP-graph segments in the middle of the backward pass, where a fork onto a
+            # side stream may still be open: the segment would end with unjoined work
+            raise RuntimeError("HYPEL_SIDE_STREAMS and synchronised batch norm exclude each other")
         self.sess = session
         self.be = session.backend
         self.training = tower.is_training

@@ -339,6 +339,7 @@ class Session:
         self._post_guard()
 
     def momentum_step(self, lr, mu):
+        self.optimizer_kind = "momentum"  # checkpoint export: <var>/nn_core/Momentum slots, no beta powers
         self.backend.call("momentum_tf1_guarded", Ref(self.params), Ref(self.grads), Ref(self.slot_m),
                           self.params.numel(), float(lr), float(mu), self.guard_ref())
         self.global_step += 1

@@ -152,6 +152,44 @@ def test_session_export_and_restore_through_tf_bundle(tmp_path):
     assert s4.global_step == 3 and float(s4.slot_m.abs().max()) == 0.0
 
 
+def test_momentum_session_round_trips_under_the_momentum_slot_names(tmp_path):
+    """A MomentumOptimizer session (alg_param_concnn.json; common/common_nn_ops.py:225) is exported as
+    `<var>/nn_core/Momentum` -- one slot, no beta powers -- and restores to the same optimiser state."""
+    from hypelcnn_amd.classify import monitored_session_runner as M
+    from tests import parity_util as U
+    from tests.emu_backend import EmuBackend
+    alg = {"drop_out_ratio": 0.7, "filter_count": 16, "learning_rate": 3e-3, "learning_rate_decay_factor": 0.96,
+           "learning_rate_decay_step": 350, "lrelu_alpha": 0.18, "optimizer": "AdamOptimizer", "bn_decay": 0.9,
+           "l2regularizer_scale": 1e-5, "spectral_hierarchy_level": 1, "spatial_hierarchy_level": 1,
+           "degradation_coeff": 3, "use_residual": True}
+    rng = np.random.default_rng(5)
+    x = rng.random((8, 3, 3, 5)).astype(np.float32)
+    onehot = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 8)]
+
+    def fresh(seed):
+        built = U.build("HYPELCNNModel", 3, 5, 3, alg, EmuBackend(), with_eval=False)
+        built.ctx.seed = seed
+        return built, built.ctx.session()
+
+    b1, s1 = fresh(1)
+    for _ in range(3):
+        U.run_train_step(b1, x, onehot, {})
+        s1.momentum_step(1e-2, 0.9)
+    prefix = M.export_tf_checkpoint(s1, str(tmp_path / "model.ckpt-3"))
+    names = set(T.read_index(prefix + ".index"))
+    assert b"nn_core/conv_enc_0/weights/nn_core/Momentum" in names
+    assert not any(b"Adam" in n or b"_power" in n for n in names), sorted(names)[:8]
+    b2, s2 = fresh(2)
+    M.restore_checkpoint(s2, prefix)
+    np.testing.assert_array_equal(s2.params.numpy(), s1.params.numpy())
+    np.testing.assert_array_equal(s2.slot_m.numpy(), s1.slot_m.numpy())
+    assert s2.global_step == 3
+    for b, s in ((b1, s1), (b2, s2)):
+        U.run_train_step(b, x, onehot, {})
+        s.momentum_step(1e-2, 0.9)
+    np.testing.assert_array_equal(s2.params.numpy(), s1.params.numpy())
+
+
 def test_gan_session_exports_default_adam_names_with_its_beta1(tmp_path):
     """GAN optimisers keep TF's default name and beta1 = 0.5 (gan/wrappers/gan_common.py:264-265)."""
     from tests import parity_util as U
