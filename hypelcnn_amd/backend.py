@@ -34,7 +34,8 @@ MTILE_DTYPE = np.dtype([("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8"), 
 REDUCE_ENTRY_DTYPE = np.dtype([("partial_off", "<i8"), ("out_off", "<i8"), ("stride", "<i8"), ("count", "<i8"),
                                ("n_splits", "<i4"), ("flags", "<i4")])
 TILE_DTYPE = np.dtype([("group", "<i4"), ("m0", "<i4"), ("rows", "<i4"), ("seg_begin", "<i4"), ("seg_count", "<i4"),
-                       ("k0", "<i4"), ("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8")])
+                       ("k0", "<i4"), ("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8"),
+                       ("split", "<i4"), ("reserved", "<i4"), ("slab", "<u8"), ("ticket", "<u8")])
 
 
 class Ref:

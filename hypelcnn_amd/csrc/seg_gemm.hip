@@ -197,6 +197,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     struct { int64_t a_off0, b_off0; int k0; } tile;
     int m0, n0;
     int tile_index = 0;  // position in the tile table (non-MULTI): the chunk index of the epilogue reductions
+    int split_info = 0;  // K-slice record: count | index << 8 (include/hypel.h, tail splitting)
+    uint64_t slab_addr = 0, ticket_addr = 0;
     if constexpr (MULTI) {
         if (lid >= n_tiles) return;
         const hypel_mtile_t rec = reinterpret_cast<const hypel_mtile_t*>(tiles_v)[lid];
@@ -220,8 +222,12 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         grp = {t.c_off, t.seg_begin, t.seg_count, t.rows};
         tile = {t.a_off0, t.b_off0, t.k0};
         m0 = t.m0;
+        split_info = t.split;
+        slab_addr = t.slab;
+        ticket_addr = t.ticket;
     }
     const int rows_left = grp.rows - m0;  // valid rows in this tile (may exceed BM)
+    if (rows_left <= 0) return;           // empty record (padding of an XCD's share of the table)
     const int cols_left = n - n0;
 
     const int tid = threadIdx.x;
@@ -569,6 +575,64 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     }
     bias = nullptr;
 #endif
+    // ---- tail splitting: a K-slice block hands its accumulators over; the last arriver sums the slices ----
+    if constexpr (!MULTI) {
+        const int s_cnt = split_info & 0xff;
+        if (s_cnt > 1) {
+            constexpr int NV4 = NARROW ? 2 : TM * TN * 4;  // float4 per lane
+            const int s_idx = (split_info >> 8) & 0xff;
+            const int jn = n0 / BN;
+            float* slab0 = reinterpret_cast<float*>(slab_addr) + (size_t)jn * s_cnt * (BM * BN);
+            // register order: float4 q of lane `tid` at ((q * 256 + tid) * 4); write-through (sc1) 16-byte stores, so that
+            // no release fence is needed (cdna_hip_programming.md Guideline 16, recipe R1)
+            __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)slab0, 0, s_cnt * BM * BN * 4, 0x00020000);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const int own = s_idx * BM * BN * 4;
+#pragma unroll
+            for (int q = 0; q < NV4; ++q) {
+                f32x4 v;
+                if constexpr (NARROW) {
+                    v = acc16[q];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[(q >> 2) / TN][(q >> 2) % TN][(q & 3) * 4 + e];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, (q * 256 + tid) * 16, own, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the ticket is drawn
+            __syncthreads();                                   // (also: every wave has left its last MFMA phase)
+            unsigned* tk = reinterpret_cast<unsigned*>(ticket_addr) + jn;
+            unsigned* flag = reinterpret_cast<unsigned*>(lds);
+            if (tid == 0) flag[0] = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned drawn = flag[0];
+            if (drawn != (unsigned)(s_cnt - 1)) return;
+            if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            // all slices, this block's own included, in index order: every load is issued before the first add
+            f32x4 part[NV4];
+#pragma unroll
+            for (int q = 0; q < NV4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[q][e] = 0.0f;
+            for (int i = 0; i < s_cnt; ++i) {
+                u32x4 raw[NV4];
+#pragma unroll
+                for (int q = 0; q < NV4; ++q)
+                    raw[q] = __builtin_amdgcn_raw_buffer_load_b128(srs, (q * 256 + tid) * 16, i * BM * BN * 4, 16);
+#pragma unroll
+                for (int q = 0; q < NV4; ++q) part[q] += __builtin_bit_cast(f32x4, raw[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < NV4; ++q) {
+                if constexpr (NARROW) {
+                    acc16[q] = part[q];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[(q >> 2) / TN][(q >> 2) % TN][(q & 3) * 4 + e] = part[q][e];
+                }
+            }
+        }
+    }
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
     float* cbase = C + grp.c_off + (int64_t)m0 * ldc + n0;
     // bias is indexed by the absolute output column: groups of a merged level start at channel offsets
@@ -861,6 +925,9 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     // (profiles/r1_gemm_tile_choice.txt): data gradients with >= 48 reduction columns per segment and launches with
     // few blocks run faster on the narrow tile, wide filter gradients on the wide one
     int hint = (accumulate >> 8) & 3;
+    // a table with K-slice records (tail splitting) was built for ONE tile width: the hint is binding then
+    const bool split_tail = (accumulate & HYPEL_GEMM_SPLIT_TAIL) != 0;
+    HYPEL_REQUIRE(!split_tail || (hint != 0 && !bnb.partial), "hypel_seg_gemm_f32: HYPEL_GEMM_SPLIT_TAIL needs a tile width");
     const bool pairs = (accumulate & HYPEL_GEMM_PAIRED_SEGS) != 0;  // segments carry HYPEL_SEG_PAIR_FLAG
     static const int cap_on = getenv("HYPEL_GEMM_S96") ? atoi(getenv("HYPEL_GEMM_S96")) : 1;
     const bool cap96 = cap_on && (accumulate & HYPEL_GEMM_SINGLE_SEG) != 0;  // every group has one segment
@@ -869,9 +936,10 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     // padding (5 x 96, 96 + 96 + 48) and a layer's 392 row tiles x 3 or 5 column tiles fit the resident capacity where
     // 392 x 4 / x 8 of the 64-wide tiling overflow it by 2 %.  HYPEL_GEMM_FORCE_WIDTH=32|64|96: experiments.
     static const int force_w = getenv("HYPEL_GEMM_FORCE_WIDTH") ? atoi(getenv("HYPEL_GEMM_FORCE_WIDTH")) : 0;
-    if (force_w == 32) hint = 1;
-    if (force_w == 64) hint = 2;
-    if (force_w == 96) hint = 3;
+    if (force_w == 32 && !split_tail) hint = 1;
+    if (force_w == 64 && !split_tail) hint = 2;
+    if (force_w == 96 && !split_tail) hint = 3;
+    HYPEL_REQUIRE(!split_tail || hint != 3 || n > 64, "hypel_seg_gemm_f32: 96-wide slabs need n > 64");
     if (hint == 3 && n > 64 && !bnb.partial) {
         launch_cfg<4, 1, 1, 3>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats);
@@ -905,13 +973,13 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_bnbwd_f32");
         return 0;
     }
-    if (n <= 16 && mfma16 && !stats)  // the 16-wide variant has no reduction epilogues
+    if (n <= 16 && (mfma16 || split_tail) && !stats)  // the 16-wide variant has no reduction epilogues
         launch_cfg<4, 1, 1, 1, true>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st);
     else if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats, cap96);
-    else if (n <= 64 || !bn128)
+    else if (n <= 64 || !bn128 || split_tail)
         launch_cfg<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats);
     else

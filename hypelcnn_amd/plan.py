@@ -138,6 +138,17 @@ RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the dev
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
 SINGLE_SEG_HINT = os.environ.get("HYPEL_SINGLE_SEG_HINT", "1") != "0"
 GEMM_PAIRED_SEGS = 0x400    # ... HYPEL_GEMM_PAIRED_SEGS (bit of `accumulate`)
+GEMM_SPLIT_TAIL = 0x1000    # ... HYPEL_GEMM_SPLIT_TAIL: the tile table holds K-slice records, the width hint is binding
+# Tail splitting (include/hypel.h): the last tiles of every XCD's share of a forward / data-gradient launch are cut along
+# K so that the launch ends on short blocks.  HYPEL_TAIL_SPLIT = fraction of the resident blocks the slice records of a
+# launch should amount to (0 = off); HYPEL_TAIL_SLICES = slices per tile (0 = by the tile's length: 4 from 12 k-tiles,
+# 2 from 4).
+TAIL_SPLIT = float(os.environ.get("HYPEL_TAIL_SPLIT", "0"))  # measured neutral (NOTES.md): off by default
+TAIL_SLICES = int(os.environ.get("HYPEL_TAIL_SLICES", "0"))
+TAIL_MIN_TILES = int(os.environ.get("HYPEL_TAIL_MIN_TILES", "64"))  # launches with fewer row tiles are left alone
+TAIL_SLICE_KTILES = int(os.environ.get("HYPEL_TAIL_SLICE_KTILES", "8"))  # k-tiles a slice must keep
+TAIL_MAX_SLICES = int(os.environ.get("HYPEL_TAIL_MAX_SLICES", "4"))
+GEMM_BK = 32  # reduction columns per k-tile of the kernel (slices are cut at multiples of it)
 PAIR_SEGS = os.environ.get("HYPEL_PAIR_SEGS", "1") != "0"  # short data-gradient segments (k <= 16) share k-tiles
 
 
@@ -154,10 +165,33 @@ class GemmTables:
         self.keys.append(key)
         self.subkeys.append(subkey)
 
-    def finalize(self, n, pair=False):
+    @staticmethod
+    def _slice_segments(gs, S, a_ks, b_ks):
+        """Cut a tile's segment list into S parts of (nearly) equal k-tile counts, at multiples of the kernel's k-tile
+        inside a segment.  a_ks / b_ks: element distance of one reduction step in A / B."""
+        kts = [(k + GEMM_BK - 1) // GEMM_BK for _, _, k in gs]
+        total = sum(kts)
+        cuts = [total * i // S for i in range(S + 1)]
+        parts = [[] for _ in range(S)]
+        base = 0
+        for (a_off, b_off, k), kt in zip(gs, kts):
+            for i in range(S):
+                lo, hi = max(cuts[i], base), min(cuts[i + 1], base + kt)
+                if hi > lo:
+                    k_lo, k_hi = (lo - base) * GEMM_BK, min(k, (hi - base) * GEMM_BK)
+                    parts[i].append((a_off + k_lo * a_ks, b_off + k_lo * b_ks, k_hi - k_lo))
+            base += kt
+        return parts
+
+    def finalize(self, n, pair=False, split=None):
         """pair: consecutive segments of a group with k <= 16 each are marked to share one k-tile (SEG_PAIR_FLAG on
-        the first; the kernel's data-gradient variant for short segments).  self.paired = number of pairs made."""
+        the first; the kernel's data-gradient variant for short segments).  self.paired = number of pairs made.
+        split = dict(width, resident, a_ks, b_ks): tail splitting (include/hypel.h) -- the table is laid out as 8 equal
+        shares (one per XCD, what the kernel's block remap hands each XCD), the last tiles of every share are replaced
+        by K-slice records; self.split_need = (slab floats, ticket words) of scratch the launch needs, the records'
+        slab / ticket fields hold byte offsets into those two regions until _patch_split_tables adds the addresses."""
         self.paired = 0
+        self.split_need = None
         segs = []
         garr = np.zeros(len(self.groups), GROUP_DTYPE)
         tiles = []
@@ -188,15 +222,80 @@ class GemmTables:
         # all the (pixel, branch) tiles of one chunk keep re-reading stay resident in that XCD's 4 MB L2.
         # Filter-gradient launches pass key = split index (= batch-row range), for the same reason.
         tiles.sort(key=lambda t: (t[3], -t[0]))
-        sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
-        tarr = np.zeros(len(tiles), TILE_DTYPE)
-        for i, (_, g, m0, _) in enumerate(tiles):  # each record repeats what a block needs to start its tile
+
+        def record(g, m0, seg_begin=None, seg_count=None, split_word=0, slab=0, ticket=0):
             c_off, gs, rows = self.groups[g]
-            a0, b0, k0 = gs[0] if gs else (0, 0, 0)
-            if gs:
-                a0, b0, k0 = segs[int(garr[g]["seg_begin"])][:3]  # incl. the pair flag
-            tarr[i] = (g, m0, rows, garr[g]["seg_begin"], len(gs), k0, c_off, a0, b0)
+            sb = int(garr[g]["seg_begin"]) if seg_begin is None else seg_begin
+            sc = len(gs) if seg_count is None else seg_count
+            a0, b0, k0 = segs[sb][:3] if sc else (0, 0, 0)  # incl. the pair flag
+            return (g, m0, rows, sb, sc, k0, c_off, a0, b0, split_word, 0, slab, ticket)
+
+        recs = None
+        if split is not None and not self.paired and len(tiles) >= TAIL_MIN_TILES and TAIL_SPLIT > 0:
+            recs = self._tail_split(tiles, segs, n, split, record)
+        if recs is None:
+            recs = [record(g, m0) for (_, g, m0, _) in tiles]
+        sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
+        tarr = np.array(recs, TILE_DTYPE) if recs else np.zeros(0, TILE_DTYPE)
         return garr, sarr, tarr, macs
+
+    def _tail_split(self, tiles, segs, n, split, record):
+        width, resident = split["width"], split["resident"]
+        n_nt = (n + width - 1) // width
+        T = len(tiles)
+
+        def slices_of(g):
+            # a slice pays ~15 us of fixed block cost (record, first loads, slab hand-over) whatever its length: only
+            # tiles whose slices keep TAIL_SLICE_KTILES k-tiles are cut (the multi-kernel levels: up to 72 k-tiles per
+            # tile; the K <= 480 products of the 1x1 stack lost 4-10 us per launch when their tails were cut)
+            kt = sum((k + GEMM_BK - 1) // GEMM_BK for _, _, k in self.groups[g][1])
+            want = TAIL_SLICES if TAIL_SLICES else min(TAIL_MAX_SLICES, kt // TAIL_SLICE_KTILES)
+            return max(1, min(want, kt))
+
+        s_typ = max(slices_of(g) for _, g, _, _ in tiles[-64:])
+        if s_typ < 2:
+            return None
+        if T * n_nt <= resident // 2:
+            per_share = T  # the launch does not fill the device: every tile is cut
+        else:
+            t_total = min(T // 2, int(TAIL_SPLIT * resident / (s_typ * n_nt) + 0.5))
+            per_share = t_total // 8
+        if per_share < 1:
+            return None
+        shares = [tiles[T * x // 8: T * (x + 1) // 8] for x in range(8)]
+        out, slab_pos, ticket_pos, n_split = [], 0, 0, 0
+        lists = []
+        for sh in shares:
+            keep = max(0, len(sh) - per_share)
+            lst = [record(g, m0) for (_, g, m0, _) in sh[:keep]]
+            for (_, g, m0, _) in sh[keep:]:
+                S = slices_of(g)
+                if S < 2:
+                    lst.append(record(g, m0))
+                    continue
+                parts = self._slice_segments(self.groups[g][1], S, split["a_ks"], split["b_ks"])
+                parts = [p for p in parts if p]
+                S = len(parts)
+                if S < 2:
+                    lst.append(record(g, m0))
+                    continue
+                for i, part in enumerate(parts):
+                    sb = len(segs)
+                    segs.extend((int(a), int(b), int(k), 0) for a, b, k in part)
+                    lst.append(record(g, m0, sb, len(part), S | (i << 8), slab_pos * 4, ticket_pos * 4))
+                slab_pos += n_nt * S * GEMM_BM * width
+                ticket_pos += n_nt
+                n_split += 1
+            lists.append(lst)
+        if not n_split:
+            return None
+        L = max(len(l) for l in lists)
+        empty = (0,) * len(TILE_DTYPE.names)
+        for lst in lists:  # equal shares: block b runs on XCD b % 8 and takes the records of share b % 8 in order
+            out += lst + [empty] * (L - len(lst))
+        self.split_need = (slab_pos, ticket_pos)
+        self.split_tiles = n_split
+        return out
 
     def compulsory_bytes(self, n, lda, ta, ldb, tb):
         """Algorithmic HBM bytes of the launch: every DISTINCT operand element read once, every output element
@@ -460,17 +559,39 @@ class TowerPlan:
             lst.append(l2)
             return
         pair = bool(pair and PAIR_SEGS and not ta and tb and n > 16 and bnbwd is None and stats is None)
-        garr, sarr, tarr, macs = tables.finalize(n, pair=pair)
+        hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
+        if HINT_OVERRIDE and tag in HINT_OVERRIDE:  # per-launch A/B: HYPEL_HINT_OVERRIDE="fwd:conv_enc_2=1,dgrad:fc_0=2"
+            hint = HINT_OVERRIDE[tag]
+        single_seg = bool(SINGLE_SEG_HINT and not ta and bnbwd is None and
+                          all(len(segs) == 1 for _, segs, _ in tables.groups))
+        # tail splitting (forward and data-gradient launches on the main stream): the planner fixes the tile width the
+        # library would otherwise be free to choose, because the slab layout of the K-slice records depends on it
+        split = None
+        if TAIL_SPLIT > 0 and not ta and bnbwd is None and not USE_SIDE_STREAM and TILE_HINTS:
+            n_tiles_est = sum((rows + GEMM_BM - 1) // GEMM_BM for _, _, rows in tables.groups)
+            if n <= 16 and stats is None:
+                width, hint_b, bpc = 16, max(hint, 1), 7
+            elif n <= 32 or hint == 1 or (hint == 0 and n_tiles_est * ((n + 63) // 64) < 1000):
+                width, hint_b, bpc = 32, 1, (7 if single_seg and not pair else 6)
+            elif hint == 3 and n > 64:
+                width, hint_b, bpc = 96, 3, (5 if tb else 4)
+            else:
+                width, hint_b, bpc = 64, 2, (6 if tb else 5)
+            split = dict(width=width, resident=bpc * 256, a_ks=1, b_ks=(1 if tb else int(ldb)))
+        garr, sarr, tarr, macs = tables.finalize(n, pair=pair, split=split)
         if len(tarr) == 0:
             return
         if pair and tables.paired:
             accumulate = int(accumulate) | GEMM_PAIRED_SEGS
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
-        hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
-        if HINT_OVERRIDE and tag in HINT_OVERRIDE:  # per-launch A/B: HYPEL_HINT_OVERRIDE="fwd:conv_enc_2=1,dgrad:fc_0=2"
-            hint = HINT_OVERRIDE[tag]
-        if SINGLE_SEG_HINT and not ta and bnbwd is None and all(len(segs) == 1 for _, segs, _ in tables.groups):
+        if tables.split_need is not None:
+            hint = hint_b
+            accumulate = int(accumulate) | GEMM_SPLIT_TAIL
+            self.__dict__.setdefault("_split_tables", []).append((tarr, t_t))
+            self.scratch_sizes["ksplit_slabs"] = max(self.scratch_sizes.get("ksplit_slabs", 1), tables.split_need[0])
+            self.scratch_sizes["ksplit_tickets"] = max(self.scratch_sizes.get("ksplit_tickets", 1), tables.split_need[1])
+        if single_seg:
             accumulate = int(accumulate) | GEMM_SINGLE_SEG
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
                 Ref(t_t), int(len(tarr)), bias_ref, int(accumulate) | (hint << 8))
@@ -495,6 +616,9 @@ class TowerPlan:
             name = "seg_gemm_stats_f32"
             args = args + (None,)
         l = Launch(name, args, flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag)
+        if tables.split_need is not None:
+            l.meta = {"tail_split_tiles": int(tables.split_tiles), "records": int(len(tarr)),
+                      "slab_mb": tables.split_need[0] * 4 / 1e6}
         if stats is not None:
             self._scratch(l, len(args) - 1, "scratch_partial", stats)
         lst.append(l)
@@ -631,12 +755,27 @@ class TowerPlan:
             if tw.n_dropout and not self.external_masks and not getattr(self, "_step_in_loss", False):
                 self.bwd.append(Launch("step_inc", (self._ref("step_ctr"),), tag="rng"))
         # shared scratch (stream order makes reuse safe)
+        self._finish_scratch()
+
+    def _finish_scratch(self):
+        """Shared scratch (stream order makes reuse safe): allocate every region at its largest request, resolve the
+        launches' scratch arguments, and give the K-slice records of the tail-split tables their device addresses."""
         for name, size in self.scratch_sizes.items():
             self._alloc(name, size)
         for launch, pos, name in self._pending_scratch:
             args = list(launch.args)
             args[pos] = self._ref(name)
             launch.args = tuple(args)
+        if getattr(self, "_split_tables", None) and getattr(self.be, "name", "") == "hip":
+            import torch
+            slab0 = self.buffers["ksplit_slabs"].data_ptr()
+            tick0 = self.buffers["ksplit_tickets"].data_ptr()
+            for tarr, t_t in self._split_tables:
+                sel = (tarr["split"] & 0xff) > 1
+                tarr["slab"][sel] += np.uint64(slab0)
+                tarr["ticket"][sel] += np.uint64(tick0)
+                t_t.copy_(torch.from_numpy(np.ascontiguousarray(tarr).view(np.uint8).reshape(-1)))
+            self._split_tables = []
 
     def _scratch(self, launch, pos, name, size=0):
         self.scratch_sizes[name] = max(self.scratch_sizes.get(name, 1), int(size))
@@ -1712,12 +1851,7 @@ class PhasePlan(TowerPlan):
             if getattr(self, "_side_open", False):
                 self.bwd.append(self._join_sides())
             self._emit_regularisers()
-        for name, size in self.scratch_sizes.items():
-            self._alloc(name, size)
-        for launch, pos, name in self._pending_scratch:
-            args = list(launch.args)
-            args[pos] = self._ref(name)
-            launch.args = tuple(args)
+        self._finish_scratch()
 
     # ---- fused generator ----
     def _gen_refs(self, node):

@@ -73,10 +73,23 @@ typedef struct { int64_t a_off; int64_t b_off; int32_t k; int32_t reserved; } hy
 typedef struct { int64_t c_off; int32_t seg_begin; int32_t seg_count; int32_t rows; int32_t reserved; } hypel_group_t;
 typedef struct {
     int32_t group; int32_t m0;                         /* output rows [m0, min(m0 + 128, rows)) of groups[group] */
-    int32_t rows; int32_t seg_begin; int32_t seg_count; /* copies of groups[group] */
+    int32_t rows; int32_t seg_begin; int32_t seg_count; /* copies of groups[group] (a K-slice record: its own segments) */
     int32_t k0; int64_t c_off; int64_t a_off0; int64_t b_off0; /* c_off copy; segs[seg_begin] copy (0 if none) */
+    int32_t split; int32_t reserved;                   /* K-slice record: count | index << 8 (0 = whole tile), see below */
+    uint64_t slab; uint64_t ticket;                    /* device addresses of the tile's partial slabs / ticket words */
 } hypel_tile_t;
 #define HYPEL_GEMM_BM 128
+/* Tail splitting.  The blocks of a launch start together and live 60-80 us each, so a launch ends in a long decay
+ * while the last round drains (15-20 % of its time at the sizes of this model).  The LAST tiles of every XCD's share
+ * of the tile table may therefore be cut along K into `count` slice records (same group / m0 / c_off, each with its own
+ * segment range that covers one part of the reduction): every slice block writes its accumulators to
+ * slab + ((column_tile * count + index) * 128 * tile_width) floats (write-through stores), draws a ticket from
+ * ticket[column_tile] (zero before the first launch; the last arriver resets it), and the block that draws
+ * count - 1 sums the `count` slabs IN INDEX ORDER (deterministic, no float atomics) and runs the ordinary epilogue
+ * (bias, accumulate, shortcut gradient, statistics).  A table with slice records must be launched with
+ * HYPEL_GEMM_SPLIT_TAIL in `accumulate` and a binding tile width in bits 8-9 (1 = 32, 2 = 64, 3 = 96; n <= 16: 16),
+ * because the slab layout depends on it.  An all-zero record is an empty block (padding of an XCD's share). */
+#define HYPEL_GEMM_SPLIT_TAIL 0x1000
 /* Short segments (data gradients through convolutions with <= 16 filters: K = 15 in the narrowest HYPELCNN level):
  * a segment whose `k` has HYPEL_SEG_PAIR_FLAG set (real k = k & ~flag, <= 16) shares ONE 32-column k-tile with the
  * NEXT segment of its group (k <= 16, flag clear); the tile record's k0 copy carries the flag too.  Launches whose
@@ -91,7 +104,7 @@ typedef struct {
 
 /* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint
  * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks, 3 = 128x96 blocks for n > 64) -- results do not
- * depend on it; bit 10 = HYPEL_GEMM_PAIRED_SEGS. */
+ * depend on it; bit 10 = HYPEL_GEMM_PAIRED_SEGS; bit 11 = HYPEL_GEMM_SINGLE_SEG; bit 12 = HYPEL_GEMM_SPLIT_TAIL. */
 int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb, int32_t trans_b,
                        float* c, int64_t ldc, int32_t n, const hypel_group_t* groups, const hypel_seg_t* segs,
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,

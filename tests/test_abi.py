@@ -55,7 +55,7 @@ def test_signature_table_matches_header():
 
 def test_table_struct_layouts_match_header():
     from hypelcnn_amd.backend import GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE
-    assert SEG_DTYPE.itemsize == 24 and GROUP_DTYPE.itemsize == 24 and TILE_DTYPE.itemsize == 48
+    assert SEG_DTYPE.itemsize == 24 and GROUP_DTYPE.itemsize == 24 and TILE_DTYPE.itemsize == 72
     assert SEG_DTYPE.fields["b_off"][1] == 8 and SEG_DTYPE.fields["k"][1] == 16
     assert GROUP_DTYPE.fields["seg_begin"][1] == 8 and GROUP_DTYPE.fields["rows"][1] == 16
 

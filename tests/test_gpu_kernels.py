@@ -190,6 +190,54 @@ def test_seg_gemm_stats_epilogue(hip, rows, k, n, hint):
     np.testing.assert_allclose(b.h["mv"].cpu().numpy(), 0.95 + 0.05 * y.var(0, ddof=1), rtol=1e-4)
 
 
+@pytest.mark.parametrize("rows,k,n,tb_,width,slices,kind", [
+    (128 * 70 + 37, 480, 480, 0, 96, 4, "stats"), (128 * 66, 145, 120, 0, 32, 2, "bias"),
+    (128 * 80 + 5, 240, 240, 1, 64, 3, "res"), (128 * 64, 96, 15, 0, 16, 2, "plain"),
+    (128 * 72 + 100, 300, 200, 1, 32, 4, "acc"), (128 * 65, 64, 60, 0, 64, 2, "bias")])
+def test_seg_gemm_tail_split(hip, monkeypatch, rows, k, n, tb_, width, slices, kind):
+    """Tail splitting (include/hypel.h): the last tiles of every XCD share are K-slice records; slabs + tickets + the last
+    arriver's fixed-order sum must reproduce the unsplit product -- with every epilogue (bias, accumulate, shortcut
+    gradient, statistics), every tile width, ragged rows / columns, twice in a row (the tickets reset themselves)."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TAIL_MIN_TILES", 1)
+    monkeypatch.setattr(plan, "TAIL_SLICES", slices)
+    monkeypatch.setattr(plan, "TAIL_SPLIT", 1.0)
+    rng = np.random.default_rng(rows + n + k)
+    b = Both(hip)
+    a = (rng.standard_normal((rows, k)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((n, k) if tb_ else (k, n)) * 0.5).astype(np.float32)
+    ldb = k if tb_ else n
+    tb = _tables(b, [(0, [(0, 0, k)], rows)])
+    garr, sarr, tarr, _ = tb.finalize(n, split=dict(width=width, resident=1536, a_ks=1, b_ks=(1 if tb_ else ldb)))
+    assert tb.split_need is not None and ((tarr["split"] & 0xff) > 1).any() and len(tarr) % 8 == 0
+    slabs = hip.zeros(tb.split_need[0])
+    tickets = hip.zeros(tb.split_need[1])
+    t_hip = tarr.copy()
+    sel = (t_hip["split"] & 0xff) > 1
+    t_hip["slab"][sel] += np.uint64(slabs.data_ptr())
+    t_hip["ticket"][sel] += np.uint64(tickets.data_ptr())
+    hint = {16: 1, 32: 1, 64: 2, 96: 3}[width]
+    flags = 0x1000 | (hint << 8)
+    c0 = rng.standard_normal(rows * n).astype(np.float32)
+    for nm, arr in (("a", a), ("w", w), ("y", c0), ("g", garr), ("s", sarr), ("bias", rng.standard_normal(n).astype(np.float32)),
+                    ("res", rng.standard_normal((rows, n)).astype(np.float32)),
+                    ("part", np.zeros(((rows + 127) // 128) * 2 * n, np.float32))):
+        b.arr(nm, arr)
+    b.e["t"] = b.emu.upload(tarr)
+    b.h["t"] = hip.upload(t_hip)
+    for rep in range(2):
+        if kind == "stats":
+            b.run("seg_gemm_stats_f32", "a", k, 0, "w", ldb, tb_, "y", n, n, "g", "s", "t", len(tarr), None, flags, "part")
+            b.check("part", rtol=1e-3, atol=2e-4)
+        elif kind == "res":
+            b.run("seg_gemm_res_f32", "a", k, 0, "w", ldb, tb_, "y", n, n, "g", "s", "t", len(tarr), None, flags, "res", n, None)
+        else:
+            b.run("seg_gemm_f32", "a", k, 0, "w", ldb, tb_, "y", n, n, "g", "s", "t", len(tarr),
+                  "bias" if kind == "bias" else None, flags | (1 if kind == "acc" else 0))
+        b.check("y", rtol=2e-4, atol=2e-5)
+    assert int(tickets.view(torch.int32).abs().max()) == 0, "the last arrivers must leave the tickets at zero"
+
+
 @pytest.mark.parametrize("cin,cout,mapped,acc,act,hint", [(120, 240, True, 0, 1, 1), (240, 120, True, 1, 1, 2),
                                                            (60, 60, False, 0, 0, 0), (145, 480, True, 0, 3, 2),
                                                            (33, 48, None, 1, 1, 1)])

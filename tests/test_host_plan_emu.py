@@ -128,6 +128,23 @@ def test_channel_part_split_with_batch_norm_matches_oracle(monkeypatch):
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 
+def test_tail_split_tables_match_oracle(monkeypatch):
+    """Tail splitting (include/hypel.h): with the thresholds forced down, the forward and data-gradient tables of a toy
+    HYPELCNN carry K-slice records; the emulation checks that the slices of a tile cover its reduction exactly once,
+    and the whole step still equals the oracle."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TAIL_MIN_TILES", 1)
+    monkeypatch.setattr(plan, "TAIL_SLICES", 3)
+    alg = dict(ALG_H, filter_count=96)
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 5, 40, 4, alg, 70, 29)
+    ct = U.run_train_step(built, x, onehot, masks)
+    split = [l for l in ct.plan.fwd + ct.plan.bwd if l.meta.get("tail_split_tiles")]
+    assert any(l.tag.startswith("fwd:") for l in split) and any(l.tag.startswith("dgrad:") for l in split), \
+        [l.tag for l in split]
+    assert all(l.args[14] & 0x1000 and (l.args[14] >> 8) & 3 for l in split)
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
+
+
 def test_dgrad_segment_split_matches_oracle(monkeypatch):
     """Data gradient of an unfolded multi-kernel level: the per-pixel segment list is cut into chunks that write
     partial copies of dX, summed by one reduce (DUALCNN levels; HYPELCNN levels fold their shortcut instead)."""
