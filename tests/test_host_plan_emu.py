@@ -135,6 +135,7 @@ def test_tail_split_tables_match_oracle(monkeypatch):
     from hypelcnn_amd import plan
     monkeypatch.setattr(plan, "TAIL_MIN_TILES", 1)
     monkeypatch.setattr(plan, "TAIL_SLICES", 3)
+    monkeypatch.setattr(plan, "TAIL_SPLIT", 1.0)  # off by default (measured neutral)
     alg = dict(ALG_H, filter_count=96)
     built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 5, 40, 4, alg, 70, 29)
     ct = U.run_train_step(built, x, onehot, masks)
