@@ -107,6 +107,7 @@ SIGNATURES = {
     "gather_patches_f32": [_P, _P, _I64, _I64, _I32, _I32, _P, _I64, _I32, _P],
     "gather_patches_2x_f32": [_P, _P, _I64, _I64, _I32, _I32, _I32, _P, _I64, _I32, _P],
     "augment_patches_f32": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gather_pairs_f32": [_P, _P, _P, _I64, _I32, _P, _P, _P, _F, _P, _P],
     "argmax_scatter": [_P, _I64, _I64, _I32, _P, _P, _I64],
     "lrn_fwd": [_P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64],
     "lrn_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64, _I32],
@@ -165,6 +166,7 @@ def bind_collective(name, args):
         ref, count = args
 
         def call():
+            note_collective()
             dist.all_reduce(ref.t[ref.off:ref.off + count], op=dist.ReduceOp.SUM)
     else:
         src, count, dst = args
@@ -175,15 +177,27 @@ def bind_collective(name, args):
             # and poll an event -- which invalidates a HIP-graph capture that happens to be under way on the compute
             # stream ("operation not permitted on an event last recorded in a capturing stream", 1 run in 8)
             world = dist.get_world_size()
+            note_collective()
             dist.all_gather_into_tensor(dst.t[dst.off:dst.off + world * count], src.t[src.off:src.off + count])
 
     call.host = True
     return call
 
 
+_collective_epoch = [0]  # bumped by every collective the package issues (note_collective)
+
+
+def note_collective():
+    """Called right before any torch.distributed collective of the package: a HIP-graph capture must not start while
+    the RCCL watchdog still polls that collective (HipBackend.settle_before_capture waits it out -- once per burst of
+    captures, not once per capture, as long as no collective was issued in between)."""
+    _collective_epoch[0] += 1
+
+
 class HipBackend:
     """Launches hand-written gfx950 kernels through the C-ABI on a torch CUDA(HIP) stream."""
     name = "hip"
+    _settled_epoch = -1  # value of the collective epoch at the last settle_before_capture() pause
     _streams = {}  # device index -> (main stream, side stream), shared by every backend object of the process
 
     def __init__(self, device=None):
@@ -290,8 +304,12 @@ class HipBackend:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
             return
+        if HipBackend._settled_epoch == _collective_epoch[0]:
+            return  # no collective since the last pause: the watchdog has nothing new to poll (a burst of captures --
+            #         every batch size of a run, TrainStep.precapture -- pays the pause once)
         torch.cuda.synchronize(self.device)
         time.sleep(float(os.environ.get("HYPEL_CAPTURE_SETTLE_S", "0.5")))
+        HipBackend._settled_epoch = _collective_epoch[0]
 
     def capture(self, launches, settled=False):
         """Capture a list of bound launches into a hipGraphExec; returns a replay callable.

@@ -186,6 +186,8 @@ def run_monitored_session(cross_entropy, log_dir, class_range, save_checkpoint_s
             getattr(augmentation_info.shadow_struct, "shadow_op_initializer", None) is not None:
         augmentation_info.shadow_struct.shadow_op_initializer(None, sess)
     importer.init_tensors(sess, training_tensor, training_nn_params)  # InitHook (:40-45)
+    if sess.dist is not None and hasattr(train_step, "precapture"):
+        train_step.precapture()  # full batch + ragged tail now, not next to a live all-reduce later
 
     validation_hook = ValidationHook(validation_nn_params, validation_tensor, class_range, required_steps,
                                      validation_steps, importer)

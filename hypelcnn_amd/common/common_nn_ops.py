@@ -335,6 +335,22 @@ class BatchIterator:
             return torch.randperm(n, generator=self._gen).to(self.backend.device)
         return torch.arange(n, device=self.backend.device)
 
+    def batch_shapes(self):
+        """[(samples on this rank, samples in the global batch)] of every batch this iterator can produce: the full batch
+        and, for an epoch-limited run, the ragged tail -- what a training loop needs to plan and capture BEFORE its
+        first step (under data parallelism a HIP-graph capture next to live collectives costs a 0.5 s pause)."""
+        world, rank = self._dp()
+        shapes = [(self.batch_size, self.batch_size * world)]
+        n = len(self.arrays) if self.arrays is not None else 0
+        if n and self.num_epochs is not None:
+            total = n * (self.num_epochs if self.shuffle else 1)
+            tail = total % (self.batch_size * world)
+            if tail and not (world > 1 and self.collective and tail < world):
+                mine = len(range(rank, tail, world))
+                if mine:
+                    shapes.append((mine, tail))
+        return shapes
+
     def next_batch(self):
         """Returns (x [b,P,P,C] float32, onehot [b,classes] float32, labels int64) or None when exhausted."""
         n = len(self.arrays)
@@ -519,6 +535,13 @@ class TrainOp:
             ct.capture()
         return ct
 
+    def precapture(self):
+        """Plan and capture every batch shape the iterator will deliver, in one burst (one watchdog pause under data
+        parallelism: HipBackend.settle_before_capture), instead of paying for a new shape in the middle of the run."""
+        shapes = self.iterator.batch_shapes() if hasattr(self.iterator, "batch_shapes") else []
+        for nb, global_nb in shapes:
+            self.compiled(nb, global_nb)
+
     def run(self, batch=None):
         sess = self.ctx.session()
         if batch is None:
@@ -607,6 +630,8 @@ class MetricOpsHolder:
         import torch.distributed as dist
         if self._confusion_dev is not None and dist.is_available() and dist.is_initialized() and \
                 dist.get_world_size() > 1:
+            from hypelcnn_amd.backend import note_collective
+            note_collective()
             dist.all_reduce(self._confusion_dev, op=dist.ReduceOp.SUM)
 
     @property

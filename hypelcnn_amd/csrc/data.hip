@@ -122,7 +122,41 @@ __global__ void argmax_scatter_kernel(const float* __restrict__ logits, int64_t 
     raster[(int64_t)points[2 * i + 1] * raster_w + points[2 * i]] = (uint8_t)best;
 }
 
+// One (normal, shadow) spectrum pair per 64-lane row pass: gather + the regulariser swap of
+// perform_shadow_augmentation_random (gan/gan_train_for_shadow.py:171-182).
+__global__ void gather_pairs_kernel(const float* __restrict__ normal, const float* __restrict__ shadow,
+                                    const int64_t* __restrict__ idx, int64_t n, int bands, const float* __restrict__ ratio,
+                                    const float* __restrict__ u1, const float* __restrict__ u2, float rate,
+                                    float* __restrict__ out_x, float* __restrict__ out_y) {
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t src = idx[i];
+        const bool swap_x = ratio != nullptr && u1[i] < rate, swap_y = ratio != nullptr && u2[i] < rate;
+        for (int b = threadIdx.x; b < bands; b += blockDim.x) {
+            float x = normal[src * bands + b];
+            float y = shadow[src * bands + b];
+            // the reference draws the two decisions independently and builds the second pair from the ALREADY swapped
+            // normal spectrum (normal_images_rand / ratio): reproduced
+            if (swap_x) x = y * ratio[b];
+            if (swap_y) y = x / ratio[b];
+            out_x[i * bands + b] = x;
+            out_y[i * bands + b] = y;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int hypel_gather_pairs_f32(const float* normal, const float* shadow, const int64_t* idx, int64_t n, int32_t bands,
+                                      const float* ratio, const float* u1, const float* u2, float rate, float* out_x,
+                                      float* out_y, hypel_stream_t stream) {
+    HYPEL_REQUIRE(normal && shadow && idx && out_x && out_y && n > 0 && bands > 0, "hypel_gather_pairs_f32");
+    HYPEL_REQUIRE(ratio == nullptr || (u1 && u2), "hypel_gather_pairs_f32");
+    const int block = bands >= 192 ? 256 : (bands >= 96 ? 128 : 64);
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3(hypel_grid_1d(n, 1, 256 * 32)), dim3(block), 0, ST, normal, shadow, idx, n,
+                       bands, ratio, u1, u2, rate, out_x, out_y);
+    HYPEL_CHECK_LAUNCH("hypel_gather_pairs_f32");
+    return 0;
+}
 
 extern "C" int hypel_gather_patches_f32(const float* casi, const float* lidar, int64_t hp, int64_t wp, int32_t cc,
                                         int32_t cl, const int32_t* points, int64_t n, int32_t p, float* out,

@@ -16,6 +16,7 @@ import torch
 
 from hypelcnn_amd.common.cmd_parser import add_parse_cmds_for_json_loader, add_parse_cmds_for_loaders, \
     add_parse_cmds_for_loggers, add_parse_cmds_for_opt, add_parse_cmds_for_trainers, type_ensure_strtobool
+from hypelcnn_amd.backend import Ref
 from hypelcnn_amd.common.common_nn_ops import get_loader_from_name
 from hypelcnn_amd.common.common_ops import replace_abbrs
 from hypelcnn_amd.gan.wrapper_registry import get_sampling_map, get_wrapper_dict
@@ -56,8 +57,11 @@ class PairIterator:
     """load_op (reference :147-168): paired (normal, shadow) spectra resident on the device, shuffle_and_repeat over
     `epoch` epochs, per-sample regulariser swap (perform_shadow_augmentation_random :171-182), batch(drop_remainder)."""
 
-    def __init__(self, normal, shadow, batch_size, iteration_count, shadow_ratio, reg_support_rate, device, seed=1234):
+    def __init__(self, normal, shadow, batch_size, iteration_count, shadow_ratio, reg_support_rate, device, seed=1234,
+                 backend=None):
         n = normal.shape[0]
+        self.backend = backend
+        self._out = None
         self.normal = torch.as_tensor(normal.reshape(n, -1), dtype=torch.float32).to(device)
         self.shadow = torch.as_tensor(shadow.reshape(n, -1), dtype=torch.float32).to(device)
         self.batch_size = batch_size
@@ -79,15 +83,33 @@ class PairIterator:
         take = self.batch_size * world
         if self.pos + take > self.order.numel():
             return None
-        idx = self.order[self.pos:self.pos + take][rank::world]
+        idx = self.order[self.pos:self.pos + take][rank::world].contiguous()
         self.pos += take
-        x, y = self.normal.index_select(0, idx), self.shadow.index_select(0, idx)
+        be = self.backend
+        if be is None:  # no kernel library handed in (host-side tests of the iterator): the same arithmetic in torch
+            x, y = self.normal.index_select(0, idx), self.shadow.index_select(0, idx)
+            if self.rate > 0 and self.ratio is not None:
+                u1 = (torch.rand(take, generator=self.gen) * 0.98 + 0.01)[rank::world].to(x.device).unsqueeze(1)
+                u2 = (torch.rand(take, generator=self.gen) * 0.98 + 0.01)[rank::world].to(x.device).unsqueeze(1)
+                x = torch.where(u1 < self.rate, y * self.ratio, x)
+                y = torch.where(u2 < self.rate, x / self.ratio, y)
+            return x.contiguous(), y.contiguous()
+        # one library launch: gather + regulariser swap (hypel_gather_pairs_f32), into buffers that live as long as
+        # the iterator; the two uniform draws per pair come from the host generator (seeded, identical on every rank)
+        nb, bands = int(idx.numel()), self.normal.shape[1]
+        if self._out is None or self._out[0].numel() != nb * bands:
+            self._out = (torch.empty(nb * bands, dtype=torch.float32, device=self.normal.device),
+                         torch.empty(nb * bands, dtype=torch.float32, device=self.normal.device))
+        u1 = u2 = ratio = None
         if self.rate > 0 and self.ratio is not None:
-            u1 = (torch.rand(take, generator=self.gen) * 0.98 + 0.01)[rank::world].to(x.device).unsqueeze(1)
-            u2 = (torch.rand(take, generator=self.gen) * 0.98 + 0.01)[rank::world].to(x.device).unsqueeze(1)
-            x = torch.where(u1 < self.rate, y * self.ratio, x)
-            y = torch.where(u2 < self.rate, x / self.ratio, y)
-        return x.contiguous(), y.contiguous()
+            u = torch.rand(2, take, generator=self.gen) * 0.98 + 0.01
+            u = u[:, rank::world].contiguous().reshape(-1).to(self.normal.device, non_blocking=True)
+            u1, u2, ratio = Ref(u, 0), Ref(u, nb), Ref(self.ratio.reshape(-1))
+            self._keep = u
+        be.call("gather_pairs_f32", Ref(self.normal.reshape(-1)), Ref(self.shadow.reshape(-1)), Ref(idx), nb, bands, ratio,
+                u1, u2, float(self.rate), Ref(self._out[0]), Ref(self._out[1]))
+        self._keep_idx = idx
+        return self._out[0].view(nb, bands), self._out[1].view(nb, bands)
 
 
 def create_stats(generated_y, images_x, shadow_ratio):
@@ -164,7 +186,7 @@ def run_session(params, base_log_path, backend=None):
                                          gen_discriminator_lr=flags.gen_discriminator_lr)
     sess = train_ops.ctx.session()
     iterator = PairIterator(normal, shadow, flags.batch_size, flags.step, shadow_ratio,
-                            flags.regularization_support_rate, sess.backend.device)
+                            flags.regularization_support_rate, sess.backend.device, backend=sess.backend)
     gan_train(train_ops, iterator, log_dir, flags.step, save_checkpoint_steps=flags.validation_steps)
     save_gan_checkpoint(sess, log_dir, sess.global_step)
     # final quality statistic on a sample of the pairs (the reference's PeerValidationHook tracks the same scalars)

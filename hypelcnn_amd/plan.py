@@ -133,6 +133,12 @@ SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
 LOSS_TAIL = os.environ.get("HYPEL_LOSS_TAIL", "1") != "0"  # xent / MSE sums, non-finite flag, step counter: one finaliser
 MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
 DP_SYNC_WORK = float(os.environ.get("HYPEL_DP_SYNC_WORK", "0.5"))  # share of the filter-gradient work before the sync point
+# Gradient buckets of the data-parallel exchange: two (one sync point) up to DP_TWO_BUCKET_BYTES of weight gradients,
+# above that one bucket per DP_BUCKET_BYTES (at most DP_MAX_BUCKETS), so that a ring all-reduce of a large model
+# (DUALCNN: 1.03 GB, >= 12 ms over xGMI) is pipelined under the backward pass instead of going out in one piece
+DP_TWO_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_TWO_BUCKET_MB", "256")) * (1 << 20))
+DP_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_BUCKET_MB", "128")) * (1 << 20))
+DP_MAX_BUCKETS = int(os.environ.get("HYPEL_DP_MAX_BUCKETS", "8"))
 HINT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_HINT_OVERRIDE", "").split(",") if kv)}
 RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the device holds at once
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
@@ -625,8 +631,9 @@ class TowerPlan:
         return fused_bnbwd
 
     def _dp_sync_node(self):
-        """Data-parallel overlap: the node index (walking backward) after which >= 60 % of the weight-gradient
-        bytes are final, with the flat range [lo, hi) they occupy.  Weights are laid out in creation order
+        """Data-parallel overlap: [(node index, lo, hi)] -- walking backward, the nodes after which the weight gradients
+        at flat offsets [lo, hi) are final.  Small models (H13: 32.6 MB) get ONE point: the node after which >= 60 % of the
+        weight-gradient bytes are final; large ones one point per DP_BUCKET_BYTES.  Weights are laid out in creation order
         (Session.finalize_variables), i.e. in node order, so that range is one contiguous tail.
         The merged filter-gradient launch is flushed at this point, so the point also has to cut the filter-gradient
         WORK into two useful halves: at the first node that satisfies the byte rule (H13: fc_0, 75 % of the bytes but 8 %
@@ -647,6 +654,24 @@ class TowerPlan:
         total = sum(hi - lo for _, lo, hi, _ in sized)
         total_macs = sum(m for _, _, _, m in sized)
         hi_all = max(hi for _, _, hi, _ in sized)
+        if 4 * total > DP_TWO_BUCKET_BYTES:
+            # large model: one sync point per DP_BUCKET_BYTES of finished weight gradients (walking backward), the last
+            # one early enough that >= 10 % of the filter-gradient work is still ahead to hide it
+            n_buckets = max(4, min(DP_MAX_BUCKETS, -(-4 * total // DP_BUCKET_BYTES)))
+            points, acc, acc_macs = [], 0, 0
+            for k in range(len(sized) - 1, 0, -1):
+                idx, lo, hi, macs = sized[k]
+                acc += hi - lo
+                acc_macs += macs
+                tail_lo = min(l for _, l, _, _ in sized[k:])
+                contiguous = sum(h - l for _, l, h, _ in sized[k:]) == hi_all - tail_lo
+                if not contiguous or acc_macs > 0.9 * total_macs:
+                    continue
+                if acc >= total * (len(points) + 1) / n_buckets:
+                    points.append((idx, tail_lo, hi_all))
+                    if len(points) == n_buckets - 1:
+                        break
+            return points or None
         acc = acc_macs = 0
         best = None
         for k in range(len(sized) - 1, 0, -1):  # never the first layer: nothing would be left to overlap with
@@ -663,7 +688,7 @@ class TowerPlan:
                 best = (idx, tail_lo, hi_all)
                 if acc_macs >= DP_SYNC_WORK * total_macs:
                     break
-        return best
+        return [best] if best is not None else None
 
     # ------------------------------------------------------------------ consumers / epilogue fusion
     @staticmethod
@@ -733,7 +758,8 @@ class TowerPlan:
         if self.loss is not None:
             self._emit_loss()
         if self.training and self.loss is not None:
-            sync_at = self._dp_sync_node() if getattr(self.sess, "dist", None) is not None else None
+            sync_pts = self._dp_sync_node() if getattr(self.sess, "dist", None) is not None else None
+            sync_map = {p[0]: p for p in (sync_pts or [])}
             for idx in range(len(tw.nodes) - 1, -1, -1):
                 node = tw.nodes[idx]
                 if isinstance(node, G.LinearNode):
@@ -742,9 +768,10 @@ class TowerPlan:
                     self._bwd_post(idx, node)
                 elif isinstance(node, G.LRNNode):
                     self._bwd_lrn(idx, node)
-                if sync_at is not None and idx == sync_at[0]:
-                    # every weight gradient at flat offsets >= sync_at[1] is final once the side stream is joined:
-                    # the session starts their all-reduce here, under the rest of the backward pass
+                if idx in sync_map:
+                    # every weight gradient at flat offsets >= lo is final once the side stream is joined: the session
+                    # starts the all-reduce of what no earlier point covered here, under the rest of the backward pass
+                    sync_at = sync_map[idx]
                     self._flush_wgrads()
                     if getattr(self, "_side_open", False):
                         self.bwd.append(self._join_sides())

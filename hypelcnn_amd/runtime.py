@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import graph as G
-from .backend import Ref
+from .backend import Ref, note_collective
 from .plan import PhasePlan, TowerPlan
 
 
@@ -322,6 +322,7 @@ class Session:
             lo, hi = self.group_ranges[gname]
             if hi > lo:
                 view = self.grads[lo:hi]
+                note_collective()
                 dist.all_reduce(view, op=dist.ReduceOp.SUM)
                 view.mul_(1.0 / self.dist[0])
 
@@ -416,6 +417,7 @@ class Session:
             return
         self.dist = (dist.get_world_size(), dist.get_rank())
         if broadcast:
+            note_collective()
             dist.broadcast(self.params, src=0)
             dist.broadcast(self.state, src=0)
 
@@ -425,6 +427,7 @@ class Session:
             return
         import torch.distributed as dist
         # the plan scales the loss gradient by 1/world at its source (TowerPlan._emit_loss), so the SUM is the mean
+        note_collective()
         dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
 
     def train_step_exchange(self, ct, hook_ranges=True):
@@ -451,6 +454,7 @@ class Session:
                         reduce_range(chi, hi)
                     return
             if hi > lo:
+                note_collective()
                 works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
                 covered.append((lo, hi))
 
@@ -471,5 +475,6 @@ class Session:
         if self.dist is None:
             return
         import torch.distributed as dist
+        note_collective()
         dist.all_reduce(self.state, op=dist.ReduceOp.SUM)
         self.state.mul_(1.0 / self.dist[0])

@@ -343,6 +343,14 @@ int hypel_augment_patches_f32(const float* x, const int64_t* idx, int64_t n, int
                               const float* delta, float* out, hypel_stream_t stream);
 int hypel_argmax_scatter(const float* logits, int64_t ld, int64_t n, int32_t c, const int32_t* points,
                          uint8_t* raster, int64_t raster_w, hypel_stream_t stream);
+/* The GAN trainer's tf.data stage (gan/gan_train_for_shadow.py:147-182: from_tensor_slices -> shuffle_and_repeat ->
+ * map(perform_shadow_augmentation_random) -> batch): pair i of the batch = (normal[idx[i]], shadow[idx[i]]), both
+ * [pool][bands] resident in HBM; with ratio != NULL the regulariser swap of :171-182 -- u1[i] < rate replaces the normal
+ * spectrum by shadow * ratio, u2[i] < rate then replaces the shadow spectrum by (the possibly replaced) normal / ratio;
+ * u1 / u2 are the two uniform draws per pair (host RNG, the reference's tf.random.uniform([1], 0.01, 0.99)). */
+int hypel_gather_pairs_f32(const float* normal, const float* shadow, const int64_t* idx, int64_t n, int32_t bands,
+                           const float* ratio, const float* u1, const float* u2, float rate, float* out_x, float* out_y,
+                           hypel_stream_t stream);
 
 /* ---- LRN (tf.nn.local_response_normalization, CONCNNModel.py:37,41) -------------------------------------- */
 int hypel_lrn_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t radius, float bias, float alpha,

@@ -136,6 +136,20 @@ class EmuBackend:
                     q = ((y0 + py) * lidar_wp + x0 + px) * cl
                     o[i, py, px, cc:] = la[q:q + cl]
 
+    def k_gather_pairs_f32(self, normal, shadow, idx, n, bands, ratio, u1, u2, rate, out_x, out_y):
+        """gan_train_for_shadow.py:147-182: gather the pairs, then the two independent regulariser swaps -- the second
+        one built from the already swapped normal spectrum, as in the reference."""
+        ix = _arr(idx, np.int64)[:n]
+        x = _arr(normal).reshape(-1, bands)[ix].copy()
+        y = _arr(shadow).reshape(-1, bands)[ix].copy()
+        if ratio is not None:
+            rt = _arr(ratio)[:bands]
+            a, b = _arr(u1)[:n] < np.float32(rate), _arr(u2)[:n] < np.float32(rate)
+            x[a] = y[a] * rt
+            y[b] = x[b] / rt
+        _arr(out_x)[: n * bands] = x.reshape(-1)
+        _arr(out_y)[: n * bands] = y.reshape(-1)
+
     def k_augment_patches_f32(self, x, idx, n, p, c, rot_k, pick, ratio, alt, flip_lr, flip_ud, delta, out):
         ix = np.arange(n) if idx is None else _arr(idx, np.int64)[:n]
         xa = _arr(x)

@@ -114,6 +114,55 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert torch.equal(torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt"))
 
 
+ALG_DUAL = {"drop_out_ratio": 0.7, "filter_count": 96, "learning_rate": 3e-4, "learning_rate_decay_factor": 0.96,
+            "learning_rate_decay_step": 350, "lrelu_alpha": 0.18, "optimizer": "AdamOptimizer", "bn_decay": 0.95,
+            "l2regularizer_scale": 1e-5, "hs_lidar_diff": 1}
+
+
+def _dual_worker(rank, world, port, outdir):
+    """DUALCNN (the 1.03 GB model of BASELINE configs[2], here at toy width) with the bucket thresholds forced down:
+    the backward pass carries several sync points, each all-reduce covers what no earlier one did, and the result
+    equals the flat all-reduce bit for bit."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hypelcnn_amd import plan
+    plan.DP_TWO_BUCKET_BYTES = 0
+    plan.DP_BUCKET_BYTES = 64 << 10
+    from tests import parity_util as U
+    from tests.emu_backend import EmuBackend
+    built = U.build("DUALCNNModel", 7, 9, 4, ALG_DUAL, EmuBackend(), with_eval=False)
+    sess = built.ctx.session()
+    rng = np.random.default_rng(5)
+    x = rng.random((4, 7, 7, 9)).astype(np.float32)[rank::2]
+    onehot = np.eye(4, dtype=np.float32)[rng.integers(0, 4, 4)][rank::2]
+    ct = U.run_train_step(built, x, onehot, U.make_masks(built, 2, np.random.default_rng(9)))
+    sess.allreduce_gradients()
+    plain = sess.grads.clone()
+    pts = ct.sync_points
+    assert len(pts) >= 3, pts
+    los = [lo for _, lo, _ in pts]
+    assert los == sorted(los, reverse=True) and len(set(los)) == len(los), "each point finishes a longer tail"
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, **kw: (calls.append(t.numel()), orig(t, **kw))[1]
+    sess.train_step_exchange(ct)
+    dist.all_reduce = orig
+    assert len(calls) == len(pts) + 1 and sum(calls) == sess.grads.numel(), (calls, sess.grads.numel())
+    torch.testing.assert_close(sess.grads, plain, rtol=0, atol=0)
+    torch.save({"g": sess.grads.clone(), "n_points": len(pts)}, os.path.join(outdir, f"d{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_dualcnn_bucketed_exchange(tmp_path):
+    port = _free_port()
+    mp.spawn(_dual_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d0, d1 = torch.load(tmp_path / "d0.pt"), torch.load(tmp_path / "d1.pt")
+    assert torch.equal(d0["g"], d1["g"]) and d0["n_points"] == d1["n_points"] >= 3
+
+
 def _iter_worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -150,12 +199,14 @@ def _iter_worker(rank, world, port, outdir):
         tr = cno.BatchIterator((1, 1, 2), 3, 4, True, 1, None)
         tr.collective = True
         tr.initializer(data[:n], labels[:n], EmuBackend())
+        announced = tr.batch_shapes()  # what a training loop captures before its first step
         sizes = []
         while True:
             b = tr.next_batch()
             if b is None:
                 break
             sizes.append((int(b[0].shape[0]), tr.last_global_count))
+        assert set(sizes) == set(announced), (sizes, announced)
         tails[n] = sizes
     torch.save({"batches": got, "conf": conf, "tails": tails}, os.path.join(outdir, f"it{rank}.pt"))
     dist.destroy_process_group()

@@ -728,6 +728,27 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.check("db", rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("bands,n,with_ratio", [(64, 2048, True), (360, 100, True), (144, 33, False)])
+def test_gather_pairs_bit_exact(hip, bands, n, with_ratio):
+    """The GAN trainer's input stage as one library launch: gather + the two regulariser swaps, bit for bit."""
+    rng = np.random.default_rng(bands + n)
+    pool = 3000
+    b = Both(hip)
+    b.arr("normal", rng.random((pool, bands)).astype(np.float32))
+    b.arr("shadow", rng.random((pool, bands)).astype(np.float32))
+    b.arr("idx", rng.integers(0, pool, n).astype(np.int64))
+    b.arr("ratio", (1.0 + rng.random(bands)).astype(np.float32))
+    b.arr("u", (rng.random(2 * n) * 0.98 + 0.01).astype(np.float32))
+    b.arr("ox", np.zeros(n * bands, np.float32))
+    b.arr("oy", np.zeros(n * bands, np.float32))
+    if with_ratio:
+        b.run("gather_pairs_f32", "normal", "shadow", "idx", n, bands, "ratio", "u", ("u", n), 0.4, "ox", "oy")
+    else:
+        b.run("gather_pairs_f32", "normal", "shadow", "idx", n, bands, None, None, None, 0.0, "ox", "oy")
+    for nm in ("ox", "oy"):
+        np.testing.assert_array_equal(b.h[nm].cpu().numpy(), b.e[nm].numpy(), err_msg=nm)
+
+
 def test_gan_generator_valu_kernels_in_a_subprocess():
     """The generator runs on the matrix cores (gan_mfma.hip) from 16 bands on; gan.hip's wave-per-sample and register-tiled
     kernels remain the path for B < 16 / B > 384 and under HYPEL_GAN_MFMA=0 (the library reads the switch once per
