@@ -85,6 +85,16 @@ constexpr int BK_NARROW = HYPEL_GEMM_BK_NARROW;
                            // 1 = A B products, 2 = A B^T, 4 = A^T B, 8 = A^T B^T; 16 = also the 128x32 variants;
                            // 32 = k-contiguous operands are transposed into the pair-interleaved image as well
 #endif
+#ifndef HYPEL_GEMM_BATCHED_EPILOGUE
+#define HYPEL_GEMM_BATCHED_EPILOGUE 2  // 1: read-modify-write epilogues of full tiles issue all loads before the stores;
+                                       // 2: every full tile's epilogue on raw buffer accesses (one offset + scalar row step)
+#endif
+#ifndef HYPEL_GEMM_HOIST_EPI
+#define HYPEL_GEMM_HOIST_EPI 1  // bias / shortcut column ranges requested before the k loop
+#endif
+#ifndef HYPEL_GEMM_EARLY_SEG
+#define HYPEL_GEMM_EARLY_SEG 1  // next segment record requested before the LDS hand-over of the current k-tile
+#endif
 #ifndef HYPEL_GEMM_ADDTID
 #define HYPEL_GEMM_ADDTID 0  // 1: unpadded LDS images are written with ds_write_addtid_b32 (no address VGPR: 2 cycles
 #endif                       // per wave-store instead of 4, MI355X_MICROARCH.md LDS table)
@@ -433,11 +443,49 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                   std::integral_constant<int, B_RSTEP>{}, std::integral_constant<int, B_PER_THREAD>{});
     };
 
+    // Epilogue operands that only depend on the block's position -- the shortcut gradient's column ranges and the bias --
+    // are requested BEFORE the k loop: at the end of the block they would be one more dependent round trip in front of
+    // the gather passes (HYPEL_GEMM_HOIST_EPI=0: load them in the epilogue).
+    [[maybe_unused]] int h_o0[TN], h_o1[TN];
+    [[maybe_unused]] float h_bv[TN];
+    constexpr bool HOIST = HYPEL_GEMM_HOIST_EPI && !NARROW && !BNB && !TA && TM * TN == 1;  // wider tiles: 6 more live
+    if constexpr (HOIST) {                                                                 // registers cost a wave per SIMD
+        const int bias_c0 = bias ? (int)(grp.c_off % ldc) + n0 : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = (wn * TN + j) * 32 + l31;
+            const bool okc = col < cols_left;
+            h_bv[j] = bias && okc ? bias[bias_c0 + col] : 0.0f;
+            h_o0[j] = n0 + col;
+            h_o1[j] = n0 + col + 1;
+            if (res && res_start && okc) {
+                h_o0[j] = res_start[n0 + col];
+                h_o1[j] = res_start[n0 + col + 1];
+            }
+        }
+    }
     if (have) load_tiles(seg, lk);
 
     while (have) {
         const bool paired = PAIR && (seg.k & HYPEL_SEG_PAIR_FLAG);
         const int kvalid = paired ? 16 + seg2.k : min(BK, seg.k - lk);
+#if HYPEL_GEMM_EARLY_SEG
+        // advance the (segment, k) cursor NOW and request the next segment record before the LDS hand-over below: behind
+        // the second barrier the scalar load sat directly in front of the address arithmetic of the next tile's loads
+        // -- one exposed round trip per segment, i.e. per k-tile in the data gradients of the multi-kernel levels
+        // (segments of 15-60 reduction columns)
+        lk += BK;
+        if (paired || lk >= seg.k) {
+            ls += paired ? 2 : 1;
+            lk = 0;
+            if (ls < s_end) {
+                seg = segs[ls];
+                if constexpr (PAIR)
+                    if (seg.k & HYPEL_SEG_PAIR_FLAG) seg2 = segs[ls + 1];
+            }
+        }
+        have = ls < s_end;
+#endif
         __syncthreads();  // previous tile's MFMAs are done reading LDS
         constexpr bool A_TID = HYPEL_GEMM_ADDTID && !RD64 && A_PITCH == A_COLS;
         constexpr bool B_TID = HYPEL_GEMM_ADDTID && !RD64 && B_PITCH == B_COLS && B_THREADS == 256;
@@ -474,7 +522,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         if constexpr (A_TID || B_TID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // invisible to hipcc's counter
         __syncthreads();
 
-        // advance the (segment, k) cursor and put the next tile's loads in flight
+        // put the next tile's loads in flight
+#if !HYPEL_GEMM_EARLY_SEG
         lk += BK;
         if (paired || lk >= seg.k) {
             ls += paired ? 2 : 1;
@@ -486,6 +535,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             }
         }
         have = ls < s_end;
+#endif
         if (have) load_tiles(seg, lk);
 
         // One straight-line path (no per-tile branches, so the accumulators stay put and the compiler
@@ -724,10 +774,39 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                 o0 = res_start[n0 + col];
                 o1 = res_start[n0 + col + 1];
             }
+            if (HYPEL_GEMM_BATCHED_EPILOGUE > 1 && !res && rows_left >= wm * 32 + 32) {
+                // full 32-row slab: raw buffer accesses, one per-lane offset, rows stepped by a scalar (see below)
+                const int ldc4 = __builtin_amdgcn_readfirstlane((int)ldc * 4);
+                const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, 0x7ffffff0, 0x00020000);
+                const int cvo = ((wm * 32 + 4 * lq) * (int)ldc + col) * 4;
+                float v[8];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int q = 0; q < 8; ++q) v[q] = acc16[q >> 2][q & 3] + bv;
+                if (accumulate) {
+                    float old[8];
+                    int so = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) put(wm * 32 + t * 16 + 4 * lq + e, col, acc16[t][e], bv, o0, o1);
+                    for (int q = 0; q < 8; ++q) {
+                        old[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, cvo, so, 0));
+                        const int step = (q & 3) == 3 ? 13 * ldc4 : ldc4;
+                        asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += old[q];
+                }
+                int so = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), crs, cvo, so, 0);
+                    const int step = (q & 3) == 3 ? 13 * ldc4 : ldc4;
+                    asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) put(wm * 32 + t * 16 + 4 * lq + e, col, acc16[t][e], bv, o0, o1);
+            }
         }
     } else {
         float bs0[TN], bs1[TN];
@@ -740,11 +819,20 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                 if (!(row_act[i] && col_act[j])) continue;
                 const int col = (wn * TN + j) * 32 + l31;
                 if (col >= cols_left) continue;
-                const float bv = bias ? bias[bias_col0 + col] : 0.0f;
-                int o0 = n0 + col, o1 = n0 + col + 1;
-                if (res && res_start) {
-                    o0 = res_start[n0 + col];
-                    o1 = res_start[n0 + col + 1];
+                float bv;
+                int o0, o1;
+                if constexpr (HOIST) {
+                    bv = h_bv[j];
+                    o0 = h_o0[j];
+                    o1 = h_o1[j];
+                } else {
+                    bv = bias ? bias[bias_col0 + col] : 0.0f;
+                    o0 = n0 + col;
+                    o1 = n0 + col + 1;
+                    if (res && res_start) {
+                        o0 = res_start[n0 + col];
+                        o1 = res_start[n0 + col + 1];
+                    }
                 }
                 if (BNB && bnb.partial) {
                     // The value just written IS the finished gradient dZ of the producing layer's output (this launch
@@ -776,6 +864,59 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                     }
                     bs0[j] += s0;
                     bs1[j] += s1;
+                } else if (HYPEL_GEMM_BATCHED_EPILOGUE && (HYPEL_GEMM_BATCHED_EPILOGUE > 1 || accumulate || res) &&
+                           rows_left >= (wm * TM + i) * 32 + 32) {
+                    // Read-modify-write epilogue of a FULL 32-row accumulator tile with every addend IN FLIGHT before the
+                    // first store.  As `put` writes it, hipcc must keep each load behind the previous element's store
+                    // (they may alias): 16 x (1 + gathered addends) dependent round trips per lane, 15-40 us of a
+                    // data-gradient block's ~60 us life.  Here: one pass of 16 raw buffer loads for the old C values, one
+                    // pass per gathered addend (a lane without a g-th addend fetches out of range = 0; the pass count is
+                    // wave-uniform), the sums in the same order as `put` (bit-identical), then 16 stores.  One per-lane
+                    // offset per pass, the row step as a running scalar: no address registers beyond the 16 values.
+                    const int row0 = (wm * TM + i) * 32 + 4 * lhi;
+                    const int kOOBe = 0x7fffffff;
+                    const int ldc4 = __builtin_amdgcn_readfirstlane((int)ldc * 4);
+                    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, 0x7ffffff0, 0x00020000);
+                    const int cvo = (row0 * (int)ldc + col) * 4;
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e] + bv;
+                    if (accumulate) {
+                        float old[16];
+                        int so = 0;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, cvo, so, 0));
+                            const int step = (e & 3) == 3 ? 5 * ldc4 : ldc4;
+                            asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] += old[e];
+                    }
+                    if (res) {
+                        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, 0x7ffffff0, 0x00020000);
+                        const int ldr4 = __builtin_amdgcn_readfirstlane((int)ldr * 4);
+                        for (int g = 0; __any(o0 + g < o1); ++g) {
+                            const int rvo = o0 + g < o1 ? (row0 * (int)ldr + o0 + g) * 4 : kOOBe;
+                            float add[16];
+                            int so = 0;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                add[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, rvo, so, 0));
+                                const int step = (e & 3) == 3 ? 5 * ldr4 : ldr4;
+                                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+                            }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] += add[e];
+                        }
+                    }
+                    int so = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), crs, cvo, so, 0);
+                        const int step = (e & 3) == 3 ? 5 * ldc4 : ldc4;
+                        asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
