@@ -133,11 +133,14 @@ SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
 LOSS_TAIL = os.environ.get("HYPEL_LOSS_TAIL", "1") != "0"  # xent / MSE sums, non-finite flag, step counter: one finaliser
 MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
 DP_SYNC_WORK = float(os.environ.get("HYPEL_DP_SYNC_WORK", "0.5"))  # share of the filter-gradient work before the sync point
-# Gradient buckets of the data-parallel exchange: two (one sync point) up to DP_TWO_BUCKET_BYTES of weight gradients,
-# above that one bucket per DP_BUCKET_BYTES (at most DP_MAX_BUCKETS), so that a ring all-reduce of a large model
-# (DUALCNN: 1.03 GB, >= 12 ms over xGMI) is pipelined under the backward pass instead of going out in one piece
-DP_TWO_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_TWO_BUCKET_MB", "256")) * (1 << 20))
-DP_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_BUCKET_MB", "128")) * (1 << 20))
+# Gradient buckets of the data-parallel exchange: two by default (one sync point: >= 60 % of the bytes leave under the
+# second half of the backward pass).  More buckets are available for large models -- one sync point per DP_BUCKET_BYTES
+# once the weight gradients exceed DP_TWO_BUCKET_BYTES -- but every extra sync point flushes the merged filter-gradient
+# launch early: measured on the 1-rank RCCL self-test, DUALCNN (1.03 GB of gradients, 357 ms/step) pays +0.7 % for two
+# buckets, +3.8 % for five, +4.6 % for eight, while the tail a second bucket leaves exposed is ~410 MB = 2-5 ms (~1 %)
+# of ring all-reduce.  Hence off by default (HYPEL_DP_TWO_BUCKET_MB=256 switches the byte rule on).
+DP_TWO_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_TWO_BUCKET_MB", "1048576")) * (1 << 20))
+DP_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_BUCKET_MB", "256")) * (1 << 20))
 DP_MAX_BUCKETS = int(os.environ.get("HYPEL_DP_MAX_BUCKETS", "8"))
 HINT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_HINT_OVERRIDE", "").split(",") if kv)}
 RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the device holds at once
@@ -657,7 +660,7 @@ class TowerPlan:
         if 4 * total > DP_TWO_BUCKET_BYTES:
             # large model: one sync point per DP_BUCKET_BYTES of finished weight gradients (walking backward), the last
             # one early enough that >= 10 % of the filter-gradient work is still ahead to hide it
-            n_buckets = max(4, min(DP_MAX_BUCKETS, -(-4 * total // DP_BUCKET_BYTES)))
+            n_buckets = max(3, min(DP_MAX_BUCKETS, -(-4 * total // DP_BUCKET_BYTES)))
             points, acc, acc_macs = [], 0, 0
             for k in range(len(sized) - 1, 0, -1):
                 idx, lo, hi, macs = sized[k]
