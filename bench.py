@@ -508,7 +508,8 @@ def main():
                 "avg_launch_us": ms * 1e3 / n_launch,
                 "gemm_ms_per_step": ms / ev_steps,
                 "algorithmic_gflop_per_step": flops / ev_steps / 1e9,
-                "algorithmic_bytes_per_launch": measure_gemm_events.bytes_per_launch}
+                "algorithmic_bytes_per_launch": measure_gemm_events.bytes_per_launch,
+                "kernel_launches_per_step": len(ct.serial_launches()) + 1}  # every launch of the step + the optimiser
         if world == 1 and not args.no_cpu_baseline and args.workload == "hypelcnn":
             cpu = cpu_baseline()
     if rank == 0 and not classifier:
