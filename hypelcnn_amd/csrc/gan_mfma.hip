@@ -26,9 +26,15 @@ typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int GM_ROWS = 16;     // samples per row tile
-constexpr int GM_WAVES = 8;     // wavefronts per block (two per SIMD)
+#ifndef GM_WAVES_N
+#define GM_WAVES_N 8
+#endif
+#ifndef GM_MAXT_N
+#define GM_MAXT_N 3
+#endif
+constexpr int GM_WAVES = GM_WAVES_N;  // wavefronts per block (two per SIMD)
 constexpr int GM_THREADS = 64 * GM_WAVES;
-constexpr int GM_MAXT = 3;      // column tiles per wave: bands <= 16 * 8 * 3
+constexpr int GM_MAXT = GM_MAXT_N;    // column tiles per wave: bands <= 16 * GM_WAVES * GM_MAXT
 constexpr int GM_MAX_BANDS = 16 * GM_WAVES * GM_MAXT;
 #ifndef GM_PIPE
 #define GM_PIPE 0  // 1: fragments of the next 16-column chunk requested by hand ahead of the current chunk's MFMAs
