@@ -727,6 +727,77 @@ __global__ void nce_kernel(const float* __restrict__ g, int64_t ldg, const float
             }
 }
 
+// The same with P and E known at compile time (the reference's defaults: 6 or 7 slices of the band axis, embedding size
+// 2): both operand rows and the P^2 logits live in registers, every logit and every exponential is computed ONCE (the
+// generic kernel above walks the logits four times with its operands re-read from memory inside the loops: 57 us for
+// 4096 samples, this one ~6).  Same arithmetic order per logit; the sums run in the same (a, b) order.
+template <int P, int E>
+__global__ void nce_fixed_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ r, int64_t ldr,
+                                 int64_t n, float inv_tau, float gcoef, float* __restrict__ loss_ps,
+                                 float* __restrict__ dg, int64_t lddg, int acc_dg, float* __restrict__ dr, int64_t lddr,
+                                 int acc_dr) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    float gv[P * E], rv[P * E], l[P][P];
+#pragma unroll
+    for (int i = 0; i < P * E; ++i) {
+        gv[i] = g[s * ldg + i];
+        rv[i] = r[s * ldr + i];
+    }
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+            float d = 0.0f;
+#pragma unroll
+            for (int k = 0; k < E; ++k) d += gv[a * E + k] * rv[b * E + k];
+            l[a][b] = d * inv_tau;
+            mx = fmaxf(mx, l[a][b]);
+        }
+    float se = 0.0f, diag = 0.0f;
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+            const float ex = expf(l[a][b] - mx);
+            se += ex;
+            if (a == b) diag += l[a][b];
+            l[a][b] = ex;  // from here on: the exponentials
+        }
+    loss_ps[s] = (float)P * (mx + logf(se)) - diag;
+    if (!dg && !dr) return;
+    const float inv_se = 1.0f / se;
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) l[a][b] = (float)P * l[a][b] * inv_se - (a == b ? 1.0f : 0.0f);  // d logits
+    if (dg) {
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int b = 0; b < P; ++b) acc += l[a][b] * rv[b * E + k];
+                float* q = dg + s * lddg + a * E + k;
+                *q = (acc_dg ? *q : 0.0f) + gcoef * inv_tau * acc;
+            }
+    }
+    if (dr) {
+#pragma unroll
+        for (int b = 0; b < P; ++b)
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int a = 0; a < P; ++a) acc += l[a][b] * gv[a * E + k];
+                float* q = dr + s * lddr + b * E + k;
+                *q = (acc_dr ? *q : 0.0f) + gcoef * inv_tau * acc;
+            }
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -896,8 +967,17 @@ extern "C" int hypel_nce_loss(const float* g, int64_t ldg, const float* r, int64
                               hypel_stream_t stream) {
     HYPEL_REQUIRE(g && r && loss && ws && n > 0 && p > 0 && e > 0 && tau > 0.0f, "hypel_nce_loss");
     // ws: [n] per-sample losses followed by 1024 floats of reduction scratch
-    hipLaunchKernelGGL(nce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ST, g, ldg, r, ldr, n, p, e,
-                       1.0f / tau, (float)(weight / (double)n), ws, dg, lddg, acc_dg, dr, lddr, acc_dr);
+    const dim3 grid((unsigned)((n + 63) / 64));
+    const float gcoef = (float)(weight / (double)n);
+#define HYPEL_NCE(P_, E_)                                                                                              \
+    hipLaunchKernelGGL((nce_fixed_kernel<P_, E_>), grid, dim3(64), 0, ST, g, ldg, r, ldr, n, 1.0f / tau, gcoef, ws, dg, \
+                       lddg, acc_dg, dr, lddr, acc_dr)
+    if (p == 6 && e == 2) HYPEL_NCE(6, 2);
+    else if (p == 7 && e == 2) HYPEL_NCE(7, 2);
+    else
+        hipLaunchKernelGGL(nce_kernel, grid, dim3(64), 0, ST, g, ldg, r, ldr, n, p, e, 1.0f / tau, gcoef, ws, dg, lddg,
+                           acc_dg, dr, lddr, acc_dr);
+#undef HYPEL_NCE
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, (int)n, (double)weight / (double)n, loss,
                        accumulate_loss);
     HYPEL_CHECK_LAUNCH("hypel_nce_loss");
