@@ -363,10 +363,13 @@ int hypel_lrn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, in
  * Fused generator (shadowdata_generator_model :43-90): x[N][B] -> out[N][B]; seven 1-channel SAME 1-D convolutions
  * over the band axis with kernel sizes B, B/2, B/4, B/8, B/4, B/2, B, leaky-ReLU(0.1), skip sums
  * n_i = c_i + n_{i-1} + n_{i-2}, tanh on the last layer; only_encoder != 0 stops after layer 4 and returns n4.
- * w = the layers' kernels concatenated (TF variables netK/weights [k,1,1]), b = 7 biases.  One wavefront per
- * sample, everything in LDS.  The backward recomputes the forward per sample; weight / bias gradients are
- * written as per-block partial sums pw[blocks][sum k], pb[blocks][8] with blocks = hypel_gan_generator_blocks(n)
- * (reduce with hypel_reduce_splits_f32).  dx may be NULL. */
+ * w = the layers' kernels concatenated (TF variables netK/weights [k,1,1]), b = 7 biases.  From 16 to 384 bands the
+ * stack runs on the matrix cores (csrc/gan_mfma.hip: a 1-channel SAME convolution over B bands of N samples is
+ * X[N x B] . T[B x B] with T banded Toeplitz; 16 samples per block, activations in LDS, the taps as the MFMA B operand
+ * straight from a zero-margined table, filter gradient = diagonal sums of X^T dZ tiles accumulated per tile offset);
+ * otherwise one wavefront (or two) per sample on the vector ALUs (csrc/gan.hip).  The backward recomputes the forward;
+ * weight / bias gradients are written as per-block partial sums pw[blocks][sum k], pb[blocks][8] with
+ * blocks = hypel_gan_generator_blocks(n) (reduce with hypel_reduce_splits_f32; every slab is written).  dx may be NULL. */
 int hypel_gan_generator_blocks(int64_t n);
 int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w, const float* b,
                             int32_t only_encoder, float* out, int64_t ldo, hypel_stream_t stream);
