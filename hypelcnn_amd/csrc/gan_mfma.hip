@@ -40,6 +40,9 @@ constexpr int GM_MAX_BANDS = 16 * GM_WAVES * GM_MAXT;
 #define GM_PIPE 0  // 1: fragments of the next 16-column chunk requested by hand ahead of the current chunk's MFMAs
                    // (measured slower than hipcc's own schedule: forward 62 vs 51 us, backward 177 vs 167 us at N = 4096)
 #endif
+#ifndef GM_DIAG
+#define GM_DIAG 0
+#endif
 #ifndef GM_FWD_ROLLED
 #define GM_FWD_ROLLED 0  // forward kernel: 1 = rolled layer loop (54 vs 51 us); the backward kernel's recompute is always
                          // rolled (unrolled it spills > 200 registers)
@@ -68,14 +71,18 @@ __host__ __device__ inline int gm_woff(int bands, int l) {
     return o;
 }
 // dynamic LDS: forward = 3 activation images + 2 tap tables; backward = 5 images + 2 tap tables + G tiles
+__host__ __device__ inline int gm_raw(int bands) {  // floats of the block's LDS copy of every layer's taps + 8 biases
+    return (gm_woff(bands, 7) + 8 + 3) / 4 * 4;
+}
 __host__ __device__ inline size_t gm_fwd_lds(int bands) {
     const GmGeo g = gm_geo(bands);
-    return sizeof(float) * (3 * (size_t)GM_ROWS * g.pitch + 2 * 3 * (size_t)g.bp);
+    return sizeof(float) * (3 * (size_t)GM_ROWS * g.pitch + 2 * 3 * (size_t)g.bp + gm_raw(bands));
 }
 __host__ __device__ inline int gm_atiles(int bands) { return (bands + 30) / 16 + 2; }  // upper bound of the tile offsets a
 __host__ __device__ inline size_t gm_bwd_lds(int bands) {
     const GmGeo g = gm_geo(bands);
-    return sizeof(float) * (5 * (size_t)GM_ROWS * g.pitch + 6 * (size_t)g.bp + (size_t)gm_atiles(bands) * 16 * GM_GP + 64);
+    return sizeof(float) * (5 * (size_t)GM_ROWS * g.pitch + 6 * (size_t)g.bp + (size_t)gm_atiles(bands) * 16 * GM_GP + 64 +
+                            gm_raw(bands));
 }
 
 // ---- one 16 x 16 output tile of  src[16 x B] . T  (MIRROR = false)  or  src . T^T  (MIRROR = true) -----------------
@@ -94,45 +101,68 @@ __device__ __forceinline__ gm_f32x4 gm_conv_tile(const float* __restrict__ src, 
     gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const float* ap = src + r * g.pitch + kq;
     const float* tp = MIRROR ? wz + g.bp + (j0 + r) + pad - kq : wz + g.bp - (j0 + r) + pad + kq;
-    // the fragments of chunk kc + 16 are requested before the MFMAs of chunk kc issue (a wave has one partner on its
-    // SIMD: without this every chunk exposes an LDS round trip)
-    int kc = lo & ~15;
-    if (kc > hi) return acc;
-    float a[4], b[4];
+    // j0 / ksz / pad are wave-uniform (the callers take the wave index through readfirstlane), so this is a scalar
+    // loop.  Two chunks per trip, the fragments of one requested while the other's four MFMAs run: left to itself
+    // hipcc loaded two fragments, waited, issued two MFMAs, and again -- the LDS round trip exposed twice per chunk
+    // (61 cycles per MFMA and SIMD instead of 32).
+    const int k0 = lo & ~15;
+    const int nch = hi >= k0 ? ((hi - k0) >> 4) + 1 : 0;
+#if GM_DIAG == 4  // timing diagnostics: everything but the products
+    acc[0] = (float)nch;
+    return acc;
+#elif GM_DIAG
+    for (int c = 0; c < nch; ++c)
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 16 * c + 4 * s;
+            const float av = GM_DIAG == 1 ? ap[k] : 1.0f + (float)s;
+            const float bv = GM_DIAG == 2 ? (MIRROR ? tp[-k] : tp[k]) : 2.0f + (float)s;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+    return acc;
+#else
+    if (nch == 0) return acc;
+    float a0[4], b0[4], a1[4], b1[4];
+    auto fetch = [&](int c, float (&a)[4], float (&b)[4]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        a[s] = ap[kc + 4 * s];
-        b[s] = MIRROR ? tp[-(kc + 4 * s)] : tp[kc + 4 * s];
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 16 * c + 4 * s;
+            a[s] = ap[k];
+            b[s] = MIRROR ? tp[-k] : tp[k];
+        }
+    };
+    auto mac = [&](const float (&a)[4], const float (&b)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    };
+    fetch(0, a0, b0);
+    int c = 0;
+    for (; c + 2 < nch; c += 2) {
+        fetch(c + 1, a1, b1);
+        mac(a0, b0);
+        fetch(c + 2, a0, b0);
+        mac(a1, b1);
     }
-#if !GM_PIPE
-    for (; kc <= hi; kc += 16) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kc + 4 * s], MIRROR ? tp[-(kc + 4 * s)] : tp[kc + 4 * s], acc, 0, 0, 0);
+    if (c + 1 < nch) {  // two chunks left
+        fetch(c + 1, a1, b1);
+        mac(a0, b0);
+        mac(a1, b1);
+    } else {
+        mac(a0, b0);
     }
     return acc;
 #endif
-    for (; kc + 16 <= hi; kc += 16) {
-        float an[4], bn[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            an[s] = ap[kc + 16 + 4 * s];
-            bn[s] = MIRROR ? tp[-(kc + 16 + 4 * s)] : tp[kc + 16 + 4 * s];
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            a[s] = an[s];
-            b[s] = bn[s];
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-    return acc;
 }
 
-__device__ __forceinline__ void gm_fill_taps(float* wz, const GmGeo g, const float* __restrict__ w, int ksz, int tid) {
+// Every layer's taps and the 8 biases are copied into LDS ONCE per block (gm_stage_raw); a layer's zero-margined table
+// is then built from that copy: a global round trip in front of every layer's barrier (7 per forward, 14 per
+// backward) was ~10 % of the kernels.
+__device__ __forceinline__ void gm_stage_raw(float* raw, int bands, const float* __restrict__ w,
+                                             const float* __restrict__ bias, int tid) {
+    const int wtotal = gm_woff(bands, 7);
+    for (int i = tid; i < wtotal; i += GM_THREADS) raw[i] = w[i];
+    if (tid < 8) raw[wtotal + tid] = tid < 7 ? bias[tid] : 0.0f;
+}
+__device__ __forceinline__ void gm_fill_taps(float* wz, const GmGeo g, const float* w, int ksz, int tid) {
     // only [bp, bp + bands) can ever hold taps; the margins were zeroed once
     for (int i = tid; i < g.bands; i += GM_THREADS) wz[g.bp + i] = i < ksz ? w[i] : 0.0f;
 }
@@ -143,11 +173,11 @@ __device__ __forceinline__ void gm_fill_taps(float* wz, const GmGeo g, const flo
 // Returns the image index that holds the result (n4 or tanh output); with out != nullptr the result also goes to global.
 template <bool ENC, bool KEEP, bool ROLLED = true>
 __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, const GmGeo g,
-                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                          const float* w, const float* bias,  // the block's LDS copy (gm_stage_raw)
                                           float* __restrict__ out, int64_t ldo, int rows_valid, int tid,
                                           float (&keep)[6][GM_MAXT][4], unsigned (&mask)[7]) {
     constexpr int L = ENC ? 4 : 7;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile loops are wave-uniform
     const int col = lane & 15, rg = lane >> 4;
     const int img = GM_ROWS * g.pitch;
     int woff = 0;
@@ -238,7 +268,9 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
     float* const bufs[3] = {gm_lds, gm_lds + GM_ROWS * g.pitch, gm_lds + 2 * GM_ROWS * g.pitch};
     float* wz0 = gm_lds + 3 * GM_ROWS * g.pitch;
     float* wz1 = wz0 + 3 * g.bp;
+    float* raw = wz1 + 3 * g.bp;
     gm_zero(gm_lds, 3 * GM_ROWS * g.pitch + 6 * g.bp, tid);  // image padding and tap margins stay zero
+    gm_stage_raw(raw, bands, w, bias, tid);
     __syncthreads();
     float keep[6][GM_MAXT][4];
     unsigned mask[7];
@@ -247,7 +279,8 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
         const int64_t r0 = t * GM_ROWS;
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
-        gm_forward<ENC, false, GM_FWD_ROLLED != 0>(gm_lds, wz0, wz1, g, w, bias, out + r0 * ldo, ldo, rows_valid, tid, keep, mask);
+        gm_forward<ENC, false, GM_FWD_ROLLED != 0>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7), out + r0 * ldo, ldo,
+                                                   rows_valid, tid, keep, mask);
         __syncthreads();  // the next row tile overwrites bufs[0]
     }
 }
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     constexpr int L = ENC ? 4 : 7;
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, rg = lane >> 4;
     const int img = GM_ROWS * g.pitch;
     float* const bufs[3] = {gm_lds, gm_lds + img, gm_lds + 2 * img};  // forward images, then the gradient ring
@@ -271,8 +304,10 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     float* wz = gm_lds + 5 * img;
     float* wz2 = wz + 3 * g.bp;    // second tap table of the forward recompute
     float* G = wz2 + 3 * g.bp;     // [a][16][GM_GP]
-    float* red = G + gm_atiles(bands) * 16 * GM_GP;  // [GM_WAVES] bias-gradient partials
+    float* red = G + gm_atiles(bands) * 16 * GM_GP;  // [GM_WAVES] bias-gradient partials, [GM_WAVES + l] their sums
+    float* raw = red + 64;                            // LDS copy of every layer's taps + biases
     gm_zero(gm_lds, 5 * img + 6 * g.bp, tid);
+    gm_stage_raw(raw, bands, w, bias, tid);
     __syncthreads();
 
     float dwacc[7];  // thread t owns tap t of every layer; red[GM_WAVES + l] collects the bias gradients
@@ -280,22 +315,33 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     for (int l = 0; l < 7; ++l) dwacc[l] = 0.0f;
     if (tid < 7) red[GM_WAVES + tid] = 0.0f;
 
+#if GM_DIAG == 5
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tmark = clock64();
+#define GM_MARK(i) { const long long now_ = clock64(); dbg[i] += now_ - tmark; tmark = now_; }
+#else
+#define GM_MARK(i)
+#endif
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int64_t r0 = t * GM_ROWS;
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
+        GM_MARK(0)
         float keep[6][GM_MAXT][4];
         unsigned mask[7];
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
-        const int res = gm_forward<ENC, true>(gm_lds, wz, wz2, g, w, bias, nullptr, 0, rows_valid, tid, keep, mask);
+        const int res = gm_forward<ENC, true>(gm_lds, wz, wz2, g, raw, raw + gm_woff(bands, 7), nullptr, 0, rows_valid, tid,
+                                              keep, mask);
         __syncthreads();
         // gradient ring: Da = dn_l (complete), Db = partial dn_{l-1}, Dc = dn_{l-2} being initialised
         float* Da = bufs[(res + 1) % 3];
         float* Db = bufs[(res + 2) % 3];
         float* Dc = bufs[res];  // still holds the forward result until the top layer has read it
         const float* fwd_out = bufs[res];
+        GM_MARK(1)  // forward recompute
         gm_load_rows(Da, g, dout + r0 * lddo, lddo, rows_valid, tid);
         __syncthreads();
+        GM_MARK(2)  // dout load
         int woff = gm_woff(bands, L);
         // One rolled loop over the layers (the kept activations / branch bits of layer l are picked by wave-uniform
         // selects): unrolled, the seven bodies needed > 200 scalar and > 200 vector spill slots.
@@ -309,7 +355,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #pragma unroll
             for (int q = 0; q < 7; ++q) mk = q == l ? mask[q] : mk;
             // ---- step A: dz_l, skip gradients, bias gradient; n_{l-1} from the registers (or x) into X ----
-            gm_fill_taps(wz, g, w + woff, ksz, tid);
+            gm_fill_taps(wz, g, raw + woff, ksz, tid);
             float dbl = 0.0f;
 #pragma unroll
             for (int m = 0; m < GM_MAXT; ++m) {
@@ -357,6 +403,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                 for (int wv = 0; wv < GM_WAVES; ++wv) s += red[wv];
                 red[GM_WAVES + l] += s;
             }
+            GM_MARK(3)  // step A
             // ---- step B: filter gradient.  Tile offset a: diagonals d = i - j in [16 a - 15, 16 a + 15] ----
             const int a_lo = -((pad + 15) / 16), a_hi = (ksz - 1 - pad + 15) / 16;
             for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
@@ -397,6 +444,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                 for (int e = 0; e < 4; ++e) gt[(4 * rg + e) * GM_GP + col] = acc[e];
             }
             __syncthreads();
+            GM_MARK(4)  // step B products
             if (tid < ksz) {  // tap t = d + pad: sum the diagonal d of G, tiles ascending, rows ascending
                 const int d = tid - pad;
                 float s = 0.0f;
@@ -412,6 +460,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                 for (int q = 0; q < 7; ++q)
                     if (q == l) dwacc[q] += s;
             }
+            GM_MARK(5)  // diagonal sums
             // ---- step C: data gradient dn_{l-1} += dz_l . T^T ----
             if (l > 0 || dx != nullptr) {
 #pragma unroll
@@ -427,6 +476,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                 }
             }
             __syncthreads();
+            GM_MARK(6)  // step C
             float* old = Da;
             Da = Db;
             Db = Dc;
@@ -458,6 +508,11 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         woff += ksz;
     }
     if (tid < 8) pb[(size_t)blockIdx.x * 8 + tid] = tid < L ? red[GM_WAVES + tid] : 0.0f;
+#if GM_DIAG == 5
+    GM_MARK(7)
+    if (tid == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 8; ++i) pb[i] = (float)dbg[i];
+#endif
 }
 
 }  // namespace
