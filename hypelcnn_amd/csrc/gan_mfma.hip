@@ -40,6 +40,9 @@ constexpr int GM_MAX_BANDS = 16 * GM_WAVES * GM_MAXT;
 #define GM_PIPE 0  // 1: fragments of the next 16-column chunk requested by hand ahead of the current chunk's MFMAs
                    // (measured slower than hipcc's own schedule: forward 62 vs 51 us, backward 177 vs 167 us at N = 4096)
 #endif
+#ifndef GM_TWO_CHAINS
+#define GM_TWO_CHAINS 1
+#endif
 #ifndef GM_DIAG
 #define GM_DIAG 0
 #endif
@@ -130,9 +133,19 @@ __device__ __forceinline__ gm_f32x4 gm_conv_tile(const float* __restrict__ src, 
             b[s] = MIRROR ? tp[-k] : tp[k];
         }
     };
+    // two accumulator chains (k-steps 0, 2 / 1, 3 of every chunk), added at the end: a 16x16x4 MFMA issues every 32
+    // cycles but its result is ready after 40, and a wave has one partner on its SIMD
+    gm_f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
     auto mac = [&](const float (&a)[4], const float (&b)[4]) {
+#if GM_TWO_CHAINS
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc2, 0, 0, 0);
+#else
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+#endif
     };
     fetch(0, a0, b0);
     int c = 0;
@@ -149,6 +162,10 @@ __device__ __forceinline__ gm_f32x4 gm_conv_tile(const float* __restrict__ src, 
     } else {
         mac(a0, b0);
     }
+#if GM_TWO_CHAINS
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
+#endif
     return acc;
 #endif
 }
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
             // ---- step B: filter gradient.  Tile offset a: diagonals d = i - j in [16 a - 15, 16 a + 15] ----
             const int a_lo = -((pad + 15) / 16), a_hi = (ksz - 1 - pad + 15) / 16;
             for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
-                gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};  // two chains (see gm_conv_tile)
                 const int j_lo = max(0, -a), j_hi = min(g.nt - 1, g.nt - 1 - a);
                 // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; n = 4 s + kq
                 const float* ap = X + rg * g.pitch + 16 * a + col;
@@ -427,8 +444,10 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                         na[s] = ap[16 * (jt + 1) + 4 * s * g.pitch];
                         nb[s] = bp[16 * (jt + 1) + 4 * s * g.pitch];
                     }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         fa[s] = na[s];
@@ -436,9 +455,13 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                     }
                 }
                 if (j_lo <= j_hi) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += accb[e];
                 float* gt = G + (a - a_lo) * 16 * GM_GP;  // [i_local = 4 rg + e][j_local = col]
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gt[(4 * rg + e) * GM_GP + col] = acc[e];

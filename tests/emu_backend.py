@@ -729,6 +729,24 @@ def _gen_forward(x, w, b, bands, only_encoder):
     return a, slopes, c7
 
 
+def generator_knife_edge_rows(x, w, b, bands, only_encoder, eps=1e-6):
+    """Samples with a hidden pre-activation within eps of 0: there the leaky-ReLU branch is decided by the rounding of an
+    fp32 sum of up to 360 terms, and a flipped branch changes that sample's gradients by O(1) -- not a parity question.
+    The generator tests re-draw such samples (tests/test_gpu_kernels.py)."""
+    ks, offs = _gen_layout(bands)
+    a = [np.asarray(x, np.float64)]
+    w, b = np.asarray(w, np.float64), np.asarray(b, np.float64)
+    near = np.zeros(a[0].shape[0], bool)
+    for i in range(1, (4 if only_encoder else 6) + 1):
+        c = _conv1d_same(a[-1], w[offs[i - 1]:offs[i]]) + b[i - 1]
+        near |= (np.abs(c) < eps).any(axis=1)
+        v = c * np.where(c > 0, 1.0, 0.1) + a[-1]
+        if i >= 2:
+            v = v + a[-2]
+        a.append(v)
+    return np.nonzero(near)[0]
+
+
 def _emu_generator_blocks(n):
     return int(max(1, min(512, (n + 3) // 4)))
 

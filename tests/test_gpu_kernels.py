@@ -7,6 +7,7 @@ import torch
 
 from hypelcnn_amd.backend import GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
 from hypelcnn_amd.plan import GemmTables
+from tests import emu_backend
 from tests.emu_backend import EmuBackend
 
 pytestmark = pytest.mark.gpu
@@ -706,9 +707,20 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     ks = [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
     wtot = sum(ks)
     b = Both(hip)
-    b.arr("x", rng.random((n, bands)).astype(np.float32))
-    b.arr("w", (rng.standard_normal(wtot) * 0.3 / np.sqrt(np.repeat(ks, ks))).astype(np.float32))
-    b.arr("bias", (rng.standard_normal(8) * 0.05).astype(np.float32))
+    x = rng.random((n, bands)).astype(np.float32)
+    w = (rng.standard_normal(wtot) * 0.3 / np.sqrt(np.repeat(ks, ks))).astype(np.float32)
+    bias = (rng.standard_normal(8) * 0.05).astype(np.float32)
+    # samples whose leaky-ReLU branch hangs on the rounding of an fp32 sum are re-drawn ((360, 70): one pre-activation of
+    # 2.2e-8 in layer 1 -- whichever way it falls, that sample's dx differs by 0.04 from the other answer)
+    for _ in range(20):
+        rows = emu_backend.generator_knife_edge_rows(x, w, bias, bands, only_enc)
+        if len(rows) == 0:
+            break
+        x[rows] = rng.random((len(rows), bands)).astype(np.float32)
+    assert len(rows) == 0
+    b.arr("x", x)
+    b.arr("w", w)
+    b.arr("bias", bias)
     b.arr("out", np.zeros(n * bands, np.float32))
     b.run("gan_generator_fwd", "x", bands, n, bands, "w", "bias", only_enc, "out", bands)
     b.check("out", rtol=5e-5, atol=5e-6)  # fp32 sums over up to 360 taps x 7 layers vs the float64 spec
