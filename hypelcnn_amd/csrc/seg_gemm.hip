@@ -834,7 +834,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                         o1 = res_start[n0 + col + 1];
                     }
                 }
-                if (BNB && bnb.partial) {
+                const bool full_tile = rows_left >= (wm * TM + i) * 32 + 32;
+                if (BNB && bnb.partial && !(HYPEL_GEMM_BATCHED_EPILOGUE && full_tile)) {
                     // The value just written IS the finished gradient dZ of the producing layer's output (this launch
                     // is its last writer): feed the batch-norm / activation backward reduction of that layer from it
                     // -- sum(dyh) and sum(dyh * xhat) per column, dyh = dZ * act'(pre) -- instead of a separate pass
@@ -864,8 +865,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                     }
                     bs0[j] += s0;
                     bs1[j] += s1;
-                } else if (HYPEL_GEMM_BATCHED_EPILOGUE && (HYPEL_GEMM_BATCHED_EPILOGUE > 1 || accumulate || res) &&
-                           rows_left >= (wm * TM + i) * 32 + 32) {
+                } else if (HYPEL_GEMM_BATCHED_EPILOGUE &&
+                           (HYPEL_GEMM_BATCHED_EPILOGUE > 1 || accumulate || res || (BNB && bnb.partial)) && full_tile) {
                     // Read-modify-write epilogue of a FULL 32-row accumulator tile with every addend IN FLIGHT before the
                     // first store.  As `put` writes it, hipcc must keep each load behind the previous element's store
                     // (they may alias): 16 x (1 + gathered addends) dependent round trips per lane, 15-40 us of a
@@ -878,6 +879,28 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                     const int ldc4 = __builtin_amdgcn_readfirstlane((int)ldc * 4);
                     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, 0x7ffffff0, 0x00020000);
                     const int cvo = (row0 * (int)ldc + col) * 4;
+                    // batch-norm backward reduction of the producing layer (see the element-wise form above): its 16
+                    // values of Y and the column's (mean, rstd, beta) are requested FIRST, behind them the addends
+                    float yv[BNB ? 16 : 1], mu = 0.0f, rs = 0.0f, be = 0.0f;
+                    if constexpr (BNB) {
+                        if (bnb.partial) {
+                            const int colabs = (int)(grp.c_off % ldc) + n0 + col;
+                            mu = bnb.mean[colabs];
+                            rs = bnb.rstd[colabs];
+                            be = bnb.beta[colabs];
+                            const float* yb = bnb.y + (grp.c_off / ldc + m0) * bnb.ldy;
+                            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, 0x7ffffff0, 0x00020000);
+                            const int ldy4 = __builtin_amdgcn_readfirstlane((int)bnb.ldy * 4);
+                            const int yvo = (row0 * (int)bnb.ldy + colabs) * 4;
+                            int so = 0;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                yv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo, so, 0));
+                                const int step = (e & 3) == 3 ? 5 * ldy4 : ldy4;
+                                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+                            }
+                        }
+                    }
                     float v[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e] + bv;
@@ -916,6 +939,20 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), crs, cvo, so, 0);
                         const int step = (e & 3) == 3 ? 5 * ldc4 : ldc4;
                         asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+                    }
+                    if constexpr (BNB) {
+                        if (bnb.partial) {
+                            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {  // rows ascending, as in the element-wise form
+                                const float xhat = hypel_bn_xhat(yv[e], mu, rs);
+                                const float dyh = v[e] * hypel_act_grad(hypel_bn_pre(xhat, be), bnb.act, bnb.alpha);
+                                s0 += dyh;
+                                s1 += dyh * xhat;
+                            }
+                            bs0[j] += s0;
+                            bs1[j] += s1;
+                        }
                     }
                 } else {
 #pragma unroll
