@@ -113,6 +113,8 @@ SIGNATURES = {
     "lrn_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64, _I32],
     "gan_generator_fwd": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64],
     "gan_generator_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P],
+    "gan_generator_fwd_keep": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _P],
+    "gan_generator_bwd_kept": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P],
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
     "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
     "l2norm_fwd": [_P, _I64, _I64, _I32, _P, _I64, _P],
@@ -150,6 +152,8 @@ def load_library(path=LIB_PATH):
     lib.hypel_device_info.argtypes = [ctypes.POINTER(_I32), ctypes.POINTER(_I32)]
     lib.hypel_gan_generator_blocks.argtypes = [_I64]
     lib.hypel_gan_generator_blocks.restype = ctypes.c_int
+    lib.hypel_gan_generator_keep_floats.argtypes = [_I64, _I32, _I32]
+    lib.hypel_gan_generator_keep_floats.restype = ctypes.c_int64
     return lib
 
 
@@ -247,6 +251,9 @@ class HipBackend:
 
     def gan_generator_blocks(self, n):
         return int(self.lib.hypel_gan_generator_blocks(int(n)))
+
+    def gan_generator_keep_floats(self, n, bands, only_encoder):
+        return int(self.lib.hypel_gan_generator_keep_floats(int(n), int(bands), int(only_encoder)))
 
     # -- launches --
     def bind(self, name, args, stream=None):

@@ -826,11 +826,13 @@ static size_t gt_bwd_lds(int bands, int only_encoder) {
 // gan_mfma.hip: the generator on the matrix cores for wide spectra (bands > 128).  HYPEL_GAN_MFMA=0 keeps the
 // register-tiled VALU kernels below (experiments, parity cross-checks).
 bool hypel_gm_supported(int bands);
+int64_t hypel_gm_keep_floats(int64_t n, int bands, int only_encoder);
 int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
-                 float* out, int64_t ldo, int blocks, hipStream_t st);
+                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep);
 int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
                  const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
-                 int blocks, hipStream_t st);
+                 int blocks, hipStream_t st, const float* keep);
+
 static bool gan_use_mfma(int bands) {
     static const int on = getenv("HYPEL_GAN_MFMA") ? atoi(getenv("HYPEL_GAN_MFMA")) : 1;
     return on && hypel_gm_supported(bands);
@@ -843,12 +845,11 @@ extern "C" int hypel_gan_generator_blocks(int64_t n) {
     return (int)b;
 }
 
-extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w,
-                                       const float* b, int32_t only_encoder, float* out, int64_t ldo,
-                                       hypel_stream_t stream) {
+static int gan_generator_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w, const float* b,
+                                  int32_t only_encoder, float* out, int64_t ldo, float* keep, hypel_stream_t stream) {
     HYPEL_REQUIRE(x && w && b && out && n > 0 && bands >= 8, "hypel_gan_generator_fwd");
     if (gan_use_mfma(bands)) {
-        hypel_gm_fwd(x, ldx, n, bands, w, b, only_encoder, out, ldo, 2 * hypel_gan_generator_blocks(n), ST);
+        hypel_gm_fwd(x, ldx, n, bands, w, b, only_encoder, out, ldo, 2 * hypel_gan_generator_blocks(n), ST, keep);
         HYPEL_CHECK_LAUNCH("hypel_gan_generator_fwd");
         return 0;
     }
@@ -873,14 +874,31 @@ extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, i
     return 0;
 }
 
-extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n,
-                                       int32_t bands, const float* w, const float* b, int32_t only_encoder, float* dx,
-                                       int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
+extern "C" int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w,
+                                       const float* b, int32_t only_encoder, float* out, int64_t ldo,
                                        hypel_stream_t stream) {
+    return gan_generator_fwd_impl(x, ldx, n, bands, w, b, only_encoder, out, ldo, nullptr, stream);
+}
+
+extern "C" int64_t hypel_gan_generator_keep_floats(int64_t n, int32_t bands, int32_t only_encoder) {
+    return n > 0 && gan_use_mfma(bands) ? hypel_gm_keep_floats(n, bands, only_encoder) : 0;
+}
+
+extern "C" int hypel_gan_generator_fwd_keep(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w,
+                                            const float* b, int32_t only_encoder, float* out, int64_t ldo, float* keep,
+                                            hypel_stream_t stream) {
+    HYPEL_REQUIRE(keep == nullptr || hypel_gan_generator_keep_floats(n, bands, only_encoder) > 0,
+                  "hypel_gan_generator_fwd_keep: no kept activations for this band count");
+    return gan_generator_fwd_impl(x, ldx, n, bands, w, b, only_encoder, out, ldo, keep, stream);
+}
+
+static int gan_generator_bwd_impl(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,
+                                  const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
+                                  int32_t accumulate_dx, float* pw, float* pb, const float* keep, hypel_stream_t stream) {
     HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && bands >= 8, "hypel_gan_generator_bwd");
     if (gan_use_mfma(bands)) {
         hypel_gm_bwd(x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb,
-                     hypel_gan_generator_blocks(n), ST);
+                     hypel_gan_generator_blocks(n), ST, keep);
         HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd");
         return 0;
     }
@@ -903,6 +921,24 @@ extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float*
                        ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb);
     HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd");
     return 0;
+}
+
+extern "C" int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n,
+                                       int32_t bands, const float* w, const float* b, int32_t only_encoder, float* dx,
+                                       int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
+                                       hypel_stream_t stream) {
+    return gan_generator_bwd_impl(x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb,
+                                  nullptr, stream);
+}
+
+extern "C" int hypel_gan_generator_bwd_kept(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n,
+                                            int32_t bands, const float* w, const float* b, int32_t only_encoder,
+                                            float* dx, int64_t lddx, int32_t accumulate_dx, float* pw, float* pb,
+                                            const float* keep, hypel_stream_t stream) {
+    HYPEL_REQUIRE(keep == nullptr || hypel_gan_generator_keep_floats(n, bands, only_encoder) > 0,
+                  "hypel_gan_generator_bwd_kept: no kept activations for this band count");
+    return gan_generator_bwd_impl(x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb, keep,
+                                  stream);
 }
 
 extern "C" int hypel_gan_loss(int32_t mode, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,

@@ -273,12 +273,25 @@ __device__ __forceinline__ void gm_load_rows(float* img, const GmGeo g, const fl
     }
 }
 
+// ---- activations kept for the backward pass ---------------------------------------------------------------------------
+// A forward pass whose backward follows (hypel_gan_generator_fwd_keep) leaves what gm_forward<KEEP> holds in registers
+// -- the layer outputs n_1.. in MFMA C layout, the leaky-ReLU branch bits, the tanh output -- in a caller-provided buffer,
+// lane-native: float4 (slot, m) of thread `tid` of row tile t at ((t * GM_KEEP_V4(ENC) + slot * GM_MAXT + m) * 512 + tid)
+// float4s, two uint4 of branch bits behind them.  The backward kernel then starts from that copy instead of recomputing
+// the forward (29 % of its time at B = 360): 188 KB per 16 samples written and read once at HBM speed.
 template <bool ENC>
+struct GmKeep {
+    static constexpr int SLOTS = ENC ? 3 : 7;  // n_1..n_3 | n_1..n_6 + the tanh output
+    static constexpr int V4 = SLOTS * GM_MAXT + 2;  // float4 per thread and row tile
+};
+
+template <bool ENC, bool STASH>
 __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                                             int64_t n, int bands,
                                                                             const float* __restrict__ w,
                                                                             const float* __restrict__ bias,
-                                                                            float* __restrict__ out, int64_t ldo) {
+                                                                            float* __restrict__ out, int64_t ldo,
+                                                                            float* __restrict__ stash) {
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
     const int tid = threadIdx.x;
@@ -296,19 +309,48 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
         const int64_t r0 = t * GM_ROWS;
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
-        gm_forward<ENC, false, GM_FWD_ROLLED != 0>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7), out + r0 * ldo, ldo,
-                                                   rows_valid, tid, keep, mask);
+        const int res = gm_forward<ENC, STASH, STASH || GM_FWD_ROLLED != 0>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7),
+                                                                          out + r0 * ldo, ldo, rows_valid, tid, keep, mask);
         __syncthreads();  // the next row tile overwrites bufs[0]
+        if constexpr (STASH) {
+            const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            gm_f32x4* sp = reinterpret_cast<gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
+#pragma unroll
+            for (int q = 0; q < (ENC ? 3 : 6); ++q)
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m) {
+                    if (wave + GM_WAVES * m >= g.nt) break;
+                    sp[(q * GM_MAXT + m) * GM_THREADS] = gm_f32x4{keep[q][m][0], keep[q][m][1], keep[q][m][2], keep[q][m][3]};
+                }
+            if constexpr (!ENC) {
+                const float* y = bufs[res];
+                const int col = lane & 15, rg = lane >> 4;
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m) {
+                    const int jt = wave + GM_WAVES * m;
+                    if (jt >= g.nt) break;
+                    const int o = 4 * rg * g.pitch + 16 * jt + col;
+                    sp[(6 * GM_MAXT + m) * GM_THREADS] = gm_f32x4{y[o], y[o + g.pitch], y[o + 2 * g.pitch], y[o + 3 * g.pitch]};
+                }
+            }
+            typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
+            gm_u32x4* mp = reinterpret_cast<gm_u32x4*>(sp + GmKeep<ENC>::SLOTS * GM_MAXT * GM_THREADS);
+            mp[0] = gm_u32x4{mask[0], mask[1], mask[2], mask[3]};
+            if constexpr (!ENC) {
+                mp[GM_THREADS] = gm_u32x4{mask[4], mask[5], 0u, 0u};
+                __syncthreads();  // the tanh image has been read
+            }
+        }
     }
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
 // pw[blocks][sum k], pb[blocks][8]: this block's partial filter / bias gradients (summed over its row tiles).
-template <bool ENC>
+template <bool ENC, bool STASH>
 __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dx, int64_t lddx, int accumulate_dx,
-    float* __restrict__ pw, float* __restrict__ pb, int wtotal, int slabs) {
+    float* __restrict__ pw, float* __restrict__ pb, int wtotal, int slabs, const float* __restrict__ stash) {
     constexpr int L = ENC ? 4 : 7;
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
@@ -346,9 +388,42 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         GM_MARK(0)
         float keep[6][GM_MAXT][4];
         unsigned mask[7];
-        gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
-        const int res = gm_forward<ENC, true>(gm_lds, wz, wz2, g, raw, raw + gm_woff(bands, 7), nullptr, 0, rows_valid, tid,
-                                              keep, mask);
+        [[maybe_unused]] float ylast[GM_MAXT][4];  // STASH: the tanh output of this lane's elements
+        int res = 0;
+        if constexpr (STASH) {  // the forward pass left its activations behind (see GmKeep)
+            const gm_f32x4* sp = reinterpret_cast<const gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m) {
+                    gm_f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (q < (ENC ? 3 : 6) && wave + GM_WAVES * m < g.nt) v = sp[(q * GM_MAXT + m) * GM_THREADS];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) keep[q][m][e] = v[e];
+                }
+            if constexpr (!ENC) {
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m) {
+                    gm_f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (wave + GM_WAVES * m < g.nt) v = sp[(6 * GM_MAXT + m) * GM_THREADS];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ylast[m][e] = v[e];
+                }
+            }
+            typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
+            const gm_u32x4* mp = reinterpret_cast<const gm_u32x4*>(sp + GmKeep<ENC>::SLOTS * GM_MAXT * GM_THREADS);
+            const gm_u32x4 m0 = mp[0];
+            mask[0] = m0[0]; mask[1] = m0[1]; mask[2] = m0[2]; mask[3] = m0[3];
+            mask[4] = mask[5] = mask[6] = 0u;
+            if constexpr (!ENC) {
+                const gm_u32x4 m1 = mp[GM_THREADS];
+                mask[4] = m1[0]; mask[5] = m1[1];
+            }
+        } else {
+            gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
+            res = gm_forward<ENC, true>(gm_lds, wz, wz2, g, raw, raw + gm_woff(bands, 7), nullptr, 0, rows_valid, tid, keep,
+                                        mask);
+        }
         __syncthreads();
         // gradient ring: Da = dn_l (complete), Db = partial dn_{l-1}, Dc = dn_{l-2} being initialised
         float* Da = bufs[(res + 1) % 3];
@@ -389,7 +464,9 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                         const float gd = Da[o];
                         float f;
                         if (top_tanh) {
-                            const float y = fwd_out[o];
+                            float y;
+                            if constexpr (STASH) y = ylast[m][e];
+                            else y = fwd_out[o];
                             f = 1.0f - y * y;
                         } else {
                             f = ((mk >> (4 * m + e)) & 1u) ? 1.0f : 0.1f;
@@ -548,44 +625,52 @@ bool hypel_gm_supported(int bands) {
     return bands >= min_bands && bands >= 16 && bands <= GM_MAX_BANDS && gm_bwd_lds(bands) <= 160 * 1024;
 }
 
+// floats of the kept-activation buffer of one forward pass over n samples (0: this band count runs on gan.hip's kernels)
+int64_t hypel_gm_keep_floats(int64_t n, int bands, int only_encoder) {
+    if (!hypel_gm_supported(bands)) return 0;
+    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
+    return tiles * (only_encoder ? GmKeep<true>::V4 : GmKeep<false>::V4) * GM_THREADS * 4;
+}
+
+#define GM_LAUNCH(K, ...)                                                                                         \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        hipLaunchKernelGGL(K, dim3(grid), dim3(GM_THREADS), lds, st, __VA_ARGS__);                                \
+    } while (0)
+
 int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
-                 float* out, int64_t ldo, int blocks, hipStream_t st) {
+                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep) {
     const size_t lds = gm_fwd_lds(bands);
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     const int grid = (int)(tiles < blocks ? tiles : blocks);
     if (only_encoder) {
-        (void)hipFuncSetAttribute((const void*)gan_generator_fwd_mfma_kernel<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gan_generator_fwd_mfma_kernel<true>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, n, bands, w, b,
-                           out, ldo);
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, true>), x, ldx, n, bands, w, b, out, ldo, keep);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, false>), x, ldx, n, bands, w, b, out, ldo, keep);
     } else {
-        (void)hipFuncSetAttribute((const void*)gan_generator_fwd_mfma_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gan_generator_fwd_mfma_kernel<false>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, n, bands, w,
-                           b, out, ldo);
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true>), x, ldx, n, bands, w, b, out, ldo, keep);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false>), x, ldx, n, bands, w, b, out, ldo, keep);
     }
     return 0;
 }
 
 int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
                  const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
-                 int blocks, hipStream_t st) {
+                 int blocks, hipStream_t st, const float* keep) {
     const size_t lds = gm_bwd_lds(bands);
     int wtotal = 0;
     for (int l = 0; l < 7; ++l) wtotal += gm_ksz(bands, l);
     // every one of the `blocks` partial slabs is written (the planner's reduce sums all of them)
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     const int grid = (int)(tiles < blocks ? tiles : blocks);
+#define GM_BWD_ARGS x, ldx, dout, lddo, n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks, keep
     if (only_encoder) {
-        (void)hipFuncSetAttribute((const void*)gan_generator_bwd_mfma_kernel<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gan_generator_bwd_mfma_kernel<true>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, dout, lddo, n,
-                           bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks);
+        if (keep) GM_LAUNCH((gan_generator_bwd_mfma_kernel<true, true>), GM_BWD_ARGS);
+        else GM_LAUNCH((gan_generator_bwd_mfma_kernel<true, false>), GM_BWD_ARGS);
     } else {
-        (void)hipFuncSetAttribute((const void*)gan_generator_bwd_mfma_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gan_generator_bwd_mfma_kernel<false>, dim3(grid), dim3(GM_THREADS), lds, st, x, ldx, dout, lddo,
-                           n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks);
+        if (keep) GM_LAUNCH((gan_generator_bwd_mfma_kernel<false, true>), GM_BWD_ARGS);
+        else GM_LAUNCH((gan_generator_bwd_mfma_kernel<false, false>), GM_BWD_ARGS);
     }
+#undef GM_BWD_ARGS
     return 0;
 }
+#undef GM_LAUNCH

@@ -70,6 +70,7 @@ SIDE_STREAMS = max(1, int(os.environ.get("HYPEL_SIDE_STREAMS", "0") or 0))
 # but measured SLOWER on MI355X (8.65 vs 7.88 ms/step): every block pays the round trip of a device-scope atomic
 # through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
 FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
+GEN_KEEP = os.environ.get("HYPEL_GEN_KEEP", "1") != "0"  # generator backward starts from the forward pass's kept activations
 TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
 SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
 SMALL_BN_ROWS = 1024  # hypel_bn_act_small_*: rows kept in registers (32 row lanes x 32 rows)
@@ -1894,10 +1895,12 @@ class PhasePlan(TowerPlan):
         s_st = self.storage_of(src)
         st = self._new_value(out, f"z:{idx}")
         w0, b0, _ = self._gen_refs(node)
-        self.fwd.append(Launch("gan_generator_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c,
-                                                     self._p(w0), self._p(b0), int(node.only_encoder),
-                                                     self._ref(st.buf), st.ld), nbytes=8 * self.nb * src.c,
-                               tag="gen-fwd"))
+        l = Launch("gan_generator_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c, self._p(w0),
+                                         self._p(b0), int(node.only_encoder), self._ref(st.buf), st.ld),
+                   nbytes=8 * self.nb * src.c, tag="gen-fwd")
+        self.fwd.append(l)
+        self._gen_fwd = getattr(self, "_gen_fwd", {})
+        self._gen_fwd[idx] = l  # _bwd_generator turns it into the activation-keeping form when a backward pass follows
 
     def _bwd_generator(self, idx, node):
         src, out = node.src, node.out
@@ -1912,6 +1915,17 @@ class PhasePlan(TowerPlan):
         l1 = Launch("gan_generator_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
                                           z_st.ld, self.nb, src.c, self._p(w0), self._p(b0), int(node.only_encoder),
                                           dx, lddx, acc, None, None), nbytes=12 * self.nb * src.c, tag="gen-bwd")
+        keep_n = self.be.gan_generator_keep_floats(self.nb, src.c, int(node.only_encoder)) if GEN_KEEP else 0
+        if keep_n > 0:
+            # the forward pass of this application leaves its activations for this launch (hypel.h: bit-identical to
+            # recomputing them; 188 KB per 16 samples at 360 bands)
+            self._alloc(f"gkeep:{idx}", keep_n)
+            kref = self._ref(f"gkeep:{idx}")
+            f = self._gen_fwd[idx]
+            f.name, f.args = "gan_generator_fwd_keep", tuple(f.args) + (kref,)
+            f.bytes += 4 * keep_n
+            l1.name, l1.args = "gan_generator_bwd_kept", tuple(l1.args) + (kref,)
+            l1.bytes += 4 * keep_n
         self._scratch(l1, 12, "scratch_gen_w", blocks * wtotal)
         self._scratch(l1, 13, "scratch_gen_b", blocks * 8)
         self.bwd.append(l1)

@@ -376,6 +376,19 @@ int hypel_gan_generator_fwd(const float* x, int64_t ldx, int64_t n, int32_t band
 int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,
                             const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
                             int32_t accumulate_dx, float* pw, float* pb, hypel_stream_t stream);
+
+/* The same pair with the forward pass's activations KEPT for the backward pass instead of recomputed there (29 % of the
+ * matrix-core backward kernel at B = 360): hypel_gan_generator_fwd_keep leaves the layer outputs, leaky-ReLU branch bits and
+ * the tanh output of every 16-sample tile in `keep` (hypel_gan_generator_keep_floats(n, bands, only_encoder) floats; an
+ * opaque, lane-native layout), hypel_gan_generator_bwd_kept of the SAME (x, w, b, n, bands, only_encoder) starts from it:
+ * bit-identical to the recomputing pair.  keep_floats == 0: this band count runs on the VALU kernels, which always
+ * recompute -- pass keep = NULL (then the calls are hypel_gan_generator_fwd / _bwd). */
+int64_t hypel_gan_generator_keep_floats(int64_t n, int32_t bands, int32_t only_encoder);
+int hypel_gan_generator_fwd_keep(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w, const float* b,
+                                 int32_t only_encoder, float* out, int64_t ldo, float* keep, hypel_stream_t stream);
+int hypel_gan_generator_bwd_kept(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,
+                                 const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
+                                 int32_t accumulate_dx, float* pw, float* pb, const float* keep, hypel_stream_t stream);
 /* tensorflow_gan losses: mode 0: weight*mean((a-target)^2) (least squares, pass weight/2),
  * mode 1: weight*mean(|a-b|) (cycle consistency / absolute_difference), mode 2: weight*mean(a) (Wasserstein).
  * loss[0] (+)= value; da / db (nullable) (+)= gradient.  ws >= 1024 floats. */

@@ -906,3 +906,10 @@ EmuBackend.k_l2norm_fwd = _k_l2norm_fwd
 EmuBackend.k_l2norm_bwd = _k_l2norm_bwd
 EmuBackend.k_nce_loss = _k_nce_loss
 EmuBackend.gan_generator_blocks = lambda self, n: _emu_generator_blocks(n)
+# kept activations: the emulation recomputes (the product's two pairs are bit-identical); a nominal buffer size so that
+# the planner takes the same path as on the device
+EmuBackend.gan_generator_keep_floats = lambda self, n, bands, only_encoder: 16 if 16 <= bands <= 384 else 0
+EmuBackend.k_gan_generator_fwd_keep = lambda self, x, ldx, n, bands, w, b, enc, out, ldo, keep: _k_gan_generator_fwd(
+    self, x, ldx, n, bands, w, b, enc, out, ldo)
+EmuBackend.k_gan_generator_bwd_kept = lambda self, x, ldx, dout, lddo, n, bands, w, b, enc, dx, lddx, acc, pw, pb, keep: \
+    _k_gan_generator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, enc, dx, lddx, acc, pw, pb)

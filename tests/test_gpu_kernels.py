@@ -740,6 +740,45 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.check("db", rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("bands,n,only_enc", [(360, 4096, 0), (360, 70, 1), (64, 2048, 0), (144, 37, 0), (16, 5, 1),
+                                              (200, 1000, 1)])
+def test_gan_generator_kept_activations_bit_identical(hip, bands, n, only_enc):
+    """hypel_gan_generator_fwd_keep + _bwd_kept (the backward pass starts from the activations the forward pass left
+    behind) == hypel_gan_generator_fwd + _bwd (it recomputes them), bit for bit: out, dx and every partial slab."""
+    rng = np.random.default_rng(bands + n)
+    ks = [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
+    wtot = sum(ks)
+    x = torch.from_numpy(rng.random((n, bands)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal(wtot) * 0.3 / np.sqrt(np.repeat(ks, ks))).astype(np.float32)).cuda()
+    bias = torch.from_numpy((rng.standard_normal(8) * 0.05).astype(np.float32)).cuda()
+    dout = torch.from_numpy(rng.standard_normal((n, bands)).astype(np.float32)).cuda()
+    blocks = hip.gan_generator_blocks(n)
+    keep_n = hip.gan_generator_keep_floats(n, bands, only_enc)
+    assert keep_n > 0
+    res = []
+    for kept in (False, True):
+        out = torch.zeros(n, bands, device="cuda")
+        dx = torch.ones(n, bands, device="cuda")
+        pw = torch.zeros(blocks * wtot, device="cuda")
+        pb = torch.zeros(blocks * 8, device="cuda")
+        if kept:
+            keep = torch.full((keep_n,), float("nan"), device="cuda")
+            hip.call("gan_generator_fwd_keep", Ref(x), bands, n, bands, Ref(w), Ref(bias), only_enc, Ref(out), bands, Ref(keep))
+            hip.call("gan_generator_bwd_kept", Ref(x), bands, Ref(dout), bands, n, bands, Ref(w), Ref(bias), only_enc, Ref(dx),
+                     bands, 1, Ref(pw), Ref(pb), Ref(keep))
+        else:
+            hip.call("gan_generator_fwd", Ref(x), bands, n, bands, Ref(w), Ref(bias), only_enc, Ref(out), bands)
+            hip.call("gan_generator_bwd", Ref(x), bands, Ref(dout), bands, n, bands, Ref(w), Ref(bias), only_enc, Ref(dx),
+                     bands, 1, Ref(pw), Ref(pb))
+        hip.synchronize()
+        res.append([t.cpu().numpy() for t in (out, dx, pw, pb)])
+    for a, b_, name in zip(res[0], res[1], ("out", "dx", "pw", "pb")):
+        assert np.isfinite(b_).all(), name
+        np.testing.assert_array_equal(a, b_, err_msg=name)
+    # band counts of gan.hip's VALU kernels keep nothing
+    assert hip.gan_generator_keep_floats(n, 8, only_enc) == 0
+
+
 @pytest.mark.parametrize("bands,n,with_ratio", [(64, 2048, True), (360, 100, True), (144, 33, False)])
 def test_gather_pairs_bit_exact(hip, bands, n, with_ratio):
     """The GAN trainer's input stage as one library launch: gather + the two regulariser swaps, bit for bit."""
