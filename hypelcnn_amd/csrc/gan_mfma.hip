@@ -188,11 +188,22 @@ __device__ __forceinline__ void gm_fill_taps(float* wz, const GmGeo g, const flo
 // `bands` and for rows without a sample).  KEEP: every lane keeps the layers' outputs (its 12 elements per layer, MFMA
 // C layout: column = lane & 15, row = 4 (lane >> 4) + e) and the leaky-ReLU branch bits for the backward pass.
 // Returns the image index that holds the result (n4 or tanh output); with out != nullptr the result also goes to global.
-template <bool ENC, bool KEEP, bool ROLLED = true>
+template <bool ENC>
+struct GmKeep {
+    static constexpr int SLOTS = ENC ? 3 : 7;  // n_1..n_3 | n_1..n_6 + the tanh output
+    static constexpr int V4 = SLOTS * GM_MAXT + 2;  // float4 per thread and row tile
+};
+
+typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
+
+// STASH: every layer's outputs / branch bits go straight from the epilogue to this thread's place in the kept-activation
+// buffer (`stash` = the row tile's base + tid, in float4): nothing stays in registers, the unrolled forward stays cheap.
+template <bool ENC, bool KEEP, bool ROLLED = true, bool STASH = false>
 __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, const GmGeo g,
                                           const float* w, const float* bias,  // the block's LDS copy (gm_stage_raw)
                                           float* __restrict__ out, int64_t ldo, int rows_valid, int tid,
-                                          float (&keep)[6][GM_MAXT][4], unsigned (&mask)[7]) {
+                                          float (&keep)[6][GM_MAXT][4], unsigned (&mask)[7],
+                                          gm_f32x4* __restrict__ stash = nullptr) {
     constexpr int L = ENC ? 4 : 7;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile loops are wave-uniform
     const int col = lane & 15, rg = lane >> 4;
@@ -228,6 +239,7 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
             const int j0 = 16 * jt;
             const gm_f32x4 acc = gm_conv_tile<false>(src, wz, g, j0, ksz, pad, lane);
             const int c = j0 + col;
+            [[maybe_unused]] gm_f32x4 kept = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = 4 * rg + e;
@@ -251,11 +263,19 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
 #pragma unroll
                     for (int q = 0; q < 6; ++q) keep[q][m][e] = q == l ? y : keep[q][m][e];
                 }
+                if constexpr (STASH) kept[e] = y;
+            }
+            if constexpr (STASH) {  // slots n_1..n_3 (encoder) / n_1..n_6 + the tanh output
+                if (ENC ? l < 3 : true) stash[(l * GM_MAXT + m) * GM_THREADS] = kept;
             }
         }
         if constexpr (KEEP) {
 #pragma unroll
             for (int q = 0; q < 7; ++q) mask[q] = q == l ? mk : mask[q];
+        }
+        if constexpr (STASH) {  // branch bits of layer l: word l of the two uint4 behind the slots
+            if (l < (ENC ? 4 : 6))
+                reinterpret_cast<unsigned*>(stash + GmKeep<ENC>::SLOTS * GM_MAXT * GM_THREADS + (l >> 2) * GM_THREADS)[l & 3] = mk;
         }
     }
     return L % 3;
@@ -279,12 +299,6 @@ __device__ __forceinline__ void gm_load_rows(float* img, const GmGeo g, const fl
 // lane-native: float4 (slot, m) of thread `tid` of row tile t at ((t * GM_KEEP_V4(ENC) + slot * GM_MAXT + m) * 512 + tid)
 // float4s, two uint4 of branch bits behind them.  The backward kernel then starts from that copy instead of recomputing
 // the forward (29 % of its time at B = 360): 188 KB per 16 samples written and read once at HBM speed.
-template <bool ENC>
-struct GmKeep {
-    static constexpr int SLOTS = ENC ? 3 : 7;  // n_1..n_3 | n_1..n_6 + the tanh output
-    static constexpr int V4 = SLOTS * GM_MAXT + 2;  // float4 per thread and row tile
-};
-
 template <bool ENC, bool STASH>
 __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                                             int64_t n, int bands,
@@ -309,38 +323,11 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
         const int64_t r0 = t * GM_ROWS;
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
-        const int res = gm_forward<ENC, STASH, STASH || GM_FWD_ROLLED != 0>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7),
-                                                                          out + r0 * ldo, ldo, rows_valid, tid, keep, mask);
+        gm_f32x4* sp = nullptr;
+        if constexpr (STASH) sp = reinterpret_cast<gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
+        gm_forward<ENC, false, GM_FWD_ROLLED != 0, STASH>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7), out + r0 * ldo, ldo,
+                                                          rows_valid, tid, keep, mask, sp);
         __syncthreads();  // the next row tile overwrites bufs[0]
-        if constexpr (STASH) {
-            const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-            gm_f32x4* sp = reinterpret_cast<gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
-#pragma unroll
-            for (int q = 0; q < (ENC ? 3 : 6); ++q)
-#pragma unroll
-                for (int m = 0; m < GM_MAXT; ++m) {
-                    if (wave + GM_WAVES * m >= g.nt) break;
-                    sp[(q * GM_MAXT + m) * GM_THREADS] = gm_f32x4{keep[q][m][0], keep[q][m][1], keep[q][m][2], keep[q][m][3]};
-                }
-            if constexpr (!ENC) {
-                const float* y = bufs[res];
-                const int col = lane & 15, rg = lane >> 4;
-#pragma unroll
-                for (int m = 0; m < GM_MAXT; ++m) {
-                    const int jt = wave + GM_WAVES * m;
-                    if (jt >= g.nt) break;
-                    const int o = 4 * rg * g.pitch + 16 * jt + col;
-                    sp[(6 * GM_MAXT + m) * GM_THREADS] = gm_f32x4{y[o], y[o + g.pitch], y[o + 2 * g.pitch], y[o + 3 * g.pitch]};
-                }
-            }
-            typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
-            gm_u32x4* mp = reinterpret_cast<gm_u32x4*>(sp + GmKeep<ENC>::SLOTS * GM_MAXT * GM_THREADS);
-            mp[0] = gm_u32x4{mask[0], mask[1], mask[2], mask[3]};
-            if constexpr (!ENC) {
-                mp[GM_THREADS] = gm_u32x4{mask[4], mask[5], 0u, 0u};
-                __syncthreads();  // the tanh image has been read
-            }
-        }
     }
 }
 
