@@ -113,6 +113,9 @@ SIGNATURES = {
     "lrn_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _P, _I64, _I32],
     "gan_generator_fwd": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64],
     "gan_generator_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P],
+    "dense_stack_fwd": [_P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _I64],
+    "dense_stack_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _I64, _I32,
+                        _P, _P],
     "gan_generator_fwd_keep": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _P],
     "gan_generator_bwd_kept": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P],
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
@@ -152,6 +155,10 @@ def load_library(path=LIB_PATH):
     lib.hypel_device_info.argtypes = [ctypes.POINTER(_I32), ctypes.POINTER(_I32)]
     lib.hypel_gan_generator_blocks.argtypes = [_I64]
     lib.hypel_gan_generator_blocks.restype = ctypes.c_int
+    lib.hypel_dense_stack_blocks.argtypes = [_I64]
+    lib.hypel_dense_stack_blocks.restype = ctypes.c_int
+    lib.hypel_dense_stack_supported.argtypes = [_I32] * 6
+    lib.hypel_dense_stack_supported.restype = ctypes.c_int
     lib.hypel_gan_generator_keep_floats.argtypes = [_I64, _I32, _I32]
     lib.hypel_gan_generator_keep_floats.restype = ctypes.c_int64
     return lib
@@ -251,6 +258,13 @@ class HipBackend:
 
     def gan_generator_blocks(self, n):
         return int(self.lib.hypel_gan_generator_blocks(int(n)))
+
+    def dense_stack_blocks(self, n):
+        return int(self.lib.hypel_dense_stack_blocks(int(n)))
+
+    def dense_stack_supported(self, widths):
+        w = list(widths) + [0] * (5 - len(widths))
+        return len(widths) <= 5 and bool(self.lib.hypel_dense_stack_supported(len(widths) - 1, *[int(v) for v in w]))
 
     def gan_generator_keep_floats(self, n, bands, only_encoder):
         return int(self.lib.hypel_gan_generator_keep_floats(int(n), int(bands), int(only_encoder)))

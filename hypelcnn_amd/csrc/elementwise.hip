@@ -155,7 +155,11 @@ __global__ void reduce_splits_v4_kernel(const float* __restrict__ partial, int64
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count4; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = q * 4;
         const int64_t o = ldc > 0 ? (i / n) * ldc + (i % n) : i;
-        float4 s = accumulate ? *reinterpret_cast<const float4*>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // the slabs are summed FIRST and the old value added last, as in the wave kernel: two contributions that are
+        // exact negatives of each other (the last bias of a Wasserstein critic: +1/N and -1/N per sample) then cancel
+        // exactly whichever kernel the slab count selects
+        const float4 old = accumulate ? *reinterpret_cast<const float4*>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias) {
             const float* bp = bias + (int)(i % n);
             s.x += bp[0]; s.y += bp[1]; s.z += bp[2]; s.w += bp[3];
@@ -165,6 +169,7 @@ __global__ void reduce_splits_v4_kernel(const float* __restrict__ partial, int64
             const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)k * stride + o);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+        s.x += old.x; s.y += old.y; s.z += old.z; s.w += old.w;
         *reinterpret_cast<float4*>(out + o) = s;
     }
 }
@@ -176,11 +181,11 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, int64_t 
         // ldc > 0: element i is (row i / n, column i % n) of an [rows x n] window with leading dimension ldc,
         // on both the partial slabs and the output
         const int64_t o = ldc > 0 ? (i / n) * ldc + (i % n) : i;
-        float s = accumulate ? out[o] : 0.0f;
-        if (bias) s += bias[(int)(i % n)];
+        const float old = accumulate ? out[o] : 0.0f;
+        float s = bias ? bias[(int)(i % n)] : 0.0f;
 #pragma unroll 8
         for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * stride + o];
-        out[o] = s;
+        out[o] = s + old;  // slabs first, the old value last (see the float4 variant)
     }
 }
 

@@ -18,7 +18,8 @@ def shadowdata_discriminator_model(generated_data, generator_input, is_training,
         net1 = g.fully_connected(generated_data, band_size)
         net2 = g.fully_connected(net1, band_size)
         net3 = g.fully_connected(net2, band_size // 2, weights_regularizer=None, activation_fn=None)
-    return net3
+    # at narrow band counts (<= 128: Gulfport) the three layers of one application are one launch per direction
+    return g.fuse_dense_stack(net3)
 
 
 def shadowdata_feature_discriminator_model(generated_data, patch_count, embedded_feature_size, is_training, scale):

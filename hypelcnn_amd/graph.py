@@ -320,6 +320,29 @@ class GeneratorNode:
         self.out = None
 
 
+class DenseStackNode:
+    """A chain of narrow tf_slim.fully_connected layers (biases, optional leaky-ReLU) as ONE fused op per direction
+    (hypel_dense_stack_fwd / _bwd): shadowdata_discriminator_model at narrow band counts (shadow_data_models.py:95-121)."""
+
+    def __init__(self, src, layers, alpha):
+        self.src = src
+        self.layers = layers  # [(weights Variable [cin, cout], biases Variable [cout], leaky: bool)]
+        self.alpha = alpha
+        self.out = None
+
+    @property
+    def weights(self):
+        return [w for w, _, _ in self.layers]
+
+    @property
+    def biases(self):
+        return [b for _, b, _ in self.layers]
+
+    @property
+    def widths(self):
+        return [self.layers[0][0].shape[0]] + [w.shape[1] for w, _, _ in self.layers]
+
+
 class FeatStackNode:
     """tf.math.l2_normalize (whole-tensor norm) of each slice embedding [N,E], stacked to [N, P*E]
     (gan/shadow_data_models.py:147-149)."""
@@ -639,6 +662,62 @@ def _merge_patch_mlps(embeddings):
         tower.nodes.insert(pos + l, merged)
         src, prev_cout, out = merged.out, cout, merged.out
     return out, len(chains), prev_cout
+
+
+DENSE_STACK = os.environ.get("HYPEL_DENSE_STACK", "1") != "0"
+DENSE_STACK_MAX_WIDTH = 128  # hypel.h: hypel_dense_stack_supported
+
+
+def dense_stack_fits(widths):
+    """hypel_dense_stack_supported's rule (csrc/dense_stack.hip): activations, gradients and EVERY layer's weights of
+    a 16-sample tile live in the 160 KB of LDS."""
+    if not (2 <= len(widths) <= 5 and all(1 <= v <= DENSE_STACK_MAX_WIDTH for v in widths)):
+        return False
+    w16 = (max(widths) + 15) // 16 * 16
+    p = w16 // 32 * 32 + 18
+    p = p if p >= w16 else p + 32
+    return (8 * 16 * p + sum((c + 3) // 4 * 4 * p for c in widths[:-1]) + sum(widths[1:])) * 4 <= 160 * 1024
+
+
+def fuse_dense_stack(t):
+    """`t` = the output of a chain of plain fully-connected layers (biases, no normaliser, activation None or leaky-ReLU
+    with one alpha, every intermediate consumed by the next layer only) on a [N, C] tensor: when every width is at most
+    128 the chain is re-recorded as ONE DenseStackNode -- one launch per direction instead of ~5 forward / ~12 backward
+    launches of a few microseconds each (the CycleGAN step at 64 bands is nothing but such launches).  Returns the tensor
+    to use in place of `t` (`t` itself when the chain does not qualify).  Variables keep their TensorFlow names."""
+    if not DENSE_STACK:
+        return t
+    chain, cur = [], t
+    while len(chain) < 4:
+        n = cur.node
+        if not (isinstance(n, LinearNode) and n.kind == "dense" and len(n.branches) == 1 and len(n.sources) == 1
+                and not n.has_bn and n.has_bias and not n.residuals and n.dropout_keep is None and cur.root is None
+                and cur.consumers == (0 if not chain else 1)):
+            break
+        if n.act is not None and n.act.kind != "lrelu":
+            break
+        src = n.sources[0]
+        if src.hw is not None or src.pixmap is not None:
+            break
+        chain.append(n)
+        cur = src
+    chain = chain[::-1]
+    if len(chain) < 2:
+        return t
+    alphas = {n.act.alpha for n in chain if n.act is not None}
+    widths = [chain[0].sources[0].c] + [n.branches[0].cout for n in chain]
+    if len(alphas) > 1 or not dense_stack_fits(widths):
+        return t
+    tower = t.tower
+    pos = tower.nodes.index(chain[0])
+    for n in chain:
+        tower.nodes.remove(n)
+        n.out.absorbed = True
+    node = DenseStackNode(chain[0].sources[0], [(n.branches[0].w, n.branches[0].bias, n.act is not None) for n in chain],
+                          alphas.pop() if alphas else 0.0)
+    node.out = SymTensor(tower, None, widths[-1], node=node)
+    tower.nodes.insert(pos, node)
+    return node.out
 
 
 def feature_stack(embeddings):

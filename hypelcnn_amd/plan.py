@@ -1801,7 +1801,7 @@ class PhasePlan(TowerPlan):
                 if b.bias is not None:
                     out.append(b.bias)
             return out
-        if isinstance(node, G.GeneratorNode):
+        if isinstance(node, (G.GeneratorNode, G.DenseStackNode)):
             return list(node.weights) + list(node.biases)
         return []
 
@@ -1855,6 +1855,8 @@ class PhasePlan(TowerPlan):
                 self._fwd_linear(idx, node)
             elif isinstance(node, G.GeneratorNode):
                 self._fwd_generator(idx, node)
+            elif isinstance(node, G.DenseStackNode):
+                self._fwd_densestack(idx, node)
             elif isinstance(node, G.FeatStackNode):
                 self._fwd_featstack(idx, node)
             elif isinstance(node, G.PostNode):
@@ -1874,6 +1876,8 @@ class PhasePlan(TowerPlan):
                     self._bwd_linear(idx, node)
                 elif isinstance(node, G.GeneratorNode):
                     self._bwd_generator(idx, node)
+                elif isinstance(node, G.DenseStackNode):
+                    self._bwd_densestack(idx, node)
                 elif isinstance(node, G.FeatStackNode):
                     self._bwd_featstack(idx, node)
                 elif isinstance(node, G.PostNode):
@@ -1935,6 +1939,55 @@ class PhasePlan(TowerPlan):
             self._scratch(l2, 0, "scratch_gen_w", blocks * wtotal)
             l3 = Launch("reduce_splits_f32", (None, 8, blocks, self._g(b0), 7, wacc, None, 0, 0), tag="gen-db")
             self._scratch(l3, 0, "scratch_gen_b", blocks * 8)
+            self.bwd += [l2, l3]
+
+    # ---- fused fully-connected stack (narrow discriminators) ----
+    def _densestack_args(self, node):
+        self._assert_contiguous(node.weights)
+        self._assert_contiguous(node.biases)
+        widths = node.widths
+        if not self.be.dense_stack_supported(widths):
+            raise RuntimeError(f"fused fully-connected stack {widths} is not supported by the library")
+        mask = sum(1 << l for l, (_, _, leaky) in enumerate(node.layers) if leaky)
+        return (len(node.layers), *(widths + [0] * (5 - len(widths))), mask, float(node.alpha))
+
+    def _fwd_densestack(self, idx, node):
+        src, out = node.src, node.out
+        s_st = self.storage_of(src)
+        st = self._new_value(out, f"z:{idx}")
+        macs = sum(w.size for w in node.weights)
+        self.fwd.append(Launch("dense_stack_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb,
+                                                   *self._densestack_args(node), self._p(node.weights[0]),
+                                                   self._p(node.biases[0]), self._ref(st.buf), st.ld),
+                               flops=2 * self.nb * macs, nbytes=4 * self.nb * (src.c + out.c), tag="dense-stack-fwd"))
+
+    def _bwd_densestack(self, idx, node):
+        src, out = node.src, node.out
+        s_st = self.storage_of(src)
+        z_st = self.storage[id(out)]
+        w0, b0 = node.weights[0], node.biases[0]
+        wtotal, btotal = sum(w.size for w in node.weights), sum(b.size for b in node.biases)
+        blocks = self.be.dense_stack_blocks(self.nb)
+        dx, lddx, acc = None, 0, 0
+        if self._needs_grad(src):
+            gst, acc = self._grad_target(src)
+            dx, lddx = self._ref(gst.buf, gst.ch_off), gst.ld
+        l1 = Launch("dense_stack_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf), z_st.ld,
+                                        self.nb, *self._densestack_args(node), self._p(w0), self._p(b0), dx, lddx, acc, None,
+                                        None), flops=6 * self.nb * wtotal, nbytes=4 * self.nb * (2 * src.c + out.c),
+                    tag="dense-stack-bwd")
+        n_args = len(l1.args)
+        self._scratch(l1, n_args - 2, "scratch_ds_w", blocks * wtotal)
+        self._scratch(l1, n_args - 1, "scratch_ds_b", blocks * btotal)
+        self.bwd.append(l1)
+        if self._trains(node.weights):
+            wacc = self._param_acc(w0)
+            for v in node.weights[1:] + node.biases:
+                self._param_acc(v)
+            l2 = Launch("reduce_splits_f32", (None, wtotal, blocks, self._g(w0), wtotal, wacc, None, 0, 0), tag="ds-dw")
+            self._scratch(l2, 0, "scratch_ds_w", blocks * wtotal)
+            l3 = Launch("reduce_splits_f32", (None, btotal, blocks, self._g(b0), btotal, wacc, None, 0, 0), tag="ds-db")
+            self._scratch(l3, 0, "scratch_ds_b", blocks * btotal)
             self.bwd += [l2, l3]
 
     # ---- feature stack (global l2 normalise per slice, stacked) ----

@@ -389,6 +389,26 @@ int hypel_gan_generator_fwd_keep(const float* x, int64_t ldx, int64_t n, int32_t
 int hypel_gan_generator_bwd_kept(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,
                                  const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
                                  int32_t accumulate_dx, float* pw, float* pb, const float* keep, hypel_stream_t stream);
+
+/* ---- a short stack of narrow fully-connected layers in one launch per direction ------------------------------------
+ * shadowdata_discriminator_model (gan/shadow_data_models.py:95-121): flatten -> tf_slim.fully_connected B -> B -> B -> B/2
+ * with biases, leaky-ReLU(0.1) on the first two.  When every width is <= 128 (the Gulfport stacks, B = 64) the whole stack
+ * of one application runs out of LDS, 16 samples per block, on v_mfma_f32_16x16x4_f32 -- instead of one GEMM + one
+ * activation launch per layer forward and ~12 launches backward, each a few microseconds of launch latency.
+ *   n_layers <= 4, widths w0 -> w1 -> ... (unused trailing widths 0); bit l of act_mask: leaky-ReLU(alpha) after layer l.
+ *   w: the layers' [cin][cout] matrices one after the other (tf_slim `weights`), b: their biases one after the other.
+ *   bwd: recomputes the forward; dx may be NULL; pw[blocks][sum cin*cout] / pb[blocks][sum cout] are per-block partial
+ *   filter / bias gradients, blocks = hypel_dense_stack_blocks(n) -- every slab is written; sum them in slab order with
+ *   hypel_reduce_splits_f32 (deterministic).  hypel_dense_stack_supported: 1 when the shape runs here. */
+int hypel_dense_stack_supported(int32_t n_layers, int32_t w0, int32_t w1, int32_t w2, int32_t w3, int32_t w4);
+int hypel_dense_stack_blocks(int64_t n);
+int hypel_dense_stack_fwd(const float* x, int64_t ldx, int64_t n, int32_t n_layers, int32_t w0, int32_t w1, int32_t w2,
+                          int32_t w3, int32_t w4, int32_t act_mask, float alpha, const float* w, const float* b, float* out,
+                          int64_t ldo, hypel_stream_t stream);
+int hypel_dense_stack_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t n_layers,
+                          int32_t w0, int32_t w1, int32_t w2, int32_t w3, int32_t w4, int32_t act_mask, float alpha,
+                          const float* w, const float* b, float* dx, int64_t lddx, int32_t accumulate_dx, float* pw,
+                          float* pb, hypel_stream_t stream);
 /* tensorflow_gan losses: mode 0: weight*mean((a-target)^2) (least squares, pass weight/2),
  * mode 1: weight*mean(|a-b|) (cycle consistency / absolute_difference), mode 2: weight*mean(a) (Wasserstein).
  * loss[0] (+)= value; da / db (nullable) (+)= gradient.  ws >= 1024 floats. */

@@ -905,6 +905,75 @@ EmuBackend.k_l2_reg = _k_l2_reg
 EmuBackend.k_l2norm_fwd = _k_l2norm_fwd
 EmuBackend.k_l2norm_bwd = _k_l2norm_bwd
 EmuBackend.k_nce_loss = _k_nce_loss
+def _ds_layers(n_layers, widths, act_mask, w, b):
+    ws, bs, wo, bo = [], [], 0, 0
+    for l in range(n_layers):
+        cin, cout = widths[l], widths[l + 1]
+        ws.append(_arr(w)[wo:wo + cin * cout].reshape(cin, cout).astype(np.float64))
+        bs.append(_arr(b)[bo:bo + cout].astype(np.float64))
+        wo += cin * cout
+        bo += cout
+    return ws, bs, [bool((act_mask >> l) & 1) for l in range(n_layers)], wo, bo
+
+
+def _ds_forward(x, ws, bs, lrelu, alpha):
+    a = [x]
+    for wl, bl, act in zip(ws, bs, lrelu):
+        v = a[-1] @ wl + bl
+        a.append(np.where(v > 0, v, alpha * v) if act else v)
+    return a
+
+
+def _k_dense_stack_fwd(self, x, ldx, n, n_layers, w0, w1, w2, w3, w4, act_mask, alpha, w, b, out, ldo):
+    widths = [w0, w1, w2, w3, w4]
+    ws, bs, lrelu, _, _ = _ds_layers(n_layers, widths, act_mask, w, b)
+    a = _ds_forward(_mat(x, ldx, n, w0).astype(np.float64), ws, bs, lrelu, alpha)
+    _mat(out, ldo, n, widths[n_layers])[...] = a[-1].astype(np.float32)
+
+
+def _k_dense_stack_bwd(self, x, ldx, dout, lddo, n, n_layers, w0, w1, w2, w3, w4, act_mask, alpha, w, b, dx, lddx, acc,
+                       pw, pb):
+    widths = [w0, w1, w2, w3, w4]
+    ws, bs, lrelu, wtotal, btotal = _ds_layers(n_layers, widths, act_mask, w, b)
+    a = _ds_forward(_mat(x, ldx, n, w0).astype(np.float64), ws, bs, lrelu, alpha)
+    g = _mat(dout, lddo, n, widths[n_layers]).astype(np.float64)
+    dws, dbs = [None] * n_layers, [None] * n_layers
+    for l in range(n_layers - 1, -1, -1):
+        if lrelu[l]:
+            g = np.where(a[l + 1] > 0, g, alpha * g)
+        dbs[l] = g.sum(0)
+        dws[l] = a[l].T @ g
+        g = g @ ws[l].T
+    if dx is not None:
+        d = _mat(dx, lddx, n, w0)
+        d[...] = (d if acc else 0) + g.astype(np.float32)
+    blocks = _emu_dense_stack_blocks(n)
+    pwv = _arr(pw)[: blocks * wtotal].reshape(blocks, wtotal)
+    pbv = _arr(pb)[: blocks * btotal].reshape(blocks, btotal)
+    pwv[...] = 0
+    pbv[...] = 0
+    pwv[0] = np.concatenate([d.reshape(-1) for d in dws])
+    pbv[0] = np.concatenate(dbs)
+
+
+def _emu_dense_stack_blocks(n):
+    return int(max(1, min(256, (n + 15) // 16)))
+
+
+EmuBackend.k_dense_stack_fwd = _k_dense_stack_fwd
+EmuBackend.k_dense_stack_bwd = _k_dense_stack_bwd
+EmuBackend.dense_stack_blocks = lambda self, n: _emu_dense_stack_blocks(n)
+def _emu_dense_stack_supported(widths):
+    """mirror of hypel_dense_stack_supported: <= 4 layers, widths <= 128, all images + weights within 160 KB of LDS"""
+    if not (2 <= len(widths) <= 5 and all(1 <= v <= 128 for v in widths)):
+        return False
+    w16 = (max(widths) + 15) // 16 * 16
+    p = w16 // 32 * 32 + 18
+    p = p if p >= w16 else p + 32
+    return (8 * 16 * p + sum((c + 3) // 4 * 4 * p for c in widths[:-1]) + sum(widths[1:])) * 4 <= 160 * 1024
+
+
+EmuBackend.dense_stack_supported = lambda self, widths: _emu_dense_stack_supported(list(widths))
 EmuBackend.gan_generator_blocks = lambda self, n: _emu_generator_blocks(n)
 # kept activations: the emulation recomputes (the product's two pairs are bit-identical); a nominal buffer size so that
 # the planner takes the same path as on the device

@@ -37,6 +37,12 @@ def test_phase_gradients_match_oracle(hip, kind, bands, patches, n):
     U.inject(sess, params)
     worst = U.check_phase_gradients(cfg, ops, params, x, y, tol=5e-5)
     print(f"\n{kind} B={bands}: worst phase-gradient error {worst:.2e} (relative to the tensor maximum)")
+    # narrow discriminators (every width <= 128) run as ONE launch per direction, wide ones layer by layer
+    names = set()
+    for phase in ops.loss.phases:
+        plan = ops._compiled(sess, phase, n).plan
+        names |= {l.name for l in plan.fwd + plan.bwd}
+    assert ("dense_stack_bwd" in names) == (bands <= 128), sorted(names)
 
 
 def test_cyclegan_graph_replay_and_training_on_dummy_pairs(hip):

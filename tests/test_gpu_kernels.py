@@ -740,6 +740,45 @@ def test_gan_generator_fwd_bwd(hip, bands, n, only_enc):
     b.check("db", rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("widths,n,act_mask,want_dx", [((64, 64, 64, 32), 2048, 0b011, True), ((64, 64, 64, 32), 37, 0b011, False),
+                                                       ((96, 96, 48), 300, 0b01, True), ((60, 60, 15, 30, 2), 1000, 0b1111, True),
+                                                       ((17, 5), 20, 0b0, True), ((100, 37, 64, 9), 5000, 0b101, True)])
+def test_dense_stack_fwd_bwd(hip, widths, n, act_mask, want_dx):
+    """The one-launch fully-connected stack (discriminator at narrow band counts) against the float64 definition:
+    output, input gradient (accumulating into a pre-filled buffer) and the slab-reduced filter / bias gradients."""
+    rng = np.random.default_rng(sum(widths) + n)
+    L = len(widths) - 1
+    wq = list(widths) + [0] * (5 - len(widths))
+    assert hip.dense_stack_supported(widths)
+    wtot = sum(a * b_ for a, b_ in zip(widths, widths[1:]))
+    btot = sum(widths[1:])
+    b = Both(hip)
+    b.arr("x", rng.standard_normal((n, widths[0])).astype(np.float32))
+    b.arr("w", np.concatenate([(rng.standard_normal(a * c) * np.sqrt(2.0 / a)) for a, c in zip(widths, widths[1:])]).astype(np.float32))
+    b.arr("bias", (rng.standard_normal(btot) * 0.1).astype(np.float32))
+    b.arr("out", np.zeros(n * widths[-1], np.float32))
+    b.run("dense_stack_fwd", "x", widths[0], n, L, *wq, act_mask, 0.1, "w", "bias", "out", widths[-1])
+    b.check("out", rtol=2e-5, atol=2e-6)
+    blocks = hip.dense_stack_blocks(n)
+    assert blocks == b.emu.dense_stack_blocks(n)
+    b.arr("dout", rng.standard_normal((n, widths[-1])).astype(np.float32))
+    b.arr("dx", rng.standard_normal((n, widths[0])).astype(np.float32))
+    b.arr("pw", np.full(blocks * wtot, 7.0, np.float32))
+    b.arr("pb", np.full(blocks * btot, 7.0, np.float32))
+    b.arr("dw", np.zeros(wtot, np.float32))
+    b.arr("db", np.zeros(btot, np.float32))
+    b.run("dense_stack_bwd", "x", widths[0], "dout", widths[-1], n, L, *wq, act_mask, 0.1, "w", "bias",
+          "dx" if want_dx else None, widths[0], 1, "pw", "pb")
+    if want_dx:
+        b.check("dx", rtol=5e-5, atol=5e-6)
+    b.run("reduce_splits_f32", "pw", wtot, blocks, "dw", wtot, 0, None, 0, 0)
+    b.run("reduce_splits_f32", "pb", btot, blocks, "db", btot, 0, None, 0, 0)
+    b.check("dw", rtol=1e-4, atol=1e-5)
+    b.check("db", rtol=1e-4, atol=1e-5)
+    assert not hip.dense_stack_supported((360, 360, 360, 180)) and not hip.dense_stack_supported((128, 128, 128, 64))
+    assert b.emu.dense_stack_supported(widths) and not b.emu.dense_stack_supported((128, 128, 128, 64))
+
+
 @pytest.mark.parametrize("bands,n,only_enc", [(360, 4096, 0), (360, 70, 1), (64, 2048, 0), (144, 37, 0), (16, 5, 1),
                                               (200, 1000, 1)])
 def test_gan_generator_kept_activations_bit_identical(hip, bands, n, only_enc):

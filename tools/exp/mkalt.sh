@@ -7,7 +7,7 @@ SRC=${3:-seg_gemm.hip}
 mkdir -p alt build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wall -Wno-unused-function $2 -c $SRC -o /tmp/alt_$1.o
 OBJS=""
-for s in seg_gemm.hip elementwise.hip gan.hip gan_mfma.hip data.hip abi.cpp; do
+for s in seg_gemm.hip elementwise.hip gan.hip gan_mfma.hip dense_stack.hip data.hip abi.cpp; do
   if [ "$s" = "$SRC" ]; then OBJS="$OBJS /tmp/alt_$1.o"; else OBJS="$OBJS build/$s.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o alt/libhypel_$1.so $OBJS
