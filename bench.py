@@ -218,7 +218,8 @@ def generator_exact_macs(bands, only_encoder):
 
 def measure_gan_events(ops, nb, bands, steps):
     """Eager replay of every phase of the GAN step with a HIP event pair around each generator launch (forward:
-    2 * MAC FLOP per sample; backward = recompute + data gradient + filter gradient: 6 * MAC).  Also counts the
+    2 * MAC FLOP per sample; backward = data gradient + filter gradient: 4 * MAC -- the backward pass starts from the
+    activations its forward pass kept, and a recompute would not be algorithmic work anyway).  Also counts the
     launches of a step (kernel boundaries are what bounds the B = 64 stacks)."""
     sess = ops.ctx.session()
     towers = list(sess._compiled.values())
@@ -234,9 +235,9 @@ def measure_gan_events(ops, nb, bands, steps):
                     a.record()
                     f()
                     b.record()
-                    bwd = l.name.endswith("bwd")
+                    bwd = "_bwd" in l.name  # gan_generator_bwd / gan_generator_bwd_kept
                     enc = bool(l.args[8] if bwd else l.args[6])
-                    evs.append((a, b, (6 if bwd else 2) * generator_exact_macs(bands, enc) * nb))
+                    evs.append((a, b, (4 if bwd else 2) * generator_exact_macs(bands, enc) * nb))
                 else:
                     f()
         torch.cuda.synchronize()
@@ -527,8 +528,8 @@ def main():
                     "generator_launches_per_step": n_gen, "generator_ms_per_step": gen_ms,
                     "generator_share_of_step": gen_ms / step_ms_mean,
                     "algorithmic_gflop_per_step": gen_flops / 1e9,
-                    "flop_convention": "exact taps; forward 2 MAC, backward 6 MAC per sample (recompute + data + filter "
-                                       "gradient)",
+                    "flop_convention": "exact taps; forward 2 FLOP per MAC, backward 4 (data + filter gradient; no "
+                                       "recompute is counted)",
                     "launches_per_step": n_launch, "launch_floor_ms": launch_floor_ms}
         else:
             # cfg4 (B = 64): 12 k multiply-adds per sample and generator pass -- neither HBM nor the matrix cores bound
