@@ -86,6 +86,7 @@ SIGNATURES = {
     "rstd_from_var": [_P, _I32, _F, _P],
     "bn_act_fwd": [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64],
     "bn_act_bwd_reduce": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P],
+    "act_bias_bwd_reduce": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _P, _I64, _I32, _P, _P, _I64],
     "bn_act_bwd_sums": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P, _P, _P, _P, _I32],
     "bwd_reduce_finalize": [_P, _I32, _I32, _P, _P, _I32],
     "bn_act_bwd_apply": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _P, _I64],

@@ -644,11 +644,15 @@ __device__ __forceinline__ void bwd_reduce_tail(const BwdFin& f, const float* pa
                           shd);
 }
 
+// DY (layers WITHOUT batch norm only): the pass also writes dY = dZ * act'(y) (* mask) -- there the input gradient does
+// not depend on the column sums, so the reduction pass of the bias gradient delivers dY as well and the separate
+// hypel_bn_act_bwd_apply launch (one more read of dZ and Y) goes away (hypel_act_bias_bwd_reduce).
+template <bool DY>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
-    BwdFin fin) {
+    BwdFin fin, float* __restrict__ dy, int64_t lddy) {
     __shared__ float sh[2][STAT_TY][STAT_TX];
     const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
     const int col = blockIdx.y * STAT_TX + tx;
@@ -660,6 +664,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
         for (int64_t r = r0 + ty; r < r1; r += STAT_TY) {
             float dyh, xhat;
             bwd_elem(dz, lddz, y, ldy, r, col, mean, rstd, beta, act, alpha, mask, ldm, dyh, xhat);
+            if constexpr (DY) dy[r * lddy + col] = dyh;
             s0 += dyh;
             s1 += dyh * xhat;
         }
@@ -686,11 +691,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     bwd_reduce_tail(fin, partial, c);
 }
 
+template <bool DY>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
     const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
-    BwdFin fin) {
+    BwdFin fin, float* __restrict__ dy, int64_t lddy) {
     __shared__ float sh[2][STAT_V4_TY][STAT_TX];
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int col = blockIdx.y * STAT_TX + tq * 4;
@@ -715,6 +721,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
             if (mask) mv4 = *reinterpret_cast<const float4*>(mask + r * ldm + col);
             const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w}, gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
             const float mv[4] = {mv4.x, mv4.y, mv4.z, mv4.w};
+            [[maybe_unused]] float dv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float xhat = yv[q], pre = yv[q];
@@ -725,9 +732,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
                 float g = gv[q];
                 if (mask) g *= mv[q];
                 const float dyh = g * hypel_act_grad(pre, act, alpha);
+                if constexpr (DY) dv[q] = dyh;
                 s0[q] += dyh;
                 s1[q] += dyh * xhat;
             }
+            if constexpr (DY) *reinterpret_cast<float4*>(dy + r * lddy + col) = make_float4(dv[0], dv[1], dv[2], dv[3]);
         }
     }
     *reinterpret_cast<float4*>(&sh[0][ty][tq * 4]) = make_float4(s0[0], s0[1], s0[2], s0[3]);
@@ -1444,18 +1453,24 @@ extern "C" int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32
 static int launch_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
                              const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
                              const float* mask, int64_t ldm, int32_t chunk_rows, float* partial, const BwdFin& fin,
-                             hypel_stream_t stream) {
+                             hypel_stream_t stream, float* dy = nullptr, int64_t lddy = 0) {
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
     static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
     const bool v4 = v4_on && (c % 4 == 0) && (lddz % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dz & 15) == 0) &&
-                    (((uintptr_t)y & 15) == 0) && (!mask || ((ldm % 4 == 0) && (((uintptr_t)mask & 15) == 0)));
-    if (v4)
-        hipLaunchKernelGGL(bn_act_bwd_reduce_v4_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST,
-                           dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
-                           fin);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, dz,
-                           lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial, fin);
+                    (((uintptr_t)y & 15) == 0) && (!mask || ((ldm % 4 == 0) && (((uintptr_t)mask & 15) == 0))) &&
+                    (!dy || ((lddy % 4 == 0) && (((uintptr_t)dy & 15) == 0)));
+    const dim3 grid(n_chunks, (c + STAT_TX - 1) / STAT_TX);
+#define HYPEL_BWD_REDUCE(K, D)                                                                                          \
+    hipLaunchKernelGGL(K<D>, grid, dim3(256), 0, ST, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, \
+                       chunk_rows, partial, fin, dy, lddy)
+    if (v4) {
+        if (dy) HYPEL_BWD_REDUCE(bn_act_bwd_reduce_v4_kernel, true);
+        else HYPEL_BWD_REDUCE(bn_act_bwd_reduce_v4_kernel, false);
+    } else {
+        if (dy) HYPEL_BWD_REDUCE(bn_act_bwd_reduce_kernel, true);
+        else HYPEL_BWD_REDUCE(bn_act_bwd_reduce_kernel, false);
+    }
+#undef HYPEL_BWD_REDUCE
     return 0;
 }
 
@@ -1480,6 +1495,17 @@ extern "C" int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float*
     launch_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
                       BwdFin{counters, sums, dparam, accumulate}, stream);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_sums");
+    return 0;
+}
+
+extern "C" int hypel_act_bias_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                         int32_t c, int32_t act, float alpha, const float* mask, int64_t ldm,
+                                         int32_t chunk_rows, float* partial, float* dy, int64_t lddy,
+                                         hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && y && partial && dy && rows > 0 && c > 0 && chunk_rows > 0 && lddy >= c, "hypel_act_bias_bwd_reduce");
+    launch_bwd_reduce(dz, lddz, y, ldy, rows, c, nullptr, nullptr, nullptr, act, alpha, mask, ldm, chunk_rows, partial,
+                      BwdFin{nullptr, nullptr, nullptr, 0}, stream, dy, lddy);
+    HYPEL_CHECK_LAUNCH("hypel_act_bias_bwd_reduce");
     return 0;
 }
 

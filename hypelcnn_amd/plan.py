@@ -70,6 +70,8 @@ SIDE_STREAMS = max(1, int(os.environ.get("HYPEL_SIDE_STREAMS", "0") or 0))
 # but measured SLOWER on MI355X (8.65 vs 7.88 ms/step): every block pays the round trip of a device-scope atomic
 # through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
 FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
+# layers without batch norm: the bias-gradient reduction also writes dY (no separate activation-backward launch)
+ACT_BIAS_BWD = os.environ.get("HYPEL_ACT_BIAS_BWD", "1") != "0"
 GEN_KEEP = os.environ.get("HYPEL_GEN_KEEP", "1") != "0"  # generator backward starts from the forward pass's kept activations
 TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
 SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
@@ -1393,6 +1395,17 @@ class TowerPlan:
                 self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
                 self._scratch(l1, 16, "sums", 2 * c)
                 self.bwd.append(l1)
+            elif (ACT_BIAS_BWD and not has_bn and dy is not None and (code != 0 or mask is not None)
+                  and not self.sync_bn):
+                # no batch norm: dY = dZ * act'(y) needs no column sum -- the bias-gradient reduction writes it too
+                l1 = Launch("act_bias_bwd_reduce", (dz, c, y_ref, c, rows, c, code, alpha, mask, c, chunk, None, dy, c),
+                            nbytes=12 * rows * c, tag="post-bwd-reduce+apply")
+                self._scratch(l1, 11, "scratch_partial", n_chunks * 2 * c)
+                l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, pacc), tag="post-bwd-finalize")
+                self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
+                self._scratch(l2, 3, "sums", 2 * c)
+                self.bwd += [l1, l2]
+                return
             else:
                 l1 = Launch("bn_act_bwd_reduce", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
                                                   chunk, None), nbytes=8 * rows * c, tag="post-bwd-reduce")

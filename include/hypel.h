@@ -242,6 +242,15 @@ int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float* y, int64_t
                           const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
                           const float* mask, int64_t ldm, int32_t chunk_rows, float* partial, int32_t* counters,
                           float* sums, float* dparam, int32_t accumulate, hypel_stream_t stream);
+
+/* hypel_bn_act_bwd_reduce for a layer WITHOUT batch norm (tf_slim.fully_connected / conv2d with biases:
+ * shadow_data_models.py:95-146, DUALCNNModel.py:48-54,99-100) that ALSO writes dY = dZ * act'(y) (* mask): there dY
+ * needs no column sum, so the pass that reduces the bias gradient delivers it and hypel_bn_act_bwd_apply (one more read
+ * of dZ and Y, one more launch) is not needed.  partial as hypel_bn_act_bwd_reduce (finish with
+ * hypel_bwd_reduce_finalize); dy may alias dz. */
+int hypel_act_bias_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                              int32_t act, float alpha, const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
+                              float* dy, int64_t lddy, hypel_stream_t stream);
 /* backward pass 2: dy = rstd*(dyh - sums0/M - xhat*sums1/M)   (or dy = dyh without normalisation).
  * dy may alias dz. */
 int hypel_bn_act_bwd_apply(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,

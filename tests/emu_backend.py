@@ -424,6 +424,11 @@ class EmuBackend:
                                  partial)
         self.k_bwd_reduce_finalize(partial, (rows + chunk_rows - 1) // chunk_rows, c, sums, dparam, accumulate)
 
+    def k_act_bias_bwd_reduce(self, dz, lddz, y, ldy, rows, c, act, alpha, mask, ldm, chunk_rows, partial, dy, lddy):
+        dyh, _ = self._dyh(dz, lddz, y, ldy, rows, c, None, None, None, act, alpha, mask, ldm)
+        self.k_bn_act_bwd_reduce(dz, lddz, y, ldy, rows, c, None, None, None, act, alpha, mask, ldm, chunk_rows, partial)
+        _mat(dy, lddy, rows, c)[...] = dyh.astype(np.float32)
+
     def k_bn_act_small_fwd(self, y, ldy, rows, c, eps, beta, act, alpha, mask, ldm, mean, rstd, mm, mv, decay, z, ldz):
         ym = _mat(y, ldy, rows, c).astype(np.float64)
         mu = ym.mean(0)

@@ -555,6 +555,29 @@ def test_post_op_forward_backward(hip, act, use_bn, use_mask, nres):
     b.check("dy", rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("rows,c,act,use_mask,in_place", [(2048, 64, 1, False, True), (4096, 360, 1, False, True),
+                                                          (1000, 37, 1, True, False), (41472, 240, 2, False, True)])
+def test_act_bias_bwd_reduce_writes_dy(hip, rows, c, act, use_mask, in_place):
+    """hypel_act_bias_bwd_reduce == hypel_bn_act_bwd_reduce + hypel_bn_act_bwd_apply for a layer without batch norm."""
+    rng = np.random.default_rng(rows + c)
+    b = Both(hip)
+    b.arr("y", rng.standard_normal((rows, c)).astype(np.float32))
+    b.arr("dz", rng.standard_normal((rows, c)).astype(np.float32))
+    b.arr("mask", (rng.random((rows, c)) < 0.7).astype(np.float32) / 0.7)
+    chunk = 256
+    nch = (rows + chunk - 1) // chunk
+    b.arr("part", np.zeros(nch * 2 * c, np.float32))
+    b.arr("sums", np.zeros(2 * c, np.float32))
+    b.arr("dparam", rng.standard_normal(c).astype(np.float32))
+    b.arr("dy", np.zeros(rows * c, np.float32))
+    out = "dz" if in_place else "dy"
+    b.run("act_bias_bwd_reduce", "dz", c, "y", c, rows, c, act, 0.18, "mask" if use_mask else None, c, chunk, "part", out, c)
+    b.check(out, rtol=1e-6, atol=1e-7)
+    b.check("part", rtol=1e-4, atol=1e-5)
+    b.run("bwd_reduce_finalize", "part", nch, c, "sums", "dparam", 1)
+    b.check("dparam", rtol=2e-5, atol=2e-5)
+
+
 def test_losses(hip):
     rng = np.random.default_rng(1)
     n, c = 1000, 15
