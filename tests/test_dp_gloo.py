@@ -362,3 +362,59 @@ def test_two_rank_training_episode_runs_in_lock_step(tmp_path, sync_bn):
     train0 = [p for p in r0["plans"] if p[0]]
     assert train0 and all(p[4] == 2 and p[3] == sync_bn for p in train0), r0["plans"]
     assert sorted(p[1] for p in train0) == [20, 25], train0  # the full batch and the short last one
+
+
+def _gan_setup(n, bands, backend):
+    from oracle import gan as OG
+    from tests import gan_util as GU
+    cfg = OG.GanConfig("cycle_gan", bands, max_steps=20, generator_lr=2e-3, discriminator_lr=1e-3)
+    params = GU.fp32(OG.init_gan_params("cycle_gan", bands, np.random.default_rng(2), dtype=np.float64, zero_generator=False))
+    wrapper, model, loss, ops = GU.build(cfg, n, backend)
+    ops.use_pool = False  # the tensor pool draws per rank; the exchange is what is under test
+    sess = ops.ctx.session()
+    GU.inject(sess, params)
+    return ops, sess
+
+
+def _gan_batch(bands):
+    rng = np.random.default_rng(11)
+    return (torch.as_tensor(rng.random((8, bands)).astype(np.float32)),
+            torch.as_tensor((rng.random((8, bands)) * 0.5).astype(np.float32)))
+
+
+def _gan_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu_backend import EmuBackend
+    bands = 16
+    ops, sess = _gan_setup(4, bands, EmuBackend())
+    x, y = _gan_batch(bands)
+    for _ in range(2):
+        ops.run_step(x[rank::2].contiguous(), y[rank::2].contiguous())
+    names = set()
+    for ct in ops.last_losses.values():
+        names |= {l.name for l in ct.plan.fwd + ct.plan.bwd}
+    torch.save({"p": sess.params.clone(), "names": sorted(names), "step": sess.global_step}, os.path.join(outdir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_cyclegan_steps_equal_one_device_at_the_global_batch(tmp_path):
+    """The GAN train ops under data parallelism (gan_common.py: per-phase all-reduce of the phase's variable groups): two
+    ranks on disjoint halves of 8 pairs take the same two CycleGAN steps as one device on all 8 (every loss is a batch
+    mean, nothing in the CycleGAN stacks couples samples) -- with the fused generator and the fused discriminator stack."""
+    port = _free_port()
+    mp.spawn(_gan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    assert torch.equal(r0["p"], r1["p"]) and r0["step"] == 2, "ranks stay in lock step"
+    assert "dense_stack_bwd" in r0["names"] and "gan_generator_bwd_kept" in r0["names"], r0["names"]
+    sys.path.insert(0, ROOT)
+    from tests.emu_backend import EmuBackend
+    ops, sess = _gan_setup(8, 16, EmuBackend())
+    x, y = _gan_batch(16)
+    for _ in range(2):
+        ops.run_step(x, y)
+    scale = float(sess.params.abs().max())
+    torch.testing.assert_close(r0["p"], sess.params, rtol=2e-4, atol=2e-6 * scale)
