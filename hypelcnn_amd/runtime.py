@@ -318,11 +318,21 @@ class Session:
         if self.dist is None:
             return
         import torch.distributed as dist
-        for gname in groups:
-            lo, hi = self.group_ranges[gname]
+        # adjacent groups travel in one call; RCCL averages in the collective (gloo, the CPU test backend, cannot)
+        ranges = []
+        for lo, hi in sorted(self.group_ranges[g] for g in groups):
             if hi > lo:
-                view = self.grads[lo:hi]
-                note_collective()
+                if ranges and ranges[-1][1] == lo:
+                    ranges[-1][1] = hi
+                else:
+                    ranges.append([lo, hi])
+        avg = dist.get_backend() == "nccl"
+        for lo, hi in ranges:
+            view = self.grads[lo:hi]
+            note_collective()
+            if avg:
+                dist.all_reduce(view, op=dist.ReduceOp.AVG)
+            else:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM)
                 view.mul_(1.0 / self.dist[0])
 
