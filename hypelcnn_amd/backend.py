@@ -121,6 +121,9 @@ SIGNATURES = {
     "gan_generator_bwd_kept": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P],
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
     "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
+    "gan_loss_slot": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I64, _I32, _P, _I64, _I32, _P],
+    "l2_reg_slot": [_P, _I64, _F, _P, _P],
+    "loss_finalize_slots": [_P, _I32, _P, _I32],
     "l2norm_fwd": [_P, _I64, _I64, _I32, _P, _I64, _P],
     "l2norm_parts_fwd": [_P, _I64, _I64, _I32, _I32, _P, _I64, _P],
     "l2norm_parts_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _I64, _I32],

@@ -72,6 +72,8 @@ SIDE_STREAMS = max(1, int(os.environ.get("HYPEL_SIDE_STREAMS", "0") or 0))
 FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
 # layers without batch norm: the bias-gradient reduction also writes dY (no separate activation-backward launch)
 ACT_BIAS_BWD = os.environ.get("HYPEL_ACT_BIAS_BWD", "1") != "0"
+# GAN loss terms and regularisers leave weighted partials in slots; one finaliser launch per train op sums them
+LOSS_SLOTS = os.environ.get("HYPEL_LOSS_SLOTS", "1") != "0"
 GEN_KEEP = os.environ.get("HYPEL_GEN_KEEP", "1") != "0"  # generator backward starts from the forward pass's kept activations
 TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
 SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
@@ -1899,6 +1901,7 @@ class PhasePlan(TowerPlan):
             if getattr(self, "_side_open", False):
                 self.bwd.append(self._join_sides())
             self._emit_regularisers()
+            self._finish_loss_slots()
         self._finish_scratch()
 
     # ---- fused generator ----
@@ -2067,8 +2070,10 @@ class PhasePlan(TowerPlan):
         nb = self.nb
         a_st = self.storage_of(term.a)
         a_ref = self._ref(a_st.buf, a_st.ch_off)
-        acc_loss = 1 if ti > 0 else 0
         da, ldda, acc_a = self._grad_ref(term.a)
+        acc_loss = 1 if getattr(self, "_loss_written", False) else 0
+        if term.kind == "nce" or not LOSS_SLOTS:
+            self._loss_written = True
         if term.kind == "nce":
             b_st = self.storage_of(term.b)
             db, lddb, acc_b = self._grad_ref(term.b)
@@ -2084,11 +2089,37 @@ class PhasePlan(TowerPlan):
             b_st = self.storage_of(term.b)
             b_ref, ldb = self._ref(b_st.buf, b_st.ch_off), b_st.ld
             db, lddb, acc_b = self._grad_ref(term.b)
+        if LOSS_SLOTS:
+            # the term's weighted partial sums go to a slot of their own; ONE finaliser adds every slot of the op up
+            l = Launch("gan_loss_slot", (mode, a_ref, a_st.ld, b_ref, ldb, nb, term.a.c, float(term.target),
+                                         float(term.weight), da, ldda, acc_a, db, lddb, acc_b, None), tag="loss-" + term.kind)
+            self._loss_slot(l, 15)
+            self.fwd.append(l)
+            return
         l = Launch("gan_loss", (mode, a_ref, a_st.ld, b_ref, ldb, nb, term.a.c, float(term.target), float(term.weight),
                                 self._ref("loss"), acc_loss, da, ldda, acc_a, db, lddb, acc_b, None),
                    tag="loss-" + term.kind)
         self._scratch(l, 17, "scratch_red")
         self.fwd.append(l)
+
+    def _loss_slot(self, launch, pos):
+        """Give a deferred loss term the next 1024-float slot of the op's slot buffer (allocated in _finish_loss_slots)."""
+        self._slot_launches = getattr(self, "_slot_launches", [])
+        self._slot_launches.append((launch, pos))
+
+    def _finish_loss_slots(self):
+        pend = getattr(self, "_slot_launches", [])
+        if not pend:
+            return
+        self._alloc("loss_slots", 1024 * len(pend))
+        for k, (launch, pos) in enumerate(pend):
+            args = list(launch.args)
+            args[pos] = self._ref("loss_slots", 1024 * k)
+            launch.args = tuple(args)
+        self.bwd.append(Launch("loss_finalize_slots", (self._ref("loss_slots"), len(pend), self._ref("loss"),
+                                                       1 if getattr(self, "_loss_written", False) else 0),
+                               tag="loss-finalize"))
+        self._slot_launches = []
 
     def _emit_regularisers(self):
         """tfgan.gan_loss adds the trained scope's regularisation losses (shadow_data_models.py:96,129).  Variables
@@ -2107,7 +2138,12 @@ class PhasePlan(TowerPlan):
             else:
                 runs.append([off, size, scale])
         for off, size, scale in runs:
-            l = Launch("l2_reg", (Ref(self.sess.params, off), size, scale, self._ref("loss"), 1,
-                                  Ref(self.sess.grads, off), None), tag="l2-reg")
-            self._scratch(l, 6, "scratch_red")
+            if LOSS_SLOTS:
+                l = Launch("l2_reg_slot", (Ref(self.sess.params, off), size, scale, Ref(self.sess.grads, off), None),
+                           tag="l2-reg")
+                self._loss_slot(l, 4)
+            else:
+                l = Launch("l2_reg", (Ref(self.sess.params, off), size, scale, self._ref("loss"), 1,
+                                      Ref(self.sess.grads, off), None), tag="l2-reg")
+                self._scratch(l, 6, "scratch_red")
             self.bwd.append(l)

@@ -842,6 +842,28 @@ def _k_l2_reg(self, w, count, scale, loss, accumulate_loss, dw, ws):
         _arr(dw)[:count] += (scale * wv).astype(np.float32)
 
 
+def _k_gan_loss_slot(self, mode, a, lda, b, ldb, rows, c, target, weight, da, ldda, acc_da, db, lddb, acc_db, slot):
+    tmp = np.zeros(1, np.float32)
+    _k_gan_loss(self, mode, a, lda, b, ldb, rows, c, target, weight, Ref(torch.from_numpy(tmp)), 0, da, ldda, acc_da, db,
+                lddb, acc_db, None)
+    sl = _arr(slot)[:1024]
+    sl[...] = 0.0
+    sl[0] = tmp[0]
+
+
+def _k_l2_reg_slot(self, w, count, scale, dw, slot):
+    tmp = np.zeros(1, np.float32)
+    _k_l2_reg(self, w, count, scale, Ref(torch.from_numpy(tmp)), 0, dw, None)
+    sl = _arr(slot)[:1024]
+    sl[...] = 0.0
+    sl[0] = tmp[0]
+
+
+def _k_loss_finalize_slots(self, slots, n_slots, loss, accumulate_loss):
+    lv = _arr(loss)
+    lv[0] = (lv[0] if accumulate_loss else 0.0) + _arr(slots)[: n_slots * 1024].astype(np.float64).sum()
+
+
 def _k_l2norm_fwd(self, x, ldx, rows, c, y, ldy, stat):
     xv = _mat(x, ldx, rows, c).astype(np.float64)
     ss = (xv * xv).sum()
@@ -907,6 +929,9 @@ EmuBackend.k_gan_generator_fwd = _k_gan_generator_fwd
 EmuBackend.k_gan_generator_bwd = _k_gan_generator_bwd
 EmuBackend.k_gan_loss = _k_gan_loss
 EmuBackend.k_l2_reg = _k_l2_reg
+EmuBackend.k_gan_loss_slot = _k_gan_loss_slot
+EmuBackend.k_l2_reg_slot = _k_l2_reg_slot
+EmuBackend.k_loss_finalize_slots = _k_loss_finalize_slots
 EmuBackend.k_l2norm_fwd = _k_l2norm_fwd
 EmuBackend.k_l2norm_bwd = _k_l2norm_bwd
 EmuBackend.k_nce_loss = _k_nce_loss
