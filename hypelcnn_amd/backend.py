@@ -74,6 +74,7 @@ SIGNATURES = {
                            _P, _I64, _P, _P, _P, _I32, _F, _P],
     "seg_gemm_res_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P],
     "reduce_splits_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I32, _I64],
+    "reduce_splits_pair_f32": [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I32, _I32],
     "seg_gemm_multi_f32": [_P, _I32, _I32, _I32, _P, _P, _I32],
     "reduce_splits_multi_f32": [_P, _P, _I32],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],

@@ -148,6 +148,27 @@ __global__ void reduce_splits_wave_kernel(const float* __restrict__ partial, int
     }
 }
 
+// Two reductions over the same number of slabs in one launch (the filter and the bias gradients of a fused stack:
+// generator, narrow discriminator): output i < count0 belongs to the first, the rest to the second; per output the same
+// lanes-over-slabs butterfly as reduce_splits_wave_kernel (bit-identical to two separate launches).
+__global__ void reduce_splits_wave_pair_kernel(const float* __restrict__ p0, int64_t stride0, int64_t count0,
+                                               float* __restrict__ out0, const float* __restrict__ p1, int64_t stride1,
+                                               int64_t count1, float* __restrict__ out1, int n_splits, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < count0 + count1; i += n_waves) {
+        const bool first = i < count0;
+        const float* __restrict__ p = first ? p0 : p1;
+        const int64_t stride = first ? stride0 : stride1, o = first ? i : i - count0;
+        float* __restrict__ out = first ? out0 : out1;
+        float s = 0.0f;
+        for (int k = lane; k < n_splits; k += 64) s += p[(int64_t)k * stride + o];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) out[o] = accumulate ? out[o] + s : s;
+    }
+}
+
 // float4 variant (count, n, ldc, stride multiples of 4; 16-byte aligned bases)
 __global__ void reduce_splits_v4_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
                                         float* __restrict__ out, int64_t count4, int accumulate,
@@ -1342,6 +1363,22 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
                            partial, stride, n_splits, out, count, accumulate, bias, n, ldc);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
     return 0;
+}
+
+extern "C" int hypel_reduce_splits_pair_f32(const float* partial0, int64_t stride0, int64_t count0, float* out0,
+                                            const float* partial1, int64_t stride1, int64_t count1, float* out1,
+                                            int32_t n_splits, int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(partial0 && out0 && partial1 && out1 && n_splits >= 1 && count0 > 0 && count1 > 0,
+                  "hypel_reduce_splits_pair_f32");
+    if (n_splits >= 32 && count0 <= 65536 && count1 <= 65536) {  // the form hypel_reduce_splits_f32 would pick for both
+        hipLaunchKernelGGL(reduce_splits_wave_pair_kernel, dim3(hypel_grid_1d((count0 + count1) * 64, 256)), dim3(256), 0, ST,
+                           partial0, stride0, count0, out0, partial1, stride1, count1, out1, n_splits, accumulate);
+        HYPEL_CHECK_LAUNCH("hypel_reduce_splits_pair_f32");
+        return 0;
+    }
+    int rc = hypel_reduce_splits_f32(partial0, stride0, n_splits, out0, count0, accumulate, nullptr, 0, 0, stream);
+    if (rc == 0) rc = hypel_reduce_splits_f32(partial1, stride1, n_splits, out1, count1, accumulate, nullptr, 0, 0, stream);
+    return rc;
 }
 
 extern "C" int hypel_reduce_splits_multi_f32(const float* base, const hypel_reduce_entry_t* entries, int32_t n_entries,

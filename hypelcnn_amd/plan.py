@@ -1951,11 +1951,12 @@ class PhasePlan(TowerPlan):
         self.bwd.append(l1)
         if self._trains(node.weights):
             wacc = self._param_acc(w0)
-            l2 = Launch("reduce_splits_f32", (None, wtotal, blocks, self._g(w0), wtotal, wacc, None, 0, 0), tag="gen-dw")
+            # filter and bias slabs in one launch
+            l2 = Launch("reduce_splits_pair_f32", (None, wtotal, wtotal, self._g(w0), None, 8, 7, self._g(b0), blocks, wacc),
+                        tag="gen-dw+db")
             self._scratch(l2, 0, "scratch_gen_w", blocks * wtotal)
-            l3 = Launch("reduce_splits_f32", (None, 8, blocks, self._g(b0), 7, wacc, None, 0, 0), tag="gen-db")
-            self._scratch(l3, 0, "scratch_gen_b", blocks * 8)
-            self.bwd += [l2, l3]
+            self._scratch(l2, 4, "scratch_gen_b", blocks * 8)
+            self.bwd.append(l2)
 
     # ---- fused fully-connected stack (narrow discriminators) ----
     def _densestack_args(self, node):
@@ -2000,11 +2001,11 @@ class PhasePlan(TowerPlan):
             wacc = self._param_acc(w0)
             for v in node.weights[1:] + node.biases:
                 self._param_acc(v)
-            l2 = Launch("reduce_splits_f32", (None, wtotal, blocks, self._g(w0), wtotal, wacc, None, 0, 0), tag="ds-dw")
+            l2 = Launch("reduce_splits_pair_f32", (None, wtotal, wtotal, self._g(w0), None, btotal, btotal, self._g(b0),
+                                                   blocks, wacc), tag="ds-dw+db")
             self._scratch(l2, 0, "scratch_ds_w", blocks * wtotal)
-            l3 = Launch("reduce_splits_f32", (None, btotal, blocks, self._g(b0), btotal, wacc, None, 0, 0), tag="ds-db")
-            self._scratch(l3, 0, "scratch_ds_b", blocks * btotal)
-            self.bwd += [l2, l3]
+            self._scratch(l2, 4, "scratch_ds_b", blocks * btotal)
+            self.bwd.append(l2)
 
     # ---- feature stack (global l2 normalise per slice, stacked) ----
     def _fwd_featstack(self, idx, node):

@@ -180,6 +180,13 @@ int hypel_reduce_splits_multi_f32(const float* base, const hypel_reduce_entry_t*
 int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_splits, float* out, int64_t count,
                             int32_t accumulate, const float* bias, int32_t n, int64_t ldc, hypel_stream_t stream);
 
+/* Two hypel_reduce_splits_f32 (dense, no bias) over the same n_splits slabs in one launch -- the filter and the bias
+ * gradients a fused stack (hypel_gan_generator_bwd, hypel_dense_stack_bwd) leaves per block; bit-identical to the two
+ * separate calls. */
+int hypel_reduce_splits_pair_f32(const float* partial0, int64_t stride0, int64_t count0, float* out0,
+                                 const float* partial1, int64_t stride1, int64_t count1, float* out1, int32_t n_splits,
+                                 int32_t accumulate, hypel_stream_t stream);
+
 /* ---- batch norm statistics (tf_slim.batch_norm fused, HYPELCNNModel.py:37,43-44) ------------------
  * partial[chunk][0][c] = mean of the chunk's rows, partial[chunk][1][c] = sum of squared deviations.
  * chunk = `chunk_rows` consecutive rows (last may be short). */

@@ -401,6 +401,10 @@ class EmuBackend:
         else:
             ov[idx] = tot.astype(np.float32)
 
+    def k_reduce_splits_pair_f32(self, p0, stride0, count0, out0, p1, stride1, count1, out1, n_splits, accumulate):
+        self.k_reduce_splits_f32(p0, stride0, n_splits, out0, count0, accumulate)
+        self.k_reduce_splits_f32(p1, stride1, n_splits, out1, count1, accumulate)
+
     def k_col_stats_partial(self, x, ld, rows, c, chunk_rows, partial):
         xm = _mat(x, ld, rows, c)
         n_chunks = (rows + chunk_rows - 1) // chunk_rows

@@ -578,6 +578,22 @@ def test_act_bias_bwd_reduce_writes_dy(hip, rows, c, act, use_mask, in_place):
     b.check("dparam", rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("splits,c0,c1,acc", [(128, 10240, 160, 0), (512, 1305, 7, 1), (3, 1000, 8, 1), (40, 70000, 5, 0)])
+def test_reduce_splits_pair_bit_identical(hip, splits, c0, c1, acc):
+    """hypel_reduce_splits_pair_f32 == two hypel_reduce_splits_f32, bit for bit (whichever kernel form the shapes pick)."""
+    rng = np.random.default_rng(splits + c0)
+    p0 = torch.from_numpy(rng.standard_normal(splits * c0).astype(np.float32)).cuda()
+    p1 = torch.from_numpy(rng.standard_normal(splits * (c1 + 1)).astype(np.float32)).cuda()
+    init0 = torch.from_numpy(rng.standard_normal(c0).astype(np.float32)).cuda()
+    init1 = torch.from_numpy(rng.standard_normal(c1).astype(np.float32)).cuda()
+    a0, a1, b0, b1 = init0.clone(), init1.clone(), init0.clone(), init1.clone()
+    hip.call("reduce_splits_f32", Ref(p0), c0, splits, Ref(a0), c0, acc, None, 0, 0)
+    hip.call("reduce_splits_f32", Ref(p1), c1 + 1, splits, Ref(a1), c1, acc, None, 0, 0)
+    hip.call("reduce_splits_pair_f32", Ref(p0), c0, c0, Ref(b0), Ref(p1), c1 + 1, c1, Ref(b1), splits, acc)
+    hip.synchronize()
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
 def test_losses(hip):
     rng = np.random.default_rng(1)
     n, c = 1000, 15
