@@ -28,6 +28,11 @@ ABI_VERSION = 2  # include/hypel.h HYPEL_ABI_VERSION: a library built from other
 SEG_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("k", "<i4"), ("reserved", "<i4")])
 GROUP_DTYPE = np.dtype([("c_off", "<i8"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("rows", "<i4"),
                         ("reserved", "<i4")])
+LOSS_TERM_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("da_off", "<i8"), ("db_off", "<i8"), ("lda", "<i8"),
+                            ("ldb", "<i8"), ("ldda", "<i8"), ("lddb", "<i8"), ("rows", "<i8"), ("mode", "<i4"), ("c", "<i4"),
+                            ("acc_da", "<i4"), ("acc_db", "<i4"), ("target", "<f4"), ("gcoef", "<f4"), ("pscale", "<f4"),
+                            ("slot", "<i4")])
+LOSS_NONE = -(1 << 63)
 MTILE_DTYPE = np.dtype([("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8"), ("m0", "<i4"), ("rows", "<i4"),
                         ("n0", "<i4"), ("n", "<i4"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("k0", "<i4"),
                         ("flags", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"), ("reserved", "<i4")])
@@ -122,9 +127,8 @@ SIGNATURES = {
     "gan_generator_bwd_kept": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P],
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
     "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
-    "gan_loss_slot": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I64, _I32, _P, _I64, _I32, _P],
-    "l2_reg_slot": [_P, _I64, _F, _P, _P],
     "loss_finalize_slots": [_P, _I32, _P, _I32],
+    "loss_terms_slots": [_P, _P, _I32, _P],
     "l2norm_fwd": [_P, _I64, _I64, _I32, _P, _I64, _P],
     "l2norm_parts_fwd": [_P, _I64, _I64, _I32, _I32, _P, _I64, _P],
     "l2norm_parts_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _I64, _I32],

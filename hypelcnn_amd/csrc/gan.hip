@@ -958,28 +958,68 @@ extern "C" int hypel_gan_loss(int32_t mode, const float* a, int64_t lda, const f
 }
 
 // ---- loss terms with a DEFERRED sum: every term of a train op leaves its (already weighted) block partials in its own
-// 1024-float slot; ONE hypel_loss_finalize_slots at the end of the op adds the slots up in index order.  A CycleGAN
-// generator op has six terms + regularisers: six finaliser launches of ~4.7 us less.
+// 1024-float slot; ONE hypel_loss_finalize_slots at the end of the op adds the slots up in index order, and terms that
+// write different gradient buffers share one launch.  A CycleGAN generator op has six terms + regularisers: thirteen
+// launches of ~4.7 us become three.
 constexpr int LOSS_SLOT = 1024;
 
-extern "C" int hypel_gan_loss_slot(int32_t mode, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,
-                                   int32_t c, float target, float weight, float* da, int64_t ldda, int32_t acc_da,
-                                   float* db, int64_t lddb, int32_t acc_db, float* slot, hypel_stream_t stream) {
-    HYPEL_REQUIRE(a && slot && rows > 0 && c > 0 && mode >= 0 && mode <= 2, "hypel_gan_loss_slot");
-    HYPEL_REQUIRE(mode != 1 || b != nullptr, "hypel_gan_loss_slot");
-    const double count = (double)rows * c;
-    // always LOSS_SLOT blocks: a block without a row writes 0 into its place
-    hipLaunchKernelGGL(gan_loss_partial_kernel, dim3(LOSS_SLOT), dim3(256), 0, ST, mode, a, lda, b, ldb, rows, c, target,
-                       (float)(weight / count), da, ldda, acc_da, db, lddb, acc_db, slot, (float)(weight / count));
-    HYPEL_CHECK_LAUNCH("hypel_gan_loss_slot");
-    return 0;
+// Several loss terms in ONE launch (blockIdx.y = term; every operand addressed relative to one base pointer, like the
+// merged filter-gradient products): modes 0-2 as hypel_gan_loss, mode 3 = l2 regulariser (a = w, rows = count, c = 1,
+// da = dw, always accumulated, gcoef = scale).  A term's weighted block partials go to its slot.
+__global__ __launch_bounds__(256) void loss_terms_kernel(const float* __restrict__ base,
+                                                          const hypel_loss_term_t* __restrict__ terms,
+                                                          float* __restrict__ slots) {
+    __shared__ float sh[4];
+    const hypel_loss_term_t t = terms[blockIdx.y];
+    const float* __restrict__ a = base + t.a_off;
+    const float* __restrict__ b = t.b_off == HYPEL_LOSS_NONE ? nullptr : base + t.b_off;
+    float* __restrict__ da = t.da_off == HYPEL_LOSS_NONE ? nullptr : const_cast<float*>(base) + t.da_off;
+    float* __restrict__ db = t.db_off == HYPEL_LOSS_NONE ? nullptr : const_cast<float*>(base) + t.db_off;
+    float s = 0.0f;
+    if (t.mode == 3) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.rows; i += (int64_t)gridDim.x * 256) {
+            const float v = a[i];
+            s += v * v;
+            if (da) da[i] += t.gcoef * v;
+        }
+    } else {
+        for (int64_t row = blockIdx.x; row < t.rows; row += gridDim.x)
+            for (int col = threadIdx.x; col < t.c; col += 256) {
+                const float av = a[row * t.lda + col];
+                float val, ga, gb = 0.0f;
+                if (t.mode == 0) {
+                    const float d = av - t.target;
+                    val = d * d;
+                    ga = 2.0f * d;
+                } else if (t.mode == 1) {
+                    const float d = av - b[row * t.ldb + col];
+                    val = fabsf(d);
+                    ga = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+                    gb = -ga;
+                } else {
+                    val = av;
+                    ga = 1.0f;
+                }
+                s += val;
+                if (da) {
+                    float* p = da + row * t.ldda + col;
+                    *p = (t.acc_da ? *p : 0.0f) + t.gcoef * ga;
+                }
+                if (db) {
+                    float* p = db + row * t.lddb + col;
+                    *p = (t.acc_db ? *p : 0.0f) + t.gcoef * gb;
+                }
+            }
+    }
+    const float tot = block_sum_256(s, sh);
+    if (threadIdx.x == 0) slots[(int64_t)t.slot * LOSS_SLOT + blockIdx.x] = tot * t.pscale;
 }
 
-extern "C" int hypel_l2_reg_slot(const float* w, int64_t count, float scale, float* dw, float* slot,
-                                 hypel_stream_t stream) {
-    HYPEL_REQUIRE(w && slot && count > 0, "hypel_l2_reg_slot");
-    hipLaunchKernelGGL(l2_reg_kernel, dim3(LOSS_SLOT), dim3(256), 0, ST, w, count, scale, dw, slot, 0.5f * scale);
-    HYPEL_CHECK_LAUNCH("hypel_l2_reg_slot");
+extern "C" int hypel_loss_terms_slots(const float* base, const hypel_loss_term_t* terms, int32_t n_terms, float* slots,
+                                      hypel_stream_t stream) {
+    HYPEL_REQUIRE(base && terms && slots && n_terms > 0, "hypel_loss_terms_slots");
+    hipLaunchKernelGGL(loss_terms_kernel, dim3(LOSS_SLOT, n_terms), dim3(256), 0, ST, base, terms, slots);
+    HYPEL_CHECK_LAUNCH("hypel_loss_terms_slots");
     return 0;
 }
 

@@ -1880,6 +1880,7 @@ class PhasePlan(TowerPlan):
                 raise TypeError(node)
         for ti, term in enumerate(self.terms):
             self._emit_term(ti, term)
+        self._flush_loss_terms()
         if self.terms:
             for idx in range(len(self.tower.nodes) - 1, -1, -1):
                 node = self.tower.nodes[idx]
@@ -2076,6 +2077,7 @@ class PhasePlan(TowerPlan):
         if term.kind == "nce" or not LOSS_SLOTS:
             self._loss_written = True
         if term.kind == "nce":
+            self._flush_loss_terms()  # the batched terms before it keep their place in the order of gradient writes
             b_st = self.storage_of(term.b)
             db, lddb, acc_b = self._grad_ref(term.b)
             l = Launch("nce_loss", (a_ref, a_st.ld, self._ref(b_st.buf, b_st.ch_off), b_st.ld, nb, int(term.parts),
@@ -2091,11 +2093,12 @@ class PhasePlan(TowerPlan):
             b_ref, ldb = self._ref(b_st.buf, b_st.ch_off), b_st.ld
             db, lddb, acc_b = self._grad_ref(term.b)
         if LOSS_SLOTS:
-            # the term's weighted partial sums go to a slot of their own; ONE finaliser adds every slot of the op up
-            l = Launch("gan_loss_slot", (mode, a_ref, a_st.ld, b_ref, ldb, nb, term.a.c, float(term.target),
-                                         float(term.weight), da, ldda, acc_a, db, lddb, acc_b, None), tag="loss-" + term.kind)
-            self._loss_slot(l, 15)
-            self.fwd.append(l)
+            # the term's weighted partial sums go to a slot of their own; ONE finaliser adds every slot of the op up, and
+            # terms that write different gradient buffers share ONE launch (_flush_loss_terms)
+            coef = float(term.weight) / (nb * term.a.c)
+            self._batch_loss_term(self.fwd, dict(mode=mode, a=a_ref, lda=a_st.ld, b=b_ref, ldb=ldb, rows=nb, c=term.a.c,
+                                                 target=float(term.target), gcoef=coef, pscale=coef, da=da, ldda=ldda,
+                                                 acc_da=acc_a, db=db, lddb=lddb, acc_db=acc_b))
             return
         l = Launch("gan_loss", (mode, a_ref, a_st.ld, b_ref, ldb, nb, term.a.c, float(term.target), float(term.weight),
                                 self._ref("loss"), acc_loss, da, ldda, acc_a, db, lddb, acc_b, None),
@@ -2103,21 +2106,78 @@ class PhasePlan(TowerPlan):
         self._scratch(l, 17, "scratch_red")
         self.fwd.append(l)
 
+    def _batch_loss_term(self, lst, t):
+        """Collect a deferred loss term; terms of a batch run concurrently in one launch, so a term that writes a gradient
+        buffer an earlier term of the batch writes (or reads) closes that batch first."""
+        batch = self.__dict__.setdefault("_term_batch", [])
+        if batch and self._term_list is not lst:
+            self._flush_loss_terms()
+            batch = self._term_batch
+        def spans(u, keys):
+            out = []
+            for k, ldk in keys:
+                r = u[k]
+                if r is not None:
+                    n = u["rows"] if u["mode"] == 3 else (u["rows"] - 1) * u[ldk] + u["c"]
+                    out.append((id(r.t), r.off, r.off + n))
+            return out
+
+        def hit(xs, ys):
+            return any(a[0] == b[0] and a[1] < b[2] and b[1] < a[2] for a in xs for b in ys)
+
+        outs, ins = spans(t, (("da", "ldda"), ("db", "lddb"))), spans(t, (("a", "lda"), ("b", "ldb")))
+        for u in batch:
+            u_outs, u_ins = spans(u, (("da", "ldda"), ("db", "lddb"))), spans(u, (("a", "lda"), ("b", "ldb")))
+            if hit(outs, u_outs + u_ins) or hit(ins, u_outs):
+                self._flush_loss_terms()
+                break
+        self._term_list = lst
+        self._term_batch.append(t)
+
+    def _flush_loss_terms(self):
+        from .backend import LOSS_NONE, LOSS_TERM_DTYPE
+        batch = self.__dict__.get("_term_batch") or []
+        self._term_batch = []
+        if not batch:
+            return
+        base = Ref(self.sess.params)
+        base_ptr = base.ptr()
+
+        def rel(ref):
+            if ref is None:
+                return LOSS_NONE
+            d = ref.ptr() - base_ptr
+            assert d % 4 == 0
+            return d // 4
+
+        first = getattr(self, "_n_loss_slots", 0)
+        self._n_loss_slots = first + len(batch)
+        arr = np.array([(rel(t["a"]), rel(t["b"]), rel(t["da"]), rel(t["db"]), t["lda"], t["ldb"], t["ldda"], t["lddb"],
+                         t["rows"], t["mode"], t["c"], t["acc_da"], t["acc_db"], t["target"], t["gcoef"], t["pscale"],
+                         first + k) for k, t in enumerate(batch)], LOSS_TERM_DTYPE)
+        e_t = self.be.upload(arr)
+        self.tables.append(e_t)
+        l = Launch("loss_terms_slots", (base, Ref(e_t), len(batch), None), tag=f"loss-terms/{len(batch)}")
+        self._loss_slot(l, 3)
+        self._term_list.append(l)
+
     def _loss_slot(self, launch, pos):
         """Give a deferred loss term the next 1024-float slot of the op's slot buffer (allocated in _finish_loss_slots)."""
         self._slot_launches = getattr(self, "_slot_launches", [])
         self._slot_launches.append((launch, pos))
 
     def _finish_loss_slots(self):
+        self._flush_loss_terms()
         pend = getattr(self, "_slot_launches", [])
-        if not pend:
+        n_slots = getattr(self, "_n_loss_slots", 0)
+        if not pend or not n_slots:
             return
-        self._alloc("loss_slots", 1024 * len(pend))
-        for k, (launch, pos) in enumerate(pend):
+        self._alloc("loss_slots", 1024 * n_slots)
+        for launch, pos in pend:
             args = list(launch.args)
-            args[pos] = self._ref("loss_slots", 1024 * k)
+            args[pos] = self._ref("loss_slots")
             launch.args = tuple(args)
-        self.bwd.append(Launch("loss_finalize_slots", (self._ref("loss_slots"), len(pend), self._ref("loss"),
+        self.bwd.append(Launch("loss_finalize_slots", (self._ref("loss_slots"), n_slots, self._ref("loss"),
                                                        1 if getattr(self, "_loss_written", False) else 0),
                                tag="loss-finalize"))
         self._slot_launches = []
@@ -2140,9 +2200,11 @@ class PhasePlan(TowerPlan):
                 runs.append([off, size, scale])
         for off, size, scale in runs:
             if LOSS_SLOTS:
-                l = Launch("l2_reg_slot", (Ref(self.sess.params, off), size, scale, Ref(self.sess.grads, off), None),
-                           tag="l2-reg")
-                self._loss_slot(l, 4)
+                self._batch_loss_term(self.bwd, dict(mode=3, a=Ref(self.sess.params, off), lda=0, b=None, ldb=0, rows=size,
+                                                     c=1, target=0.0, gcoef=scale, pscale=0.5 * scale,
+                                                     da=Ref(self.sess.grads, off), ldda=0, acc_da=1, db=None, lddb=0,
+                                                     acc_db=0))
+                continue
             else:
                 l = Launch("l2_reg", (Ref(self.sess.params, off), size, scale, self._ref("loss"), 1,
                                       Ref(self.sess.grads, off), None), tag="l2-reg")

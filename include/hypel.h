@@ -436,15 +436,25 @@ int hypel_l2_reg(const float* w, int64_t count, float scale, float* loss, int32_
                  float* ws, hypel_stream_t stream);
 
 /* The same terms with a DEFERRED sum: every loss term of a train op (tfgan tuple losses, cycle / identity L1, the scope's
- * l2 regularisers) leaves its weighted block partials in its own slot of 1024 floats; ONE hypel_loss_finalize_slots at
- * the end of the op adds slots [0, n_slots) in index order into the op's loss -- one finaliser launch per op instead of
- * one per term.  Gradients are written exactly as by hypel_gan_loss / hypel_l2_reg. */
-int hypel_gan_loss_slot(int32_t mode, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t c,
-                        float target, float weight, float* da, int64_t ldda, int32_t acc_da, float* db, int64_t lddb,
-                        int32_t acc_db, float* slot, hypel_stream_t stream);
-int hypel_l2_reg_slot(const float* w, int64_t count, float scale, float* dw, float* slot, hypel_stream_t stream);
+ * l2 regularisers) leaves its weighted block partials in its own slot of 1024 floats (hypel_loss_terms_slots); ONE
+ * hypel_loss_finalize_slots at the end of the op adds slots [0, n_slots) in index order into the op's loss -- one
+ * finaliser launch per op instead of one per term. */
 int hypel_loss_finalize_slots(const float* slots, int32_t n_slots, float* loss, int32_t accumulate_loss,
                               hypel_stream_t stream);
+
+/* Several of those terms in ONE launch.  Offsets are in elements relative to `base` (HYPEL_LOSS_NONE = operand absent);
+ * mode 0-2 as hypel_gan_loss (gcoef = weight / (rows * c), pscale = the same), mode 3 = hypel_l2_reg (a = w, rows =
+ * count, da = dw, gcoef = scale, pscale = scale / 2).  Two terms of one launch must not write the same gradient buffer. */
+#define HYPEL_LOSS_NONE INT64_MIN
+typedef struct {
+    int64_t a_off, b_off, da_off, db_off;
+    int64_t lda, ldb, ldda, lddb, rows;
+    int32_t mode, c, acc_da, acc_db;
+    float target, gcoef, pscale;
+    int32_t slot;
+} hypel_loss_term_t;
+int hypel_loss_terms_slots(const float* base, const hypel_loss_term_t* terms, int32_t n_terms, float* slots,
+                           hypel_stream_t stream);
 /* tf.math.l2_normalize(axis=None) over the whole [rows x c] tensor (shadow_data_models.py:147).
  * stat[0] = sum x^2, stat[1] = rsqrt(max(sum, 1e-12)). */
 /* `parts` adjacent [rows x c] column blocks of one matrix, each normalised by its own whole-block norm, in one

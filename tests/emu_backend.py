@@ -10,7 +10,7 @@ import torch
 
 import ctypes
 
-from hypelcnn_amd.backend import (COLLECTIVES, GROUP_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref,
+from hypelcnn_amd.backend import (COLLECTIVES, GROUP_DTYPE, LOSS_NONE, LOSS_TERM_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref,
                                   bind_collective)
 
 
@@ -846,21 +846,45 @@ def _k_l2_reg(self, w, count, scale, loss, accumulate_loss, dw, ws):
         _arr(dw)[:count] += (scale * wv).astype(np.float32)
 
 
-def _k_gan_loss_slot(self, mode, a, lda, b, ldb, rows, c, target, weight, da, ldda, acc_da, db, lddb, acc_db, slot):
-    tmp = np.zeros(1, np.float32)
-    _k_gan_loss(self, mode, a, lda, b, ldb, rows, c, target, weight, Ref(torch.from_numpy(tmp)), 0, da, ldda, acc_da, db,
-                lddb, acc_db, None)
-    sl = _arr(slot)[:1024]
-    sl[...] = 0.0
-    sl[0] = tmp[0]
+def _k_loss_terms_slots(self, base, terms, n_terms, slots):
+    ents = terms.t.numpy()[terms.off:].view(LOSS_TERM_DTYPE)[:n_terms]
+    sl = _arr(slots)
+    for e in ents:
+        rows, c, mode = int(e["rows"]), int(e["c"]), int(e["mode"])
+        slot = sl[int(e["slot"]) * 1024:(int(e["slot"]) + 1) * 1024]
+        slot[...] = 0.0
 
+        def mat(off, ld):
+            if int(off) == LOSS_NONE:
+                return None
+            flat = _at(base, int(off), (rows - 1) * int(ld) + c)
+            return np.lib.stride_tricks.as_strided(flat, shape=(rows, c), strides=(int(ld) * 4, 4))
 
-def _k_l2_reg_slot(self, w, count, scale, dw, slot):
-    tmp = np.zeros(1, np.float32)
-    _k_l2_reg(self, w, count, scale, Ref(torch.from_numpy(tmp)), 0, dw, None)
-    sl = _arr(slot)[:1024]
-    sl[...] = 0.0
-    sl[0] = tmp[0]
+        if mode == 3:
+            w = _at(base, int(e["a_off"]), rows).astype(np.float64)
+            slot[0] = np.float32(float(e["pscale"]) * (w * w).sum())
+            if int(e["da_off"]) != LOSS_NONE:
+                _at(base, int(e["da_off"]), rows)[...] += (float(e["gcoef"]) * w).astype(np.float32)
+            continue
+        av = mat(e["a_off"], e["lda"]).astype(np.float64)
+        if mode == 0:
+            d = av - float(e["target"])
+            val, ga, gb = (d * d).sum(), 2 * d, None
+        elif mode == 1:
+            d = av - mat(e["b_off"], e["ldb"])
+            val, ga = np.abs(d).sum(), np.sign(d)
+            gb = -ga
+        else:
+            val, ga, gb = av.sum(), np.ones_like(av), None
+        slot[0] = np.float32(float(e["pscale"]) * val)
+        for off, ld, acc, gr in ((e["da_off"], e["ldda"], e["acc_da"], ga), (e["db_off"], e["lddb"], e["acc_db"], gb)):
+            m = mat(off, ld)
+            if m is not None and gr is not None:
+                upd = (float(e["gcoef"]) * gr).astype(np.float32)
+                if int(acc):
+                    m += upd
+                else:
+                    m[...] = upd
 
 
 def _k_loss_finalize_slots(self, slots, n_slots, loss, accumulate_loss):
@@ -933,9 +957,8 @@ EmuBackend.k_gan_generator_fwd = _k_gan_generator_fwd
 EmuBackend.k_gan_generator_bwd = _k_gan_generator_bwd
 EmuBackend.k_gan_loss = _k_gan_loss
 EmuBackend.k_l2_reg = _k_l2_reg
-EmuBackend.k_gan_loss_slot = _k_gan_loss_slot
-EmuBackend.k_l2_reg_slot = _k_l2_reg_slot
 EmuBackend.k_loss_finalize_slots = _k_loss_finalize_slots
+EmuBackend.k_loss_terms_slots = _k_loss_terms_slots
 EmuBackend.k_l2norm_fwd = _k_l2norm_fwd
 EmuBackend.k_l2norm_bwd = _k_l2norm_bwd
 EmuBackend.k_nce_loss = _k_nce_loss

@@ -55,7 +55,8 @@ def test_signature_table_matches_header():
 
 
 def test_table_struct_layouts_match_header():
-    from hypelcnn_amd.backend import GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE
+    from hypelcnn_amd.backend import GROUP_DTYPE, LOSS_TERM_DTYPE, SEG_DTYPE, TILE_DTYPE
+    assert LOSS_TERM_DTYPE.itemsize == 104 and LOSS_TERM_DTYPE.fields["mode"][1] == 72 and LOSS_TERM_DTYPE.fields["slot"][1] == 100
     assert SEG_DTYPE.itemsize == 24 and GROUP_DTYPE.itemsize == 24 and TILE_DTYPE.itemsize == 72
     assert SEG_DTYPE.fields["b_off"][1] == 8 and SEG_DTYPE.fields["k"][1] == 16
     assert GROUP_DTYPE.fields["seg_begin"][1] == 8 and GROUP_DTYPE.fields["rows"][1] == 16
