@@ -674,6 +674,88 @@ __global__ __launch_bounds__(1024) void l2norm_bwd_kernel(const float* __restric
     }
 }
 
+// The same two kernels for parts of at most 16 K elements (the CUT embeddings: 4096 x 2 per part): a thread's <= 16
+// elements stay in registers between the reduction and the scaling pass, 32-bit index arithmetic, wave shuffles + one
+// 16-entry LDS hop instead of a 10-level LDS tree (forward 8.9 -> ~5 us, backward 14.7 -> ~6 us at 4096 x 12).
+constexpr int L2N_R = 16;
+
+__device__ __forceinline__ double l2n_block_sum(double s, double* sh16) {
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh16[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh16[w];  // every thread, fixed order
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void l2norm_fwd_small_kernel(const float* __restrict__ x, int ldx, int rows, int c,
+                                                                float* __restrict__ y, int ldy,
+                                                                float* __restrict__ stat) {
+    __shared__ double sh16[16];
+    x += blockIdx.x * c;
+    y += blockIdx.x * c;
+    stat += 2 * blockIdx.x;
+    const int total = rows * c;
+    float v[L2N_R];
+    int off_y[L2N_R];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < L2N_R; ++k) {
+        const int i = threadIdx.x + 1024 * k;
+        const int r = i / c, q = i - r * c;
+        v[k] = i < total ? x[r * ldx + q] : 0.0f;
+        off_y[k] = r * ldy + q;
+    }
+#pragma unroll
+    for (int k = 0; k < L2N_R; ++k) s += (double)v[k] * v[k];
+    const double ss = l2n_block_sum(s, sh16);
+    const float inv = (float)(1.0 / sqrt(ss > 1e-12 ? ss : 1e-12));
+    if (threadIdx.x == 0) {
+        stat[0] = (float)ss;
+        stat[1] = inv;
+    }
+#pragma unroll
+    for (int k = 0; k < L2N_R; ++k)
+        if ((int)threadIdx.x + 1024 * k < total) y[off_y[k]] = v[k] * inv;
+}
+
+__global__ __launch_bounds__(1024) void l2norm_bwd_small_kernel(const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ dy, int lddy, int rows, int c,
+                                                                const float* __restrict__ stat, float* __restrict__ dx,
+                                                                int lddx, int accumulate) {
+    __shared__ double sh16[16];
+    x += blockIdx.x * c;
+    dy += blockIdx.x * c;
+    dx += blockIdx.x * c;
+    stat += 2 * blockIdx.x;
+    const int total = rows * c;
+    const float inv = stat[1], ss = stat[0];
+    float xv[L2N_R], gv[L2N_R], old[L2N_R];
+    int off_d[L2N_R];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < L2N_R; ++k) {
+        const int i = threadIdx.x + 1024 * k;
+        const int r = i / c, q = i - r * c;
+        const bool in = i < total;
+        xv[k] = in ? x[r * ldx + q] : 0.0f;
+        gv[k] = in ? dy[r * lddy + q] : 0.0f;
+        off_d[k] = r * lddx + q;
+        old[k] = in && accumulate ? dx[off_d[k]] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < L2N_R; ++k) s += (double)xv[k] * (double)gv[k];
+    const float dot = (float)l2n_block_sum(s, sh16);
+    const float coef = ss > 1e-12f ? dot * inv * inv * inv : 0.0f;
+#pragma unroll
+    for (int k = 0; k < L2N_R; ++k)
+        if ((int)threadIdx.x + 1024 * k < total) {
+            const float g = gv[k] * inv - xv[k] * coef;
+            dx[off_d[k]] = accumulate ? old[k] + g : g;
+        }
+}
+
 // patch-NCE (cut_wrapper.py:360-420): per sample logits[p][q] = <g_p, r_q>/tau over e, labels = eye(P) flattened:
 //   loss_n = P * logsumexp(all P^2 logits) - sum_p logits[p][p];  d logits = P*softmax - eye.
 __global__ void nce_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ r, int64_t ldr,
@@ -1046,7 +1128,12 @@ extern "C" int hypel_l2_reg(const float* w, int64_t count, float scale, float* l
 extern "C" int hypel_l2norm_parts_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t parts, float* y,
                                       int64_t ldy, float* stat, hypel_stream_t stream) {
     HYPEL_REQUIRE(x && y && stat && rows > 0 && c > 0 && parts > 0, "hypel_l2norm_parts_fwd");
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, rows, c, y, ldy, stat);
+    const bool small = rows * c <= L2N_R * 1024 && rows * (ldx > ldy ? ldx : ldy) < (1ll << 30);
+    if (small)
+        hipLaunchKernelGGL(l2norm_fwd_small_kernel, dim3(parts), dim3(1024), 0, ST, x, (int)ldx, (int)rows, c, y, (int)ldy,
+                           stat);
+    else
+        hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, rows, c, y, ldy, stat);
     HYPEL_CHECK_LAUNCH("hypel_l2norm_parts_fwd");
     return 0;
 }
@@ -1055,8 +1142,13 @@ extern "C" int hypel_l2norm_parts_bwd(const float* x, int64_t ldx, const float* 
                                       int32_t c, int32_t parts, const float* stat, float* dx, int64_t lddx,
                                       int32_t accumulate, hypel_stream_t stream) {
     HYPEL_REQUIRE(x && dy && dx && stat && rows > 0 && c > 0 && parts > 0, "hypel_l2norm_parts_bwd");
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
-                       accumulate);
+    const int64_t ldmax = ldx > lddy ? (ldx > lddx ? ldx : lddx) : (lddy > lddx ? lddy : lddx);
+    if (rows * c <= L2N_R * 1024 && rows * ldmax < (1ll << 30))
+        hipLaunchKernelGGL(l2norm_bwd_small_kernel, dim3(parts), dim3(1024), 0, ST, x, (int)ldx, dy, (int)lddy, (int)rows, c,
+                           stat, dx, (int)lddx, accumulate);
+    else
+        hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
+                           accumulate);
     HYPEL_CHECK_LAUNCH("hypel_l2norm_parts_bwd");
     return 0;
 }

@@ -893,9 +893,10 @@ def test_gan_generator_valu_kernels_in_a_subprocess():
     assert "12 passed" in r.stdout, r.stdout[-500:]
 
 
-def test_l2norm_parts(hip):
+@pytest.mark.parametrize("rows,e,parts", [(4096, 2, 6), (100, 3, 7), (8192, 2, 2), (20000, 5, 3)])
+def test_l2norm_parts(hip, rows, e, parts):
+    """register-resident form for parts of <= 16 K elements, the looping form beyond"""
     rng = np.random.default_rng(5)
-    rows, e, parts = 4096, 2, 6
     b = Both(hip)
     b.arr("x", rng.standard_normal((rows, parts * e)).astype(np.float32))
     b.arr("dy", rng.standard_normal((rows, parts * e)).astype(np.float32))
