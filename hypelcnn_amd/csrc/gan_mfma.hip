@@ -532,17 +532,39 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
             }
             __syncthreads();
             GM_MARK(4)  // step B products
-            if (tid < ksz) {  // tap t = d + pad: sum the diagonal d of G, tiles ascending, rows ascending
+#ifndef GM_NO_DIAGSUM
+#define GM_NO_DIAGSUM 0
+#endif
+            if (!GM_NO_DIAGSUM && tid < ksz) {  // tap t = d + pad: sum the diagonal d of G, tiles ascending, rows ascending
                 const int d = tid - pad;
                 float s = 0.0f;
                 const int a0 = (d + 15 >= 0 ? (d + 15) / 16 : -((-(d + 15) + 15) / 16));  // floor((d + 15) / 16)
-                for (int a = a0 - 1; a <= a0; ++a) {
-                    if (a < a_lo || a > a_hi) continue;
+                // every candidate element is fetched (absent ones from G[0], then replaced by 0) before the first add: as
+                // two nested loops with data-dependent bounds this was <= 32 dependent LDS round trips per thread and layer
+                // -- 28 % of the kernel at 64 bands, 9 % at 360
+                float v[2][16];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int a = a0 - 1 + t;
                     const int dl = d - 16 * a;  // i_local - j_local
-                    if (dl < -15 || dl > 15) continue;
-                    const float* gt = G + (a - a_lo) * 16 * GM_GP;
-                    for (int il = max(0, dl); il <= min(15, 15 + dl); ++il) s += gt[il * GM_GP + (il - dl)];
+                    const bool tile_ok = a >= a_lo && a <= a_hi;
+                    // element il of the diagonal sits at gt[il * (GM_GP + 1) - dl]: one base per tile, immediate offsets;
+                    // an absent element is read from wherever that lands inside the block's LDS and replaced by 0
+                    // (volatile: hipcc otherwise sinks every load under its predicate -- 32 branches, each with its own
+                    // LDS round trip)
+                    typedef const volatile __attribute__((address_space(3))) float* gm_lds_vptr;
+                    const gm_lds_vptr bp = (gm_lds_vptr)(G + (tile_ok ? a - a_lo : 0) * 16 * GM_GP - (tile_ok ? dl : 0));
+                    const int lo = tile_ok ? max(0, dl) : 16, hi = min(15, 15 + dl);
+#pragma unroll
+                    for (int il = 0; il < 16; ++il) {
+                        const float x = bp[il * (GM_GP + 1)];
+                        v[t][il] = (il >= lo && il <= hi) ? x : 0.0f;
+                    }
                 }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int il = 0; il < 16; ++il) s += v[t][il];  // tiles ascending, rows ascending
 #pragma unroll
                 for (int q = 0; q < 7; ++q)
                     if (q == l) dwacc[q] += s;

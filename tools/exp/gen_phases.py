@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from hypelcnn_amd.backend import HipBackend, Ref
 be = HipBackend()
-n, bands = 4096, 360
+n, bands = int(os.environ.get("GP_N", 4096)), int(os.environ.get("GP_B", 360))
 ks = [bands >> s for s in (0, 1, 2, 3, 2, 1, 0)]
 wt = sum(ks)
 rng = np.random.default_rng(0)
