@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("HYPEL_LIB_PATH") or os.path.join(_HERE, "csrc", "libh
 MAX_SIDE_STREAMS = 4  # side streams a plan may fork filter gradients onto (plan.SIDE_STREAMS <= this)
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 GEMM_BM = 128
-ABI_VERSION = 2  # include/hypel.h HYPEL_ABI_VERSION: a library built from other headers is refused at load time
+ABI_VERSION = 3  # include/hypel.h HYPEL_ABI_VERSION: a library built from other headers is refused at load time
 
 SEG_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("k", "<i4"), ("reserved", "<i4")])
 GROUP_DTYPE = np.dtype([("c_off", "<i8"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("rows", "<i4"),

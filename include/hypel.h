@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* hypel_stream_t; /* hipStream_t */
 
-#define HYPEL_ABI_VERSION 2  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
+#define HYPEL_ABI_VERSION 3  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
 
 /* activation codes (leaky_relu: HYPELCNNModel.py:39, DUALCNNModel.py:18, shadow_data_models.py:53;
  * relu: tf_slim default, CONCNNModel.py; sigmoid: HYPELCNNModel.py:93; tanh: shadow_data_models.py:86) */

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(decl) >= 30
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in hypel.h but not exported"
-    assert lib.hypel_version() == 2
+    assert lib.hypel_version() == 3
     assert lib.hypel_last_error() is not None
 
 
