@@ -48,6 +48,10 @@ class CompiledTower:
         buf = self.plan.buffers[st.buf]
         nb = self.plan.nb
         own = self.plan.storage[id(sym.owner)]
+        if sym.hw is None and st.pixmap is None and sym.owner.npix == 1:
+            # [N, C] tensors (every GAN value): a VIEW of the buffer, no gather / permute kernels -- the pool pass-through
+            # of a GAN step fetches two of them per step
+            return buf[: nb * own.ld].view(nb, own.ld)[:, st.ch_off:st.ch_off + st.c]
         full = buf[: sym.owner.npix * nb * own.ld].reshape(sym.owner.npix, nb, own.ld)
         pm = list(range(sym.npix)) if st.pixmap is None else st.pixmap
         v = full[pm][:, :, st.ch_off:st.ch_off + st.c]
