@@ -363,8 +363,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) by
+        # re-executing this command under torch.distributed.run; rank 0 of that job prints the one JSON line
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL / cross-process tensors on this driver)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     # HYPEL_DIST_BACKEND=gloo: rehearse the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices;
     # RCCL refuses that).  The driver's runs use nccl (= RCCL), one rank per GPU.
@@ -383,7 +397,7 @@ def main():
         else:
             dist.init_process_group(backend_name)
 
-    from hypelcnn_amd.backend import HipBackend
+    from hypelcnn_amd.backend import HipBackend, note_collective
     be = HipBackend()
     classifier = args.workload in CLASSIFIER_WORKLOADS
     if classifier:
@@ -425,12 +439,14 @@ def main():
     n_prewarm = max(2, min(500, int(0.05 / max(est, 1e-6)) + 1))
     if use_dist:
         t = torch.tensor([n_prewarm], device="cuda", dtype=torch.int32)
+        note_collective()  # a later HIP-graph capture must wait this collective out (backend.settle_before_capture)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n_prewarm = int(t[0])
     for _ in range(n_prewarm):
         one_step()
     n_prewarm += 3
     if use_dist:
+        note_collective()
         dist.barrier()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -441,12 +457,14 @@ def main():
         evs[i + 1].record()
     torch.cuda.synchronize()
     if use_dist:
+        note_collective()
         dist.barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2]
     if use_dist:
         t = torch.tensor([dt], device="cuda")
+        note_collective()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     loss = loss_fn()
@@ -456,7 +474,9 @@ def main():
         # data-parallel invariant: every rank holds bit-identical weights after the same all-reduced updates
         digest = torch.stack([sess.params.double().sum(), sess.params.double().abs().max()])
         lo, hi = digest.clone(), digest.clone()
+        note_collective()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        note_collective()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(torch.equal(lo, hi))
 
@@ -476,6 +496,7 @@ def main():
         for _ in range(5):
             piped_step()
         if use_dist:
+            note_collective()
             dist.barrier()
         torch.cuda.synchronize()
         tp = time.perf_counter()
@@ -484,10 +505,12 @@ def main():
             piped_step()
         torch.cuda.synchronize()
         if use_dist:
+            note_collective()
             dist.barrier()
         dtp = time.perf_counter() - tp
         if use_dist:
             t = torch.tensor([dtp], device="cuda")
+            note_collective()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtp = float(t[0])
         pipeline = {"what": "same train step with the device input pipeline in the loop: epoch permutation over a "
@@ -546,6 +569,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = gan_cpu_baseline(kind, bands)
     if use_dist:
+        note_collective()
         dist.barrier()
     if rank == 0:
         if classifier:
@@ -562,6 +586,8 @@ def main():
                      "hip_graph": ctx.capture_graphs, "loss": loss}
             if in_sync is not None:
                 cfg_d["dp_weights_identical_across_ranks"] = in_sync
+            if use_dist:
+                cfg_d["communicator"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
             if world > 1:
                 cfg_d["batch_norm"] = "synchronised (global batch)" if args.sync_bn else "per rank"
             if mac:

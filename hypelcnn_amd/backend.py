@@ -207,6 +207,16 @@ def bind_collective(name, args):
 _collective_epoch = [0]  # bumped by every collective the package issues (note_collective)
 
 
+def _pg_sequence_number():
+    """Collective sequence number of the default process group (None when the build does not expose it): moves with
+    every collective issued on it, whoever issued it."""
+    try:
+        import torch.distributed as dist
+        return int(dist.distributed_c10d._get_default_group()._get_sequence_number_for_group())
+    except Exception:  # noqa: BLE001 -- private API: absent / renamed means "unknown", the package epoch still counts
+        return None
+
+
 def note_collective():
     """Called right before any torch.distributed collective of the package: a HIP-graph capture must not start while
     the RCCL watchdog still polls that collective (HipBackend.settle_before_capture waits it out -- once per burst of
@@ -334,12 +344,16 @@ class HipBackend:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
             return
-        if HipBackend._settled_epoch == _collective_epoch[0]:
+        # "anything issued since the last pause?" = the package's own epoch (note_collective) AND the process group's
+        # collective sequence number, which also moves for dist.* calls made outside the package (bench.py, user code);
+        # HYPEL_CAPTURE_SETTLE_ALWAYS=1 pauses before every capture regardless
+        epoch = (_collective_epoch[0], _pg_sequence_number())
+        if os.environ.get("HYPEL_CAPTURE_SETTLE_ALWAYS") != "1" and HipBackend._settled_epoch == epoch:
             return  # no collective since the last pause: the watchdog has nothing new to poll (a burst of captures --
             #         every batch size of a run, TrainStep.precapture -- pays the pause once)
         torch.cuda.synchronize(self.device)
         time.sleep(float(os.environ.get("HYPEL_CAPTURE_SETTLE_S", "0.5")))
-        HipBackend._settled_epoch = _collective_epoch[0]
+        HipBackend._settled_epoch = (_collective_epoch[0], _pg_sequence_number())
 
     def capture(self, launches, settled=False):
         """Capture a list of bound launches into a hipGraphExec; returns a replay callable.

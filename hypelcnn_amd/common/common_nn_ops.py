@@ -527,6 +527,10 @@ class TrainOp:
         self.momentum = opt[1] if isinstance(opt, (tuple, list)) and opt[0] == "MomentumOptimizer" else None
         if self.momentum is None and opt != "AdamOptimizer":
             raise ValueError(f"unknown optimizer {opt!r}")
+        if self.momentum is not None:
+            # known from the configuration, not from the first step: a step-0 checkpoint of a MomentumOptimizer run is
+            # exported under <var>/nn_core/Momentum as well (tf_checkpoint.session_to_variables)
+            ctx.session().optimizer_kind = "momentum"
 
     def compiled(self, nb, global_nb=None):
         sess = self.ctx.session()

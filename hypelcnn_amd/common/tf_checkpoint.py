@@ -385,6 +385,8 @@ def variables_to_session(sess, variables):
                 b = variables.get(v.name + sv) if sv is not None else None
                 if a is None or (sv is not None and b is None):
                     continue
+                if sv is None:  # a Momentum slot: the session is a MomentumOptimizer run (export keeps the spelling)
+                    sess.optimizer_kind = "momentum"
                 m[v.offset:v.offset + v.size] = numpy.asarray(a, numpy.float32).reshape(-1)
                 if b is not None:
                     vv[v.offset:v.offset + v.size] = numpy.asarray(b, numpy.float32).reshape(-1)

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
     });
 }
 
-__device__ __forceinline__ void bwd_elem(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y,
+__device__ __forceinline__ void bwd_elem(const float* dz, int64_t lddz, const float* __restrict__ y,
                                          int64_t ldy, int64_t row, int col, const float* __restrict__ mean,
                                          const float* __restrict__ rstd, const float* __restrict__ beta, int act,
                                          float alpha, const float* __restrict__ mask, int64_t ldm, float& dyh,
@@ -668,12 +668,13 @@ __device__ __forceinline__ void bwd_reduce_tail(const BwdFin& f, const float* pa
 // DY (layers WITHOUT batch norm only): the pass also writes dY = dZ * act'(y) (* mask) -- there the input gradient does
 // not depend on the column sums, so the reduction pass of the bias gradient delivers dY as well and the separate
 // hypel_bn_act_bwd_apply launch (one more read of dZ and Y) goes away (hypel_act_bias_bwd_reduce).
+// dy may alias dz (in-place post-op backward, include/hypel.h): neither pointer is __restrict__
 template <bool DY>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
-    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
+    const float* dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
-    BwdFin fin, float* __restrict__ dy, int64_t lddy) {
+    BwdFin fin, float* dy, int64_t lddy) {
     __shared__ float sh[2][STAT_TY][STAT_TX];
     const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
     const int col = blockIdx.y * STAT_TX + tx;
@@ -714,10 +715,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 
 template <bool DY>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
-    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
+    const float* dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
-    BwdFin fin, float* __restrict__ dy, int64_t lddy) {
+    BwdFin fin, float* dy, int64_t lddy) {
     __shared__ float sh[2][STAT_V4_TY][STAT_TX];
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int col = blockIdx.y * STAT_TX + tq * 4;
@@ -787,9 +788,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
 
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
-    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
+    const float* dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int64_t ldm, const float* __restrict__ sums, float* __restrict__ dy,
+    float alpha, const float* __restrict__ mask, int64_t ldm, const float* __restrict__ sums, float* dy,
     int64_t lddy, int tx_log2, int64_t stat_rows) {
     const float inv_m = 1.0f / (float)stat_rows;  // rows the sums run over: `rows`, or the global batch (synchronised BN)
     ew_loop<VEC>(rows, c, tx_log2, [&](int64_t row, int col) {
@@ -1206,9 +1207,9 @@ __global__ __launch_bounds__(1024) void bn_act_small_fwd_kernel(
 
 template <bool FULL>
 __global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
-    const float* __restrict__ dz, int lddz, const float* __restrict__ y, int ldy, int rows, int c,
+    const float* dz, int lddz, const float* __restrict__ y, int ldy, int rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
-    float alpha, const float* __restrict__ mask, int ldm, float* __restrict__ dy, int lddy,
+    float alpha, const float* __restrict__ mask, int ldm, float* dy, int lddy,
     float* __restrict__ dparam, int accumulate) {
     __shared__ float2 sh[SMALL_TY / 2][SMALL_TX];
     const int tx = threadIdx.x & (SMALL_TX - 1), ty = threadIdx.x / SMALL_TX;

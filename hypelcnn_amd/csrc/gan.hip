@@ -542,8 +542,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 __global__ __launch_bounds__(256) void gan_loss_partial_kernel(int mode, const float* __restrict__ a, int64_t lda,
                                                                 const float* __restrict__ b, int64_t ldb,
                                                                 int64_t rows, int c, float target, float gcoef,
-                                                                float* __restrict__ da, int64_t ldda, int acc_da,
-                                                                float* __restrict__ db, int64_t lddb, int acc_db,
+                                                                float* da, int64_t ldda, int acc_da,
+                                                                float* db, int64_t lddb, int acc_db,
                                                                 float* __restrict__ ws, float pscale) {
     __shared__ float sh[4];
     float s = 0.0f;
@@ -1055,8 +1055,8 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const float* __restrict
     const hypel_loss_term_t t = terms[blockIdx.y];
     const float* __restrict__ a = base + t.a_off;
     const float* __restrict__ b = t.b_off == HYPEL_LOSS_NONE ? nullptr : base + t.b_off;
-    float* __restrict__ da = t.da_off == HYPEL_LOSS_NONE ? nullptr : const_cast<float*>(base) + t.da_off;
-    float* __restrict__ db = t.db_off == HYPEL_LOSS_NONE ? nullptr : const_cast<float*>(base) + t.db_off;
+    float* da = t.da_off == HYPEL_LOSS_NONE ? nullptr : const_cast<float*>(base) + t.da_off;
+    float* db = t.db_off == HYPEL_LOSS_NONE ? nullptr : const_cast<float*>(base) + t.db_off;
     float s = 0.0f;
     if (t.mode == 3) {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.rows; i += (int64_t)gridDim.x * 256) {

@@ -198,7 +198,7 @@ def run_session(params, base_log_path, backend=None):
     gen.set_input("y" if "in:y" in b and "in:x" not in b else "x", src)
     gen.forward()
     ratio = shadow_ratio if shadow_ratio is not None else numpy.ones(bands, numpy.float32)
-    div_mean, div_upper, _, _ = create_stats(gen.value(the_gan_loss.generate_outputs[0]), src,
+    div_mean, div_upper, _, _ = create_stats(gen.value(the_gan_loss.generate_outputs[0], copy=False), src,
                                              torch.as_tensor(ratio, dtype=torch.float32).to(src.device))
     return [div_upper, div_mean]
 

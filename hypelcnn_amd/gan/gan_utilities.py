@@ -54,7 +54,8 @@ class GeneratorAugmenter:
         ct = sess.compile_phase(self.tower, spectra.shape[0], outputs=[self.out], key="augment")
         ct.set_input("x", spectra)
         ct.forward()
-        conv = ct.value(self.out).reshape(n, p1, p2, self.bands)
+        # with a LiDAR channel the concat below copies; without one the caller gets its own tensor (not a plan-buffer view)
+        conv = ct.value(self.out, copy=c <= self.bands).reshape(n, p1, p2, self.bands)
         if c > self.bands:
             conv = torch.cat([conv, patches[..., self.bands:]], dim=3)
         return conv

@@ -142,7 +142,7 @@ class GANTrainOps:
                 self._feed(gen, x, y, fed)
                 gen.forward()
                 for name, t in phase.pool:
-                    fresh = gen.value(t)
+                    fresh = gen.value(t, copy=False)  # consumed (pool query / set_input copy) before the next forward
                     if self.pool_override is not None:
                         val = self.pool_override(name, fresh)
                     elif self.use_pool:

@@ -42,16 +42,18 @@ class CompiledTower:
         dst = self.plan.buffers["in:" + name]
         dst.copy_(tensor.reshape(-1).to(dst.dtype), non_blocking=True)
 
-    def value(self, sym, nhwc=True):
-        """Fetch a tensor of the tower as [N, H, W, C] / [N, C] (host-side check helper)."""
+    def value(self, sym, nhwc=True, copy=True):
+        """Fetch a tensor of the tower as [N, H, W, C] / [N, C].  copy=True (default): the caller owns the result.
+        copy=False: an [N, C] tensor comes back as a VIEW of the plan buffer (no gather / permute / copy kernels) that the
+        next forward() / forward_backward() at this batch size OVERWRITES -- for callers that consume it before then
+        (the GAN tensor pool's pass-through fetches two such tensors per step)."""
         st = self.plan.storage_of(sym)
         buf = self.plan.buffers[st.buf]
         nb = self.plan.nb
         own = self.plan.storage[id(sym.owner)]
         if sym.hw is None and st.pixmap is None and sym.owner.npix == 1:
-            # [N, C] tensors (every GAN value): a VIEW of the buffer, no gather / permute kernels -- the pool pass-through
-            # of a GAN step fetches two of them per step
-            return buf[: nb * own.ld].view(nb, own.ld)[:, st.ch_off:st.ch_off + st.c]
+            v = buf[: nb * own.ld].view(nb, own.ld)[:, st.ch_off:st.ch_off + st.c]
+            return v.clone() if copy else v
         full = buf[: sym.owner.npix * nb * own.ld].reshape(sym.owner.npix, nb, own.ld)
         pm = list(range(sym.npix)) if st.pixmap is None else st.pixmap
         v = full[pm][:, :, st.ch_off:st.ch_off + st.c]
@@ -136,8 +138,18 @@ class CompiledTower:
     def capture(self):
         """Capture forward (+ backward) into HIP graphs: one host call per step instead of ~300.  A step with sync
         points or host-side collectives becomes a chain of graphs with those calls in between."""
-        self.forward_backward() if self.bwd else self.forward()  # warm: first-use allocations / lazy module loads
+        # warm run (first-use allocations / lazy module loads) on whatever the input buffers hold: it must not move the
+        # trained state -- batch-norm moving averages, the dropout step counter, the non-finite flag -- away from a run
+        # without capture, so those are put back afterwards
+        sess = self.plan.sess
+        keep = [(t, t.clone()) for t in (getattr(sess, "state", None), self.plan.buffers.get("step_ctr")) if t is not None]
+        if getattr(sess, "grads", None) is not None and getattr(sess, "n_train", None) is not None:
+            flag = sess.grads[sess.n_train:sess.n_train + 1]
+            keep.append((flag, flag.clone()))
+        self.forward_backward() if self.bwd else self.forward()
         self.be.synchronize()
+        for t, saved in keep:
+            t.copy_(saved)
         items = self._items(bool(self.bwd))
         settle = getattr(self.be, "settle_before_capture", None)
         if settle is not None:

@@ -33,7 +33,9 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(decl) >= 30
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in hypel.h but not exported"
-    assert lib.hypel_version() == 3
+    header = int(re.search(r"#define\s+HYPEL_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    from hypelcnn_amd import backend
+    assert lib.hypel_version() == header == backend.ABI_VERSION
     assert lib.hypel_last_error() is not None
 
 
