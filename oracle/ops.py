@@ -148,6 +148,37 @@ def conv1d_same(x, w, b=None):
     n, L, ci = xv.shape
     k, _, co = wv.shape
     pl, _ = same_pad(k)
+    if ci == 1 and co == 1:
+        # the generator's single-channel layers: the same sum over taps written as ONE product with the banded Toeplitz
+        # matrix T[l + d][l] = w[j], d = j - pl (a [N x L] x [L x L] BLAS call instead of k batched 1x1 products --
+        # what lets the float64 oracle run the GAN phases at the batch sizes BASELINE quotes, N = 2048 / 4096)
+        T = np.zeros((L, L), dtype=xv.dtype)
+        ds = []
+        for j in range(k):
+            d = j - pl
+            l0, l1 = max(0, -d), min(L, L - d)
+            if l1 <= l0:
+                continue
+            ds.append((j, d))
+            idx = np.arange(l0, l1)
+            T[idx + d, idx] = wv[j, 0, 0]
+        x2 = xv[:, :, 0]
+        out = (x2 @ T)[:, :, None]
+        if b is not None:
+            out = out + b.v
+
+        def back1(g):
+            g2 = g[:, :, 0]
+            _acc(x, (g2 @ T.T)[:, :, None])
+            M = x2.T @ g2  # M[i][l] = sum_n x[n][i] g[n][l]; dw[j] = sum_l M[l + d][l]
+            dwv = np.zeros_like(wv)
+            for (j, d) in ds:
+                dwv[j, 0, 0] = np.trace(M, offset=-d)
+            _acc(w, dwv)
+            if b is not None:
+                _acc(b, g.reshape(-1, co).sum(0))
+
+        return Var(out, (x, w) if b is None else (x, w, b), back1)
     out = np.zeros((n, L, co), dtype=xv.dtype)
     taps = []
     for j in range(k):

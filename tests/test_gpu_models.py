@@ -395,3 +395,37 @@ def test_backend_objects_share_the_device_stream_pair(hip):
     built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 5, 11, 4, SMALL_H, 6, 11)
     ct = U.run_train_step(built, x, onehot, masks)
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, SMALL_H, tol_logit=2e-4, tol_grad=1e-4)
+
+
+def test_concnn_shipped_config_vs_oracle(hip):
+    """CONCNNModel at its SHIPPED configuration (modelconfigs/alg_param_concnn.json: filter_count 128, i.e. three 128-filter
+    branches 1x1 / 3x3 / 5x5 -> a 384-channel concat under a radius-5 LRN, eight 384-wide 1x1 convolutions, ReLU, biases,
+    two dropouts, dense head; /root/reference/nnmodel/CONCNNModel.py:23-64) on GRSS2013-shaped 5x5x145 patches, 15 classes,
+    batch 64, against the float64 oracle: logits, loss, every gradient, then one MomentumOptimizer(0.9) step."""
+    alg = _alg("alg_param_concnn.json")
+    assert alg["filter_count"] == 128 and alg["optimizer"][0] == "MomentumOptimizer"
+    nb = 64
+    built, sess, params, x, onehot, masks = _case(hip, "CONCNNModel", 5, 145, 15, alg, nb, 2024)
+    ct = U.run_train_step(built, x, onehot, masks)
+    names = {l.name for l in ct.plan.fwd + ct.plan.bwd}
+    assert {"lrn_fwd", "lrn_bwd"} <= names, sorted(names)
+    ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "CONCNNModel", 15, alg, tol_logit=1e-3,
+                                     tol_grad=1e-4)
+    got = ct.value(built.y_conv).cpu().numpy()
+    assert (got.argmax(1) == ref["logits"].argmax(1)).all()
+    # one TF1 Momentum step (accum = mu * accum + g; var -= lr * accum): exact on the device gradients, and within
+    # lr * |g_dev - g_oracle| of the oracle trainer's parameters
+    g_dev = {k: sess.get_gradient("nn_core/" + k).astype(np.float64) for k in ref["grads"]}
+    lr0 = built.lr.eval(0)
+    mu = alg["optimizer"][1]
+    sess.momentum_step(lr0, mu)
+    assert sess.optimizer_kind == "momentum"
+    for k, g in ref["grads"].items():
+        gotp = sess.get_variable("nn_core/" + k)
+        exp = params[k].copy()
+        OT.momentum_tf1_step(exp, g_dev[k], np.zeros_like(exp), lr0, mu)
+        assert np.abs(gotp - exp).max() <= 2e-7 * max(1.0, np.abs(exp).max()), k
+        exp_o = params[k].copy()
+        OT.momentum_tf1_step(exp_o, g, np.zeros_like(exp_o), lr0, mu)
+        assert np.abs(gotp - exp_o).max() <= lr0 * 1e-4 * max(np.abs(g).max(), 1e-6) + 2e-7 * max(1.0, np.abs(exp).max()), k
+    print(f"\nCONCNN (384-channel LRN, batch {nb}): logits {err:.2e}, worst grad {worst}")
