@@ -1247,6 +1247,23 @@ __global__ __launch_bounds__(1024) void bn_act_small_bwd_kernel(
     small_store_rows<FULL>(dy, lddy, rows, col, ok, g);
 }
 
+// ------------------------------------------------------------------------------------- 2-D block copies
+// (packed weight image of a merged multi-kernel level <-> the HWIO variables / their gradient slots)
+__global__ __launch_bounds__(256) void copy_blocks_kernel(const float* __restrict__ base,
+                                                           const hypel_copy_block_t* __restrict__ entries) {
+    const hypel_copy_block_t e = entries[blockIdx.x];
+    const float* src = base + e.src_off;
+    float* dst = const_cast<float*>(base) + e.dst_off;
+    const int total = e.rows * e.cols;
+    const bool acc = (e.flags & 1) != 0;
+    for (int i = threadIdx.x + blockIdx.y * 256; i < total; i += 256 * gridDim.y) {
+        const int r = i / e.cols, c = i - r * e.cols;
+        const float v = src[(int64_t)r * e.src_ld + c];
+        float* d = dst + (int64_t)r * e.dst_ld + c;
+        *d = acc ? *d + v : v;
+    }
+}
+
 // ------------------------------------------------------------------------------------- metrics
 __global__ void argmax_confusion_kernel(const float* __restrict__ logits, int64_t ld, int64_t n, int c,
                                         const int32_t* __restrict__ labels, int32_t* __restrict__ pred,
@@ -1363,6 +1380,15 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256, red_max_blocks())), dim3(256), 0, ST,
                            partial, stride, n_splits, out, count, accumulate, bias, n, ldc);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
+    return 0;
+}
+
+extern "C" int hypel_copy_blocks_f32(const float* base, const hypel_copy_block_t* entries, int32_t n_entries,
+                                     hypel_stream_t stream) {
+    HYPEL_REQUIRE(base && entries && n_entries >= 0, "hypel_copy_blocks_f32");
+    if (n_entries == 0) return 0;
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(n_entries, 4), dim3(256), 0, ST, base, entries);
+    HYPEL_CHECK_LAUNCH("hypel_copy_blocks_f32");
     return 0;
 }
 

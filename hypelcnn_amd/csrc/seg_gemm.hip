@@ -142,8 +142,11 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // (columns 0-15 from the first, 16-31 from the second).  A data gradient through a convolution with 15 filters (the
 // narrowest HYPELCNN level, DUALCNN's last levels) otherwise stages, synchronises and walks a whole 32-column k-tile
 // for 15 useful columns.  A segment whose k has HYPEL_SEG_PAIR_FLAG set is paired with the next one of its group.
+// VARN (forward 128x64 blocks): the groups of the launch differ in their column count (hypel_tile_t.n, merged levels);
+// the MFMA phase then has one variant per number of active accumulator tiles.  A separate instantiation: as a shared
+// code path the second variant cost the 128x64 forward kernel 20 registers (82 -> 102: 4 instead of 5 waves per SIMD).
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
-          bool PAIR = false>
+          bool PAIR = false, bool VARN = false>
 __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
@@ -155,10 +158,15 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                                                         const int32_t* __restrict__ res_start,
                                                         float* __restrict__ stats, BnBwdEpi bnb) {
     constexpr int BM = WM * TM * 32;
-    constexpr int BN = NARROW ? 16 : WN * TN * 32;
+    // NARROW with TN = 4 (forward only): 128x64 blocks whose waves own 32 rows x FOUR 16-column tiles -- the merged
+    // form of a multi-kernel level with <= 16 filters per branch (groups of 15 / 30 / 45 / 60 output columns, see
+    // hypel_tile_t.n): the A tile is staged once for up to four branches and the MFMA work stays exact to 16 columns
+    constexpr int NT16 = NARROW ? TN : 1;  // 16-column accumulator tiles per wave
+    constexpr int BN = NARROW ? 16 * NT16 : WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
-    static_assert(!NARROW || (WM == 4 && TM == 1 && TN == 1), "narrow variant: 4 x 1 waves of 32 x 16");
+    static_assert(!NARROW || (WM == 4 && TM == 1 && (TN == 1 || (TN == 4 && !TA && !TB && !MULTI))),
+                  "narrow variant: 4 x 1 waves of 32 x 16 (forward: 32 x 64)");
     // LDS images (rows x pitch), global row order preserved
     constexpr int BK = NARROW ? BK_NARROW : BK_WIDE;
     constexpr int A_ROWS = TA ? BK : BM;
@@ -184,7 +192,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int A_PITCH = TA ? (NARROW ? BM + 16 : BM) : (NARROW || RD64 ? BK + 2 : BK + 1);
     constexpr int B_ROWS = TB ? BN : BK;
     constexpr int B_COLS = TB ? BK : BN;
-    constexpr int B_PITCH = TB ? (NARROW || RD64 ? BK + 2 : BK + 1) : BN;
+    constexpr int B_PITCH = TB ? (NARROW || RD64 ? BK + 2 : BK + 1) : (NARROW && NT16 > 1 ? BN + 16 : BN);
     constexpr int A_PER_THREAD = A_ROWS * A_COLS / 256;
     // a 96-column B row does not divide the 256 threads: then only the first (256 / B_COLS) * B_COLS = 192 threads
     // stage B (two rows of 96 per pass), the fourth wave sits that part out
@@ -232,6 +240,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         grp = {t.c_off, t.seg_begin, t.seg_count, t.rows};
         tile = {t.a_off0, t.b_off0, t.k0};
         m0 = t.m0;
+        if (t.n > 0) n = t.n;  // this tile's group has its own column count (merged multi-kernel levels)
         split_info = t.split;
         slab_addr = t.slab;
         ticket_addr = t.ticket;
@@ -239,6 +248,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     const int rows_left = grp.rows - m0;  // valid rows in this tile (may exceed BM)
     if (rows_left <= 0) return;           // empty record (padding of an XCD's share of the table)
     const int cols_left = n - n0;
+    if (cols_left <= 0) return;  // the grid is sized for the widest group of the launch
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,10 +267,10 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     const int b_col = b_stager ? tid % B_COLS : 0x3fffffff / 4, b_row0 = b_stager ? tid / B_COLS : 0;
 
     f32x16 acc[NARROW ? 1 : TM][NARROW ? 1 : TN];
-    f32x4 acc16[2];  // NARROW: rows [0,16) and [16,32) of the wave's 32 x 16 tile
+    f32x4 acc16[2 * NT16];  // NARROW: [t * NT16 + j] = rows [16 t, 16 t + 16) x columns [16 j, 16 j + 16) of the wave's tile
     if constexpr (NARROW) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2 * NT16; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc16[t][e] = 0.0f;
     } else {
@@ -282,9 +292,15 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        col_act[j] = (wn * TN + j) * 32 < cols_left;
+        col_act[j] = (wn * TN + j) * (NARROW ? 16 : 32) < cols_left;
         any_col = any_col || col_act[j];
     }
+    // active accumulator column tiles are a prefix: their count, as a scalar (merged levels: a 64-wide block may
+    // serve a group of 15 - 60 columns; the MFMA phase below runs the variant for exactly that many)
+    int tn_act = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) tn_act += col_act[j] ? 1 : 0;
+    tn_act = __builtin_amdgcn_readfirstlane(tn_act);
     const bool any_act = any_row && any_col;
     // per-lane LDS read bases (k advances by immediate offsets in the unrolled loop)
     const int l15 = lane & 15, lq = lane >> 4;  // 16x16x4 fragments: row / column = lane & 15, k = lane >> 4
@@ -545,7 +561,34 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 #if HYPEL_GEMM_SETPRIO
             __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
 #endif
-            if constexpr (NARROW) {
+            if constexpr (NARROW && NT16 > 1) {
+                // one straight-line variant per number of active 16-column tiles (a wave-uniform switch: the
+                // accumulators stay where they are, no MFMA is exec-masked)
+                auto phase = [&](auto nact_c) {
+                    constexpr int NACT = decltype(nact_c)::value;
+#pragma unroll
+                    for (int q = 0; q < BK / CHUNK; ++q) {
+                        if (q > 0 && kvalid <= q * CHUNK) break;
+#pragma unroll
+                        for (int k4 = q * (CHUNK / 4); k4 < (q + 1) * (CHUNK / 4); ++k4) {
+                            const float a0 = As[a_rd + k4 * A_K4STEP];
+                            const float a1 = As[a_rd + A_TILE16 + k4 * A_K4STEP];
+                            float b[NACT];
+#pragma unroll
+                            for (int j = 0; j < NACT; ++j) b[j] = Bs[b_rd + 16 * j + k4 * B_K4STEP];
+#pragma unroll
+                            for (int j = 0; j < NACT; ++j) {
+                                acc16[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], acc16[j], 0, 0, 0);
+                                acc16[NT16 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j], acc16[NT16 + j], 0, 0, 0);
+                            }
+                        }
+                    }
+                };
+                if (tn_act >= 4) phase(std::integral_constant<int, 4>{});
+                else if (tn_act == 3) phase(std::integral_constant<int, 3>{});
+                else if (tn_act == 2) phase(std::integral_constant<int, 2>{});
+                else phase(std::integral_constant<int, 1>{});
+            } else if constexpr (NARROW) {
                 // CHUNK reduction columns at a time, as below
 #pragma unroll
                 for (int q = 0; q < BK / CHUNK; ++q) {
@@ -560,30 +603,42 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                     }
                 }
             } else if constexpr (RD64) {
-                // CHUNK reduction columns (CHUNK / 4 step pairs) at a time, skipped beyond kvalid as below
+                // CHUNK reduction columns (CHUNK / 4 step pairs) at a time, skipped beyond kvalid as below.  NACT = active
+                // 32-column accumulator tiles (a prefix): forward 128x64 blocks of a merged level serve groups of 30 - 120
+                // columns and run the one-tile variant where the second tile lies outside the group (wave-uniform switch)
+                auto phase = [&](auto nact_c) {
+                    constexpr int NACT = decltype(nact_c)::value;
 #pragma unroll
-                for (int q = 0; q < BK / CHUNK; ++q) {
-                    if (q > 0 && kvalid <= q * CHUNK) break;
+                    for (int q = 0; q < BK / CHUNK; ++q) {
+                        if (q > 0 && kvalid <= q * CHUNK) break;
 #pragma unroll
-                    for (int t = q * (CHUNK / 4); t < (q + 1) * (CHUNK / 4); ++t) {
-                        float2 a[TM], b[TN];
+                        for (int t = q * (CHUNK / 4); t < (q + 1) * (CHUNK / 4); ++t) {
+                            float2 a[TM], b[NACT];
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            a[i] = *reinterpret_cast<const float2*>(&As[a_rd + i * A_PTILE + t * A_PSTEP]);
+                            for (int i = 0; i < TM; ++i)
+                                a[i] = *reinterpret_cast<const float2*>(&As[a_rd + i * A_PTILE + t * A_PSTEP]);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            b[j] = *reinterpret_cast<const float2*>(&Bs[b_rd + j * B_PTILE + t * B_PSTEP]);
+                            for (int j = 0; j < NACT; ++j)
+                                b[j] = *reinterpret_cast<const float2*>(&Bs[b_rd + j * B_PTILE + t * B_PSTEP]);
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+                            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                                for (int j = 0; j < NACT; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+                            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                                for (int j = 0; j < NACT; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        }
                     }
+                };
+                constexpr bool PREFIX = VARN && TN == 2 && TM == 1 && !TA && !TB && !MULTI && !BNB && !PAIR;
+                if constexpr (PREFIX) {
+                    if (tn_act >= 2) phase(std::integral_constant<int, 2>{});
+                    else phase(std::integral_constant<int, 1>{});
+                } else {
+                    phase(std::integral_constant<int, TN>{});
                 }
             } else {
             // 16 reduction columns (8 MFMA k-steps) at a time; the chunks of a short k-tile beyond kvalid are skipped
@@ -629,7 +684,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     if constexpr (!MULTI) {
         const int s_cnt = split_info & 0xff;
         if (s_cnt > 1) {
-            constexpr int NV4 = NARROW ? 2 : TM * TN * 4;  // float4 per lane
+            constexpr int NV4 = NARROW ? 2 * NT16 : TM * TN * 4;  // float4 per lane
             const int s_idx = (split_info >> 8) & 0xff;
             const int jn = n0 / BN;
             float* slab0 = reinterpret_cast<float*>(slab_addr) + (size_t)jn * s_cnt * (BM * BN);
@@ -766,7 +821,9 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     }
     if constexpr (NARROW) {
         // C/D layout of 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
-        const int col = l15;
+#pragma unroll
+        for (int jt = 0; jt < NT16; ++jt) {
+        const int col = 16 * jt + l15;
         if (row_act[0] && col < cols_left) {
             const float bv = bias ? bias[bias_col0 + col] : 0.0f;
             int o0 = n0 + col, o1 = n0 + col + 1;
@@ -781,7 +838,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                 const int cvo = ((wm * 32 + 4 * lq) * (int)ldc + col) * 4;
                 float v[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = acc16[q >> 2][q & 3] + bv;
+                for (int q = 0; q < 8; ++q) v[q] = acc16[(q >> 2) * NT16 + jt][q & 3] + bv;
                 if (accumulate) {
                     float old[8];
                     int so = 0;
@@ -805,8 +862,10 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) put(wm * 32 + t * 16 + 4 * lq + e, col, acc16[t][e], bv, o0, o1);
+                    for (int e = 0; e < 4; ++e)
+                        put(wm * 32 + t * 16 + 4 * lq + e, col, acc16[t * NT16 + jt][e], bv, o0, o1);
             }
+        }
         }
     } else {
         float bs0[TN], bs1[TN];
@@ -1001,9 +1060,9 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                                          : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : (TA && TM * TN == 2 ? HYPEL_OCC_BN64_TA : 3))))
 
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
-          bool PAIR = false>
+          bool PAIR = false, bool VARN = false>
 __global__ HYPEL_SGPR_ATTR HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PARAMS) {
-    seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, BNB, PAIR>(HYPEL_GEMM_ARGS);
+    seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, BNB, PAIR, VARN>(HYPEL_GEMM_ARGS);
 }
 
 // The same code under a cap of 96 scalar registers: 7 instead of 6 resident 128x32 blocks per CU (hipcc uses all 106
@@ -1048,9 +1107,15 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
                int n, const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
                const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
                hipStream_t st, float* stats = nullptr, bool cap96 = false) {
-    constexpr int BN = NARROW ? 16 : WN * TN * 32;
+    constexpr int BN = NARROW ? 16 * TN : WN * TN * 32;
     const int n_nt = MULTI ? 1 : (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
+    if constexpr (NARROW && TN > 1) {  // forward products only (dispatch checks trans_a = trans_b = 0)
+        hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, false, false, true, false>), dim3(grid), dim3(256), 0, st, a,
+                           lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,
+                           res_start, stats, BnBwdEpi{});
+        return 0;
+    } else {
     if constexpr (TM * TN == 1 && !NARROW && !MULTI) {
         if (cap96 && !ta) {  // single-segment launches on the 7-blocks-per-CU build of the 128x32 kernel
             if (tb)
@@ -1080,6 +1145,7 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
     }
 #undef HYPEL_GO
     return 0;
+    }
 }
 
 }  // namespace
@@ -1109,7 +1175,24 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const bool pairs = (accumulate & HYPEL_GEMM_PAIRED_SEGS) != 0;  // segments carry HYPEL_SEG_PAIR_FLAG
     static const int cap_on = getenv("HYPEL_GEMM_S96") ? atoi(getenv("HYPEL_GEMM_S96")) : 1;
     const bool cap96 = cap_on && (accumulate & HYPEL_GEMM_SINGLE_SEG) != 0;  // every group has one segment
+    const bool mfma16x4 = (accumulate & HYPEL_GEMM_MFMA16X4) != 0;  // merged level with <= 16 filters per branch
+    const bool var_n = (accumulate & HYPEL_GEMM_VAR_N) != 0;        // groups differ in their column count
     accumulate &= 1;
+    const bool plain_fwd = !trans_a && !trans_b && !split_tail && !pairs && !bnb.partial && !stats && !res;
+    if (mfma16x4 && n <= 64 && plain_fwd) {
+        launch_cfg<4, 1, 1, 4, true>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                                     accumulate, res, ldr, res_start, st);
+        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
+        return 0;
+    }
+    if (var_n && n > 32 && plain_fwd && hint != 1) {  // 128x64 blocks, one- and two-tile MFMA phases
+        const int n_nt = (n + 63) / 64;
+        hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 2, false, false, false, false, false, false, true>),
+                           dim3(n_tiles * n_nt), dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles,
+                           n_nt, bias, accumulate, res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
+        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
+        return 0;
+    }
     // hint 3 = 128x96 blocks (three 32x32 accumulators per wave, 5 resident blocks per CU): N = 240 / 480 tile without
     // padding (5 x 96, 96 + 96 + 48) and a layer's 392 row tiles x 3 or 5 column tiles fit the resident capacity where
     // 392 x 4 / x 8 of the 64-wide tiling overflow it by 2 %.  HYPEL_GEMM_FORCE_WIDTH=32|64|96: experiments.

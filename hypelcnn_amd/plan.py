@@ -164,6 +164,24 @@ TAIL_SLICE_KTILES = int(os.environ.get("HYPEL_TAIL_SLICE_KTILES", "8"))  # k-til
 TAIL_MAX_SLICES = int(os.environ.get("HYPEL_TAIL_MAX_SLICES", "4"))
 GEMM_BK = 32  # reduction columns per k-tile of the kernel (slices are cut at multiples of it)
 PAIR_SEGS = os.environ.get("HYPEL_PAIR_SEGS", "1") != "0"  # short data-gradient segments (k <= 16) share k-tiles
+GEMM_MFMA16X4 = 0x2000  # include/hypel.h HYPEL_GEMM_MFMA16X4: 128x64 blocks on the 16x16x4 MFMA (merged level, <= 16 filters)
+GEMM_VAR_N = 0x4000     # ... HYPEL_GEMM_VAR_N: tile records carry their group's column count
+# Merged multi-kernel levels (include/hypel.h): the nested branches of a level share one packed weight image
+# W_pack[offset][Cin][C]; per output pixel and ring of input offsets ONE product on the column range of the branches
+# that contain the ring.  HYPEL_MERGE_LEVELS: comma list of the passes that use it -- "fwd", "dgrad", "wgrad" -- or "0".
+# Measured on MI355X (round 4, NOTES 4.A; per-launch and step-level A/B on one box): the merged FORWARD pays only for
+# levels with <= 16 filters per branch (128x64 blocks on the 16x16x4 MFMA instead of 128x16: 146 -> 128 us); with 30 / 60
+# filters a branch already fills a 32- / 64-column tile, the A stagings per FLOP do not change and the mixed-width launch
+# loses 50 - 60 % (380 -> 583 us, 430 -> 687 us).  The merged DATA GRADIENT (49 instead of 84 segments per pixel) gains
+# 2 - 7 % per launch.  The merged FILTER GRADIENT moves work between the three tile-width launches without shortening
+# their sum (1584 -> 1593 us): off.  Step: 6.51 -> 6.49 ms, i.e. neutral.
+MERGE_LEVELS = set(x for x in os.environ.get("HYPEL_MERGE_LEVELS", "fwd,dgrad").split(",") if x and x != "0")
+MERGE_LEVELS_MAX_COUT = int(os.environ.get("HYPEL_MERGE_LEVELS_MAX_COUT", "32"))
+# per pass: widest branch (filters) the pass is merged for, taps per merged forward tile, forward tile-width hint
+MERGE_PASS_MAX_COUT = {k: int(os.environ.get(f"HYPEL_MERGE_{k.upper()}_MAX_COUT", d))
+                       for k, d in (("fwd", "16"), ("dgrad", "1048576"), ("wgrad", "1048576"))}
+MERGE_MAX_TAPS = int(os.environ.get("HYPEL_MERGE_MAX_TAPS", "0"))  # 0 = MAX_TAPS_PER_TILE
+MERGE_FWD_HINT = int(os.environ.get("HYPEL_MERGE_FWD_HINT", "2"))
 
 
 class GemmTables:
@@ -173,11 +191,16 @@ class GemmTables:
         self.groups = []  # (c_off, [segs], rows)
         self.keys = []  # optional locality key per group (tiles are ordered key-major)
         self.subkeys = []  # secondary locality key (phase inside a row chunk)
+        self.ns = []  # per-group column count (0 = the launch's n): the ring groups of a merged multi-kernel level
 
-    def add_group(self, c_off, segs, rows, key=None, subkey=0):
+    def add_group(self, c_off, segs, rows, key=None, subkey=0, n=0):
         self.groups.append((int(c_off), segs, int(rows)))
         self.keys.append(key)
         self.subkeys.append(subkey)
+        self.ns.append(int(n))
+
+    def n_of(self, gi, n):
+        return self.ns[gi] or n
 
     @staticmethod
     def _slice_segments(gs, S, a_ks, b_ks):
@@ -227,7 +250,7 @@ class GemmTables:
                         i += 2
                     else:
                         i += 1
-            macs += rows * ksum * n
+            macs += rows * ksum * self.n_of(gi, n)
             for m0 in range(0, rows, GEMM_BM):
                 key = (self.keys[gi] if self.keys[gi] is not None else m0 // GEMM_BM, self.subkeys[gi])
                 tiles.append((ksum * min(GEMM_BM, rows - m0), gi, m0, key))
@@ -242,7 +265,7 @@ class GemmTables:
             sb = int(garr[g]["seg_begin"]) if seg_begin is None else seg_begin
             sc = len(gs) if seg_count is None else seg_count
             a0, b0, k0 = segs[sb][:3] if sc else (0, 0, 0)  # incl. the pair flag
-            return (g, m0, rows, sb, sc, k0, c_off, a0, b0, split_word, 0, slab, ticket)
+            return (g, m0, rows, sb, sc, k0, c_off, a0, b0, split_word, self.ns[g], slab, ticket)
 
         recs = None
         if split is not None and not self.paired and len(tiles) >= TAIL_MIN_TILES and TAIL_SPLIT > 0:
@@ -326,8 +349,10 @@ class GemmTables:
             return tot
 
         a_sp, b_sp, c_el = {}, {}, set()
-        for c_off, gs, rows in self.groups:
-            c_el.add((c_off, rows))
+        n_launch = n
+        for gi, (c_off, gs, rows) in enumerate(self.groups):
+            n = self.n_of(gi, n_launch)
+            c_el.add((c_off, rows, n))
             for a_off, b_off, k in gs:
                 if ta:  # A stored [k, rows]
                     a_sp.setdefault((a_off % lda, rows), []).append((a_off // lda, a_off // lda + k))
@@ -338,7 +363,7 @@ class GemmTables:
                 else:  # B stored [k, n]
                     b_sp.setdefault((b_off % ldb, n), []).append((b_off // ldb, b_off // ldb + k))
         elems = sum(w * union(sp) for (_, w), sp in a_sp.items()) + sum(w * union(sp) for (_, w), sp in b_sp.items())
-        elems += sum(rows * n for _, rows in c_el)
+        elems += sum(rows * gn for _, rows, gn in c_el)
         return 4 * elems
 
 
@@ -554,7 +579,7 @@ class TowerPlan:
         return 1 if blocks64 < 768 else 2
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
-                   allow_split=True, res=None, stats=None, bnbwd=None, pair=False):
+                   allow_split=True, res=None, stats=None, bnbwd=None, pair=False, hint=None, flags=0):
         """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32).
         stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate).
         bnbwd = producer node index whose batch-norm backward reduction rides in this data gradient's epilogue
@@ -573,7 +598,8 @@ class TowerPlan:
             lst.append(l2)
             return
         pair = bool(pair and PAIR_SEGS and not ta and tb and n > 16 and bnbwd is None and stats is None)
-        hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
+        if hint is None:
+            hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
         if HINT_OVERRIDE and tag in HINT_OVERRIDE:  # per-launch A/B: HYPEL_HINT_OVERRIDE="fwd:conv_enc_2=1,dgrad:fc_0=2"
             hint = HINT_OVERRIDE[tag]
         single_seg = bool(SINGLE_SEG_HINT and not ta and bnbwd is None and
@@ -605,8 +631,9 @@ class TowerPlan:
             self.__dict__.setdefault("_split_tables", []).append((tarr, t_t))
             self.scratch_sizes["ksplit_slabs"] = max(self.scratch_sizes.get("ksplit_slabs", 1), tables.split_need[0])
             self.scratch_sizes["ksplit_tickets"] = max(self.scratch_sizes.get("ksplit_tickets", 1), tables.split_need[1])
-        if single_seg:
+        if single_seg and not flags:
             accumulate = int(accumulate) | GEMM_SINGLE_SEG
+        accumulate = int(accumulate) | int(flags)
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
                 Ref(t_t), int(len(tarr)), bias_ref, int(accumulate) | (hint << 8))
         name = "seg_gemm_f32"
@@ -754,6 +781,7 @@ class TowerPlan:
         if self.training:
             import torch
             self._alloc("step_ctr", 1, torch.int64)
+        pack_pos = len(self.fwd)
         for idx, node in enumerate(tw.nodes):
             if isinstance(node, G.LinearNode):
                 self._fwd_linear(idx, node)
@@ -763,6 +791,7 @@ class TowerPlan:
                 self._fwd_lrn(idx, node)
             else:
                 raise TypeError(node)
+        self._emit_level_packs(pack_pos)
         if self.loss is not None:
             self._emit_loss()
         if self.training and self.loss is not None:
@@ -836,6 +865,133 @@ class TowerPlan:
         aux["wsize"] = sum(w.size for w in ws)
         return aux
 
+    # ------------------------------------------------------------------ merged multi-kernel levels
+    def _level_layout(self, idx, node):
+        """Packed layout of a multi-kernel level whose branches are nested odd kernels of equal width on one contiguous
+        source (HYPELCNNModel.py:167-183), or None.  An input offset (dy, dx) at ring r = max(|dy|, |dx|) belongs to the
+        branches with (k - 1) / 2 >= r -- a suffix of the concat order -- i.e. to the output columns [col0[r], C).
+        Offsets are numbered ring-major; W_pack[d] is [Cin x C] (columns below col0 are never touched)."""
+        cache = self.__dict__.setdefault("_level_layouts", {})
+        if idx in cache:
+            return cache[idx]
+        lay = None
+        brs = node.branches
+        if (MERGE_LEVELS and node.kind == "conv" and len(brs) >= 2 and not node.has_bias
+                and self.nb >= TAP_SPLIT_MIN_BATCH and len(node.sources) == 1):
+            ks = [b.k for b in brs]
+            co = brs[0].cout
+            src = node.sources[0]
+            ok = (all(k % 2 == 1 for k in ks) and all(a < b for a, b in zip(ks, ks[1:])) and
+                  all(b.cout == co for b in brs) and co <= MERGE_LEVELS_MAX_COUT and src.hw is not None and
+                  self.storage_of(src).contiguous)
+            if ok:
+                rmax = (ks[-1] - 1) // 2
+                first = [next(i for i, k in enumerate(ks) if (k - 1) // 2 >= r) for r in range(rmax + 1)]
+                offs = []
+                for r in range(rmax + 1):
+                    offs += [(dy, dx, r) for dy in range(-r, r + 1) for dx in range(-r, r + 1) if max(abs(dy), abs(dx)) == r]
+                C = co * len(brs)
+                lay = dict(offs=offs, index={(dy, dx): d for d, (dy, dx, _) in enumerate(offs)}, rmax=rmax, first=first,
+                           col0=[f * co for f in first], co=co, C=C, cin=src.c, buf=f"wpack:{idx}",
+                           dense_off=[], dense_size=0)
+                pos = 0
+                for (_, _, r) in offs:  # dense image of the packed filter gradient: [d] -> [Cin x (C - col0[r])]
+                    lay["dense_off"].append(pos)
+                    pos += src.c * (C - lay["col0"][r])
+                lay["dense_size"] = pos
+                assert pos == sum(b.w.size for b in brs)
+                if any(w_ in MERGE_LEVELS and co <= MERGE_PASS_MAX_COUT[w_] for w_ in ("fwd", "dgrad")):
+                    # these passes read the packed image (the filter gradient does not)
+                    lay["packed"] = True
+                    self._alloc(lay["buf"], len(offs) * src.c * C)
+        cache[idx] = lay
+        return lay
+
+    def _level_pass(self, idx, node, what):
+        """The level's packed layout if pass `what` ("fwd" / "dgrad" / "wgrad") uses the merged form, else None."""
+        lay = self._level_layout(idx, node)
+        if lay is None or what not in MERGE_LEVELS or lay["co"] > MERGE_PASS_MAX_COUT[what]:
+            return None
+        return lay
+
+    def _emit_level_packs(self, pos):
+        """ONE hypel_copy_blocks_f32 in front of the forward pass (inserted at launch position `pos`): every
+        (branch, tap) slice [Cin x cout] of every merged level goes to its offset / column range of the level's packed
+        image (the variables keep their TF layouts)."""
+        from .backend import COPY_BLOCK_DTYPE
+        base = Ref(self.sess.params)
+        ents = []
+        for idx, node in enumerate(self.tower.nodes):
+            lay = self.__dict__.get("_level_layouts", {}).get(idx)
+            if lay is None or not lay.get("packed"):
+                continue
+            dst0 = (self._ref(lay["buf"]).ptr() - base.ptr()) // 4
+            for bi, b in enumerate(node.branches):
+                pb = (b.k - 1) // 2
+                for i in range(b.k):
+                    for j in range(b.k):
+                        d = lay["index"][(i - pb, j - pb)]
+                        ents.append((b.w.offset + (i * b.k + j) * lay["cin"] * lay["co"],
+                                     dst0 + d * lay["cin"] * lay["C"] + bi * lay["co"], lay["cin"], lay["co"], lay["co"],
+                                     lay["C"], 0, 0))
+        if not ents:
+            return
+        t = self.be.upload(np.array(ents, COPY_BLOCK_DTYPE))
+        self.tables.append(t)
+        self.fwd.insert(pos, Launch("copy_blocks_f32", (base, Ref(t), len(ents)),
+                                    nbytes=8 * sum(e[2] * e[3] for e in ents), tag="level-pack"))
+
+    def _fwd_level_merged(self, idx, node, lay, s_st, ybuf, c, h, w):
+        """Forward pass of a merged level: per output pixel and ring r the product
+        Y[p][:, col0[r]:] (+)= sum_{d in ring r, valid} X[p + d] . W_pack[d][:, col0[r]:], rings with more than
+        MAX_TAPS_PER_TILE offsets cut into chunks; every (ring chunk, channel part) writes its own copy of Y (copy 0 is Y
+        itself), summed per branch by hypel_reduce_splits_f32 as for the tap splits of the unmerged form.
+        Returns the number of copies."""
+        nb = self.nb
+        src = node.sources[0]
+        rows_all = node.out.npix * nb
+        ring_sizes = [sum(1 for o in lay["offs"] if o[2] == r) for r in range(lay["rmax"] + 1)]
+        S_r = [max(1, -(-sz // (MERGE_MAX_TAPS or MAX_TAPS_PER_TILE))) for sz in ring_sizes]
+        ws = h * w * GEMM_BM * src.c * 4
+        kp_n = max(1, min(4, -(-ws // L2_CHUNK_BYTES), src.c // 16))
+        kcuts = [min(src.c, (src.c * q // kp_n + 15) // 16 * 16) for q in range(kp_n)] + [src.c]
+        chunk0 = [sum(S_r[:r]) for r in range(lay["rmax"] + 2)]  # first chunk index of ring r
+        n_copies = chunk0[-1] * kp_n
+        if n_copies > 1:
+            self._alloc(ybuf, rows_all * c * n_copies)
+        tb = GemmTables()
+        C, cin = lay["C"], lay["cin"]
+        for p in range(h * w):
+            py, px = p // w, p % w
+            for r in range(lay["rmax"] + 1):
+                col0 = lay["col0"][r]
+                valid = [(d, (py + dy) * w + (px + dx)) for d, (dy, dx, rr) in enumerate(lay["offs"])
+                         if rr == r and 0 <= py + dy < h and 0 <= px + dx < w]
+                for kp in range(kp_n):
+                    k0, k1 = kcuts[kp], kcuts[kp + 1]
+                    segs = [(s_st.pix_off(pin) + k0, (d * cin + k0) * C + col0, k1 - k0) for d, pin in valid]
+                    for si in range(S_r[r]):
+                        chunk = segs[len(segs) * si // S_r[r]:len(segs) * (si + 1) // S_r[r]]
+                        copy = (chunk0[r] + si) * kp_n + kp
+                        tb.add_group(copy * rows_all * c + p * nb * c + col0, chunk, nb, subkey=kp, n=C - col0)
+        flags = GEMM_VAR_N | (GEMM_MFMA16X4 if lay["co"] <= 16 and C <= 64 else 0)
+        pos = len(self.fwd)
+        self._emit_gemm(self.fwd, tb, C, self._ref(s_st.buf), s_st.ld, 0, self._ref(lay["buf"]), C, 0, self._ref(ybuf), c,
+                        None, 0, f"fwd:{node.branches[0].scope}/merged", allow_split=False, hint=MERGE_FWD_HINT,
+                        flags=flags)
+        if len(self.fwd) > pos:
+            self.fwd[pos].kparts = kp_n
+        choff = 0
+        for bi, b in enumerate(node.branches):
+            copies_b = chunk0[(b.k - 1) // 2 + 1] * kp_n  # the copies that hold columns of this branch: 0 .. copies_b - 1
+            if copies_b > 1:
+                self.fwd.append(Launch("reduce_splits_f32", (self._ref(ybuf, rows_all * c + choff), rows_all * c,
+                                                             copies_b - 1, self._ref(ybuf, choff), rows_all * b.cout, 1,
+                                                             None, b.cout, c),
+                                       nbytes=4 * rows_all * b.cout * (copies_b + 1), tag="tap-split-reduce"))
+            choff += b.cout
+        return n_copies
+
     def _fwd_linear(self, idx, node):
         nb = self.nb
         out = node.out
@@ -854,13 +1010,17 @@ class TowerPlan:
             s_st = self.storage_of(src)
             h, w = src.hw
             rows_all = out.npix * nb
+            lay = self._level_pass(idx, node, "fwd")
+            if lay is not None:
+                aux["stats_in_gemm"] = False
+                self._fwd_level_merged(idx, node, lay, s_st, ybuf, c, h, w)
             # Tap splitting: a block that walks all 49 taps of a 7x7 branch runs ~4x longer than the average tile
             # and finishes alone at ~40 % MFMA utilisation.  Branches with more than MAX_TAPS_PER_TILE taps have
             # their tap list cut into S chunks; chunk s writes a partial copy Y_s of the output (same layout,
             # stored behind Y in the same buffer) and a strided reduce adds Y_1.. into Y.
             splits = {}
             kparts = 1
-            if (bias_ref is None or SPLIT_BIASED) and nb >= TAP_SPLIT_MIN_BATCH:
+            if lay is None and (bias_ref is None or SPLIT_BIASED) and nb >= TAP_SPLIT_MIN_BATCH:
                 for b in node.branches:
                     taps = min(b.k, h) * min(b.k, w)
                     if taps > MAX_TAPS_PER_TILE:
@@ -882,7 +1042,7 @@ class TowerPlan:
                 self._alloc(ybuf, rows_all * c * s_max)
             choff = 0
             by_cout = {}
-            for b in node.branches:
+            for b in (node.branches if lay is None else ()):
                 # with a bias, split branches go into a launch of their own (no bias in the GEMM: the reduce adds it)
                 key = (b.cout, bias_ref is not None and splits.get(id(b), 1) > 1)
                 by_cout.setdefault(key, []).append((b, choff))
@@ -890,7 +1050,7 @@ class TowerPlan:
             # batch-norm statistics in the epilogue: a lone 1x1 branch on contiguous input writes ONE [rows x c] matrix
             fuse_stats = (STATS_EPILOGUE and node.has_bn and node.training and len(node.branches) == 1
                           and node.branches[0].k == 1 and s_st.contiguous and s_max == 1 and c > 16
-                          and not self._small_bn(node, rows_all))
+                          and not self._small_bn(node, rows_all) and lay is None)
             aux["stats_in_gemm"] = fuse_stats
             for (cout, split_launch), items in by_cout.items():
                 biased_launch = not split_launch
@@ -1263,11 +1423,32 @@ class TowerPlan:
                 for b in node.branches:
                     by_cout.setdefault(b.cout, []).append((b, choff))
                     choff += b.cout
+                lay = self._level_pass(idx, node, "dgrad")
+                if lay is not None:
+                    by_cout = {lay["co"]: [(b, None) for b in node.branches]}  # one launch over the packed image
+                w_ref, w_ld, mtag = Ref(self.sess.params), None, ""
                 for cout, items in by_cout.items():
                     tb = GemmTables()
-                    if len(items) == 1 and items[0][0].k == 1 and gst.contiguous:
+                    if lay is not None:
+                        # merged level: an input pixel sums, per input offset d (output pixel pin - d), ONE segment over the
+                        # columns [col0[ring], C) of dY against the same columns of W_pack[d] -- 49 instead of 84 segments
+                        # of 15 .. 60 columns at the centre of a 7x7 patch
+                        w_ref, w_ld, mtag = self._ref(lay["buf"]), lay["C"], "/merged"
+                        per_pixel = []
+                        for pin in range(h * w):
+                            iy, ix = pin // w, pin % w
+                            segs = []
+                            for d, (ofy, ofx, r) in enumerate(lay["offs"]):
+                                oy, ox = iy - ofy, ix - ofx
+                                if 0 <= oy < h and 0 <= ox < w:
+                                    col0 = lay["col0"][r]
+                                    segs.append(((oy * w + ox) * nb * c + col0, d * lay["cin"] * lay["C"] + col0,
+                                                 lay["C"] - col0))
+                            per_pixel.append(segs)
+                    elif len(items) == 1 and items[0][0].k == 1 and gst.contiguous:
                         b, off = items[0]
                         tb.add_group(gst.pix_off(0), [(off, b.w.offset, cout)], src.npix * nb)
+                        per_pixel = None
                     else:
                         per_pixel = []
                         for pin in range(h * w):
@@ -1285,37 +1466,38 @@ class TowerPlan:
                                             segs.append(((oy * w + ox) * nb * c + off,
                                                          b.w.offset + (i * b.k + j) * src.c * cout, cout))
                             per_pixel.append(segs)
-                        # Segment splitting, the data-gradient twin of the forward tap splitting: an input pixel of a
-                        # multi-kernel level sums up to sum(k^2) segments (165 for the five kernels of DUALCNN) and its
-                        # block runs that much longer than a corner pixel's.  The segment list is cut into S chunks
-                        # that write partial copies of dX (same layout, in scratch), processed chunk after chunk
-                        # inside a row chunk, and a reduce adds them.  Not with a folded shortcut gradient (one epilogue).
-                        max_segs = max(len(sg) for sg in per_pixel)
-                        S = 1
-                        if (DGRAD_MAX_SEGS > 0 and fold_res is None and nb >= TAP_SPLIT_MIN_BATCH and gst.contiguous
-                                and gst.ch_off == 0 and gst.ld == src.c and max_segs > DGRAD_MAX_SEGS):
-                            S = -(-max_segs // DGRAD_MAX_SEGS)
-                        if S > 1:
-                            copy = h * w * nb * gst.ld
-                            for pin, segs in enumerate(per_pixel):
-                                for si in range(S):
-                                    chunk = segs[len(segs) * si // S:len(segs) * (si + 1) // S]
-                                    tb.add_group(si * copy + gst.pix_off(pin), chunk, nb, subkey=si)
-                            pos = len(self.bwd)
-                            self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
-                                            self._ref(gst.buf), gst.ld, None, 0, f"dgrad:{items[0][0].scope}/split")
-                            self._scratch(self.bwd[pos], 6, "scratch_dgrad", S * copy)
-                            l2 = Launch("reduce_splits_f32", (None, copy, S, self._ref(gst.buf), h * w * nb * src.c,
-                                                              acc, None, src.c, gst.ld),
-                                        nbytes=4 * h * w * nb * src.c * (S + 1), tag="dgrad-split-reduce")
-                            self._scratch(l2, 0, "scratch_dgrad", S * copy)
-                            self.bwd.append(l2)
-                            acc = 1
-                            continue
+                    # Segment splitting, the data-gradient twin of the forward tap splitting: an input pixel of a
+                    # multi-kernel level sums up to sum(k^2) segments (165 for the five kernels of DUALCNN) and its
+                    # block runs that much longer than a corner pixel's.  The segment list is cut into S chunks
+                    # that write partial copies of dX (same layout, in scratch), processed chunk after chunk
+                    # inside a row chunk, and a reduce adds them.  Not with a folded shortcut gradient (one epilogue).
+                    max_segs = max(len(sg) for sg in per_pixel) if per_pixel is not None else 0
+                    S = 1
+                    if (DGRAD_MAX_SEGS > 0 and fold_res is None and nb >= TAP_SPLIT_MIN_BATCH and gst.contiguous
+                            and gst.ch_off == 0 and gst.ld == src.c and max_segs > DGRAD_MAX_SEGS):
+                        S = -(-max_segs // DGRAD_MAX_SEGS)
+                    if S > 1:
+                        copy = h * w * nb * gst.ld
                         for pin, segs in enumerate(per_pixel):
-                            tb.add_group(gst.pix_off(pin), segs, nb)
-                    self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), cout, 1,
-                                    self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}",
+                            for si in range(S):
+                                chunk = segs[len(segs) * si // S:len(segs) * (si + 1) // S]
+                                tb.add_group(si * copy + gst.pix_off(pin), chunk, nb, subkey=si)
+                        pos = len(self.bwd)
+                        self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, w_ref, w_ld or cout, 1,
+                                        self._ref(gst.buf), gst.ld, None, 0,
+                                        f"dgrad:{items[0][0].scope}/split{mtag}")
+                        self._scratch(self.bwd[pos], 6, "scratch_dgrad", S * copy)
+                        l2 = Launch("reduce_splits_f32", (None, copy, S, self._ref(gst.buf), h * w * nb * src.c,
+                                                          acc, None, src.c, gst.ld),
+                                    nbytes=4 * h * w * nb * src.c * (S + 1), tag="dgrad-split-reduce")
+                        self._scratch(l2, 0, "scratch_dgrad", S * copy)
+                        self.bwd.append(l2)
+                        acc = 1
+                        continue
+                    for pin, segs in enumerate(per_pixel or ()):
+                        tb.add_group(gst.pix_off(pin), segs, nb)
+                    self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, w_ref, w_ld or cout, 1,
+                                    self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}{mtag}",
                                     res=fold_res, bnbwd=self._bnbwd_producer(idx, src, gst, len(by_cout)),
                                     pair=cout <= 16)
                     fold_res = None
@@ -1501,7 +1683,7 @@ class TowerPlan:
         return out
 
     def _emit_wgrad(self, tables_by_split_builder, n_groups_blocks, max_segs, slab, w0_offset, n, a_ref, lda, b_ref, ldb,
-                    tag, acc=0):
+                    tag, acc=0, unpack=None):
         """tables_by_split_builder(S) -> GemmTables whose groups write to c_off = split*slab + local."""
         s_pix, s_row = self._wgrad_splits(n_groups_blocks, max_segs)
         S = s_pix * s_row
@@ -1513,8 +1695,9 @@ class TowerPlan:
                 self._flush_wgrads()
                 pend = self._pending_wgrads
             pend.append(dict(tb=tb, S=S, slab=int(slab), w0=int(w0_offset), n=int(n), a_ref=a_ref, lda=int(lda),
-                             b_ref=b_ref, ldb=int(ldb), tag=tag, acc=int(acc)))
+                             b_ref=b_ref, ldb=int(ldb), tag=tag, acc=int(acc), unpack=unpack))
             return
+        assert unpack is None, "merged-level filter gradients need the merged launch (HYPEL_MERGE_WGRAD)"
         if S == 1:
             self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None,
                             acc, tag, allow_split=False)
@@ -1558,51 +1741,80 @@ class TowerPlan:
         self._alloc(sname, max(need, 1))
         spos = 0
         grads0 = rel(Ref(self.sess.grads))
-        by_width = {}
         entries = []
+        unpacks = []  # block copies packed gradient image -> TF-layout gradient slots (merged levels)
+
+        def col_tiles(n, merged):
+            """[(n0, tile width)] of a product with n output columns.  Ordinary products: one width per product.  The
+            per-offset products of a merged level (n = 15 .. 240): 64-wide tiles while >= 48 columns remain, then 32, 16."""
+            if not merged:
+                wdt = 16 if n <= 16 else (32 if n <= 32 else 64)
+                return [(n0, wdt) for n0 in range(0, n, wdt)]
+            out, n0 = [], 0
+            while n0 < n:
+                rem = n - n0
+                wdt = 64 if rem >= 48 else (32 if rem > 16 else 16)
+                out.append((n0, wdt))
+                n0 += wdt
+            return out
+
+        per_width = {}  # width -> dict(segs, lists, macs, nbytes, tags)
         for e in pend:
             n = e["n"]
-            width = 16 if n <= 16 else (32 if n <= 32 else 64)
+            up = e.get("unpack")
+            if up is not None:
+                # the reduction target is the level's packed gradient image (dense per-offset blocks), scattered into the
+                # variables' gradient slots afterwards
+                self._alloc(up["buf"], e["slab"])
+                out_base = rel(self._ref(up["buf"]))
+                unpacks += [(out_base + so, grads0 + do, rows, cols, sld, dld, acc, 0)
+                            for (so, do, rows, cols, sld, dld, acc) in up["entries"]]
+            else:
+                out_base = grads0 + e["w0"]
             if e["S"] > 1:
                 c_base = rel(self._ref(sname, spos))
-                entries.append((c_base, grads0 + e["w0"], e["slab"], e["slab"], e["S"], e["acc"]))
+                entries.append((c_base, out_base, e["slab"], e["slab"], e["S"], 0 if up is not None else e["acc"]))
                 spos += e["S"] * e["slab"]
                 flags = 0
             else:
-                c_base = grads0 + e["w0"]
-                flags = e["acc"]
-            e.update(width=width, c_base=c_base, flags=flags, a0=rel(e["a_ref"]), b0=rel(e["b_ref"]))
-            by_width.setdefault(width, []).append(e)
-        for width in sorted(by_width, reverse=True):
-            segs, lists, macs_total, nbytes, tags = [], [], 0, 0, []
-            for e in by_width[width]:
-                n, tb = e["n"], e["tb"]
-                tags.append(e["tag"])
-                nbytes += tb.compulsory_bytes(n, e["lda"], 1, e["ldb"], 0)
-                groups = {}
-                for gi, (c_off, gs, rows) in enumerate(tb.groups):
-                    if not gs:
-                        # a split with no reduction rows still owns its slab: the reduce reads it, so it must be zero
-                        seg_begin, ksum = len(segs), 0
-                    else:
-                        seg_begin = len(segs)
-                        ksum = 0
-                        for (a_off, b_off, k) in gs:
-                            segs.append((e["a0"] + int(a_off), e["b0"] + int(b_off), int(k), 0))
-                            ksum += k
-                    macs_total += rows * ksum * n
-                    first = segs[seg_begin] if gs else (0, 0, 0, 0)
-                    key = tb.keys[gi] if tb.keys[gi] is not None else 0
-                    recs = groups.setdefault(key, [0, []])
-                    for m0 in range(0, rows, GEMM_BM):
-                        work = ksum * min(GEMM_BM, rows - m0)
-                        for n0 in range(0, n, width):
-                            recs[1].append((work, (e["c_base"] + int(c_off), first[0], first[1], m0, rows, n0, n,
-                                                   seg_begin, len(gs), first[2], e["flags"], e["lda"], e["ldb"], n, 0)))
-                            recs[0] += work
-                for w, r in groups.values():  # inside a locality group: heavy blocks (taps with many pixel pairs) first
-                    r.sort(key=lambda t: -t[0])
-                    lists.append((w, [rec for _, rec in r]))
+                c_base = out_base
+                flags = 0 if up is not None else e["acc"]
+            a0, b0 = rel(e["a_ref"]), rel(e["b_ref"])
+            tb = e["tb"]
+            first_width = None
+            loc_groups = {}  # (width, locality key) -> [work, [(work, record)]]
+            for gi, (c_off, gs, rows) in enumerate(tb.groups):
+                gn = tb.n_of(gi, n)
+                tiles = col_tiles(gn, up is not None)
+                ksum = sum(k for _, _, k in gs)
+                key = tb.keys[gi] if tb.keys[gi] is not None else 0
+                seg_begin = {}
+                for wdt in sorted({wd for _, wd in tiles}, reverse=True):
+                    pw = per_width.setdefault(wdt, dict(segs=[], lists=[], macs=0, nbytes=0, tags=[]))
+                    if first_width is None:
+                        first_width = wdt
+                    if e["tag"] not in pw["tags"]:
+                        pw["tags"].append(e["tag"])
+                    # (a split with no reduction rows still owns its slab: the reduce reads it, so it must be zero)
+                    seg_begin[wdt] = len(pw["segs"])
+                    pw["segs"] += [(a0 + int(a_off), b0 + int(b_off), int(k), 0) for (a_off, b_off, k) in gs]
+                first = (a0 + int(gs[0][0]), b0 + int(gs[0][1]), int(gs[0][2])) if gs else (0, 0, 0)
+                for m0 in range(0, rows, GEMM_BM):
+                    work = ksum * min(GEMM_BM, rows - m0)
+                    for n0, wdt in tiles:
+                        per_width[wdt]["macs"] += min(GEMM_BM, rows - m0) * ksum * min(wdt, gn - n0)
+                        recs = loc_groups.setdefault((wdt, key), [0, []])
+                        recs[1].append((work, (c_base + int(c_off), first[0], first[1], m0, rows, n0, gn,
+                                               seg_begin[wdt], len(gs), first[2], flags, e["lda"], e["ldb"], gn, 0)))
+                        recs[0] += work
+            if first_width is not None:
+                per_width[first_width]["nbytes"] += tb.compulsory_bytes(n, e["lda"], 1, e["ldb"], 0)
+            for (wdt, _), (wk, r) in loc_groups.items():  # inside a locality group: heavy blocks first
+                r.sort(key=lambda t: -t[0])
+                per_width[wdt]["lists"].append((wk, [rec for _, rec in r]))
+        for width in sorted(per_width, reverse=True):
+            pw = per_width[width]
+            segs, lists = pw["segs"], pw["lists"]
             lists.sort(key=lambda t: -t[0])
             xcd_work, xcd_recs = [0] * 8, [[] for _ in range(8)]
             for w, r in lists:
@@ -1618,8 +1830,8 @@ class TowerPlan:
             s_t, r_t = self.be.upload(sarr), self.be.upload(arr)
             self.tables += [s_t, r_t]
             l = Launch("seg_gemm_multi_f32", (base, 1, 0, width, Ref(s_t), Ref(r_t), int(len(arr))),
-                       flops=2 * macs_total, nbytes=nbytes, tag=f"wgrad-merged/{width}")
-            l.meta = {"products": tags, "blocks": int(sum(len(r) for r in xcd_recs)),
+                       flops=2 * pw["macs"], nbytes=pw["nbytes"], tag=f"wgrad-merged/{width}")
+            l.meta = {"products": pw["tags"], "blocks": int(sum(len(r) for r in xcd_recs)),
                       "xcd_work": [int(w) for w in xcd_work]}
             self.bwd.append(l)
         if entries:
@@ -1630,6 +1842,12 @@ class TowerPlan:
                        nbytes=4 * sum(cnt * (S + 1) for (_, _, _, cnt, S, _) in entries), tag="wgrad-reduce")
             l.meta = {"splits": [int(S) for (_, _, _, _, S, _) in entries]}
             self.bwd.append(l)
+        if unpacks:
+            from .backend import COPY_BLOCK_DTYPE
+            u_t = self.be.upload(np.array(unpacks, COPY_BLOCK_DTYPE))
+            self.tables.append(u_t)
+            self.bwd.append(Launch("copy_blocks_f32", (base, Ref(u_t), len(unpacks)),
+                                   nbytes=8 * sum(u[2] * u[3] for u in unpacks), tag="level-unpack"))
 
     @staticmethod
     def _split_even(segs, S):
@@ -1637,8 +1855,55 @@ class TowerPlan:
         n = len(segs)
         return [segs[(n * s) // S:(n * (s + 1)) // S] for s in range(S)]
 
+    def _wgrad_level_merged(self, idx, node, lay, s_st, src, dy, c, h, w):
+        """Filter gradient of a merged level: per input offset d ONE product dW_pack[d] = sum_p X[p + d]^T dY[p][:, col0:]
+        with n = C - col0[ring] columns (15 .. 60 for the narrowest HYPELCNN level instead of 15 per (branch, tap)), written
+        into a dense packed image; hypel_copy_blocks_f32 scatters the [Cin x cout] slices into the HWIO gradient slots."""
+        nb = self.nb
+        C, cin, co = lay["C"], lay["cin"], lay["co"]
+        group_list = []  # (offset of the block in the dense image, [(a_off, b_off)] pixel pairs, columns)
+        for d, (ofy, ofx, r) in enumerate(lay["offs"]):
+            col0 = lay["col0"][r]
+            pairs = [(s_st.pix_off((oy + ofy) * w + ox + ofx), (oy * w + ox) * nb * c + col0)
+                     for oy in range(h) for ox in range(w) if 0 <= oy + ofy < h and 0 <= ox + ofx < w]
+            if pairs:
+                group_list.append((lay["dense_off"][d], pairs, C - col0))
+        slab = lay["dense_size"]
+        blocks = sum(((cin + GEMM_BM - 1) // GEMM_BM) * ((n_d + 63) // 64) for _, _, n_d in group_list)
+        max_segs = max(len(prs) for _, prs, _ in group_list)
+
+        def build(S, group_list=group_list, slab=slab, rows=cin, lda=s_st.ld, ldb=c, npairs=max_segs):
+            tb = GemmTables()
+            for si, (p0, p1, r0, r1) in enumerate(self._split_ranges(S[0], S[1], npairs)):
+                for (loc, pairs, n_d) in group_list:
+                    q0, q1 = len(pairs) * p0 // npairs, len(pairs) * p1 // npairs
+                    segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs[q0:q1]] if r1 > r0 else []
+                    tb.add_group(si * slab + loc, segs, rows, key=si, n=n_d)
+            return tb
+
+        ents = []
+        for bi, b in enumerate(node.branches):
+            acc = self._param_acc(b.w)
+            pb = (b.k - 1) // 2
+            for i in range(b.k):
+                for j in range(b.k):
+                    d = lay["index"][(i - pb, j - pb)]
+                    r = lay["offs"][d][2]
+                    n_d = C - lay["col0"][r]
+                    dst = b.w.offset + (i * b.k + j) * cin * co
+                    ents.append((lay["dense_off"][d] + (bi - lay["first"][r]) * co, dst, cin, co, n_d, co, acc))
+        self._emit_wgrad(build, blocks, max_segs, slab, 0, C, self._ref(s_st.buf), s_st.ld, dy, c,
+                         f"wgrad:{node.branches[0].scope}/merged", acc=0,
+                         unpack=dict(buf=f"dwpack:{idx}", entries=ents))
+
     def _wgrad_conv(self, idx, node, aux, s_st, src, dy, c, h, w):
         nb = self.nb
+        lay = self._level_pass(idx, node, "wgrad") if MERGE_WGRAD else None
+        # (every offset of the largest kernel must meet at least one pixel pair, or its block of the packed image would
+        # never be written: (k - 1) / 2 <= min(h, w) - 1)
+        if lay is not None and max(b.k for b in node.branches) <= 2 * min(h, w) - 1:
+            self._wgrad_level_merged(idx, node, lay, s_st, src, dy, c, h, w)
+            return
         choff = 0
         w_base = aux["w0"].offset
         by_cout = {}

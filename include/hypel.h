@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* hypel_stream_t; /* hipStream_t */
 
-#define HYPEL_ABI_VERSION 3  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
+#define HYPEL_ABI_VERSION 4  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
 
 /* activation codes (leaky_relu: HYPELCNNModel.py:39, DUALCNNModel.py:18, shadow_data_models.py:53;
  * relu: tf_slim default, CONCNNModel.py; sigmoid: HYPELCNNModel.py:93; tanh: shadow_data_models.py:86) */
@@ -75,7 +75,8 @@ typedef struct {
     int32_t group; int32_t m0;                         /* output rows [m0, min(m0 + 128, rows)) of groups[group] */
     int32_t rows; int32_t seg_begin; int32_t seg_count; /* copies of groups[group] (a K-slice record: its own segments) */
     int32_t k0; int64_t c_off; int64_t a_off0; int64_t b_off0; /* c_off copy; segs[seg_begin] copy (0 if none) */
-    int32_t split; int32_t reserved;                   /* K-slice record: count | index << 8 (0 = whole tile), see below */
+    int32_t split; int32_t n;                          /* K-slice record: count | index << 8 (0 = whole tile), see below;
+                                                          n > 0: THIS tile's group has n output columns (<= the launch's n) */
     uint64_t slab; uint64_t ticket;                    /* device addresses of the tile's partial slabs / ticket words */
 } hypel_tile_t;
 #define HYPEL_GEMM_BM 128
@@ -102,9 +103,23 @@ typedef struct {
  * on the hint. */
 #define HYPEL_GEMM_SINGLE_SEG 0x800
 
+/* Merged multi-kernel levels (nnmodel/HYPELCNNModel.py:167-183, DUALCNNModel.py:92-104).  The kernel sizes of a level
+ * are nested (1 c 3 c 5 c 7 ...): an input offset at ring r = max(|dy|, |dx|) belongs to every branch with
+ * k >= 2r + 1, a SUFFIX of the concat order, so its output columns are ONE contiguous range [r * cout, C).  With a
+ * packed weight image W_pack[offset][Cin][C] (hypel_copy_blocks_f32 builds it from the HWIO variables) a level is, per
+ * output pixel and ring, a plain product on that column range: groups of one launch then differ in their column
+ * count, which travels in hypel_tile_t.n (0 = the launch's n; the grid covers the widest group, blocks beyond a
+ * narrower group's columns exit).  HYPEL_GEMM_MFMA16X4 (n <= 64, trans_a = trans_b = 0): 128x64 blocks on the 16x16x4
+ * MFMA, four 16-column tiles per wave, for levels with <= 16 filters per branch; HYPEL_GEMM_VAR_N: the tile records
+ * carry column counts -- 128x64 blocks then skip an accumulator tile that lies outside their group.  Results depend
+ * on neither (a launch without them computes the unused tiles on zeros). */
+#define HYPEL_GEMM_MFMA16X4 0x2000
+#define HYPEL_GEMM_VAR_N 0x4000
+
 /* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint
  * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks, 3 = 128x96 blocks for n > 64) -- results do not
- * depend on it; bit 10 = HYPEL_GEMM_PAIRED_SEGS; bit 11 = HYPEL_GEMM_SINGLE_SEG; bit 12 = HYPEL_GEMM_SPLIT_TAIL. */
+ * depend on it; bit 10 = HYPEL_GEMM_PAIRED_SEGS; bit 11 = HYPEL_GEMM_SINGLE_SEG; bit 12 = HYPEL_GEMM_SPLIT_TAIL;
+ * bit 13 = HYPEL_GEMM_MFMA16X4; bit 14 = HYPEL_GEMM_VAR_N. */
 int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb, int32_t trans_b,
                        float* c, int64_t ldc, int32_t n, const hypel_group_t* groups, const hypel_seg_t* segs,
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
@@ -186,6 +201,19 @@ int hypel_reduce_splits_f32(const float* partial, int64_t stride, int32_t n_spli
 int hypel_reduce_splits_pair_f32(const float* partial0, int64_t stride0, int64_t count0, float* out0,
                                  const float* partial1, int64_t stride1, int64_t count1, float* out1, int32_t n_splits,
                                  int32_t accumulate, hypel_stream_t stream);
+
+/* 2-D block copies in one launch: entry e copies (or adds) a [rows x cols] block, dst[dst_off + r * dst_ld + c]
+ * (+)= src[src_off + r * src_ld + c]; offsets in elements relative to `base` (one pointer for every operand, as in
+ * hypel_seg_gemm_multi_f32), flags bit 0 = accumulate.  Builds the packed weight image of a merged multi-kernel level
+ * from its tf_slim.conv2d HWIO variables (one entry per (branch, tap): the [Cin x cout] slice goes to offset d, columns
+ * [branch * cout, (branch + 1) * cout) of W_pack) before the forward pass, and scatters the packed filter gradient back
+ * into the variables' gradient slots after the backward pass -- TF names and layouts stay at the boundary. */
+typedef struct {
+    int64_t src_off; int64_t dst_off; int32_t rows; int32_t cols; int32_t src_ld; int32_t dst_ld; int32_t flags;
+    int32_t reserved;
+} hypel_copy_block_t;
+int hypel_copy_blocks_f32(const float* base, const hypel_copy_block_t* entries, int32_t n_entries,
+                          hypel_stream_t stream);
 
 /* ---- batch norm statistics (tf_slim.batch_norm fused, HYPELCNNModel.py:37,43-44) ------------------
  * partial[chunk][0][c] = mean of the chunk's rows, partial[chunk][1][c] = sum of squared deviations.

@@ -251,6 +251,16 @@ class EmuBackend:
         # records are empty blocks.  The result is specified per group, from the group's own segment list.
         seen, slices = {}, {}
         any_split = False
+        group_n = {}  # hypel_tile_t.n: a group's own column count (merged levels); every tile of a group agrees
+        for tt in t:
+            if int(tt["rows"]) != 0:
+                gn = int(tt["n"])
+                assert 0 <= gn <= n and group_n.setdefault(int(tt["group"]), gn) == gn, "per-tile n"
+        if any(group_n.values()):
+            assert accumulate_raw & 0x4000, "tile records with their own n need HYPEL_GEMM_VAR_N"
+        if accumulate_raw & 0x2000:
+            assert n <= 64 and not ta and not tb, "HYPEL_GEMM_MFMA16X4: forward products with n <= 64"
+        n_launch = n
         for tt in t:
             if int(tt["rows"]) == 0:
                 assert not any(int(tt[f]) for f in ("group", "m0", "seg_count", "split")), "malformed empty record"
@@ -299,6 +309,7 @@ class EmuBackend:
         for gi in seen:
             grp = g[gi]
             rows = int(grp["rows"])
+            n = group_n.get(gi, 0) or n_launch
             acc = np.zeros((rows, n), np.float64)
             s_lo, s_hi = int(grp["seg_begin"]), int(grp["seg_begin"]) + int(grp["seg_count"])
             for si in range(s_lo, s_hi):
@@ -331,6 +342,20 @@ class EmuBackend:
                 cm += acc.astype(np.float32)
             else:
                 cm[...] = acc.astype(np.float32)
+
+    def k_copy_blocks_f32(self, base, entries, n_entries):
+        from hypelcnn_amd.backend import COPY_BLOCK_DTYPE
+        ents = entries.t.numpy()[entries.off:].view(COPY_BLOCK_DTYPE)[:n_entries]
+        for e in ents:
+            rows, cols, sld, dld = int(e["rows"]), int(e["cols"]), int(e["src_ld"]), int(e["dst_ld"])
+            src = np.lib.stride_tricks.as_strided(_at(base, int(e["src_off"]), (rows - 1) * sld + cols), (rows, cols),
+                                                  (sld * 4, 4))
+            dst = np.lib.stride_tricks.as_strided(_at(base, int(e["dst_off"]), (rows - 1) * dld + cols), (rows, cols),
+                                                  (dld * 4, 4))
+            if int(e["flags"]) & 1:
+                dst += src
+            else:
+                dst[...] = src
 
     def k_seg_gemm_multi_f32(self, base, ta, tb, tile_width, segs, blocks, n_blocks):
         """Specification of the merged filter-gradient launch: every block record is one 128 x tile_width output

@@ -1096,3 +1096,61 @@ def test_seg_gemm_single_segment_hint(hip, rows, k, n, tb_, kind):
         rng = np.random.default_rng(rows + n + 1)  # same dz for both passes
     if kind != "res":
         np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("co,branches,rows,cin,acc,flags_kind", [
+    (15, 4, 300, 120, 0, "mfma16x4"),   # narrowest HYPELCNN level: groups of 60 / 45 / 30 / 15 columns, 128x64 blocks on 16x16x4
+    (15, 4, 128, 33, 1, "mfma16x4"),
+    (7, 3, 70, 40, 0, "mfma16x4"),
+    (16, 4, 257, 64, 0, "mfma16x4"),
+    (30, 4, 300, 240, 0, "var_n"),      # level 1: groups of 120 / 90 / 60 / 30 columns on 128x64 blocks (one- / two-tile phases)
+    (30, 4, 129, 50, 1, "var_n"),
+    (60, 4, 200, 120, 0, "var_n"),      # level 0: 240 / 180 / 120 / 60
+    (20, 5, 90, 37, 0, "var_n"),        # DUALCNN-like: five rings
+    (30, 4, 300, 240, 0, "none"),       # the flags are hints: the plain kernels give the same result
+    (15, 4, 300, 120, 0, "none"),
+])
+def test_seg_gemm_per_tile_column_counts(hip, co, branches, rows, cin, acc, flags_kind):
+    """Merged multi-kernel levels (hypel_tile_t.n): the groups of ONE launch write column ranges [r * co, C) of different
+    widths, each from its own segments over a packed image with ldb = C; columns left of a group's range must stay
+    untouched, the grid is sized for the widest group."""
+    from hypelcnn_amd.plan import GEMM_MFMA16X4, GEMM_VAR_N
+    rng = np.random.default_rng(co * 1000 + rows)
+    C = co * branches
+    n_off = 6
+    x = rng.standard_normal((n_off + 2) * rows * cin).astype(np.float32)
+    wp = rng.standard_normal(n_off * cin * C).astype(np.float32)
+    ncopy = branches
+    y0 = rng.standard_normal(ncopy * rows * C).astype(np.float32)
+    tb = GemmTables()
+    for r in range(branches):
+        col0 = r * co
+        segs = [((d + (r % 2)) * rows * cin, d * cin * C + col0, cin) for d in range(n_off) if (d + r) % 3 != 0]
+        if r == branches - 1:
+            segs = segs[:1] + [(segs[0][0] + 3, segs[0][1] + 3 * C, cin - 3)]  # a ragged second segment
+        tb.add_group(r * rows * C + col0, segs, rows, n=C - col0)
+    garr, sarr, tarr, _ = tb.finalize(C)
+    assert set(int(v) for v in tarr["n"]) == {C - r * co for r in range(branches)}
+    b = Both(hip)
+    for nm, arr in (("x", x), ("w", wp), ("y", y0), ("g", garr), ("s", sarr), ("t", tarr)):
+        b.arr(nm, arr)
+    flags = {"mfma16x4": GEMM_VAR_N | GEMM_MFMA16X4, "var_n": GEMM_VAR_N | (2 << 8), "none": GEMM_VAR_N}[flags_kind]
+    b.run("seg_gemm_f32", "x", cin, 0, "w", C, 0, "y", C, C, "g", "s", "t", len(tarr), None, acc | flags)
+    b.check("y", rtol=3e-4, atol=3e-5)
+    got = b.h["y"].cpu().numpy().reshape(ncopy, rows, C)
+    for r in range(branches):
+        assert np.array_equal(got[r][:, :r * co], y0.reshape(ncopy, rows, C)[r][:, :r * co]), "columns left of the group"
+
+
+def test_copy_blocks(hip):
+    rng = np.random.default_rng(5)
+    buf = rng.standard_normal(200000).astype(np.float32)
+    from hypelcnn_amd.backend import COPY_BLOCK_DTYPE
+    ents = [(1000, 100000, 120, 60, 60, 240, 0, 0), (9000, 100060, 120, 60, 60, 240, 0, 0),
+            (20000, 150000, 7, 3, 5, 11, 1, 0), (30000, 160000, 1, 1, 1, 1, 1, 0), (40000, 170000, 33, 15, 45, 15, 0, 0)]
+    b = Both(hip)
+    b.arr("buf", buf)
+    b.arr("e", np.array(ents, COPY_BLOCK_DTYPE))
+    b.run("copy_blocks_f32", "buf", "e", len(ents))
+    got, ref = b.h["buf"].cpu().numpy(), b.e["buf"].numpy()
+    assert np.array_equal(got, ref)

@@ -322,11 +322,37 @@ def test_grss2013_hypelcnn_batch1024_vs_oracle(hip):
     ct = U.run_train_step(built, x, onehot, masks)
     tags = _tags(ct)
     assert "tap-split-reduce" in tags and "wgrad-reduce" in tags and "splitk-reduce" in tags
+    # the default plan runs the narrowest level's forward and every level's data gradient in the merged form
+    assert "level-pack" in tags and any(t.startswith("fwd:") and t.endswith("/merged") for t in tags) and \
+        sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 3, sorted(set(tags))
     ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 15, alg,
                                      tol_logit=1e-3, tol_grad=5e-4)
     got = ct.value(built.y_conv).cpu().numpy()
     assert (got.argmax(1) == ref["logits"].argmax(1)).all()
     print(f"\nHYPELCNN nb=1024 vs fp64 oracle: logits {err:.2e}, worst grad {worst}")
+
+
+@pytest.mark.parametrize("nb", [64, 1024])
+def test_grss2013_hypelcnn_every_level_pass_merged_vs_oracle(hip, monkeypatch, nb):
+    """The merged form of the multi-kernel levels forced for ALL three levels and ALL three passes (forward on 128x64
+    blocks with per-tile column counts -- 16x16x4 MFMA for the 15-filter level --, merged data-gradient segments, packed
+    filter gradients + scatter launch) at the benchmark's shapes, against the float64 oracle."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "MERGE_LEVELS", {"fwd", "dgrad", "wgrad"})
+    monkeypatch.setattr(plan, "MERGE_LEVELS_MAX_COUT", 1 << 20)
+    monkeypatch.setattr(plan, "MERGE_PASS_MAX_COUT", {"fwd": 1 << 20, "dgrad": 1 << 20, "wgrad": 1 << 20})
+    alg = _alg("alg_param_hypelcnn.json")
+    built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 7, 145, 15, alg, nb, 78)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    assert sum(1 for t in tags if t.startswith("fwd:") and t.endswith("/merged")) == 3, sorted(set(tags))
+    assert sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 3
+    assert "level-unpack" in tags and "level-pack" in tags
+    ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 15, alg,
+                                     tol_logit=1e-3, tol_grad=5e-4)
+    got = ct.value(built.y_conv).cpu().numpy()
+    assert (got.argmax(1) == ref["logits"].argmax(1)).all()
+    print(f"\nHYPELCNN nb={nb}, every level merged, vs fp64 oracle: logits {err:.2e}, worst grad {worst}")
 
 
 def test_avon_hypelcnn_hsi_only_two_classes_vs_oracle(hip):

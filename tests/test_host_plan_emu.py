@@ -263,3 +263,31 @@ def test_bn_backward_reduction_rides_in_the_data_gradient_epilogue(monkeypatch):
     assert "seg_gemm_bnbwd_f32" not in [l.name for l in ct2.plan.bwd]
     import torch
     torch.testing.assert_close(sess2.grads, g_fused, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("passes,patch,fc", [("fwd", 7, 48), ("fwd,dgrad,wgrad", 7, 48), ("fwd,dgrad,wgrad", 5, 96),
+                                             ("wgrad", 7, 48), ("dgrad", 5, 48)])
+def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
+    """Merged multi-kernel levels (include/hypel.h, HYPEL_GEMM_VAR_N): the nested branches of a level share one packed
+    weight image; per output pixel and ring ONE product on the column range of the branches that contain the ring
+    (forward), merged reduction segments (data gradient), per-offset products into a packed gradient image that one
+    block-copy launch scatters back into the TF-layout gradient slots (filter gradient).  Forced at a tiny batch, every
+    pass alone and together, incl. channel parts, against the float64 oracle."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "TAP_SPLIT_MIN_BATCH", 1)
+    monkeypatch.setattr(plan, "MAX_TAPS_PER_TILE", 5)
+    monkeypatch.setattr(plan, "MERGE_LEVELS", set(passes.split(",")))
+    monkeypatch.setattr(plan, "MERGE_LEVELS_MAX_COUT", 1 << 20)
+    if patch == 5:
+        monkeypatch.setattr(plan, "L2_CHUNK_BYTES", 4096)  # channel parts in the merged forward
+    alg = dict(ALG_H, filter_count=fc)
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", patch, 9, 4, alg, 5, 29)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    names = [l.name for l in ct.plan.fwd + ct.plan.bwd]
+    for what in passes.split(","):
+        assert any(t.startswith(what + ":") and t.endswith("/merged") for t in tags) or \
+            (what == "wgrad" and "level-unpack" in tags), (what, tags)
+    assert ("level-pack" in tags) == bool(set(passes.split(",")) & {"fwd", "dgrad"})
+    assert ("copy_blocks_f32" in names) == ("level-pack" in tags or "level-unpack" in tags)
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
