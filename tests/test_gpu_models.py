@@ -322,9 +322,10 @@ def test_grss2013_hypelcnn_batch1024_vs_oracle(hip):
     ct = U.run_train_step(built, x, onehot, masks)
     tags = _tags(ct)
     assert "tap-split-reduce" in tags and "wgrad-reduce" in tags and "splitk-reduce" in tags
-    # the default plan runs the narrowest level's forward and every level's data gradient in the merged form
-    assert "level-pack" in tags and any(t.startswith("fwd:") and t.endswith("/merged") for t in tags) and \
-        sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 3, sorted(set(tags))
+    # the default plan runs the narrowest level's forward and the data gradients of the levels with <= 32 filters per
+    # branch in the merged form
+    assert "level-pack" in tags and sum(1 for t in tags if t.startswith("fwd:") and t.endswith("/merged")) == 1 and \
+        sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 2, sorted(set(tags))
     ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 15, alg,
                                      tol_logit=1e-3, tol_grad=5e-4)
     got = ct.value(built.y_conv).cpu().numpy()
