@@ -83,7 +83,7 @@ SIGNATURES = {
     "reduce_splits_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I32, _I64],
     "reduce_splits_pair_f32": [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I32, _I32],
     "seg_gemm_multi_f32": [_P, _I32, _I32, _I32, _P, _P, _I32],
-    "copy_blocks_f32": [_P, _P, _I32],
+    "copy_blocks_f32": [_P, _P, _I32, _I64],
     "reduce_splits_multi_f32": [_P, _P, _I32],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
     "bn_stats_f32": [_P, _I64, _I64, _I32, _I32, _P, _P, _F, _P, _P, _P, _P, _F],
@@ -135,6 +135,8 @@ SIGNATURES = {
     "l2norm_fwd": [_P, _I64, _I64, _I32, _P, _I64, _P],
     "l2norm_parts_fwd": [_P, _I64, _I64, _I32, _I32, _P, _I64, _P],
     "l2norm_parts_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _I64, _I32],
+    "l2norm_segs_fwd": [_P, _I64, _I64, _I32, _I32, _I32, _P, _I64, _P],
+    "l2norm_segs_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _I64, _I32],
     "l2norm_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I64, _I32],
     "nce_loss": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
 }

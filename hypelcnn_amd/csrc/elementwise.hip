@@ -1254,12 +1254,31 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(const float* __restric
     const hypel_copy_block_t e = entries[blockIdx.x];
     const float* src = base + e.src_off;
     float* dst = const_cast<float*>(base) + e.dst_off;
-    const int total = e.rows * e.cols;
+    const int64_t total = (int64_t)e.rows * e.cols;
     const bool acc = (e.flags & 1) != 0;
-    for (int i = threadIdx.x + blockIdx.y * 256; i < total; i += 256 * gridDim.y) {
-        const int r = i / e.cols, c = i - r * e.cols;
-        const float v = src[(int64_t)r * e.src_ld + c];
-        float* d = dst + (int64_t)r * e.dst_ld + c;
+    // 16-byte path: whole rows of float4 on both sides (the [nb x bands] blocks of a batched GAN application)
+    if ((e.cols & 3) == 0 && (e.src_ld & 3) == 0 && (e.dst_ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const int c4 = e.cols >> 2;
+        const int64_t total4 = total >> 2;
+        for (int64_t i = threadIdx.x + (int64_t)blockIdx.y * 256; i < total4; i += 256 * (int64_t)gridDim.y) {
+            const int64_t r = i / c4;
+            const int c = (int)(i - r * c4) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(src + r * e.src_ld + c);
+            float4* d = reinterpret_cast<float4*>(dst + r * e.dst_ld + c);
+            if (acc) {
+                const float4 o = *d;
+                *d = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+            } else {
+                *d = v;
+            }
+        }
+        return;
+    }
+    for (int64_t i = threadIdx.x + (int64_t)blockIdx.y * 256; i < total; i += 256 * (int64_t)gridDim.y) {
+        const int64_t r = i / e.cols;
+        const int c = (int)(i - r * e.cols);
+        const float v = src[r * e.src_ld + c];
+        float* d = dst + r * e.dst_ld + c;
         *d = acc ? *d + v : v;
     }
 }
@@ -1384,10 +1403,13 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
 }
 
 extern "C" int hypel_copy_blocks_f32(const float* base, const hypel_copy_block_t* entries, int32_t n_entries,
-                                     hypel_stream_t stream) {
-    HYPEL_REQUIRE(base && entries && n_entries >= 0, "hypel_copy_blocks_f32");
+                                     int64_t max_block_elems, hypel_stream_t stream) {
+    HYPEL_REQUIRE(base && entries && n_entries >= 0 && max_block_elems >= 0, "hypel_copy_blocks_f32");
     if (n_entries == 0) return 0;
-    hipLaunchKernelGGL(copy_blocks_kernel, dim3(n_entries, 4), dim3(256), 0, ST, base, entries);
+    // blocks per entry: ~2048 elements (512 float4) per block, so that a few large entries still fill the device
+    const int64_t per = (max_block_elems + 2047) / 2048;
+    const int gy = (int)(per < 1 ? 1 : (per > 1024 ? 1024 : per));
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(n_entries, gy), dim3(256), 0, ST, base, entries);
     HYPEL_CHECK_LAUNCH("hypel_copy_blocks_f32");
     return 0;
 }

@@ -613,9 +613,11 @@ __global__ __launch_bounds__(1024) void l2norm_fwd_kernel(const float* __restric
                                                           float* __restrict__ stat) {
     __shared__ double sh[1024];
     __shared__ float inv_s;
-    x += (int64_t)blockIdx.x * c;  // block p normalises part p: columns [p*c, (p+1)*c)
-    y += (int64_t)blockIdx.x * c;
-    stat += 2 * blockIdx.x;
+    // block (p, g) normalises part p -- columns [p*c, (p+1)*c) -- of row segment g (rows [g*rows, (g+1)*rows): one
+    // application of a row-concatenated batch; gridDim.y = 1 for a single application)
+    x += (int64_t)blockIdx.x * c + (int64_t)blockIdx.y * rows * ldx;
+    y += (int64_t)blockIdx.x * c + (int64_t)blockIdx.y * rows * ldy;
+    stat += 2 * (blockIdx.x + blockIdx.y * gridDim.x);
     const int64_t total = rows * c;
     double s = 0.0;
 #pragma unroll 4
@@ -648,10 +650,10 @@ __global__ __launch_bounds__(1024) void l2norm_bwd_kernel(const float* __restric
                                                           float* __restrict__ dx, int64_t lddx, int accumulate) {
     __shared__ double sh[1024];
     __shared__ float dot_s;
-    x += (int64_t)blockIdx.x * c;
-    dy += (int64_t)blockIdx.x * c;
-    dx += (int64_t)blockIdx.x * c;
-    stat += 2 * blockIdx.x;
+    x += (int64_t)blockIdx.x * c + (int64_t)blockIdx.y * rows * ldx;
+    dy += (int64_t)blockIdx.x * c + (int64_t)blockIdx.y * rows * lddy;
+    dx += (int64_t)blockIdx.x * c + (int64_t)blockIdx.y * rows * lddx;
+    stat += 2 * (blockIdx.x + blockIdx.y * gridDim.x);
     const int64_t total = rows * c;
     double s = 0.0;
 #pragma unroll 4
@@ -693,9 +695,9 @@ __global__ __launch_bounds__(1024) void l2norm_fwd_small_kernel(const float* __r
                                                                 float* __restrict__ y, int ldy,
                                                                 float* __restrict__ stat) {
     __shared__ double sh16[16];
-    x += blockIdx.x * c;
-    y += blockIdx.x * c;
-    stat += 2 * blockIdx.x;
+    x += blockIdx.x * c + (int64_t)blockIdx.y * rows * ldx;
+    y += blockIdx.x * c + (int64_t)blockIdx.y * rows * ldy;
+    stat += 2 * (blockIdx.x + blockIdx.y * gridDim.x);
     const int total = rows * c;
     float v[L2N_R];
     int off_y[L2N_R];
@@ -725,10 +727,10 @@ __global__ __launch_bounds__(1024) void l2norm_bwd_small_kernel(const float* __r
                                                                 const float* __restrict__ stat, float* __restrict__ dx,
                                                                 int lddx, int accumulate) {
     __shared__ double sh16[16];
-    x += blockIdx.x * c;
-    dy += blockIdx.x * c;
-    dx += blockIdx.x * c;
-    stat += 2 * blockIdx.x;
+    x += blockIdx.x * c + (int64_t)blockIdx.y * rows * ldx;
+    dy += blockIdx.x * c + (int64_t)blockIdx.y * rows * lddy;
+    dx += blockIdx.x * c + (int64_t)blockIdx.y * rows * lddx;
+    stat += 2 * (blockIdx.x + blockIdx.y * gridDim.x);
     const int total = rows * c;
     const float inv = stat[1], ss = stat[0];
     float xv[L2N_R], gv[L2N_R], old[L2N_R];
@@ -1125,32 +1127,43 @@ extern "C" int hypel_l2_reg(const float* w, int64_t count, float scale, float* l
     return 0;
 }
 
+extern "C" int hypel_l2norm_segs_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t parts, int32_t segs,
+                                     float* y, int64_t ldy, float* stat, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && y && stat && rows > 0 && c > 0 && parts > 0 && segs > 0, "hypel_l2norm_segs_fwd");
+    const bool small = rows * c <= L2N_R * 1024 && rows * segs * (ldx > ldy ? ldx : ldy) < (1ll << 30);
+    if (small)
+        hipLaunchKernelGGL(l2norm_fwd_small_kernel, dim3(parts, segs), dim3(1024), 0, ST, x, (int)ldx, (int)rows, c, y,
+                           (int)ldy, stat);
+    else
+        hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(parts, segs), dim3(1024), 0, ST, x, ldx, rows, c, y, ldy, stat);
+    HYPEL_CHECK_LAUNCH("hypel_l2norm_segs_fwd");
+    return 0;
+}
+
+extern "C" int hypel_l2norm_segs_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows,
+                                     int32_t c, int32_t parts, int32_t segs, const float* stat, float* dx, int64_t lddx,
+                                     int32_t accumulate, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && dy && dx && stat && rows > 0 && c > 0 && parts > 0 && segs > 0, "hypel_l2norm_segs_bwd");
+    const int64_t ldmax = ldx > lddy ? (ldx > lddx ? ldx : lddx) : (lddy > lddx ? lddy : lddx);
+    if (rows * c <= L2N_R * 1024 && rows * segs * ldmax < (1ll << 30))
+        hipLaunchKernelGGL(l2norm_bwd_small_kernel, dim3(parts, segs), dim3(1024), 0, ST, x, (int)ldx, dy, (int)lddy,
+                           (int)rows, c, stat, dx, (int)lddx, accumulate);
+    else
+        hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(parts, segs), dim3(1024), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx,
+                           lddx, accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_l2norm_segs_bwd");
+    return 0;
+}
+
 extern "C" int hypel_l2norm_parts_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t parts, float* y,
                                       int64_t ldy, float* stat, hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && y && stat && rows > 0 && c > 0 && parts > 0, "hypel_l2norm_parts_fwd");
-    const bool small = rows * c <= L2N_R * 1024 && rows * (ldx > ldy ? ldx : ldy) < (1ll << 30);
-    if (small)
-        hipLaunchKernelGGL(l2norm_fwd_small_kernel, dim3(parts), dim3(1024), 0, ST, x, (int)ldx, (int)rows, c, y, (int)ldy,
-                           stat);
-    else
-        hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, rows, c, y, ldy, stat);
-    HYPEL_CHECK_LAUNCH("hypel_l2norm_parts_fwd");
-    return 0;
+    return hypel_l2norm_segs_fwd(x, ldx, rows, c, parts, 1, y, ldy, stat, stream);
 }
 
 extern "C" int hypel_l2norm_parts_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows,
                                       int32_t c, int32_t parts, const float* stat, float* dx, int64_t lddx,
                                       int32_t accumulate, hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && dy && dx && stat && rows > 0 && c > 0 && parts > 0, "hypel_l2norm_parts_bwd");
-    const int64_t ldmax = ldx > lddy ? (ldx > lddx ? ldx : lddx) : (lddy > lddx ? lddy : lddx);
-    if (rows * c <= L2N_R * 1024 && rows * ldmax < (1ll << 30))
-        hipLaunchKernelGGL(l2norm_bwd_small_kernel, dim3(parts), dim3(1024), 0, ST, x, (int)ldx, dy, (int)lddy, (int)rows, c,
-                           stat, dx, (int)lddx, accumulate);
-    else
-        hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(parts), dim3(1024), 0, ST, x, ldx, dy, lddy, rows, c, stat, dx, lddx,
-                           accumulate);
-    HYPEL_CHECK_LAUNCH("hypel_l2norm_parts_bwd");
-    return 0;
+    return hypel_l2norm_segs_bwd(x, ldx, dy, lddy, rows, c, parts, 1, stat, dx, lddx, accumulate, stream);
 }
 
 extern "C" int hypel_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, float* y, int64_t ldy,

@@ -434,7 +434,8 @@ class TowerPlan:
         st = self.storage[id(own)]
         if t.root is None:
             return st
-        return Storage(st.buf, st.nb, st.ld, t.pixmap, t.ch_off, t.c, t.npix)
+        # (st.ch_off: the owner may itself be a row-block view of a batched application group, PhasePlan)
+        return Storage(st.buf, st.nb, st.ld, t.pixmap, st.ch_off + t.ch_off, t.c, t.npix)
 
     def grad_storage_of(self, t):
         st = self.storage_of(t)
@@ -451,7 +452,7 @@ class TowerPlan:
         gname = "g:" + st.buf
         if gname not in self.buffers:
             self._alloc(gname, owner.npix * self.nb * owner.c)
-            self.grad_written[id(owner)] = False
+        self.grad_written.setdefault(id(owner), False)  # (row-block views of a batched group share one gradient buffer)
         return gname
 
     def _grad_target(self, t):
@@ -463,7 +464,8 @@ class TowerPlan:
         written = self.grad_written[id(own)]
         if not written and t.root is not None:
             full = self.storage[id(own)]
-            self.bwd.append(Launch("fill_f32", (self._ref(gst.buf), full.rows * full.ld, 0.0), tag="zero-grad-view"))
+            self.bwd.append(Launch("fill_f32", (self._ref(gst.buf, full.ch_off), full.rows * full.ld, 0.0),
+                                   tag="zero-grad-view"))
             written = True
         self.grad_written[id(own)] = True
         return gst, 1 if written else 0
@@ -938,7 +940,7 @@ class TowerPlan:
             return
         t = self.be.upload(np.array(ents, COPY_BLOCK_DTYPE))
         self.tables.append(t)
-        self.fwd.insert(pos, Launch("copy_blocks_f32", (base, Ref(t), len(ents)),
+        self.fwd.insert(pos, Launch("copy_blocks_f32", (base, Ref(t), len(ents), max(e[2] * e[3] for e in ents)),
                                     nbytes=8 * sum(e[2] * e[3] for e in ents), tag="level-pack"))
 
     def _fwd_level_merged(self, idx, node, lay, s_st, ybuf, c, h, w):
@@ -1846,7 +1848,7 @@ class TowerPlan:
             from .backend import COPY_BLOCK_DTYPE
             u_t = self.be.upload(np.array(unpacks, COPY_BLOCK_DTYPE))
             self.tables.append(u_t)
-            self.bwd.append(Launch("copy_blocks_f32", (base, Ref(u_t), len(unpacks)),
+            self.bwd.append(Launch("copy_blocks_f32", (base, Ref(u_t), len(unpacks), max(u[2] * u[3] for u in unpacks)),
                                    nbytes=8 * sum(u[2] * u[3] for u in unpacks), tag="level-unpack"))
 
     @staticmethod
@@ -2046,6 +2048,13 @@ def gen_kernel_sizes(bands):
     return [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
 
 
+# Same-weight applications of one phase as ONE application on the row-concatenated batch (no GAN network has batch
+# statistics, so D([real; fake]), enc([G(x); x; y; G(y)]), G([x; y]) and the feature-discriminator layers on 4N rows are
+# exact; cut_wrapper.py:301-339): fewer, longer launches, >= 2 resident blocks per CU for the generator kernels.
+BATCH_APPS = os.environ.get("HYPEL_GAN_BATCH_APPS", "1") != "0"
+BATCH_APPS_MAX = int(os.environ.get("HYPEL_GAN_BATCH_APPS_MAX", "8"))
+
+
 class PhasePlan(TowerPlan):
     """One train op of a GAN step (tfgan RunTrainOpsHook = one session.run): the sub-graph that the phase's loss
     terms depend on, differentiated w.r.t. the variable groups the phase trains.  `outputs` (no loss terms) gives a
@@ -2128,47 +2137,265 @@ class PhasePlan(TowerPlan):
             self.buffers["in:" + name] = shared
             self.storage[id(t)] = Storage("in:" + name, nb, t.c, None, 0, t.c, 1)
         self._alloc("loss", 1)
-        for idx, node in enumerate(self.tower.nodes):
-            if node not in self.needed:
-                continue
-            if isinstance(node, G.LinearNode):
-                self._fwd_linear(idx, node)
-            elif isinstance(node, G.GeneratorNode):
-                self._fwd_generator(idx, node)
-            elif isinstance(node, G.DenseStackNode):
-                self._fwd_densestack(idx, node)
-            elif isinstance(node, G.FeatStackNode):
-                self._fwd_featstack(idx, node)
-            elif isinstance(node, G.PostNode):
-                self._fwd_post(idx, node)
+        units = self._schedule_units()
+        for unit in units:
+            if len(unit) > 1:
+                self._fwd_group(unit)
             else:
-                raise TypeError(node)
+                self._fwd_node(*unit[0])
         for ti, term in enumerate(self.terms):
             self._emit_term(ti, term)
         self._flush_loss_terms()
         if self.terms:
-            for idx in range(len(self.tower.nodes) - 1, -1, -1):
-                node = self.tower.nodes[idx]
-                if node not in self.needed or id(node.out) not in self._grad_needed:
+            for unit in reversed(units):
+                if len(unit) > 1:
+                    self._bwd_group(unit)
+                    continue
+                idx, node = unit[0]
+                if id(node.out) not in self._grad_needed:
                     continue
                 if not self.grad_written.get(id(node.out.owner), False):
                     continue  # this application does not feed the phase's loss
-                if isinstance(node, G.LinearNode):
-                    self._bwd_linear(idx, node)
-                elif isinstance(node, G.GeneratorNode):
-                    self._bwd_generator(idx, node)
-                elif isinstance(node, G.DenseStackNode):
-                    self._bwd_densestack(idx, node)
-                elif isinstance(node, G.FeatStackNode):
-                    self._bwd_featstack(idx, node)
-                elif isinstance(node, G.PostNode):
-                    self._bwd_post(idx, node)
+                self._bwd_node(idx, node)
             self._flush_wgrads()
             if getattr(self, "_side_open", False):
                 self.bwd.append(self._join_sides())
             self._emit_regularisers()
             self._finish_loss_slots()
         self._finish_scratch()
+
+    def _fwd_node(self, idx, node):
+        if isinstance(node, G.LinearNode):
+            self._fwd_linear(idx, node)
+        elif isinstance(node, G.GeneratorNode):
+            self._fwd_generator(idx, node)
+        elif isinstance(node, G.DenseStackNode):
+            self._fwd_densestack(idx, node)
+        elif isinstance(node, G.FeatStackNode):
+            self._fwd_featstack(idx, node)
+        elif isinstance(node, G.PostNode):
+            self._fwd_post(idx, node)
+        else:
+            raise TypeError(node)
+
+    def _bwd_node(self, idx, node):
+        if isinstance(node, G.LinearNode):
+            self._bwd_linear(idx, node)
+        elif isinstance(node, G.GeneratorNode):
+            self._bwd_generator(idx, node)
+        elif isinstance(node, G.DenseStackNode):
+            self._bwd_densestack(idx, node)
+        elif isinstance(node, G.FeatStackNode):
+            self._bwd_featstack(idx, node)
+        elif isinstance(node, G.PostNode):
+            self._bwd_post(idx, node)
+
+    # ---- same-weight applications as one row-concatenated application ----
+    def _batch_signature(self, node):
+        """Hashable identity of "the same network layer" (same variables, same hyper-parameters), or None when the node
+        kind is not batched.  Only ops whose rows are independent qualify: no batch statistics, no per-tensor norms."""
+        if isinstance(node, G.GeneratorNode):
+            return ("gen", id(node.weights[0]), bool(node.only_encoder), node.src.c)
+        if isinstance(node, G.DenseStackNode):
+            return ("ds", id(node.weights[0]), node.src.c)
+        if isinstance(node, G.LinearNode) and node.kind in ("dense", "blockdense"):
+            src = node.sources[0] if len(node.sources) == 1 else None
+            if (src is None or node.has_bn or node.residuals or node.dropout_keep is not None or src.hw is not None
+                    or src.pixmap is not None or node.out.hw is not None):
+                return None
+            return ("lin", node.kind, tuple(id(b.w) for b in node.branches), src.c)
+        if isinstance(node, G.FeatStackNode):
+            # the stacked slices must be the adjacent equal-width column blocks of ONE tensor that they cover entirely: the
+            # group then concatenates that tensor, and the kernel keeps one set of norms per application (row segment)
+            srcs = node.srcs
+            own = srcs[0].owner
+            if (len(srcs) > 1 and all(t.owner is own and t.root is not None and t.c == srcs[0].c and t.hw is None
+                                      for t in srcs)
+                    and all(t.ch_off == i * srcs[0].c for i, t in enumerate(srcs)) and len(srcs) * srcs[0].c == own.c):
+                return ("feat", len(srcs), srcs[0].c)
+        return None
+
+    @staticmethod
+    def _node_src(node):
+        if isinstance(node, G.FeatStackNode):
+            return node.srcs[0].owner
+        return node.sources[0] if isinstance(node, G.LinearNode) else node.src
+
+    def _schedule_units(self):
+        """[[(idx, node), ...]]: the needed nodes in an executable order, same-weight applications grouped.  Members of a
+        group run when the last of their inputs is ready; a grouping that would make the unit graph cyclic (CycleGAN:
+        G_xy(G_yx(y)) next to G_xy(x)) is split by depth."""
+        order = [(i, n) for i, n in enumerate(self.tower.nodes) if n in self.needed]
+        if not BATCH_APPS:
+            return [[u] for u in order]
+        prod = {id(n.out): k for k, (_, n) in enumerate(order)}  # tensor owner -> position of its producer
+        deps = [sorted({prod[id(t.owner)] for t in self._node_inputs(n) if id(t.owner) in prod}) for _, n in order]
+        depth = []
+        for k in range(len(order)):
+            depth.append(1 + max([depth[d] for d in deps[k]], default=0))
+        sigs = [self._batch_signature(n) for _, n in order]
+
+        def attempt(by_depth):
+            groups = {}
+            for k, sg in enumerate(sigs):
+                key = (k,) if sg is None else ((sg, depth[k]) if by_depth else (sg,))
+                groups.setdefault(key, []).append(k)
+            units = []
+            for key, ks in groups.items():
+                srcs = [id(self._node_src(order[k][1])) for k in ks] if len(ks) > 1 else []
+                if len(ks) > 1 and len(set(srcs)) != len(srcs):
+                    units += [[k] for k in ks]  # two applications on the same tensor: their input gradients would race
+                    continue
+                for c0 in range(0, len(ks), BATCH_APPS_MAX):
+                    units.append(ks[c0:c0 + BATCH_APPS_MAX])
+            unit_of = {k: u for u, ks in enumerate(units) for k in ks}
+            udeps = [sorted({unit_of[d] for k in ks for d in deps[k]} - {u}) for u, ks in enumerate(units)]
+            if any(unit_of[d] == u for u, ks in enumerate(units) for k in ks for d in deps[k]):
+                return None  # a member depends on another member
+            done, out = set(), []
+            while len(out) < len(units):  # Kahn, ties by first member (tower order)
+                ready = [u for u in range(len(units)) if u not in done and all(d in done for d in udeps[u])]
+                if not ready:
+                    return None
+                u = min(ready, key=lambda v: units[v][0])
+                done.add(u)
+                out.append([order[k] for k in units[u]])
+            return out
+
+        return attempt(False) or attempt(True) or [[u] for u in order]
+
+    def _concat_inputs(self, tag, srcs):
+        """Storage of the row-concatenated inputs [G * nb, c] of a group.  Zero copy when the inputs already are
+        consecutive row blocks of one buffer (the outputs of the previous batched layer), else one hypel_copy_blocks_f32
+        gathers them.  Returns (storage, gathered?)."""
+        nb = self.nb
+        sts = [self.storage_of(t) for t in srcs]
+        s0 = sts[0]
+        if all(st.buf == s0.buf and st.ld == s0.ld and st.c == s0.c and st.pixmap is None and
+               st.ch_off == s0.ch_off + g * nb * s0.ld for g, st in enumerate(sts)):
+            return Storage(s0.buf, nb * len(srcs), s0.ld, None, s0.ch_off, s0.c, 1), False
+        from .backend import COPY_BLOCK_DTYPE
+        c = srcs[0].c
+        name = f"cat:{tag}"
+        self._alloc(name, len(srcs) * nb * c)
+        base = Ref(self.sess.params)
+
+        def rel(ref):
+            return (ref.ptr() - base.ptr()) // 4
+
+        ents = [(rel(self._ref(st.buf, st.ch_off)), rel(self._ref(name, g * nb * c)), nb, c, st.ld, c, 0, 0)
+                for g, st in enumerate(sts)]
+        t = self.be.upload(np.array(ents, COPY_BLOCK_DTYPE))
+        self.tables.append(t)
+        self.fwd.append(Launch("copy_blocks_f32", (base, Ref(t), len(ents), nb * c), nbytes=8 * len(srcs) * nb * c,
+                               tag="batch-gather"))
+        return Storage(name, nb * len(srcs), c, None, 0, c, 1), True
+
+    def _fwd_group(self, unit):
+        """G same-weight applications as one application on G * nb rows: a representative copy of the node runs through
+        the ordinary handler with self.nb = G * nb; the members' outputs are row-block views of its output buffer."""
+        import copy
+        nb0, G_ = self.nb, len(unit)
+        idx0, n0 = unit[0]
+        srcs = [self._node_src(n) for _, n in unit]
+        cat_st, gathered = self._concat_inputs(idx0, srcs)
+        syn_src = G.SymTensor(self.tower, None, srcs[0].c, node=None)
+        syn_src.needs_grad = any(self._needs_grad(t) for t in srcs)
+        self.storage[id(syn_src)] = cat_st
+        rep = copy.copy(n0)
+        if isinstance(n0, G.LinearNode):
+            rep.sources = [syn_src]
+        elif isinstance(n0, G.FeatStackNode):
+            w_ = n0.srcs[0].c
+            rep.srcs = [syn_src.slice_channels(i * w_, (i + 1) * w_) for i in range(len(n0.srcs))]
+            rep.segments = G_
+        else:
+            rep.src = syn_src
+        rep.out = G.SymTensor(self.tower, None, n0.out.c, node=rep)
+        if syn_src.needs_grad:
+            self._grad_needed.add(id(syn_src))
+        if any(id(n.out) in self._grad_needed for _, n in unit):
+            self._grad_needed.add(id(rep.out))
+        self.nb = nb0 * G_
+        try:
+            self._fwd_node(idx0, rep)
+        finally:
+            self.nb = nb0
+        out_st = self.storage[id(rep.out)]
+        for g, (_, n) in enumerate(unit):
+            self.storage[id(n.out)] = Storage(out_st.buf, nb0, out_st.ld, None, out_st.ch_off + g * nb0 * out_st.ld,
+                                              n.out.c, 1)
+        if id(rep.out) in self._grad_needed and self.terms and "g:" + out_st.buf not in self.buffers:
+            self._alloc("g:" + out_st.buf, G_ * nb0 * out_st.ld)  # one gradient buffer, the members' are its row blocks
+        self._groups = getattr(self, "_groups", {})
+        self._groups[idx0] = dict(rep=rep, syn_src=syn_src, srcs=srcs, gathered=gathered, cat=cat_st)
+
+    def _bwd_group(self, unit):
+        nb0, G_ = self.nb, len(unit)
+        idx0, _ = unit[0]
+        grp = self._groups[idx0]
+        rep, syn_src, srcs = grp["rep"], grp["syn_src"], grp["srcs"]
+        if id(rep.out) not in self._grad_needed:
+            return
+        written = [self.grad_written.get(id(n.out), False) for _, n in unit]
+        if not any(written):
+            return  # none of these applications feeds the phase's loss
+        out_st = self.storage[id(rep.out)]
+        gname = "g:" + out_st.buf
+        for g, ((_, n), wr) in enumerate(zip(unit, written)):
+            if not wr:  # an application without a gradient contributes zero rows
+                m_st = self.storage[id(n.out)]
+                self.bwd.append(Launch("fill_f32", (self._ref(gname, m_st.ch_off), nb0 * m_st.ld, 0.0),
+                                       tag="zero-grad-rows"))
+        self.grad_written[id(rep.out)] = True
+        # input gradient: the inputs either are row blocks of ONE buffer (outputs of the previous batched layer) -- the
+        # handler then writes straight into that buffer's gradient, blocks nobody wrote yet zeroed first so that one
+        # accumulate state serves all rows -- or were gathered: the gradient of the concatenation is scattered (added)
+        # into the members' gradient targets by one block-copy launch
+        want = [self._needs_grad(t) for t in srcs]
+        if any(want):
+            if not grp["gathered"]:
+                for t in srcs:
+                    self._ensure_grad(t.owner)
+                states = [self.grad_written.get(id(t.owner), False) for t in srcs]
+                if any(states) and not all(states):
+                    for t, wr in zip(srcs, states):
+                        if not wr:
+                            st = self.storage_of(t)
+                            self.bwd.append(Launch("fill_f32", (self._ref("g:" + st.buf, st.ch_off), nb0 * st.ld, 0.0),
+                                                   tag="zero-grad-rows"))
+                self.grad_written[id(syn_src)] = any(states)
+            else:
+                self.grad_written.pop(id(syn_src), None)
+        self.nb = nb0 * G_
+        try:
+            self._bwd_node(idx0, rep)
+        finally:
+            self.nb = nb0
+        if any(want):
+            if not grp["gathered"]:
+                for t in srcs:
+                    self.grad_written[id(t.owner)] = True
+            else:
+                from .backend import COPY_BLOCK_DTYPE
+                base = Ref(self.sess.params)
+
+                def rel(ref):
+                    return (ref.ptr() - base.ptr()) // 4
+
+                c = srcs[0].c
+                scatter = "g:" + grp["cat"].buf
+                ents = []
+                for g, (t, w_) in enumerate(zip(srcs, want)):
+                    if not w_:
+                        continue
+                    gst, acc = self._grad_target(t)
+                    ents.append((rel(self._ref(scatter, g * nb0 * c)), rel(self._ref(gst.buf, gst.ch_off)), nb0, c, c,
+                                 gst.ld, acc, 0))
+                tbl = self.be.upload(np.array(ents, COPY_BLOCK_DTYPE))
+                self.tables.append(tbl)
+                self.bwd.append(Launch("copy_blocks_f32", (base, Ref(tbl), len(ents), nb0 * c), nbytes=8 * len(ents) * nb0 * c,
+                                       tag="batch-scatter"))
 
     # ---- fused generator ----
     def _gen_refs(self, node):
@@ -2277,13 +2504,15 @@ class PhasePlan(TowerPlan):
     def _fwd_featstack(self, idx, node):
         out = node.out
         st = self._new_value(out, f"z:{idx}")
-        self._alloc(f"l2stat:{idx}", 2 * len(node.srcs))
+        segs = getattr(node, "segments", 1)  # applications of a row-concatenated batch: each keeps its own norms
+        self._alloc(f"l2stat:{idx}", 2 * len(node.srcs) * segs)
         if self._adjacent_parts(node):
             s0 = self.storage_of(node.srcs[0])
-            self.fwd.append(Launch("l2norm_parts_fwd", (self._ref(s0.buf, s0.ch_off), s0.ld, self.nb, node.srcs[0].c,
-                                                        len(node.srcs), self._ref(st.buf), st.ld,
-                                                        self._ref(f"l2stat:{idx}")), tag="l2norm"))
+            self.fwd.append(Launch("l2norm_segs_fwd", (self._ref(s0.buf, s0.ch_off), s0.ld, self.nb // segs,
+                                                       node.srcs[0].c, len(node.srcs), segs, self._ref(st.buf), st.ld,
+                                                       self._ref(f"l2stat:{idx}")), tag="l2norm"))
             return
+        assert segs == 1
         off = 0
         for p, src in enumerate(node.srcs):
             s_st = self.storage_of(src)
@@ -2306,13 +2535,21 @@ class PhasePlan(TowerPlan):
         if self._adjacent_parts(node):
             if self._needs_grad(node.srcs[0]):
                 s0 = self.storage_of(node.srcs[0])
-                accs = [self._grad_target(s) for s in node.srcs]
-                gst, acc = accs[0]
-                assert all(a[1] == acc for a in accs), "parts of one buffer share the accumulate state"
-                self.bwd.append(Launch("l2norm_parts_bwd", (self._ref(s0.buf, s0.ch_off), s0.ld,
-                                                            self._ref("g:" + st.buf), st.ld, self.nb, node.srcs[0].c,
-                                                            len(node.srcs), self._ref(f"l2stat:{idx}"),
-                                                            self._ref(gst.buf, gst.ch_off), gst.ld, acc),
+                own = node.srcs[0].owner
+                if node.srcs[0].ch_off == 0 and len(node.srcs) * node.srcs[0].c == own.c:
+                    # the parts cover their tensor: one gradient target, no zero fill in front of a partial first write
+                    gst, acc = self._grad_target(own)
+                    gst = Storage(gst.buf, gst.nb, gst.ld, None, gst.ch_off, node.srcs[0].c, 1)
+                else:
+                    accs = [self._grad_target(s) for s in node.srcs]
+                    gst, acc = accs[0]
+                    assert all(a[1] == acc for a in accs), "parts of one buffer share the accumulate state"
+                segs = getattr(node, "segments", 1)
+                self.bwd.append(Launch("l2norm_segs_bwd", (self._ref(s0.buf, s0.ch_off), s0.ld,
+                                                           self._ref("g:" + st.buf), st.ld, self.nb // segs,
+                                                           node.srcs[0].c, len(node.srcs), segs,
+                                                           self._ref(f"l2stat:{idx}"),
+                                                           self._ref(gst.buf, gst.ch_off), gst.ld, acc),
                                        tag="l2norm-bwd"))
             return
         off = 0

@@ -207,13 +207,15 @@ int hypel_reduce_splits_pair_f32(const float* partial0, int64_t stride0, int64_t
  * hypel_seg_gemm_multi_f32), flags bit 0 = accumulate.  Builds the packed weight image of a merged multi-kernel level
  * from its tf_slim.conv2d HWIO variables (one entry per (branch, tap): the [Cin x cout] slice goes to offset d, columns
  * [branch * cout, (branch + 1) * cout) of W_pack) before the forward pass, and scatters the packed filter gradient back
- * into the variables' gradient slots after the backward pass -- TF names and layouts stay at the boundary. */
+ * into the variables' gradient slots after the backward pass -- TF names and layouts stay at the boundary.  Also gathers
+ * the inputs of same-weight GAN applications into one row-concatenated batch (cut_wrapper.py:301-339) and scatters its
+ * gradient back.  max_block_elems = rows * cols of the largest entry (host knowledge: sizes the grid). */
 typedef struct {
     int64_t src_off; int64_t dst_off; int32_t rows; int32_t cols; int32_t src_ld; int32_t dst_ld; int32_t flags;
     int32_t reserved;
 } hypel_copy_block_t;
 int hypel_copy_blocks_f32(const float* base, const hypel_copy_block_t* entries, int32_t n_entries,
-                          hypel_stream_t stream);
+                          int64_t max_block_elems, hypel_stream_t stream);
 
 /* ---- batch norm statistics (tf_slim.batch_norm fused, HYPELCNNModel.py:37,43-44) ------------------
  * partial[chunk][0][c] = mean of the chunk's rows, partial[chunk][1][c] = sum of squared deviations.
@@ -492,6 +494,13 @@ int hypel_l2norm_parts_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c,
 int hypel_l2norm_parts_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,
                            int32_t parts, const float* stat, float* dx, int64_t lddx, int32_t accumulate,
                            hypel_stream_t stream);
+/* The same for `segs` row segments of `rows` rows each (the applications of a row-concatenated batch: every
+ * application keeps its own whole-tensor norms); stat holds 2 floats per (segment, part), segment-major. */
+int hypel_l2norm_segs_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, int32_t parts, int32_t segs, float* y,
+                          int64_t ldy, float* stat, hypel_stream_t stream);
+int hypel_l2norm_segs_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,
+                          int32_t parts, int32_t segs, const float* stat, float* dx, int64_t lddx, int32_t accumulate,
+                          hypel_stream_t stream);
 int hypel_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int32_t c, float* y, int64_t ldy, float* stat,
                      hypel_stream_t stream);
 int hypel_l2norm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int32_t c,

@@ -343,9 +343,10 @@ class EmuBackend:
             else:
                 cm[...] = acc.astype(np.float32)
 
-    def k_copy_blocks_f32(self, base, entries, n_entries):
+    def k_copy_blocks_f32(self, base, entries, n_entries, max_block_elems):
         from hypelcnn_amd.backend import COPY_BLOCK_DTYPE
         ents = entries.t.numpy()[entries.off:].view(COPY_BLOCK_DTYPE)[:n_entries]
+        assert all(int(e["rows"]) * int(e["cols"]) <= max_block_elems for e in ents), "max_block_elems"
         for e in ents:
             rows, cols, sld, dld = int(e["rows"]), int(e["cols"]), int(e["src_ld"]), int(e["dst_ld"])
             src = np.lib.stride_tricks.as_strided(_at(base, int(e["src_off"]), (rows - 1) * sld + cols), (rows, cols),
@@ -950,6 +951,17 @@ def _k_l2norm_parts_bwd(self, x, ldx, dy, lddy, rows, c, parts, stat, dx, lddx, 
         _k_l2norm_bwd(self, x + p * c, ldx, dy + p * c, lddy, rows, c, stat + 2 * p, dx + p * c, lddx, accumulate)
 
 
+def _k_l2norm_segs_fwd(self, x, ldx, rows, c, parts, segs, y, ldy, stat):
+    for g in range(segs):
+        _k_l2norm_parts_fwd(self, x + g * rows * ldx, ldx, rows, c, parts, y + g * rows * ldy, ldy, stat + 2 * parts * g)
+
+
+def _k_l2norm_segs_bwd(self, x, ldx, dy, lddy, rows, c, parts, segs, stat, dx, lddx, accumulate):
+    for g in range(segs):
+        _k_l2norm_parts_bwd(self, x + g * rows * ldx, ldx, dy + g * rows * lddy, lddy, rows, c, parts,
+                            stat + 2 * parts * g, dx + g * rows * lddx, lddx, accumulate)
+
+
 def _k_nce_loss(self, g, ldg, r, ldr, n, p, e, tau, weight, loss, accumulate_loss, dg, lddg, acc_dg, dr, lddr, acc_dr,
                 ws):
     gv = _mat(g, ldg, n, p * e).astype(np.float64).reshape(n, p, e)
@@ -978,6 +990,8 @@ def _k_nce_loss(self, g, ldg, r, ldr, n, p, e, tau, weight, loss, accumulate_los
 
 EmuBackend.k_l2norm_parts_fwd = _k_l2norm_parts_fwd
 EmuBackend.k_l2norm_parts_bwd = _k_l2norm_parts_bwd
+EmuBackend.k_l2norm_segs_fwd = _k_l2norm_segs_fwd
+EmuBackend.k_l2norm_segs_bwd = _k_l2norm_segs_bwd
 EmuBackend.k_gan_generator_fwd = _k_gan_generator_fwd
 EmuBackend.k_gan_generator_bwd = _k_gan_generator_bwd
 EmuBackend.k_gan_loss = _k_gan_loss

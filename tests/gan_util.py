@@ -64,8 +64,16 @@ def check_phase_gradients(cfg, ops, params, x, y, tol=2e-4):
         g_all = max(np.abs(g).max() for g in ref_grads.values())
         for k, g in ref_grads.items():
             got = sess.get_gradient(k)
-            # a gradient that is analytically zero (last bias under the Wasserstein loss: +1/N and -1/N per sample)
-            # is compared at the rounding level of the terms that cancel, not relative to itself
+            if np.abs(g).max() <= 1e-9 * g_all:
+                # RULE for analytically-zero gradients (last bias of a Wasserstein critic: +1/N per real and -1/N per fake
+                # sample; the float64 oracle gives 1e-17): the product sums contributions of total magnitude <= the loss
+                # weight (1.0: N terms of 1/N on each side) in fp32, and whether the two halves cancel EXACTLY depends on
+                # the summation tree -- two separate applications whose slab sums mirror each other do, one application
+                # on the row-concatenated batch [real; fake] (round 4) leaves the rounding of a sum of unit magnitude.
+                # The check is therefore absolute: |got| <= 8 eps_fp32 * max(1, largest gradient of the phase).
+                lim = 8 * np.finfo(np.float32).eps * max(1.0, g_all)
+                assert np.abs(got - g).max() <= lim, (phase.name, k, np.abs(got - g).max(), lim)
+                continue
             scale = max(np.abs(g).max(), 1e-5 * g_all, 1e-7)
             err = np.abs(got - g).max() / scale
             worst = max(worst, err)

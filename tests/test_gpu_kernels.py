@@ -1147,10 +1147,11 @@ def test_copy_blocks(hip):
     buf = rng.standard_normal(200000).astype(np.float32)
     from hypelcnn_amd.backend import COPY_BLOCK_DTYPE
     ents = [(1000, 100000, 120, 60, 60, 240, 0, 0), (9000, 100060, 120, 60, 60, 240, 0, 0),
-            (20000, 150000, 7, 3, 5, 11, 1, 0), (30000, 160000, 1, 1, 1, 1, 1, 0), (40000, 170000, 33, 15, 45, 15, 0, 0)]
+            (20000, 150000, 7, 3, 5, 11, 1, 0), (30000, 160000, 1, 1, 1, 1, 1, 0), (40000, 170000, 33, 15, 45, 15, 0, 0),
+            (50000, 180000, 50, 64, 64, 64, 1, 0), (60000, 190000, 20, 8, 12, 16, 0, 0)]  # the last two: float4 path
     b = Both(hip)
     b.arr("buf", buf)
     b.arr("e", np.array(ents, COPY_BLOCK_DTYPE))
-    b.run("copy_blocks_f32", "buf", "e", len(ents))
+    b.run("copy_blocks_f32", "buf", "e", len(ents), 120 * 60)
     got, ref = b.h["buf"].cpu().numpy(), b.e["buf"].numpy()
     assert np.array_equal(got, ref)

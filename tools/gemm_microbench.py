@@ -74,7 +74,7 @@ def main():
         t = np.array(times[l.tag][2:])
         med = float(np.median(t))
         tot += med
-        if med > 40:
+        if med > 10:
             a = l.args
             shape = f"  n={a[8]} tiles={a[12]} ta={a[2]} tb={a[5]}" if len(a) > 12 else f"  blocks={a[6]}"
             print(f"{l.tag:34s} {l.flops / 1e9:7.2f} GF  med {med:8.1f} us  min {t.min():8.1f} us  {l.flops / med / 1e6:6.1f} TF/s"
