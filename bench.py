@@ -237,7 +237,8 @@ def measure_gan_events(ops, nb, bands, steps):
                     b.record()
                     bwd = "_bwd" in l.name  # gan_generator_bwd / gan_generator_bwd_kept
                     enc = bool(l.args[8] if bwd else l.args[6])
-                    evs.append((a, b, (4 if bwd else 2) * generator_exact_macs(bands, enc) * nb))
+                    rows = int(l.args[4] if bwd else l.args[2])  # k * nb when k same-weight applications run as one
+                    evs.append((a, b, (4 if bwd else 2) * generator_exact_macs(bands, enc) * rows))
                 else:
                     f()
         torch.cuda.synchronize()

@@ -84,6 +84,7 @@ SIGNATURES = {
     "reduce_splits_pair_f32": [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I32, _I32],
     "seg_gemm_multi_f32": [_P, _I32, _I32, _I32, _P, _P, _I32],
     "copy_blocks_f32": [_P, _P, _I32, _I64],
+    "reduce_splits_wave_multi_f32": [_P, _P, _I32, _I64],
     "reduce_splits_multi_f32": [_P, _P, _I32],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
     "bn_stats_f32": [_P, _I64, _I64, _I32, _I32, _P, _P, _F, _P, _P, _P, _P, _F],

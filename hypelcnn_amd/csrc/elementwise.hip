@@ -169,6 +169,35 @@ __global__ void reduce_splits_wave_pair_kernel(const float* __restrict__ p0, int
     }
 }
 
+// Several slab reductions in one launch, one WAVE per output element (many slabs, few outputs: the per-block filter /
+// bias gradient slabs of the fused generator and dense-stack kernels of a whole GAN phase): the outputs of all entries are
+// numbered consecutively, a wave finds its entry by walking the (short) table; per output the same lanes-over-slabs
+// butterfly as reduce_splits_wave_kernel, the old value added last.
+__global__ void reduce_splits_wave_multi_kernel(const float* __restrict__ base,
+                                                const hypel_reduce_entry_t* __restrict__ entries, int n_entries,
+                                                int64_t total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < total; i += n_waves) {
+        int64_t o = i;
+        int e = 0;
+        while (e + 1 < n_entries && o >= entries[e].count) {
+            o -= entries[e].count;
+            ++e;
+        }
+        const hypel_reduce_entry_t en = entries[e];
+        const float* __restrict__ p = base + en.partial_off + o;
+        float s = 0.0f;
+        for (int k = lane; k < en.n_splits; k += 64) s += p[(int64_t)k * en.stride];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            float* out = const_cast<float*>(base) + en.out_off + o;
+            *out = (en.flags & 1) ? *out + s : s;
+        }
+    }
+}
+
 // float4 variant (count, n, ldc, stride multiples of 4; 16-byte aligned bases)
 __global__ void reduce_splits_v4_kernel(const float* __restrict__ partial, int64_t stride, int n_splits,
                                         float* __restrict__ out, int64_t count4, int accumulate,
@@ -1399,6 +1428,16 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(hypel_grid_1d(count, 256, red_max_blocks())), dim3(256), 0, ST,
                            partial, stride, n_splits, out, count, accumulate, bias, n, ldc);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_f32");
+    return 0;
+}
+
+extern "C" int hypel_reduce_splits_wave_multi_f32(const float* base, const hypel_reduce_entry_t* entries,
+                                                  int32_t n_entries, int64_t total_count, hypel_stream_t stream) {
+    HYPEL_REQUIRE(base && entries && n_entries >= 0 && total_count >= 0, "hypel_reduce_splits_wave_multi_f32");
+    if (n_entries == 0 || total_count == 0) return 0;
+    hipLaunchKernelGGL(reduce_splits_wave_multi_kernel, dim3(hypel_grid_1d(total_count * 64, 256)), dim3(256), 0, ST, base,
+                       entries, n_entries, total_count);
+    HYPEL_CHECK_LAUNCH("hypel_reduce_splits_wave_multi_f32");
     return 0;
 }
 

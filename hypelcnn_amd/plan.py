@@ -2053,6 +2053,8 @@ def gen_kernel_sizes(bands):
 # exact; cut_wrapper.py:301-339): fewer, longer launches, >= 2 resident blocks per CU for the generator kernels.
 BATCH_APPS = os.environ.get("HYPEL_GAN_BATCH_APPS", "1") != "0"
 BATCH_APPS_MAX = int(os.environ.get("HYPEL_GAN_BATCH_APPS_MAX", "8"))
+# the per-block gradient slabs of every fused generator / dense-stack application of a train op in ONE reduction launch
+SLAB_REDUCE_MULTI = os.environ.get("HYPEL_SLAB_REDUCE_MULTI", "1") != "0"
 
 
 class PhasePlan(TowerPlan):
@@ -2158,6 +2160,7 @@ class PhasePlan(TowerPlan):
                     continue  # this application does not feed the phase's loss
                 self._bwd_node(idx, node)
             self._flush_wgrads()
+            self._flush_slab_reduces()
             if getattr(self, "_side_open", False):
                 self.bwd.append(self._join_sides())
             self._emit_regularisers()
@@ -2397,6 +2400,48 @@ class PhasePlan(TowerPlan):
                 self.bwd.append(Launch("copy_blocks_f32", (base, Ref(tbl), len(ents), nb0 * c), nbytes=8 * len(ents) * nb0 * c,
                                        tag="batch-scatter"))
 
+    # ---- per-block gradient slabs of the fused kernels: reduced once per train op ----
+    def _defer_slab_reduce(self, launch, pos_w, pos_b, blocks, w0, w_stride, w_count, b0, b_stride, b_count, acc):
+        """The backward kernel `launch` leaves `blocks` filter / bias gradient slabs (arguments pos_w / pos_b).  Instead of
+        one reduction launch per application, every application of one weight set appends its slabs to that set's
+        region and ONE hypel_reduce_splits_wave_multi_f32 at the end of the backward pass sums each region (one entry per
+        weight set and kind: two entries never write the same gradient)."""
+        sets = self.__dict__.setdefault("_slab_sets", {})
+        st = sets.setdefault(id(w0), dict(w0=w0, b0=b0, w=(w_stride, w_count), b=(b_stride, b_count), acc=acc, apps=[],
+                                         blocks=0))
+        st["apps"].append((launch, pos_w, pos_b, st["blocks"]))
+        st["blocks"] += blocks
+
+    def _flush_slab_reduces(self):
+        sets = self.__dict__.get("_slab_sets") or {}
+        self._slab_sets = {}
+        if not sets:
+            return
+        base = Ref(self.sess.params)
+
+        def rel(ref):
+            return (ref.ptr() - base.ptr()) // 4
+
+        ents, total = [], 0
+        for k, st in enumerate(sets.values()):
+            fid = self.__dict__.setdefault("_slab_bufs", 0)
+            self._slab_bufs = fid + 1
+            names = {}
+            for kind, var in (("w", st["w0"]), ("b", st["b0"])):
+                stride, count = st[kind]
+                names[kind] = f"slabs_{kind}:{fid}"
+                self._alloc(names[kind], st["blocks"] * stride)
+                ents.append((rel(self._ref(names[kind])), rel(self._g(var)), stride, count, st["blocks"], st["acc"]))
+                total += count
+            for launch, pos_w, pos_b, b0 in st["apps"]:
+                args = list(launch.args)
+                args[pos_w] = self._ref(names["w"], b0 * st["w"][0])
+                args[pos_b] = self._ref(names["b"], b0 * st["b"][0])
+                launch.args = tuple(args)
+        e_t = self.be.upload(np.array(ents, REDUCE_ENTRY_DTYPE))
+        self.tables.append(e_t)
+        self.bwd.append(Launch("reduce_splits_wave_multi_f32", (base, Ref(e_t), len(ents), total), tag="slab-reduce"))
+
     # ---- fused generator ----
     def _gen_refs(self, node):
         self._assert_contiguous(node.weights)
@@ -2439,11 +2484,15 @@ class PhasePlan(TowerPlan):
             f.bytes += 4 * keep_n
             l1.name, l1.args = "gan_generator_bwd_kept", tuple(l1.args) + (kref,)
             l1.bytes += 4 * keep_n
-        self._scratch(l1, 12, "scratch_gen_w", blocks * wtotal)
-        self._scratch(l1, 13, "scratch_gen_b", blocks * 8)
         self.bwd.append(l1)
         if self._trains(node.weights):
             wacc = self._param_acc(w0)
+            if SLAB_REDUCE_MULTI:
+                self._defer_slab_reduce(l1, 12, 13, blocks, w0, wtotal, wtotal, b0, 8, 7, wacc)
+                return
+        self._scratch(l1, 12, "scratch_gen_w", blocks * wtotal)
+        self._scratch(l1, 13, "scratch_gen_b", blocks * 8)
+        if self._trains(node.weights):
             # filter and bias slabs in one launch
             l2 = Launch("reduce_splits_pair_f32", (None, wtotal, wtotal, self._g(w0), None, 8, 7, self._g(b0), blocks, wacc),
                         tag="gen-dw+db")
@@ -2487,13 +2536,17 @@ class PhasePlan(TowerPlan):
                                         None), flops=6 * self.nb * wtotal, nbytes=4 * self.nb * (2 * src.c + out.c),
                     tag="dense-stack-bwd")
         n_args = len(l1.args)
-        self._scratch(l1, n_args - 2, "scratch_ds_w", blocks * wtotal)
-        self._scratch(l1, n_args - 1, "scratch_ds_b", blocks * btotal)
         self.bwd.append(l1)
         if self._trains(node.weights):
             wacc = self._param_acc(w0)
             for v in node.weights[1:] + node.biases:
                 self._param_acc(v)
+            if SLAB_REDUCE_MULTI:
+                self._defer_slab_reduce(l1, n_args - 2, n_args - 1, blocks, w0, wtotal, wtotal, b0, btotal, btotal, wacc)
+                return
+        self._scratch(l1, n_args - 2, "scratch_ds_w", blocks * wtotal)
+        self._scratch(l1, n_args - 1, "scratch_ds_b", blocks * btotal)
+        if self._trains(node.weights):
             l2 = Launch("reduce_splits_pair_f32", (None, wtotal, wtotal, self._g(w0), None, btotal, btotal, self._g(b0),
                                                    blocks, wacc), tag="ds-dw+db")
             self._scratch(l2, 0, "scratch_ds_w", blocks * wtotal)

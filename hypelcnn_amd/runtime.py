@@ -334,7 +334,9 @@ class Session:
         if self.dist is None:
             return
         import torch.distributed as dist
-        # adjacent groups travel in one call; RCCL averages in the collective (gloo, the CPU test backend, cannot)
+        # adjacent groups travel in one call.  ONE averaging path on every backend -- SUM, then scale by 1 / world -- so that
+        # the 2-rank gloo tests (tests/test_dp_gloo.py) exercise exactly what runs over RCCL (round 3 averaged inside the
+        # collective on RCCL only: two code paths, one of them never multi-rank-tested)
         ranges = []
         for lo, hi in sorted(self.group_ranges[g] for g in groups):
             if hi > lo:
@@ -342,15 +344,11 @@ class Session:
                     ranges[-1][1] = hi
                 else:
                     ranges.append([lo, hi])
-        avg = dist.get_backend() == "nccl"
         for lo, hi in ranges:
             view = self.grads[lo:hi]
             note_collective()
-            if avg:
-                dist.all_reduce(view, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(view, op=dist.ReduceOp.SUM)
-                view.mul_(1.0 / self.dist[0])
+            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+            view.mul_(1.0 / self.dist[0])
 
     # ---- optimiser (common_nn_ops.py:223-230) ----
     def guard_ref(self):

@@ -188,6 +188,13 @@ typedef struct {
 int hypel_reduce_splits_multi_f32(const float* base, const hypel_reduce_entry_t* entries, int32_t n_entries,
                                   hypel_stream_t stream);
 
+/* The same table for reductions with MANY slabs and few outputs (the per-block gradient slabs that the fused
+ * generator / dense-stack backward kernels of one GAN train op leave: all of them in one launch): one wavefront per
+ * output element, lanes over the slabs; total_count = sum of the entries' counts (host knowledge: sizes the grid).
+ * Two entries of one launch must not write the same output. */
+int hypel_reduce_splits_wave_multi_f32(const float* base, const hypel_reduce_entry_t* entries, int32_t n_entries,
+                                       int64_t total_count, hypel_stream_t stream);
+
 /* out[o(i)] = (accumulate ? out[o(i)] : 0) + (bias ? bias[i mod n] : 0) + sum_s partial[s*stride + o(i)], s ascending
  * (deterministic second stage of every split launch: filter gradients, FC-shaped products whose output has too
  * few tiles to fill 256 CUs, and the tap-split heavy branches of a multi-kernel level).

@@ -411,6 +411,13 @@ class EmuBackend:
             else:
                 o[...] = tot.astype(np.float32)
 
+    def k_reduce_splits_wave_multi_f32(self, base, entries, n_entries, total_count):
+        ents = entries.t.numpy()[entries.off:].view(REDUCE_ENTRY_DTYPE)[:n_entries]
+        assert sum(int(e["count"]) for e in ents) == total_count
+        outs = [(int(e["out_off"]), int(e["out_off"]) + int(e["count"])) for e in ents]
+        assert all(a[1] <= b[0] or b[1] <= a[0] for i, a in enumerate(outs) for b in outs[i + 1:]), "overlapping outputs"
+        self.k_reduce_splits_multi_f32(base, entries, n_entries)
+
     def k_reduce_splits_f32(self, partial, stride, n_splits, out, count, accumulate, bias=None, n=0, ldc=0):
         p = _arr(partial)
         idx = np.arange(count)
