@@ -1155,3 +1155,37 @@ def test_copy_blocks(hip):
     b.run("copy_blocks_f32", "buf", "e", len(ents), 120 * 60)
     got, ref = b.h["buf"].cpu().numpy(), b.e["buf"].numpy()
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("rows,e,parts,segs", [(4096, 2, 6, 4), (100, 3, 7, 2), (20000, 5, 3, 3)])
+def test_l2norm_segments(hip, rows, e, parts, segs):
+    """The applications of a row-concatenated batch keep their own whole-tensor norms: one set per (row segment, part)."""
+    rng = np.random.default_rng(6)
+    b = Both(hip)
+    c = parts * e
+    b.arr("x", (rng.standard_normal((segs * rows, c)) * (1 + np.arange(segs * rows)[:, None] // rows)).astype(np.float32))
+    b.arr("dy", rng.standard_normal((segs * rows, c)).astype(np.float32))
+    b.arr("y", np.zeros(segs * rows * c, np.float32))
+    b.arr("dx", rng.standard_normal(segs * rows * c).astype(np.float32))
+    b.arr("stat", np.zeros(2 * parts * segs, np.float32))
+    b.run("l2norm_segs_fwd", "x", c, rows, e, parts, segs, "y", c, "stat")
+    b.check("y", rtol=1e-5, atol=1e-7)
+    b.check("stat", rtol=1e-5, atol=1e-7)
+    st = b.h["stat"].cpu().numpy().reshape(segs, parts, 2)
+    assert st[1, 0, 0] > 3 * st[0, 0, 0], "each segment has its own norm"
+    b.run("l2norm_segs_bwd", "x", c, "dy", c, rows, e, parts, segs, "stat", "dx", c, 1)
+    b.check("dx", rtol=1e-4, atol=1e-6)
+
+
+def test_reduce_splits_wave_multi(hip):
+    """Every slab reduction of a GAN train op in one launch: one wave per output, entries of different slab counts."""
+    from hypelcnn_amd.backend import REDUCE_ENTRY_DTYPE
+    rng = np.random.default_rng(8)
+    buf = rng.standard_normal(600000).astype(np.float32)
+    ents = [(1000, 500000, 1305, 1305, 256, 0), (400000, 510000, 8, 7, 256, 1), (450000, 520000, 232, 232, 37, 0),
+            (470000, 530000, 8, 8, 1, 1)]
+    b = Both(hip)
+    b.arr("buf", buf)
+    b.arr("e", np.array(ents, REDUCE_ENTRY_DTYPE))
+    b.run("reduce_splits_wave_multi_f32", "buf", "e", len(ents), sum(e[3] for e in ents))
+    b.check("buf", rtol=2e-5, atol=2e-6)
