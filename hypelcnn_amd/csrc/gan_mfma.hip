@@ -77,9 +77,13 @@ __host__ __device__ inline int gm_woff(int bands, int l) {
 __host__ __device__ inline int gm_raw(int bands) {  // floats of the block's LDS copy of every layer's taps + 8 biases
     return (gm_woff(bands, 7) + 8 + 3) / 4 * 4;
 }
+#ifndef GM_FWD_ONE_TABLE
+#define GM_FWD_ONE_TABLE 1  // forward kernel: ONE tap table (a second barrier per layer instead of a second table): 80.7 instead
+                            // of 85.1 KB at 360 bands, i.e. TWO resident blocks per CU (2 x 85.1 KB > 160 KB by 5 KB)
+#endif
 __host__ __device__ inline size_t gm_fwd_lds(int bands) {
     const GmGeo g = gm_geo(bands);
-    return sizeof(float) * (3 * (size_t)GM_ROWS * g.pitch + 2 * 3 * (size_t)g.bp + gm_raw(bands));
+    return sizeof(float) * (3 * (size_t)GM_ROWS * g.pitch + (GM_FWD_ONE_TABLE ? 1 : 2) * 3 * (size_t)g.bp + gm_raw(bands));
 }
 __host__ __device__ inline int gm_atiles(int bands) { return (bands + 30) / 16 + 2; }  // upper bound of the tile offsets a
 __host__ __device__ inline size_t gm_bwd_lds(int bands) {
@@ -198,7 +202,7 @@ typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
 
 // STASH: every layer's outputs / branch bits go straight from the epilogue to this thread's place in the kept-activation
 // buffer (`stash` = the row tile's base + tid, in float4): nothing stays in registers, the unrolled forward stays cheap.
-template <bool ENC, bool KEEP, bool ROLLED = true, bool STASH = false>
+template <bool ENC, bool KEEP, bool ROLLED = true, bool STASH = false, bool ONE_TABLE = false>
 __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, const GmGeo g,
                                           const float* w, const float* bias,  // the block's LDS copy (gm_stage_raw)
                                           float* __restrict__ out, int64_t ldo, int rows_valid, int tid,
@@ -223,6 +227,9 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
     for (int l = 0; l < L; ++l) {
         const int ksz = gm_ksz(g.bands, l), pad = (ksz - 1) / 2;
         float* wz = (l & 1) ? wz1 : wz0;
+        if constexpr (ONE_TABLE) {  // wz0 == wz1: every wave must have left layer l - 1's products before its taps go
+            if (l > 0) __syncthreads();
+        }
         gm_fill_taps(wz, g, w + woff, ksz, tid);
         woff += ksz;
         __syncthreads();  // taps of layer l and the outputs of layer l - 1 are in LDS
@@ -310,10 +317,11 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
     const GmGeo g = gm_geo(bands);
     const int tid = threadIdx.x;
     float* const bufs[3] = {gm_lds, gm_lds + GM_ROWS * g.pitch, gm_lds + 2 * GM_ROWS * g.pitch};
+    constexpr bool ONE = GM_FWD_ONE_TABLE != 0;
     float* wz0 = gm_lds + 3 * GM_ROWS * g.pitch;
-    float* wz1 = wz0 + 3 * g.bp;
+    float* wz1 = ONE ? wz0 : wz0 + 3 * g.bp;
     float* raw = wz1 + 3 * g.bp;
-    gm_zero(gm_lds, 3 * GM_ROWS * g.pitch + 6 * g.bp, tid);  // image padding and tap margins stay zero
+    gm_zero(gm_lds, 3 * GM_ROWS * g.pitch + (ONE ? 3 : 6) * g.bp, tid);  // image padding and tap margins stay zero
     gm_stage_raw(raw, bands, w, bias, tid);
     __syncthreads();
     float keep[6][GM_MAXT][4];
@@ -325,8 +333,8 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
         gm_f32x4* sp = nullptr;
         if constexpr (STASH) sp = reinterpret_cast<gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
-        gm_forward<ENC, false, GM_FWD_ROLLED != 0, STASH>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7), out + r0 * ldo, ldo,
-                                                          rows_valid, tid, keep, mask, sp);
+        gm_forward<ENC, false, GM_FWD_ROLLED != 0, STASH, ONE>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7),
+                                                               out + r0 * ldo, ldo, rows_valid, tid, keep, mask, sp);
         __syncthreads();  // the next row tile overwrites bufs[0]
     }
 }
