@@ -274,7 +274,7 @@ def gan_cpu_baseline(kind, bands, seconds_budget=12.0):
                       f"logical cores); not a TensorFlow number"}
 
 
-TRAFFIC_SUMMARIES = ("r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
+TRAFFIC_SUMMARIES = ("r4_hbm_traffic.json", "r4_hbm_traffic_dualcnn.json", "r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
 
 
 def pmc_traffic(workload, nb, launches_per_step):

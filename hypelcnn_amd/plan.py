@@ -83,6 +83,7 @@ FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 # collected and go out as ONE hypel_seg_gemm_multi_f32 per tile width (+ ONE hypel_reduce_splits_multi_f32) at the end
 # of the backward pass (and at every data-parallel sync point).  A step's twenty ~25 us launch ramps/drains become three.
 MERGE_WGRAD = os.environ.get("HYPEL_MERGE_WGRAD", "1") != "0"
+WGRAD_PARALLEL = os.environ.get("HYPEL_WGRAD_PARALLEL", "0") != "0"  # measured: NOTES 4.E
 # Batch-norm statistics of a 1x1 convolution's output in the GEMM epilogue (hypel_seg_gemm_stats_f32) instead of a
 # separate pass over Y (hypel_col_stats_partial)
 STATS_EPILOGUE = os.environ.get("HYPEL_STATS_EPILOGUE", "1") != "0"
@@ -1814,7 +1815,8 @@ class TowerPlan:
             for (wdt, _), (wk, r) in loc_groups.items():  # inside a locality group: heavy blocks first
                 r.sort(key=lambda t: -t[0])
                 per_width[wdt]["lists"].append((wk, [rec for _, rec in r]))
-        for width in sorted(per_width, reverse=True):
+        par_used = []
+        for width in sorted(per_width, reverse=False if WGRAD_PARALLEL else True):
             pw = per_width[width]
             segs, lists = pw["segs"], pw["lists"]
             lists.sort(key=lambda t: -t[0])
@@ -1835,7 +1837,16 @@ class TowerPlan:
                        flops=2 * pw["macs"], nbytes=pw["nbytes"], tag=f"wgrad-merged/{width}")
             l.meta = {"products": pw["tags"], "blocks": int(sum(len(r) for r in xcd_recs)),
                       "xcd_work": [int(w) for w in xcd_work]}
+            if WGRAD_PARALLEL and width != max(per_width):
+                # experiment (NOTES 4.E): the narrower launches as parallel branches of the step's graph, so that their ramp
+                # and drain overlap the 64-wide launch's
+                k = 1 + len(par_used)
+                par_used.append(k)
+                l.stream = k
+                self.bwd.append(Launch("_fork", (k,), tag="fork"))
             self.bwd.append(l)
+        if par_used:
+            self.bwd.append(Launch("_join", tuple(par_used), tag="join"))
         if entries:
             earr = np.array([(p, o, st, cnt, S, acc) for (p, o, st, cnt, S, acc) in entries], REDUCE_ENTRY_DTYPE)
             e_t = self.be.upload(earr)

@@ -7,7 +7,7 @@
 #   rocprofv3 --kernel-trace --stats of the same cmd    -> kernel_stats_<wl>.csv (+ per_launch_<wl>.txt for classifiers)
 #   classifiers: PMC passes FETCH_SIZE / WRITE_SIZE     -> hbm_traffic_<wl>.{txt,json}, hbm_traffic_per_launch_<wl>.txt
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 WLS=${2:-"hypelcnn dualcnn cut cyclegan"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -40,5 +40,20 @@ for WL in $WLS; do
     [ -n "$S" ] && python tools/kstats.py $S 30 > $OUT/kernel_top_$WL.txt 2>&1
   fi
   rm -rf $OUT/trace_$WL   # raw traces are large; the summaries above are what gets committed
+  # the same step with the RCCL path active on a 1-rank communicator (the only multi-process check a 1-GPU box allows):
+  # what the data-parallel machinery itself costs (sync-point graph cuts, all-reduce launches, the flag exchange)
+  HYPEL_DP_SELFTEST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py $EXTRA --steps $STEPS --no-cpu-baseline --no-input-pipeline > $OUT/dp_selftest_$WL.json 2> $OUT/dp_selftest_$WL.err
 done
+python - <<PY > $OUT/dp_selftest_overhead.txt
+import json, glob, os
+print("1-rank RCCL self-test (HYPEL_DP_SELFTEST=1 under torch.distributed.run --nproc-per-node 1) vs the plain run, same box")
+for wl in "$WLS".split():
+    try:
+        a = json.loads(open("$OUT/bench_%s.json" % wl).read().strip().splitlines()[-1])
+        b = json.loads(open("$OUT/dp_selftest_%s.json" % wl).read().strip().splitlines()[-1])
+        print("%-9s plain %.4f ms/step   1-rank RCCL %.4f ms/step   %+.2f %%" % (wl, a["ms_per_step"], b["ms_per_step"], 100 * (b["ms_per_step"] / a["ms_per_step"] - 1)))
+    except Exception as e:
+        print(wl, "missing:", e)
+PY
 ls -la $OUT

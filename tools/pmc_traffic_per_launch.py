@@ -18,10 +18,21 @@ def load(path, counter):
     return [v for _, v in sorted(disp.items())]
 
 
-def last_step(lst):
+def steps_of(lst):
+    """The library's dispatches cut into steps (each begins with nhwc_to_pnc); only complete steps -- as many dispatches as
+    the last one -- are kept."""
     hk = [d for d in lst if "anonymous namespace" in d[0]]
-    starts = [i for i, d in enumerate(hk) if "nhwc_to_pnc" in d[0]]
-    return hk[starts[-1]:]
+    starts = [i for i, d in enumerate(hk) if "nhwc_to_pnc" in d[0]] + [len(hk)]
+    steps = [hk[a:b] for a, b in zip(starts[:-1], starts[1:])]
+    n = len(steps[-1])
+    return [st for st in steps if len(st) == n]
+
+
+def write_calibration(steps_w, known_bytes):
+    """Same rule as tools/pmc_traffic.py: WRITE_SIZE is calibrated on nhwc_to_pnc, which writes exactly one fp32 copy of the
+    batch (the two tools then report the same bytes for the same passes)."""
+    vals = [st[0][1] for st in steps_w if "nhwc_to_pnc" in st[0][0]]
+    return known_bytes * len(vals) / sum(vals) if vals and sum(vals) > 0 else 1.0
 
 
 def main():
@@ -32,18 +43,25 @@ def main():
         i = sys.argv.index("--workload")
         workload = sys.argv[i + 1]
         del sys.argv[i:i + 2]
-    fe, wr = last_step(load(sys.argv[1], "FETCH_SIZE")), last_step(load(sys.argv[2], "WRITE_SIZE"))
-    nb = bench.CLASSIFIER_WORKLOADS[workload][5]
+    fe_steps, wr_steps = steps_of(load(sys.argv[1], "FETCH_SIZE")), steps_of(load(sys.argv[2], "WRITE_SIZE"))
+    _, _, patch, chans, _, nb, _ = bench.CLASSIFIER_WORKLOADS[workload]
+    cal_w = write_calibration(wr_steps, nb * patch * patch * chans * 4)
     ctx, ts, lr, alg = bench.build_model(nb, EmuBackend(), workload)
     ctx.capture_graphs = False
     plan = ts.compiled(nb).plan
     launches = [l for l in plan.fwd + plan.bwd if l.name not in ("_fork", "_join")]
+
+    def mean_at(steps, j):  # average over every complete step of the passes
+        return sum(st[j][1] for st in steps) / len(steps)
+
     j = 0
     tot_alg = tot = 0.0
+    print(f"{len(fe_steps)} / {len(wr_steps)} complete steps averaged; FETCH_SIZE x 2.0, WRITE_SIZE x {cal_w:.3f} "
+          f"(calibrated on nhwc_to_pnc, as tools/pmc_traffic.py)")
     print(f"{'launch':34s} {'algorithmic MB':>15s} {'read MB':>9s} {'write MB':>9s} {'ratio':>6s}")
     for l in launches:
         n_k = 2 if l.name in ("mse", "sum_f32") else 1
-        f, w = fe[j][1] * 2, wr[j][1]
+        f, w = mean_at(fe_steps, j) * 2, mean_at(wr_steps, j) * cal_w
         j += n_k
         if not l.name.startswith("seg_gemm"):
             continue
