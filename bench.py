@@ -190,12 +190,16 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
+PRODUCT_PATHS = "hypelcnn_amd include bench.py"  # what source_fingerprint() covers
+
+
 def commit_label():
     """Short hash of the code this process runs: from git when the tree has a .git (suffix +dirty when tracked files
     differ), else from .head_commit -- only when its fingerprint matches the files on disk."""
-    commit = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()
+    # the last commit that touches the product path (later documentation / profile commits do not change what runs)
+    commit = os.popen(f"git -C {ROOT} log -1 --format=%h -- {PRODUCT_PATHS} 2>/dev/null").read().strip()
     if commit:
-        dirty = os.popen(f"git -C {ROOT} status --porcelain --untracked-files=no 2>/dev/null").read().strip()
+        dirty = os.popen(f"git -C {ROOT} status --porcelain --untracked-files=no -- {PRODUCT_PATHS} 2>/dev/null").read().strip()
         return commit + ("+dirty" if dirty else ""), None
     try:
         parts = open(os.path.join(ROOT, ".head_commit")).read().split()

@@ -4,7 +4,8 @@
 # the hash into its JSON line only when the fingerprint matches the files it runs from (a stale file prints nothing).
 #   tools/gpu.sh [--timeout S] -- '<command>'
 cd "$(dirname "$0")/.."
-h=$(git rev-parse --short HEAD)
-git diff --quiet HEAD -- . ':!.head_commit' || h="$h+dirty"
+# the last commit that touches the product path (hypelcnn_amd/, include/, bench.py): what bench.py itself reports with a .git
+h=$(git log -1 --format=%h -- hypelcnn_amd include bench.py)
+git diff --quiet HEAD -- hypelcnn_amd include bench.py || h="$h+dirty"
 echo "$h $(python -c 'import bench; print(bench.source_fingerprint())')" > .head_commit
 exec /usr/local/graft/bin/gpurun "$@"
