@@ -87,3 +87,45 @@ def test_tensor_pool_semantics():
     same = sum(1 for o, v in zip(outs[3:], vals[3:]) if torch.equal(o, v))
     assert 8 < same < 30 and any(l < i + 3 for i, l in enumerate(later))        # some historical samples returned
     assert len(pool.items) == 3
+
+
+def _phase_launches(ops, sess, n):
+    out = {}
+    for phase in ops.loss.phases:
+        plan = ops._compiled(sess, phase, n).plan
+        out[phase.name] = [l.name for l in plan.fwd + plan.bwd]
+    return out
+
+
+@pytest.mark.parametrize("kind,bands", [("cut_x2y", 24), ("cycle_gan", 16), ("dcl_gan", 16)])
+def test_same_weight_applications_run_as_one_row_concatenated_application(monkeypatch, kind, bands):
+    """Round 4 (plan.PhasePlan._schedule_units): the same-weight applications of a train op -- G([x; y]), enc on the four
+    inputs of CUT, D([real; fake]), the feature-discriminator layers, the feature stack with per-application norms -- run
+    as ONE application on the row-concatenated batch, and every per-block gradient slab of the op is summed by one launch.
+    Fewer launches, same losses and gradients as the oracle; the unbatched form stays available and agrees too.
+    CycleGAN's G_xy(G_yx(y)) next to G_xy(x) must NOT be grouped (the unit graph would be cyclic)."""
+    from hypelcnn_amd import plan
+    n = 6
+    cfg = OG.GanConfig(kind, bands, patches=4 if bands == 16 else 6, max_steps=20)
+    params = U.fp32(OG.init_gan_params(kind, bands, np.random.default_rng(2), patches=cfg.patches, dtype=np.float64,
+                                       zero_generator=False))
+    x, y = _data(n, bands, 4)
+    counts = {}
+    for batched in (True, False):
+        monkeypatch.setattr(plan, "BATCH_APPS", batched)
+        monkeypatch.setattr(plan, "SLAB_REDUCE_MULTI", batched)
+        wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
+        sess = ops.ctx.session()
+        U.inject(sess, params)
+        U.check_phase_gradients(cfg, ops, params, x, y, tol=5e-5)
+        counts[batched] = _phase_launches(ops, sess, n)
+    tot = {b: sum(len(v) for v in counts[b].values()) for b in counts}
+    assert tot[True] < tot[False], tot
+    gen_b = [l for l in counts[True]["gen" if "gen" in counts[True] else list(counts[True])[0]] if "generator_fwd" in l]
+    gen_u = [l for l in counts[False]["gen" if "gen" in counts[False] else list(counts[False])[0]] if "generator_fwd" in l]
+    if kind == "cut_x2y":
+        assert len(gen_u) == 6 and len(gen_b) == 2, (gen_u, gen_b)  # G([x; y]) and enc on four inputs
+        assert tot[True] * 2 <= tot[False] + 10, tot
+    if kind == "cycle_gan":
+        assert len(gen_b) == len(gen_u) == 4  # the four generator applications depend on each other pairwise
+        assert sum(l == "reduce_splits_wave_multi_f32" for v in counts[True].values() for l in v) == 2
