@@ -1587,6 +1587,25 @@ class TowerPlan:
                 # no batch norm: dY = dZ * act'(y) needs no column sum -- the bias-gradient reduction writes it too
                 l1 = Launch("act_bias_bwd_reduce", (dz, c, y_ref, c, rows, c, code, alpha, mask, c, chunk, None, dy, c),
                             nbytes=12 * rows * c, tag="post-bwd-reduce+apply")
+                if dparam is None:
+                    # the phase does not train this layer: only dY is wanted, the chunk sums have no reader
+                    self._scratch(l1, 11, "scratch_partial", n_chunks * 2 * c)
+                    self.bwd.append(l1)
+                    return
+                if getattr(self, "_defer_bias_sums", False):
+                    # GAN train op: the chunk sums of every such layer stay in a buffer of their own and ONE launch at the end
+                    # of the backward pass turns them all into bias gradients (PhasePlan._flush_slab_reduces)
+                    k = self.__dict__.setdefault("_bias_sum_bufs", 0)
+                    self._bias_sum_bufs = k + 1
+                    name = f"bias_sums:{k}"
+                    self._alloc(name, n_chunks * 2 * c)
+                    args = list(l1.args)
+                    args[11] = self._ref(name)
+                    l1.args = tuple(args)
+                    self.bwd.append(l1)
+                    self.__dict__.setdefault("_bias_sum_entries", []).append((self._ref(name), dparam, 2 * c, c, n_chunks,
+                                                                             pacc))
+                    return
                 self._scratch(l1, 11, "scratch_partial", n_chunks * 2 * c)
                 l2 = Launch("bwd_reduce_finalize", (None, n_chunks, c, None, dparam, pacc), tag="post-bwd-finalize")
                 self._scratch(l2, 0, "scratch_partial", n_chunks * 2 * c)
@@ -2077,6 +2096,7 @@ class PhasePlan(TowerPlan):
         self.terms = list(terms)
         self.train_groups = set(train_groups)
         self.outputs = list(outputs)
+        self._defer_bias_sums = SLAB_REDUCE_MULTI
         super().__init__(tower, nb, session, loss=None, external_masks=True, seed=seed)
 
     # ---- analysis ----
@@ -2426,7 +2446,9 @@ class PhasePlan(TowerPlan):
     def _flush_slab_reduces(self):
         sets = self.__dict__.get("_slab_sets") or {}
         self._slab_sets = {}
-        if not sets:
+        bias_entries = self.__dict__.get("_bias_sum_entries") or []
+        self._bias_sum_entries = []
+        if not sets and not bias_entries:
             return
         base = Ref(self.sess.params)
 
@@ -2434,6 +2456,9 @@ class PhasePlan(TowerPlan):
             return (ref.ptr() - base.ptr()) // 4
 
         ents, total = [], 0
+        for part_ref, out_ref, stride, count, n_splits, acc in bias_entries:  # chunk sums [chunk][2][c]: plane 0 = sum(dY)
+            ents.append((rel(part_ref), rel(out_ref), stride, count, n_splits, acc))
+            total += count
         for k, st in enumerate(sets.values()):
             fid = self.__dict__.setdefault("_slab_bufs", 0)
             self._slab_bufs = fid + 1
