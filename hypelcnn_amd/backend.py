@@ -84,6 +84,8 @@ SIGNATURES = {
     "reduce_splits_pair_f32": [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I32, _I32],
     "seg_gemm_multi_f32": [_P, _I32, _I32, _I32, _P, _P, _I32],
     "copy_blocks_f32": [_P, _P, _I32, _I64],
+    "bn_act_chunks_fwd": [_P, _I64, _I64, _I32, _P, _I32, _I32, _F, _P, _I32, _F, _P, _I64, _P, _P, _P, _P, _F, _P, _I64],
+    "bn_act_chunks_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I32, _P, _I64, _P, _I32],
     "reduce_splits_wave_multi_f32": [_P, _P, _I32, _I64],
     "reduce_splits_multi_f32": [_P, _P, _I32],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],

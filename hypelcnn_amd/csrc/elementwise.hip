@@ -1312,6 +1312,108 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------- short matrices, row-parallel
+// Batch norm of a short matrix (rows = the batch: the fully-connected tail) WITHOUT a block that owns all rows of a
+// stripe (bn_act_small_*: 31 blocks for 980 channels, a 12-17 us latency chain) and WITHOUT a finaliser launch: the
+// statistics arrive as a handful of row-chunk partials -- from the GEMM epilogue (hypel_seg_gemm_stats_f32: one
+// (mean, M2) pair per 128-row tile) or from hypel_col_stats_partial / hypel_bn_act_bwd_reduce -- and EVERY block of the
+// apply kernel merges the partials of its own 32 columns itself (n_chunks <= 64: 8 for a batch of 1024), in chunk order,
+// fp64: identical values in every block; the blocks of the first row range also write mean / rstd / moving averages
+// (forward) or the parameter gradient (backward).  Block = 32 columns x 8 row lanes, 64 rows per block.
+constexpr int CHK_ROWS = 64;
+
+__global__ __launch_bounds__(256) void bn_act_chunks_fwd_kernel(
+    const float* __restrict__ y, int64_t ldy, int rows, int c, const float* __restrict__ partial, int n_chunks,
+    int chunk_rows, float eps, const float* __restrict__ beta, int act, float alpha, const float* __restrict__ mask,
+    int64_t ldm, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ moving_mean,
+    float* __restrict__ moving_var, float decay, float* __restrict__ z, int64_t ldz) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + tx;
+    if (col >= c) return;
+    const int r0 = blockIdx.y * CHK_ROWS + ty;
+    float yv[CHK_ROWS / 8], mk[CHK_ROWS / 8];
+#pragma unroll
+    for (int i = 0; i < CHK_ROWS / 8; ++i) {  // the tile's loads are in flight while the statistics are merged
+        const int r = r0 + 8 * i;
+        yv[i] = r < rows ? y[(int64_t)r * ldy + col] : 0.0f;
+        mk[i] = (mask && r < rows) ? mask[(int64_t)r * ldm + col] : 1.0f;
+    }
+    const double shift = (double)partial[col];
+    double s = 0.0, m2 = 0.0;
+    for (int k = 0; k < n_chunks; ++k) {
+        const int n_k = min(rows, (k + 1) * chunk_rows) - k * chunk_rows;
+        const double d = (double)partial[(int64_t)k * 2 * c + col] - shift;
+        s += (double)n_k * d;
+        m2 += (double)partial[(int64_t)k * 2 * c + c + col] + (double)n_k * d * d;
+    }
+    const double n_total = (double)rows;
+    const double mean_a = shift + s / n_total;
+    double m2_a = m2 - s * s / n_total;
+    if (m2_a < 0.0) m2_a = 0.0;
+    const double var = m2_a / n_total;
+    const float mu = (float)mean_a, rs = (float)(1.0 / sqrt(var + (double)eps));
+    const float be = beta[col];
+    if (blockIdx.y == 0 && ty == 0) {
+        mean[col] = mu;
+        rstd[col] = rs;
+        if (moving_mean) {
+            const double unbiased = n_total > 1.0 ? m2_a / (n_total - 1.0) : var;
+            moving_mean[col] = (float)((double)moving_mean[col] * decay + mean_a * (1.0 - (double)decay));
+            moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CHK_ROWS / 8; ++i) {
+        const int r = r0 + 8 * i;
+        if (r < rows) {
+            float v = hypel_act(hypel_bn_pre(hypel_bn_xhat(yv[i], mu, rs), be), act, alpha);
+            if (mask) v *= mk[i];
+            z[(int64_t)r * ldz + col] = v;
+        }
+    }
+}
+
+// partial[k][0][col] = sum of dyh over row chunk k, partial[k][1][col] = sum of dyh * xhat (hypel_bn_act_bwd_reduce);
+// dy may alias dz.
+__global__ __launch_bounds__(256) void bn_act_chunks_bwd_kernel(
+    const float* dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int rows, int c,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act, float alpha,
+    const float* __restrict__ mask, int64_t ldm, const float* __restrict__ partial, int n_chunks, float* dy,
+    int64_t lddy, float* __restrict__ dparam, int accumulate) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + tx;
+    if (col >= c) return;
+    const int r0 = blockIdx.y * CHK_ROWS + ty;
+    float yv[CHK_ROWS / 8], gv[CHK_ROWS / 8];
+#pragma unroll
+    for (int i = 0; i < CHK_ROWS / 8; ++i) {
+        const int r = r0 + 8 * i;
+        yv[i] = r < rows ? y[(int64_t)r * ldy + col] : 0.0f;
+        float g = r < rows ? dz[(int64_t)r * lddz + col] : 0.0f;
+        if (mask && r < rows) g *= mask[(int64_t)r * ldm + col];
+        gv[i] = g;
+    }
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = 0; k < n_chunks; ++k) {
+        a0 += (double)partial[(int64_t)k * 2 * c + col];
+        a1 += (double)partial[(int64_t)k * 2 * c + c + col];
+    }
+    const float s0 = (float)a0, s1 = (float)a1;
+    const float mu = mean[col], rs = rstd[col], be = beta[col];
+    const float dp0 = (dparam && accumulate && blockIdx.y == 0 && ty == 0) ? dparam[col] : 0.0f;
+    const float inv_m = 1.0f / (float)rows;
+#pragma unroll
+    for (int i = 0; i < CHK_ROWS / 8; ++i) {
+        const int r = r0 + 8 * i;
+        if (r < rows) {
+            const float xhat = hypel_bn_xhat(yv[i], mu, rs);
+            const float dyh = gv[i] * hypel_act_grad(hypel_bn_pre(xhat, be), act, alpha);
+            dy[(int64_t)r * lddy + col] = rs * (dyh - s0 * inv_m - xhat * (s1 * inv_m));
+        }
+    }
+    if (dparam && blockIdx.y == 0 && ty == 0) dparam[col] = dp0 + s0;
+}
+
 // ------------------------------------------------------------------------------------- metrics
 __global__ void argmax_confusion_kernel(const float* __restrict__ logits, int64_t ld, int64_t n, int c,
                                         const int32_t* __restrict__ labels, int32_t* __restrict__ pred,
@@ -1674,6 +1776,38 @@ extern "C" int hypel_bn_act_small_bwd(const float* dz, int64_t lddz, const float
         hipLaunchKernelGGL(bn_act_small_bwd_kernel<false>, grid, dim3(1024), 0, ST, dz, (int)lddz, y, (int)ldy,
                            (int)rows, c, mean, rstd, beta, act, alpha, mask, (int)ldm, dy, (int)lddy, dparam, accumulate);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_small_bwd");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_chunks_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, const float* partial,
+                                       int32_t n_chunks, int32_t chunk_rows, float eps, const float* beta, int32_t act,
+                                       float alpha, const float* mask, int64_t ldm, float* mean, float* rstd,
+                                       float* moving_mean, float* moving_var, float decay, float* z, int64_t ldz,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(y && partial && beta && mean && rstd && z && rows > 0 && c > 0, "hypel_bn_act_chunks_fwd");
+    HYPEL_REQUIRE(n_chunks > 0 && n_chunks <= 64 && chunk_rows > 0 && (int64_t)n_chunks * chunk_rows >= rows &&
+                      (int64_t)(n_chunks - 1) * chunk_rows < rows && rows < (1 << 24),
+                  "hypel_bn_act_chunks_fwd");
+    HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_act_chunks_fwd");
+    hipLaunchKernelGGL(bn_act_chunks_fwd_kernel, dim3((c + 31) / 32, (unsigned)((rows + CHK_ROWS - 1) / CHK_ROWS)), dim3(256),
+                       0, ST, y, ldy, (int)rows, c, partial, n_chunks, chunk_rows, eps, beta, act, alpha, mask, ldm, mean,
+                       rstd, moving_mean, moving_var, decay, z, ldz);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_chunks_fwd");
+    return 0;
+}
+
+extern "C" int hypel_bn_act_chunks_bwd(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
+                                       int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
+                                       float alpha, const float* mask, int64_t ldm, const float* partial,
+                                       int32_t n_chunks, float* dy, int64_t lddy, float* dparam, int32_t accumulate,
+                                       hypel_stream_t stream) {
+    HYPEL_REQUIRE(dz && y && mean && rstd && beta && partial && dy && rows > 0 && rows < (1 << 24) && c > 0 &&
+                      n_chunks > 0 && n_chunks <= 64,
+                  "hypel_bn_act_chunks_bwd");
+    hipLaunchKernelGGL(bn_act_chunks_bwd_kernel, dim3((c + 31) / 32, (unsigned)((rows + CHK_ROWS - 1) / CHK_ROWS)), dim3(256),
+                       0, ST, dz, lddz, y, ldy, (int)rows, c, mean, rstd, beta, act, alpha, mask, ldm, partial, n_chunks, dy,
+                       lddy, dparam, accumulate);
+    HYPEL_CHECK_LAUNCH("hypel_bn_act_chunks_bwd");
     return 0;
 }
 

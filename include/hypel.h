@@ -253,6 +253,20 @@ int hypel_bn_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t c, int3
  * direction: a block owns a 32-channel stripe for all rows, so statistics + finaliser + normalise/activate/dropout
  * (forward) and both reductions + the gradient (backward; dy may alias dz) need no second kernel.  rows <= 1024.
  * Same definitions as hypel_col_stats_partial/hypel_bn_finalize/hypel_bn_act_fwd resp. the three backward calls. */
+/* The same batch norm of a short matrix, ROW-PARALLEL and without a finaliser launch (round 4): the statistics arrive as
+ * at most 64 row-chunk partials -- `partial` in the format of hypel_col_stats_partial / the epilogue of
+ * hypel_seg_gemm_stats_f32 (forward: chunk k = rows [k * chunk_rows, ...): mean, sum of squared deviations) resp. of
+ * hypel_bn_act_bwd_reduce (backward: sum dyh, sum dyh * xhat) -- and every block of the apply launch merges the partials of
+ * its own 32 columns (chunk order, fp64) before it normalises / differentiates its 64 rows; the blocks of the first row
+ * range write mean / rstd / the moving averages (forward) resp. the parameter gradient (backward).  dy may alias dz. */
+int hypel_bn_act_chunks_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, const float* partial, int32_t n_chunks,
+                            int32_t chunk_rows, float eps, const float* beta, int32_t act, float alpha, const float* mask,
+                            int64_t ldm, float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
+                            float* z, int64_t ldz, hypel_stream_t stream);
+int hypel_bn_act_chunks_bwd(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
+                            const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
+                            const float* mask, int64_t ldm, const float* partial, int32_t n_chunks, float* dy, int64_t lddy,
+                            float* dparam, int32_t accumulate, hypel_stream_t stream);
 int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, float eps, const float* beta,
                            int32_t act, float alpha, const float* mask, int64_t ldm, float* mean, float* rstd,
                            float* moving_mean, float* moving_var, float decay, float* z, int64_t ldz,

@@ -488,6 +488,19 @@ class EmuBackend:
         g = _arr(rstd)[:c] * (dyh - s0 / rows - xhat * s1 / rows)
         _mat(dy, lddy, rows, c)[...] = g.astype(np.float32)
 
+    def k_bn_act_chunks_fwd(self, y, ldy, rows, c, partial, n_chunks, chunk_rows, eps, beta, act, alpha, mask, ldm, mean,
+                            rstd, mm, mv, decay, z, ldz):
+        assert 0 < n_chunks <= 64 and (n_chunks - 1) * chunk_rows < rows <= n_chunks * chunk_rows
+        self.k_bn_finalize(partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, mm, mv, decay)
+        self.k_bn_act_fwd(y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, None, 0, None, None, 0, None, z, ldz)
+
+    def k_bn_act_chunks_bwd(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, partial, n_chunks,
+                            dy, lddy, dparam, accumulate):
+        assert 0 < n_chunks <= 64
+        sums = type(partial)(partial.t.new_zeros(2 * c))
+        self.k_bwd_reduce_finalize(partial, n_chunks, c, sums, dparam, accumulate)
+        self.k_bn_act_bwd_apply(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, dy, lddy)
+
     def k_bn_finalize(self, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, mm, mv, decay):
         po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c).astype(np.float64)
         n_a, mean_a, m2_a = 0.0, np.zeros(c), np.zeros(c)

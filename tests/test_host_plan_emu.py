@@ -254,7 +254,8 @@ def test_bn_backward_reduction_rides_in_the_data_gradient_epilogue(monkeypatch):
     n_conv_bn = sum(1 for n in built.train_tower.nodes if getattr(n, "kind", "") == "conv" and n.has_bn)
     # (layers with <= 16 channels keep the separate pass: the 16-wide GEMM variant has no reduction epilogue)
     assert names.count("seg_gemm_bnbwd_f32") >= n_conv_bn - 3
-    assert names.count("bn_act_bwd_reduce") <= 3
+    # (the fully-connected tail's row-parallel batch norm has a reduction launch of its own: tag post-bwd-reduce-chunks)
+    assert sum(1 for l in ct.plan.bwd if l.name == "bn_act_bwd_reduce" and l.tag == "post-bwd-reduce") <= 3
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
     g_fused = sess.grads.clone()
     monkeypatch.setattr(plan, "BNBWD_EPILOGUE", False)
@@ -290,4 +291,20 @@ def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
             (what == "wgrad" and "level-unpack" in tags), (what, tags)
     assert ("level-pack" in tags) == bool(set(passes.split(",")) & {"fwd", "dgrad"})
     assert ("copy_blocks_f32" in names) == ("level-pack" in tags or "level-unpack" in tags)
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
+
+
+def test_row_parallel_batch_norm_of_the_fc_tail_matches_oracle(monkeypatch):
+    """HYPEL_CHUNK_BN (off by default, NOTES 4.F): the fully-connected tail's batch norm from 128-row chunk statistics --
+    out of the GEMM epilogue for the unsplit layers -- merged by the blocks of the apply launch; no finaliser launches."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "CHUNK_BN", True)
+    alg = dict(ALG_H, filter_count=96)
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 7, 9, 4, alg, 37, 41)
+    ct = U.run_train_step(built, x, onehot, masks)
+    names = [l.name for l in ct.plan.fwd + ct.plan.bwd]
+    assert names.count("bn_act_chunks_fwd") >= 6 and names.count("bn_act_chunks_fwd") == names.count("bn_act_chunks_bwd")
+    assert "bn_act_small_fwd" not in names
+    tags = [l.tag for l in ct.plan.fwd]
+    assert sum(1 for l in ct.plan.fwd if l.name == "seg_gemm_stats_f32" and l.tag.startswith("fwd:fc_")) >= 1, tags
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
