@@ -1340,11 +1340,24 @@ __global__ __launch_bounds__(256) void bn_act_chunks_fwd_kernel(
     }
     const double shift = (double)partial[col];
     double s = 0.0, m2 = 0.0;
-    for (int k = 0; k < n_chunks; ++k) {
-        const int n_k = min(rows, (k + 1) * chunk_rows) - k * chunk_rows;
-        const double d = (double)partial[(int64_t)k * 2 * c + col] - shift;
-        s += (double)n_k * d;
-        m2 += (double)partial[(int64_t)k * 2 * c + c + col] + (double)n_k * d * d;
+    for (int k0 = 0; k0 < n_chunks; k0 += 8) {  // bursts of 16 independent loads (a dependent chain of n_chunks round
+        float m[8], q[8];                       // trips otherwise: the whole kernel is a few microseconds)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = min(k0 + j, n_chunks - 1);
+            m[j] = partial[(int64_t)k * 2 * c + col];
+            q[j] = partial[(int64_t)k * 2 * c + c + col];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            if (k < n_chunks) {
+                const int n_k = min(rows, (k + 1) * chunk_rows) - k * chunk_rows;
+                const double d = (double)m[j] - shift;
+                s += (double)n_k * d;
+                m2 += (double)q[j] + (double)n_k * d * d;
+            }
+        }
     }
     const double n_total = (double)rows;
     const double mean_a = shift + s / n_total;
@@ -1394,9 +1407,20 @@ __global__ __launch_bounds__(256) void bn_act_chunks_bwd_kernel(
         gv[i] = g;
     }
     double a0 = 0.0, a1 = 0.0;
-    for (int k = 0; k < n_chunks; ++k) {
-        a0 += (double)partial[(int64_t)k * 2 * c + col];
-        a1 += (double)partial[(int64_t)k * 2 * c + c + col];
+    for (int k0 = 0; k0 < n_chunks; k0 += 8) {
+        float p0[8], p1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = min(k0 + j, n_chunks - 1);
+            p0[j] = partial[(int64_t)k * 2 * c + col];
+            p1[j] = partial[(int64_t)k * 2 * c + c + col];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < n_chunks) {
+                a0 += (double)p0[j];
+                a1 += (double)p1[j];
+            }
     }
     const float s0 = (float)a0, s1 = (float)a1;
     const float mu = mean[col], rs = rstd[col], be = beta[col];
