@@ -239,9 +239,14 @@ def measure_gan_events(ops, nb, bands, steps):
                     a.record()
                     f()
                     b.record()
-                    bwd = "_bwd" in l.name  # gan_generator_bwd / gan_generator_bwd_kept
-                    enc = bool(l.args[8] if bwd else l.args[6])
-                    rows = int(l.args[4] if bwd else l.args[2])  # k * nb when k same-weight applications run as one
+                    bwd = "_bwd" in l.name  # gan_generator_bwd / _bwd_kept / _bwd_tap
+                    if l.name.endswith("_tap"):
+                        # the full generator whose n_4 doubles as the encoder-only application on the same input: its
+                        # algorithmic work is the full generator's (the shared encoder layers are computed once)
+                        enc, rows = False, int(l.args[6] if bwd else l.args[2])
+                    else:
+                        enc = bool(l.args[8] if bwd else l.args[6])
+                        rows = int(l.args[4] if bwd else l.args[2])  # k * nb when k same-weight applications run as one
                     evs.append((a, b, (4 if bwd else 2) * generator_exact_macs(bands, enc) * rows))
                 else:
                     f()

@@ -131,6 +131,8 @@ SIGNATURES = {
                         _P, _P],
     "gan_generator_fwd_keep": [_P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _P],
     "gan_generator_bwd_kept": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P],
+    "gan_generator_fwd_tap": [_P, _I64, _I64, _I32, _P, _P, _P, _I64, _P, _I64, _P],
+    "gan_generator_bwd_tap": [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I64, _I32, _P, _P, _P],
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
     "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
     "loss_finalize_slots": [_P, _I32, _P, _I32],
@@ -176,6 +178,8 @@ def load_library(path=LIB_PATH):
     lib.hypel_dense_stack_blocks.restype = ctypes.c_int
     lib.hypel_dense_stack_supported.argtypes = [_I32] * 6
     lib.hypel_dense_stack_supported.restype = ctypes.c_int
+    lib.hypel_gan_generator_tap_supported.argtypes = [_I32]
+    lib.hypel_gan_generator_tap_supported.restype = ctypes.c_int
     lib.hypel_gan_generator_keep_floats.argtypes = [_I64, _I32, _I32]
     lib.hypel_gan_generator_keep_floats.restype = ctypes.c_int64
     return lib
@@ -292,6 +296,9 @@ class HipBackend:
     def dense_stack_supported(self, widths):
         w = list(widths) + [0] * (5 - len(widths))
         return len(widths) <= 5 and bool(self.lib.hypel_dense_stack_supported(len(widths) - 1, *[int(v) for v in w]))
+
+    def gan_generator_tap_supported(self, bands):
+        return bool(self.lib.hypel_gan_generator_tap_supported(int(bands)))
 
     def gan_generator_keep_floats(self, n, bands, only_encoder):
         return int(self.lib.hypel_gan_generator_keep_floats(int(n), int(bands), int(only_encoder)))

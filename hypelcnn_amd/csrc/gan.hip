@@ -912,10 +912,11 @@ static size_t gt_bwd_lds(int bands, int only_encoder) {
 bool hypel_gm_supported(int bands);
 int64_t hypel_gm_keep_floats(int64_t n, int bands, int only_encoder);
 int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
-                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep);
+                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep, float* enc_out = nullptr,
+                 int64_t ld_enc = 0);
 int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
                  const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
-                 int blocks, hipStream_t st, const float* keep);
+                 int blocks, hipStream_t st, const float* keep, const float* d_enc = nullptr, int64_t ld_denc = 0);
 
 static bool gan_use_mfma(int bands) {
     static const int on = getenv("HYPEL_GAN_MFMA") ? atoi(getenv("HYPEL_GAN_MFMA")) : 1;
@@ -974,6 +975,30 @@ extern "C" int hypel_gan_generator_fwd_keep(const float* x, int64_t ldx, int64_t
     HYPEL_REQUIRE(keep == nullptr || hypel_gan_generator_keep_floats(n, bands, only_encoder) > 0,
                   "hypel_gan_generator_fwd_keep: no kept activations for this band count");
     return gan_generator_fwd_impl(x, ldx, n, bands, w, b, only_encoder, out, ldo, keep, stream);
+}
+
+/* The encoder tap (include/hypel.h): the full generator also leaves n_4 -- the value an encoder-only application on the same
+ * input would compute, bit for bit -- resp. takes the gradient that reached that value.  Matrix-core kernels only. */
+extern "C" int hypel_gan_generator_tap_supported(int32_t bands) { return gan_use_mfma(bands) ? 1 : 0; }
+
+extern "C" int hypel_gan_generator_fwd_tap(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w,
+                                           const float* b, float* out, int64_t ldo, float* enc_out, int64_t ld_enc,
+                                           float* keep, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && w && b && out && enc_out && n > 0 && gan_use_mfma(bands), "hypel_gan_generator_fwd_tap");
+    hypel_gm_fwd(x, ldx, n, bands, w, b, 0, out, ldo, 2 * hypel_gan_generator_blocks(n), ST, keep, enc_out, ld_enc);
+    HYPEL_CHECK_LAUNCH("hypel_gan_generator_fwd_tap");
+    return 0;
+}
+
+extern "C" int hypel_gan_generator_bwd_tap(const float* x, int64_t ldx, const float* dout, int64_t lddo,
+                                           const float* d_enc, int64_t ld_denc, int64_t n, int32_t bands, const float* w,
+                                           const float* b, float* dx, int64_t lddx, int32_t accumulate_dx, float* pw,
+                                           float* pb, const float* keep, hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && dout && d_enc && w && b && pw && pb && n > 0 && gan_use_mfma(bands), "hypel_gan_generator_bwd_tap");
+    hypel_gm_bwd(x, ldx, dout, lddo, n, bands, w, b, 0, dx, lddx, accumulate_dx, pw, pb, hypel_gan_generator_blocks(n), ST,
+                 keep, d_enc, ld_denc);
+    HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd_tap");
+    return 0;
 }
 
 static int gan_generator_bwd_impl(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,

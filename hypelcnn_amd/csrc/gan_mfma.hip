@@ -202,12 +202,13 @@ typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
 
 // STASH: every layer's outputs / branch bits go straight from the epilogue to this thread's place in the kept-activation
 // buffer (`stash` = the row tile's base + tid, in float4): nothing stays in registers, the unrolled forward stays cheap.
-template <bool ENC, bool KEEP, bool ROLLED = true, bool STASH = false, bool ONE_TABLE = false>
+template <bool ENC, bool KEEP, bool ROLLED = true, bool STASH = false, bool ONE_TABLE = false, bool TAP = false>
 __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, const GmGeo g,
                                           const float* w, const float* bias,  // the block's LDS copy (gm_stage_raw)
                                           float* __restrict__ out, int64_t ldo, int rows_valid, int tid,
                                           float (&keep)[6][GM_MAXT][4], unsigned (&mask)[7],
-                                          gm_f32x4* __restrict__ stash = nullptr) {
+                                          gm_f32x4* __restrict__ stash = nullptr, float* __restrict__ enc_out = nullptr,
+                                          int64_t ld_enc = 0) {
     constexpr int L = ENC ? 4 : 7;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile loops are wave-uniform
     const int col = lane & 15, rg = lane >> 4;
@@ -263,6 +264,10 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
                 if (c < g.bands) {
                     dst[row * g.pitch + c] = y;
                     if (out != nullptr && l == L - 1 && row < rows_valid) out[(int64_t)row * ldo + c] = y;
+                    // encoder tap: n_4 IS the output of the encoder-only application on the same input
+                    if constexpr (TAP && !ENC) {
+                        if (l == 3 && row < rows_valid) enc_out[(int64_t)row * ld_enc + c] = y;
+                    }
                 } else {
                     y = 0.0f;
                 }
@@ -306,13 +311,15 @@ __device__ __forceinline__ void gm_load_rows(float* img, const GmGeo g, const fl
 // lane-native: float4 (slot, m) of thread `tid` of row tile t at ((t * GM_KEEP_V4(ENC) + slot * GM_MAXT + m) * 512 + tid)
 // float4s, two uint4 of branch bits behind them.  The backward kernel then starts from that copy instead of recomputing
 // the forward (29 % of its time at B = 360): 188 KB per 16 samples written and read once at HBM speed.
-template <bool ENC, bool STASH>
+// TAP (full generator only): a separate instantiation, so that the plain kernels keep their register counts
+template <bool ENC, bool STASH, bool TAP = false>
 __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                                             int64_t n, int bands,
                                                                             const float* __restrict__ w,
                                                                             const float* __restrict__ bias,
                                                                             float* __restrict__ out, int64_t ldo,
-                                                                            float* __restrict__ stash) {
+                                                                            float* __restrict__ stash,
+                                                                            float* __restrict__ enc_out, int64_t ld_enc) {
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
     const int tid = threadIdx.x;
@@ -333,19 +340,21 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
         gm_f32x4* sp = nullptr;
         if constexpr (STASH) sp = reinterpret_cast<gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
-        gm_forward<ENC, false, GM_FWD_ROLLED != 0, STASH, ONE>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7),
-                                                               out + r0 * ldo, ldo, rows_valid, tid, keep, mask, sp);
+        gm_forward<ENC, false, GM_FWD_ROLLED != 0, STASH, ONE, TAP>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7),
+                                                                    out + r0 * ldo, ldo, rows_valid, tid, keep, mask, sp,
+                                                                    TAP ? enc_out + r0 * ld_enc : nullptr, ld_enc);
         __syncthreads();  // the next row tile overwrites bufs[0]
     }
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
 // pw[blocks][sum k], pb[blocks][8]: this block's partial filter / bias gradients (summed over its row tiles).
-template <bool ENC, bool STASH>
+template <bool ENC, bool STASH, bool TAP = false>
 __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dx, int64_t lddx, int accumulate_dx,
-    float* __restrict__ pw, float* __restrict__ pb, int wtotal, int slabs, const float* __restrict__ stash) {
+    float* __restrict__ pw, float* __restrict__ pb, int wtotal, int slabs, const float* __restrict__ stash,
+    const float* __restrict__ d_enc, int64_t ld_denc) {
     constexpr int L = ENC ? 4 : 7;
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
@@ -456,7 +465,11 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #pragma unroll
                     for (int q = 0; q < 6; ++q) xin = q == l - 1 ? keep[q][m][e] : xin;
                     if (c < g.bands) {
-                        const float gd = Da[o];
+                        float gd = Da[o];
+                        // encoder tap: the gradient that reached the encoder-only application's output joins dn_4
+                        if constexpr (TAP && !ENC) {
+                            if (l == 3 && 4 * rg + e < rows_valid) gd += d_enc[(r0 + 4 * rg + e) * ld_denc + c];
+                        }
                         float f;
                         if (top_tanh) {
                             float y;
@@ -656,33 +669,39 @@ int64_t hypel_gm_keep_floats(int64_t n, int bands, int only_encoder) {
     } while (0)
 
 int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
-                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep) {
+                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep, float* enc_out, int64_t ld_enc) {
     const size_t lds = gm_fwd_lds(bands);
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     const int grid = (int)(tiles < blocks ? tiles : blocks);
     if (only_encoder) {
-        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, true>), x, ldx, n, bands, w, b, out, ldo, keep);
-        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, false>), x, ldx, n, bands, w, b, out, ldo, keep);
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, false>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
+    } else if (enc_out) {
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
     } else {
-        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true>), x, ldx, n, bands, w, b, out, ldo, keep);
-        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false>), x, ldx, n, bands, w, b, out, ldo, keep);
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
     }
     return 0;
 }
 
 int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
                  const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
-                 int blocks, hipStream_t st, const float* keep) {
+                 int blocks, hipStream_t st, const float* keep, const float* d_enc, int64_t ld_denc) {
     const size_t lds = gm_bwd_lds(bands);
     int wtotal = 0;
     for (int l = 0; l < 7; ++l) wtotal += gm_ksz(bands, l);
     // every one of the `blocks` partial slabs is written (the planner's reduce sums all of them)
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     const int grid = (int)(tiles < blocks ? tiles : blocks);
-#define GM_BWD_ARGS x, ldx, dout, lddo, n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks, keep
+#define GM_BWD_ARGS x, ldx, dout, lddo, n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks, keep, d_enc, ld_denc
     if (only_encoder) {
         if (keep) GM_LAUNCH((gan_generator_bwd_mfma_kernel<true, true>), GM_BWD_ARGS);
         else GM_LAUNCH((gan_generator_bwd_mfma_kernel<true, false>), GM_BWD_ARGS);
+    } else if (d_enc) {
+        if (keep) GM_LAUNCH((gan_generator_bwd_mfma_kernel<false, true, true>), GM_BWD_ARGS);
+        else GM_LAUNCH((gan_generator_bwd_mfma_kernel<false, false, true>), GM_BWD_ARGS);
     } else {
         if (keep) GM_LAUNCH((gan_generator_bwd_mfma_kernel<false, true>), GM_BWD_ARGS);
         else GM_LAUNCH((gan_generator_bwd_mfma_kernel<false, false>), GM_BWD_ARGS);

@@ -2135,6 +2135,11 @@ BATCH_APPS = os.environ.get("HYPEL_GAN_BATCH_APPS", "1") != "0"
 BATCH_APPS_MAX = int(os.environ.get("HYPEL_GAN_BATCH_APPS_MAX", "8"))
 # the per-block gradient slabs of every fused generator / dense-stack application of a train op in ONE reduction launch
 SLAB_REDUCE_MULTI = os.environ.get("HYPEL_SLAB_REDUCE_MULTI", "1") != "0"
+# An encoder-only generator application on a tensor that the FULL generator of the same train op (same variables) also
+# consumes is that application's n_4 (cut_wrapper.py:301-339: gen(x) and gen(x, only_encoder), gen(y) and gen(y, only_encoder)):
+# the full launch writes it too (hypel_gan_generator_fwd_tap) and its backward takes the gradient that reached it
+# (hypel_gan_generator_bwd_tap) -- the encoder-only launches of those tensors disappear.
+GEN_TAP = os.environ.get("HYPEL_GAN_GEN_TAP", "1") != "0"
 
 
 class PhasePlan(TowerPlan):
@@ -2191,6 +2196,18 @@ class PhasePlan(TowerPlan):
             needed.add(id(t.node))
             stack += [i.owner for i in self._node_inputs(t.node)]
         self.needed = [n for n in self.tower.nodes if id(n) in needed]
+        self._taps, self._tapped = {}, {}  # id(full generator node) -> the encoder output it also produces; id(enc node) -> full node
+        # (only with the dependency-driven schedule of _schedule_units: in tower order an encoder application may precede the
+        # full one it would be read from)
+        if GEN_TAP and BATCH_APPS and hasattr(self.be, "gan_generator_tap_supported"):
+            fulls = {(id(n.weights[0]), id(n.src)): n for n in self.needed
+                     if isinstance(n, G.GeneratorNode) and not n.only_encoder}
+            for e in self.needed:
+                if isinstance(e, G.GeneratorNode) and e.only_encoder:
+                    f = fulls.get((id(e.weights[0]), id(e.src)))
+                    if f is not None and id(f) not in self._taps and self.be.gan_generator_tap_supported(e.src.c):
+                        self._taps[id(f)] = e.out
+                        self._tapped[id(e)] = f
         self._grad_needed = set()
         for n in self.needed:
             vs = self._node_vars(n)
@@ -2237,8 +2254,17 @@ class PhasePlan(TowerPlan):
                 idx, node = unit[0]
                 if id(node.out) not in self._grad_needed:
                     continue
+                tap = self._taps.get(id(node))
+                tap_written = tap is not None and self.grad_written.get(id(tap), False)
                 if not self.grad_written.get(id(node.out.owner), False):
-                    continue  # this application does not feed the phase's loss
+                    if not tap_written:
+                        continue  # this application does not feed the phase's loss
+                    # only the encoder output read from this application carries a gradient: zero for its own output
+                    gname = self._ensure_grad(node.out.owner)
+                    st = self.storage[id(node.out.owner)]
+                    self.bwd.append(Launch("fill_f32", (self._ref(gname, st.ch_off), st.rows * st.ld, 0.0),
+                                           tag="zero-grad-rows"))
+                    self.grad_written[id(node.out.owner)] = True
                 self._bwd_node(idx, node)
             self._flush_wgrads()
             self._flush_slab_reduces()
@@ -2279,7 +2305,7 @@ class PhasePlan(TowerPlan):
         """Hashable identity of "the same network layer" (same variables, same hyper-parameters), or None when the node
         kind is not batched.  Only ops whose rows are independent qualify: no batch statistics, no per-tensor norms."""
         if isinstance(node, G.GeneratorNode):
-            return ("gen", id(node.weights[0]), bool(node.only_encoder), node.src.c)
+            return ("gen", id(node.weights[0]), bool(node.only_encoder), node.src.c, id(node) in self._taps)
         if isinstance(node, G.DenseStackNode):
             return ("ds", id(node.weights[0]), node.src.c)
         if isinstance(node, G.LinearNode) and node.kind in ("dense", "blockdense"):
@@ -2309,14 +2335,23 @@ class PhasePlan(TowerPlan):
         """[[(idx, node), ...]]: the needed nodes in an executable order, same-weight applications grouped.  Members of a
         group run when the last of their inputs is ready; a grouping that would make the unit graph cyclic (CycleGAN:
         G_xy(G_yx(y)) next to G_xy(x)) is split by depth."""
-        order = [(i, n) for i, n in enumerate(self.tower.nodes) if n in self.needed]
+        order = [(i, n) for i, n in enumerate(self.tower.nodes) if n in self.needed and id(n) not in self._tapped]
         if not BATCH_APPS:
             return [[u] for u in order]
         prod = {id(n.out): k for k, (_, n) in enumerate(order)}  # tensor owner -> position of its producer
+        for k, (_, n) in enumerate(order):  # an encoder tap is produced by its full generator's launch
+            if id(n) in self._taps:
+                prod[id(self._taps[id(n)])] = k
         deps = [sorted({prod[id(t.owner)] for t in self._node_inputs(n) if id(t.owner) in prod}) for _, n in order]
-        depth = []
+        depth = [0] * len(order)  # (with encoder taps a consumer may precede its producer in tower order: no single sweep)
+
+        def depth_of(k):
+            if depth[k] == 0:
+                depth[k] = 1 + max([depth_of(d) for d in deps[k]], default=0)
+            return depth[k]
+
         for k in range(len(order)):
-            depth.append(1 + max([depth[d] for d in deps[k]], default=0))
+            depth_of(k)
         sigs = [self._batch_signature(n) for _, n in order]
 
         def attempt(by_depth):
@@ -2396,6 +2431,13 @@ class PhasePlan(TowerPlan):
         else:
             rep.src = syn_src
         rep.out = G.SymTensor(self.tower, None, n0.out.c, node=rep)
+        taps = [self._taps.get(id(n)) for _, n in unit]
+        syn_tap = None
+        if taps[0] is not None:  # (the signature keeps tapped and untapped applications apart)
+            syn_tap = G.SymTensor(self.tower, None, taps[0].c, node=rep)
+            self._taps[id(rep)] = syn_tap
+            if any(id(t) in self._grad_needed for t in taps):
+                self._grad_needed.add(id(syn_tap))
         if syn_src.needs_grad:
             self._grad_needed.add(id(syn_src))
         if any(id(n.out) in self._grad_needed for _, n in unit):
@@ -2411,8 +2453,15 @@ class PhasePlan(TowerPlan):
                                               n.out.c, 1)
         if id(rep.out) in self._grad_needed and self.terms and "g:" + out_st.buf not in self.buffers:
             self._alloc("g:" + out_st.buf, G_ * nb0 * out_st.ld)  # one gradient buffer, the members' are its row blocks
+        if syn_tap is not None:
+            t_st = self.storage[id(syn_tap)]
+            for g, t in enumerate(taps):
+                self.storage[id(t)] = Storage(t_st.buf, nb0, t_st.ld, None, t_st.ch_off + g * nb0 * t_st.ld, t.c, 1)
+            if id(syn_tap) in self._grad_needed and self.terms and "g:" + t_st.buf not in self.buffers:
+                self._alloc("g:" + t_st.buf, G_ * nb0 * t_st.ld)
         self._groups = getattr(self, "_groups", {})
-        self._groups[idx0] = dict(rep=rep, syn_src=syn_src, srcs=srcs, gathered=gathered, cat=cat_st)
+        self._groups[idx0] = dict(rep=rep, syn_src=syn_src, srcs=srcs, gathered=gathered, cat=cat_st, taps=taps,
+                                  syn_tap=syn_tap)
 
     def _bwd_group(self, unit):
         nb0, G_ = self.nb, len(unit)
@@ -2422,16 +2471,27 @@ class PhasePlan(TowerPlan):
         if id(rep.out) not in self._grad_needed:
             return
         written = [self.grad_written.get(id(n.out), False) for _, n in unit]
-        if not any(written):
+        taps, syn_tap = grp["taps"], grp["syn_tap"]
+        tap_written = [t is not None and self.grad_written.get(id(t), False) for t in taps]
+        if not any(written) and not any(tap_written):
             return  # none of these applications feeds the phase's loss
         out_st = self.storage[id(rep.out)]
         gname = "g:" + out_st.buf
+        if gname not in self.buffers:
+            self._alloc(gname, G_ * nb0 * out_st.ld)
         for g, ((_, n), wr) in enumerate(zip(unit, written)):
             if not wr:  # an application without a gradient contributes zero rows
                 m_st = self.storage[id(n.out)]
                 self.bwd.append(Launch("fill_f32", (self._ref(gname, m_st.ch_off), nb0 * m_st.ld, 0.0),
                                        tag="zero-grad-rows"))
         self.grad_written[id(rep.out)] = True
+        if syn_tap is not None and any(tap_written):
+            for t, wr in zip(taps, tap_written):
+                if not wr:
+                    m_st = self.storage[id(t)]
+                    self.bwd.append(Launch("fill_f32", (self._ref("g:" + m_st.buf, m_st.ch_off), nb0 * m_st.ld, 0.0),
+                                           tag="zero-grad-rows"))
+            self.grad_written[id(syn_tap)] = True
         # input gradient: the inputs either are row blocks of ONE buffer (outputs of the previous batched layer) -- the
         # handler then writes straight into that buffer's gradient, blocks nobody wrote yet zeroed first so that one
         # accumulate state serves all rows -- or were gathered: the gradient of the concatenation is scattered (added)
@@ -2539,9 +2599,17 @@ class PhasePlan(TowerPlan):
         s_st = self.storage_of(src)
         st = self._new_value(out, f"z:{idx}")
         w0, b0, _ = self._gen_refs(node)
-        l = Launch("gan_generator_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c, self._p(w0),
-                                         self._p(b0), int(node.only_encoder), self._ref(st.buf), st.ld),
-                   nbytes=8 * self.nb * src.c, tag="gen-fwd")
+        tap = self._taps.get(id(node))
+        if tap is not None:
+            # the encoder-only application on the same input is this launch's n_4
+            t_st = self._new_value(tap, f"ztap:{idx}")
+            l = Launch("gan_generator_fwd_tap", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c, self._p(w0),
+                                                 self._p(b0), self._ref(st.buf), st.ld, self._ref(t_st.buf), t_st.ld, None),
+                       nbytes=12 * self.nb * src.c, tag="gen-fwd+enc")
+        else:
+            l = Launch("gan_generator_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c, self._p(w0),
+                                             self._p(b0), int(node.only_encoder), self._ref(st.buf), st.ld),
+                       nbytes=8 * self.nb * src.c, tag="gen-fwd")
         self.fwd.append(l)
         self._gen_fwd = getattr(self, "_gen_fwd", {})
         self._gen_fwd[idx] = l  # _bwd_generator turns it into the activation-keeping form when a backward pass follows
@@ -2556,28 +2624,46 @@ class PhasePlan(TowerPlan):
         if self._needs_grad(src):
             gst, acc = self._grad_target(src)
             dx, lddx = self._ref(gst.buf, gst.ch_off), gst.ld
-        l1 = Launch("gan_generator_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
-                                          z_st.ld, self.nb, src.c, self._p(w0), self._p(b0), int(node.only_encoder),
-                                          dx, lddx, acc, None, None), nbytes=12 * self.nb * src.c, tag="gen-bwd")
+        tap = self._taps.get(id(node))
+        tap_grad = tap is not None and self.grad_written.get(id(tap), False)
         keep_n = self.be.gan_generator_keep_floats(self.nb, src.c, int(node.only_encoder)) if GEN_KEEP else 0
+        kref = None
         if keep_n > 0:
             # the forward pass of this application leaves its activations for this launch (hypel.h: bit-identical to
             # recomputing them; 188 KB per 16 samples at 360 bands)
             self._alloc(f"gkeep:{idx}", keep_n)
             kref = self._ref(f"gkeep:{idx}")
             f = self._gen_fwd[idx]
-            f.name, f.args = "gan_generator_fwd_keep", tuple(f.args) + (kref,)
+            if f.name == "gan_generator_fwd_tap":
+                f.args = tuple(f.args[:-1]) + (kref,)
+            else:
+                f.name, f.args = "gan_generator_fwd_keep", tuple(f.args) + (kref,)
             f.bytes += 4 * keep_n
-            l1.name, l1.args = "gan_generator_bwd_kept", tuple(l1.args) + (kref,)
-            l1.bytes += 4 * keep_n
+        if tap_grad:
+            # one backward pass for the full application and the encoder-only one read from it: the gradient that reached
+            # the encoder output joins dn_4
+            t_st = self.storage[id(tap)]
+            l1 = Launch("gan_generator_bwd_tap", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
+                                                  z_st.ld, self._ref("g:" + t_st.buf, t_st.ch_off), t_st.ld, self.nb, src.c,
+                                                  self._p(w0), self._p(b0), dx, lddx, acc, None, None, kref),
+                        nbytes=16 * self.nb * src.c + 4 * keep_n, tag="gen-bwd+enc")
+            pw_pos, pb_pos = 13, 14
+        else:
+            l1 = Launch("gan_generator_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
+                                              z_st.ld, self.nb, src.c, self._p(w0), self._p(b0), int(node.only_encoder),
+                                              dx, lddx, acc, None, None), nbytes=12 * self.nb * src.c, tag="gen-bwd")
+            if kref is not None:
+                l1.name, l1.args = "gan_generator_bwd_kept", tuple(l1.args) + (kref,)
+                l1.bytes += 4 * keep_n
+            pw_pos, pb_pos = 12, 13
         self.bwd.append(l1)
         if self._trains(node.weights):
             wacc = self._param_acc(w0)
             if SLAB_REDUCE_MULTI:
-                self._defer_slab_reduce(l1, 12, 13, blocks, w0, wtotal, wtotal, b0, 8, 7, wacc)
+                self._defer_slab_reduce(l1, pw_pos, pb_pos, blocks, w0, wtotal, wtotal, b0, 8, 7, wacc)
                 return
-        self._scratch(l1, 12, "scratch_gen_w", blocks * wtotal)
-        self._scratch(l1, 13, "scratch_gen_b", blocks * 8)
+        self._scratch(l1, pw_pos, "scratch_gen_w", blocks * wtotal)
+        self._scratch(l1, pb_pos, "scratch_gen_b", blocks * 8)
         if self._trains(node.weights):
             # filter and bias slabs in one launch
             l2 = Launch("reduce_splits_pair_f32", (None, wtotal, wtotal, self._g(w0), None, 8, 7, self._g(b0), blocks, wacc),

@@ -451,6 +451,21 @@ int hypel_gan_generator_bwd(const float* x, int64_t ldx, const float* dout, int6
  * bit-identical to the recomputing pair.  keep_floats == 0: this band count runs on the VALU kernels, which always
  * recompute -- pass keep = NULL (then the calls are hypel_gan_generator_fwd / _bwd). */
 int64_t hypel_gan_generator_keep_floats(int64_t n, int32_t bands, int32_t only_encoder);
+/* Encoder tap (round 4).  CUT applies the encoder-only generator to tensors the FULL generator of the same train op also
+ * consumes (gan/wrappers/cut_wrapper.py:301-339: gen(x), gen(x, only_encoder) -- and the same for y): the encoder output is
+ * the full generator's n_4.  hypel_gan_generator_fwd_tap = hypel_gan_generator_fwd[_keep](only_encoder = 0) that also writes
+ * enc_out[n x bands] = what hypel_gan_generator_fwd(only_encoder = 1) would write, bit for bit (keep may be NULL);
+ * hypel_gan_generator_bwd_tap = hypel_gan_generator_bwd[_kept](only_encoder = 0) that adds d_enc -- the gradient of enc_out
+ * -- to the gradient of n_4: one backward pass yields the input and filter gradients of both applications.
+ * Matrix-core kernels only: hypel_gan_generator_tap_supported(bands) != 0. */
+int hypel_gan_generator_tap_supported(int32_t bands);
+int hypel_gan_generator_fwd_tap(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w, const float* b,
+                                float* out, int64_t ldo, float* enc_out, int64_t ld_enc, float* keep,
+                                hypel_stream_t stream);
+int hypel_gan_generator_bwd_tap(const float* x, int64_t ldx, const float* dout, int64_t lddo, const float* d_enc,
+                                int64_t ld_denc, int64_t n, int32_t bands, const float* w, const float* b, float* dx,
+                                int64_t lddx, int32_t accumulate_dx, float* pw, float* pb, const float* keep,
+                                hypel_stream_t stream);
 int hypel_gan_generator_fwd_keep(const float* x, int64_t ldx, int64_t n, int32_t bands, const float* w, const float* b,
                                  int32_t only_encoder, float* out, int64_t ldo, float* keep, hypel_stream_t stream);
 int hypel_gan_generator_bwd_kept(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t bands,

@@ -814,7 +814,8 @@ def _k_gan_generator_fwd(self, x, ldx, n, bands, w, b, only_encoder, out, ldo):
     _mat(out, ldo, n, bands)[...] = (a[4] if only_encoder else np.tanh(c7)).astype(np.float32)
 
 
-def _k_gan_generator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb):
+def _k_gan_generator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb,
+                         d_enc=None, ld_denc=0):
     xs = _mat(x, ldx, n, bands).astype(np.float64)
     g = _mat(dout, lddo, n, bands).astype(np.float64)
     ks, offs = _gen_layout(bands)
@@ -839,6 +840,9 @@ def _k_gan_generator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, only_encoder,
         t = np.tanh(c7)
         layer_bwd(6, g * (1 - t * t))
     for i in range(hidden, 0, -1):
+        if i == 4 and d_enc is not None:  # encoder tap: the gradient of the encoder-only application's output joins dn_4
+            assert not only_encoder
+            da[4] = da[4] + _mat(d_enc, ld_denc, n, bands).astype(np.float64)
         gi = da[i]
         da[i - 1] = da[i - 1] + gi
         if i >= 2:
@@ -1012,7 +1016,22 @@ EmuBackend.k_l2norm_parts_fwd = _k_l2norm_parts_fwd
 EmuBackend.k_l2norm_parts_bwd = _k_l2norm_parts_bwd
 EmuBackend.k_l2norm_segs_fwd = _k_l2norm_segs_fwd
 EmuBackend.k_l2norm_segs_bwd = _k_l2norm_segs_bwd
+def _k_gan_generator_fwd_tap(self, x, ldx, n, bands, w, b, out, ldo, enc_out, ld_enc, keep):
+    """Specification of the encoder tap: the full forward, and what the encoder-only forward on the same input writes."""
+    assert 16 <= bands <= 384, "matrix-core kernels only"
+    _k_gan_generator_fwd(self, x, ldx, n, bands, w, b, 0, out, ldo)
+    _k_gan_generator_fwd(self, x, ldx, n, bands, w, b, 1, enc_out, ld_enc)
+
+
+def _k_gan_generator_bwd_tap(self, x, ldx, dout, lddo, d_enc, ld_denc, n, bands, w, b, dx, lddx, acc, pw, pb, keep):
+    assert 16 <= bands <= 384 and d_enc is not None
+    _k_gan_generator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, 0, dx, lddx, acc, pw, pb, d_enc, ld_denc)
+
+
 EmuBackend.k_gan_generator_fwd = _k_gan_generator_fwd
+EmuBackend.k_gan_generator_fwd_tap = _k_gan_generator_fwd_tap
+EmuBackend.k_gan_generator_bwd_tap = _k_gan_generator_bwd_tap
+EmuBackend.gan_generator_tap_supported = lambda self, bands: 16 <= bands <= 384
 EmuBackend.k_gan_generator_bwd = _k_gan_generator_bwd
 EmuBackend.k_gan_loss = _k_gan_loss
 EmuBackend.k_l2_reg = _k_l2_reg

@@ -124,7 +124,10 @@ def test_same_weight_applications_run_as_one_row_concatenated_application(monkey
     gen_b = [l for l in counts[True]["gen" if "gen" in counts[True] else list(counts[True])[0]] if "generator_fwd" in l]
     gen_u = [l for l in counts[False]["gen" if "gen" in counts[False] else list(counts[False])[0]] if "generator_fwd" in l]
     if kind == "cut_x2y":
-        assert len(gen_u) == 6 and len(gen_b) == 2, (gen_u, gen_b)  # G([x; y]) and enc on four inputs
+        # unbatched: six applications.  Batched: G([x; y]) whose n_4 doubles as enc(x), enc(y) (the encoder tap: one
+        # launch writes both, one backward launch takes both gradients), and enc([G(x); G(y)])
+        assert len(gen_u) == 6 and sorted(gen_b) == ["gan_generator_fwd_keep", "gan_generator_fwd_tap"], (gen_u, gen_b)
+        assert "gan_generator_bwd_tap" in counts[True]["gen"] and "gan_generator_fwd_tap" in counts[True]["feat"]
         assert tot[True] * 2 <= tot[False] + 10, tot
     if kind == "cycle_gan":
         assert len(gen_b) == len(gen_u) == 4  # the four generator applications depend on each other pairwise

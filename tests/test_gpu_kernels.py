@@ -1230,3 +1230,43 @@ def test_chunk_bn_kernels(hip, rows, c, act, use_mask, in_place):
     ref = b.e[out].numpy().reshape(rows, ld)[:, :c]
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
     b.check("dbeta", rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("bands,n,kept", [(360, 200, True), (64, 2048, True), (144, 37, False), (16, 5, False)])
+def test_gan_generator_encoder_tap(hip, bands, n, kept):
+    """The full generator also leaves n_4: bit for bit what the encoder-only application on the same input writes; its
+    backward pass takes the gradient of that value and returns the input / filter / bias gradients of BOTH applications."""
+    from tests.emu_backend import generator_knife_edge_rows
+    rng = np.random.default_rng(bands + n)
+    ks = [bands >> s for s in (0, 1, 2, 3, 2, 1, 0)]
+    wt = sum(ks)
+    w = (rng.standard_normal(wt) * 0.4 / np.sqrt(np.repeat(ks, ks))).astype(np.float32)
+    bias = (rng.standard_normal(8) * 0.1).astype(np.float32)
+    x = rng.random((n, bands)).astype(np.float32)
+    for _ in range(20):  # re-draw samples whose leaky-ReLU branch hangs on fp32 rounding (see the generator tests)
+        bad = generator_knife_edge_rows(x.astype(np.float64), w.astype(np.float64), bias.astype(np.float64), bands, False)
+        if not len(bad):
+            break
+        x[bad] = rng.random((len(bad), bands)).astype(np.float32)
+    blocks = hip.gan_generator_blocks(n)
+    b = Both(hip)
+    for nm, arr in (("x", x), ("w", w), ("b", bias), ("dout", rng.standard_normal((n, bands)).astype(np.float32)),
+                    ("denc", rng.standard_normal((n, bands)).astype(np.float32)), ("out", np.zeros(n * bands, np.float32)),
+                    ("enc", np.zeros(n * bands, np.float32)), ("enc_ref", np.zeros(n * bands, np.float32)),
+                    ("dx", np.zeros(n * bands, np.float32)), ("pw", np.zeros(blocks * wt, np.float32)),
+                    ("pb", np.zeros(blocks * 8, np.float32)), ("dw", np.zeros(wt, np.float32)), ("db", np.zeros(8, np.float32))):
+        b.arr(nm, arr)
+    keep = None
+    if kept:
+        keep = "keep"
+        b.arr("keep", np.zeros(max(16, hip.gan_generator_keep_floats(n, bands, 0)), np.float32))
+    b.run("gan_generator_fwd_tap", "x", bands, n, bands, "w", "b", "out", bands, "enc", bands, keep)
+    b.run("gan_generator_fwd", "x", bands, n, bands, "w", "b", 1, "enc_ref", bands)
+    assert torch.equal(b.h["enc"], b.h["enc_ref"]), "the tap IS the encoder-only application"
+    b.check("out", rtol=2e-4, atol=2e-5)
+    b.check("enc", rtol=2e-4, atol=2e-5)
+    b.run("gan_generator_bwd_tap", "x", bands, "dout", bands, "denc", bands, n, bands, "w", "b", "dx", bands, 0, "pw", "pb", keep)
+    b.run("reduce_splits_pair_f32", "pw", wt, wt, "dw", "pb", 8, 7, "db", blocks, 0)
+    b.check("dx", rtol=5e-4, atol=5e-5)
+    b.check("dw", rtol=5e-4, atol=5e-5)
+    b.check("db", rtol=5e-4, atol=5e-5)

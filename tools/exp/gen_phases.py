@@ -14,9 +14,17 @@ x = be.upload(rng.random((n, bands)).astype(np.float32)); d = be.upload(rng.stan
 w = be.upload((rng.standard_normal(wt) * 0.05).astype(np.float32)); b = be.upload(np.zeros(8, np.float32))
 blocks = be.gan_generator_blocks(n)
 pw = be.zeros(blocks * wt); pb = be.zeros(blocks * 8); dx = be.zeros(n * bands)
+kept = os.environ.get("GP_KEPT", "0") == "1"  # the form the train ops run: backward from the forward pass's kept activations
+out = be.zeros(n * bands)
 for enc in (0, 1):
+    keep = be.zeros(be.gan_generator_keep_floats(n, bands, enc)) if kept else None
     for _ in range(3):
-        be.call("gan_generator_bwd", Ref(x), bands, Ref(d), bands, n, bands, Ref(w), Ref(b), enc, Ref(dx), bands, 0, Ref(pw), Ref(pb))
+        if kept:
+            be.call("gan_generator_fwd_keep", Ref(x), bands, n, bands, Ref(w), Ref(b), enc, Ref(out), bands, Ref(keep))
+            be.call("gan_generator_bwd_kept", Ref(x), bands, Ref(d), bands, n, bands, Ref(w), Ref(b), enc, Ref(dx), bands, 0,
+                    Ref(pw), Ref(pb), Ref(keep))
+        else:
+            be.call("gan_generator_bwd", Ref(x), bands, Ref(d), bands, n, bands, Ref(w), Ref(b), enc, Ref(dx), bands, 0, Ref(pw), Ref(pb))
     be.synchronize()
     c = pb[:8].cpu().numpy()
     names = ["tile setup", "forward recompute", "dout load", "step A (dz, skips, X)", "step B products", "diagonal sums", "step C (dgrad)", "write-out"]
