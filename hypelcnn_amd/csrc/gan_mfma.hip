@@ -450,6 +450,17 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
             unsigned mk = 0;
 #pragma unroll
             for (int q = 0; q < 7; ++q) mk = q == l ? mask[q] : mk;
+            // encoder tap: the gradient that reached the encoder-only application's output joins dn_4 (complete in Da when
+            // layer 3 begins) -- a pass of its own over the tile: inside step A the extra operand cost 34 registers
+            if constexpr (TAP && !ENC) {
+                if (l == 3) {
+                    for (int i = tid; i < GM_ROWS * g.bp; i += GM_THREADS) {
+                        const int row = i / g.bp, c = i - row * g.bp;
+                        if (row < rows_valid && c < g.bands) Da[row * g.pitch + c] += d_enc[(r0 + row) * ld_denc + c];
+                    }
+                    __syncthreads();
+                }
+            }
             // ---- step A: dz_l, skip gradients, bias gradient; n_{l-1} from the registers (or x) into X ----
             gm_fill_taps(wz, g, raw + woff, ksz, tid);
             float dbl = 0.0f;
@@ -465,11 +476,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #pragma unroll
                     for (int q = 0; q < 6; ++q) xin = q == l - 1 ? keep[q][m][e] : xin;
                     if (c < g.bands) {
-                        float gd = Da[o];
-                        // encoder tap: the gradient that reached the encoder-only application's output joins dn_4
-                        if constexpr (TAP && !ENC) {
-                            if (l == 3 && 4 * rg + e < rows_valid) gd += d_enc[(r0 + 4 * rg + e) * ld_denc + c];
-                        }
+                        const float gd = Da[o];
                         float f;
                         if (top_tanh) {
                             float y;

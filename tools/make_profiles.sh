@@ -45,6 +45,8 @@ for WL in $WLS; do
   HYPEL_DP_SELFTEST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py $EXTRA --steps $STEPS --no-cpu-baseline --no-input-pipeline > $OUT/dp_selftest_$WL.json 2> $OUT/dp_selftest_$WL.err
 done
+# rehearsal of the bare multi-GPU command (bench.py starts its own ranks): two gloo ranks sharing this one MI355X
+HYPEL_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-input-pipeline 2> $OUT/bench_selflaunch_gloo2.err | tail -1 > $OUT/bench_selflaunch_gloo2.json
 python - <<PY > $OUT/dp_selftest_overhead.txt
 import json, glob, os
 print("1-rank RCCL self-test (HYPEL_DP_SELFTEST=1 under torch.distributed.run --nproc-per-node 1) vs the plain run, same box")
