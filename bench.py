@@ -239,11 +239,15 @@ def measure_gan_events(ops, nb, bands, steps):
                     a.record()
                     f()
                     b.record()
-                    bwd = "_bwd" in l.name  # gan_generator_bwd / _bwd_kept / _bwd_tap
+                    bwd = "_bwd" in l.name  # gan_generator_bwd / _bwd_kept / _bwd_tap / _bwd_apps
                     if l.name.endswith("_tap"):
                         # the full generator whose n_4 doubles as the encoder-only application on the same input: its
                         # algorithmic work is the full generator's (the shared encoder layers are computed once)
                         enc, rows = False, int(l.args[6] if bwd else l.args[2])
+                    elif l.name.endswith("_apps"):
+                        # several same-shaped generators, each on `n` rows of the launch (hypel.h: *_apps)
+                        enc = bool(l.args[13] if bwd else l.args[9])
+                        rows = int(l.args[4] if bwd else l.args[2]) * int(l.args[5] if bwd else l.args[3])
                     else:
                         enc = bool(l.args[8] if bwd else l.args[6])
                         rows = int(l.args[4] if bwd else l.args[2])  # k * nb when k same-weight applications run as one

@@ -133,6 +133,13 @@ SIGNATURES = {
     "gan_generator_bwd_kept": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P],
     "gan_generator_fwd_tap": [_P, _I64, _I64, _I32, _P, _P, _P, _I64, _P, _I64, _P],
     "gan_generator_bwd_tap": [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I64, _I32, _P, _P, _P],
+    "gan_generator_fwd_apps": [_P, _I64, _I64, _I32, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _P],
+    "gan_generator_bwd_apps": [_P, _I64, _P, _I64, _I64, _I32, _I64, _I64, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32,
+                               _P, _P, _P],
+    "dense_stack_fwd_apps": [_P, _I64, _I64, _I32, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P,
+                             _I64],
+    "dense_stack_bwd_apps": [_P, _I64, _P, _I64, _I64, _I32, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32,
+                             _I32, _F, _P, _P, _P, _I64, _I32, _P, _P],
     "gan_loss": [_I32, _P, _I64, _P, _I64, _I64, _I32, _F, _F, _P, _I32, _P, _I64, _I32, _P, _I64, _I32, _P],
     "l2_reg": [_P, _I64, _F, _P, _I32, _P, _P],
     "loss_finalize_slots": [_P, _I32, _P, _I32],
@@ -176,6 +183,10 @@ def load_library(path=LIB_PATH):
     lib.hypel_gan_generator_blocks.restype = ctypes.c_int
     lib.hypel_dense_stack_blocks.argtypes = [_I64]
     lib.hypel_dense_stack_blocks.restype = ctypes.c_int
+    lib.hypel_gan_generator_blocks_apps.argtypes = [_I64, _I32]
+    lib.hypel_gan_generator_blocks_apps.restype = ctypes.c_int
+    lib.hypel_dense_stack_blocks_apps.argtypes = [_I64, _I32]
+    lib.hypel_dense_stack_blocks_apps.restype = ctypes.c_int
     lib.hypel_dense_stack_supported.argtypes = [_I32] * 6
     lib.hypel_dense_stack_supported.restype = ctypes.c_int
     lib.hypel_gan_generator_tap_supported.argtypes = [_I32]
@@ -292,6 +303,12 @@ class HipBackend:
 
     def dense_stack_blocks(self, n):
         return int(self.lib.hypel_dense_stack_blocks(int(n)))
+
+    def gan_generator_blocks_apps(self, n, n_apps):
+        return int(self.lib.hypel_gan_generator_blocks_apps(int(n), int(n_apps)))
+
+    def dense_stack_blocks_apps(self, n, n_apps):
+        return int(self.lib.hypel_dense_stack_blocks_apps(int(n), int(n_apps)))
 
     def dense_stack_supported(self, widths):
         w = list(widths) + [0] * (5 - len(widths))

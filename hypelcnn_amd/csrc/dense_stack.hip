@@ -144,12 +144,26 @@ __device__ __forceinline__ void ds_layer_fwd(const float* src, float* dst, const
     }
 }
 
+// Several applications of stacks of ONE shape in one launch (hypel_dense_stack_*_apps): application g owns rows
+// [g * n, (g + 1) * n) of x / out (/ dout / dx) and the weights at w + g * w_stride, b + g * b_stride -- the two critics of a
+// CycleGAN step (same layer widths, different variables) -- and gridDim.x / n_apps consecutive blocks (and gradient slabs).
+struct DsApps {
+    int n_apps;
+    int64_t w_stride, b_stride;    // element distance of application g + 1's variables from application g's
+    int64_t pw_stride, pb_stride;  // ... of its first gradient slab (0: the slabs of all applications are consecutive)
+};
+
 __global__ __launch_bounds__(DS_THREADS) void dense_stack_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t n,
                                                                      DsShape sh, const float* __restrict__ w,
                                                                      const float* __restrict__ b, float* __restrict__ out,
-                                                                     int64_t ldo) {
+                                                                     int64_t ldo, DsApps apps) {
     extern __shared__ __attribute__((aligned(16))) float ds_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bpa = gridDim.x / apps.n_apps, app = blockIdx.x / bpa, blk = blockIdx.x - app * bpa;
+    w += app * apps.w_stride;
+    b += app * apps.b_stride;
+    x += (int64_t)app * n * ldx;
+    out += (int64_t)app * n * ldo;
     const int img = DS_ROWS * sh.pa;
     float* X = ds_lds;  // the input tile (only ever written by its DMA: the margins stay zero)
     float* P0 = ds_lds + img;
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(DS_THREADS) void dense_stack_fwd_kernel(const float
     if (wave == 1 && sh.boff[sh.n_layers] > DS_MAXW)
         for (int o = DS_MAXW; o < sh.boff[sh.n_layers]; o += DS_MAXW) ds_dma_row(b + o, bl + o, min(sh.boff[sh.n_layers] - o, DS_MAXW), lane);
     const int64_t tiles = (n + DS_ROWS - 1) / DS_ROWS;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (int64_t t = blk; t < tiles; t += bpa) {
         const int64_t r0 = t * DS_ROWS;
         const int rows_valid = (int)min((int64_t)DS_ROWS, n - r0);
         ds_load_rows(X, sh.pa, sh.width[0], x + r0 * ldx, ldx, rows_valid, tid, lane, wave);
@@ -192,9 +206,15 @@ __global__ __launch_bounds__(DS_THREADS) void dense_stack_fwd_kernel(const float
 __global__ __launch_bounds__(DS_THREADS) void dense_stack_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, DsShape sh,
     const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dx, int64_t lddx, int accumulate_dx,
-    float* __restrict__ pw, float* __restrict__ pb) {
+    float* __restrict__ pw, float* __restrict__ pb, DsApps apps) {
     extern __shared__ __attribute__((aligned(16))) float ds_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bpa = gridDim.x / apps.n_apps, app = blockIdx.x / bpa, blk = blockIdx.x - app * bpa;
+    w += app * apps.w_stride;
+    b += app * apps.b_stride;
+    x += (int64_t)app * n * ldx;
+    dout += (int64_t)app * n * lddo;
+    if (dx != nullptr) dx += (int64_t)app * n * lddx;
     const int r = lane & 15, kq = lane >> 4;
     const int trow = tid >> 4, tcol = tid & 15;  // element-wise passes: thread -> (row, column + 16 k)
     const int L = sh.n_layers, pa = sh.pa, cp = sh.cp;
@@ -213,11 +233,16 @@ __global__ __launch_bounds__(DS_THREADS) void dense_stack_bwd_kernel(
     if (wave == 1 && sh.boff[L] > DS_MAXW)
         for (int o = DS_MAXW; o < sh.boff[L]; o += DS_MAXW) ds_dma_row(b + o, bl + o, min(sh.boff[L] - o, DS_MAXW), lane);
     const int wtotal = sh.woff[L], btotal = sh.boff[L];
-    float* my_pw = pw + (int64_t)blockIdx.x * wtotal;
+    // gradient slabs: this application's share starts `pw_stride` floats behind the previous application's (the planner
+    // appends the slabs of every application of one weight set to that set's region: PhasePlan._defer_slab_reduce)
+    const int64_t slab = apps.pw_stride ? (int64_t)blk : (int64_t)blockIdx.x;
+    pw += app * apps.pw_stride;
+    pb += app * apps.pb_stride;
+    float* my_pw = pw + slab * wtotal;
     float dbacc[DS_MAXL] = {0.0f, 0.0f, 0.0f, 0.0f};  // thread t owns column t of every layer's bias gradient
     bool first_tile = true;
     const int64_t tiles = (n + DS_ROWS - 1) / DS_ROWS;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (int64_t t = blk; t < tiles; t += bpa) {
         const int64_t r0 = t * DS_ROWS;
         const int rows_valid = (int)min((int64_t)DS_ROWS, n - r0);
         if (!first_tile) __syncthreads();  // the previous tile's gradients have been consumed
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(DS_THREADS) void dense_stack_bwd_kernel(
             float v = 0.0f;
 #pragma unroll
             for (int q = 0; q < DS_MAXL; ++q) v = q == l ? dbacc[q] : v;
-            pb[(int64_t)blockIdx.x * btotal + sh.boff[l] + tid] = v;
+            pb[slab * btotal + sh.boff[l] + tid] = v;
         }
 }
 
@@ -351,6 +376,17 @@ extern "C" int hypel_dense_stack_blocks(int64_t n) {
     return (int)t;
 }
 
+/* blocks (= gradient slabs) of a launch over n_apps applications of n rows each: n_apps equal shares */
+extern "C" int hypel_dense_stack_blocks_apps(int64_t n, int32_t n_apps) {
+    if (n_apps < 1) n_apps = 1;
+    int64_t t = (n + DS_ROWS - 1) / DS_ROWS;
+    int64_t per = 256 / n_apps;
+    if (per < 1) per = 1;
+    if (t < 1) t = 1;
+    if (t > per) t = per;
+    return (int)(t * n_apps);
+}
+
 extern "C" int hypel_dense_stack_supported(int32_t n_layers, int32_t w0, int32_t w1, int32_t w2, int32_t w3, int32_t w4) {
     const int32_t widths[DS_MAXL + 1] = {w0, w1, w2, w3, w4};
     DsShape sh;
@@ -367,8 +403,25 @@ extern "C" int hypel_dense_stack_fwd(const float* x, int64_t ldx, int64_t n, int
     HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_dense_stack_fwd");
     (void)hipFuncSetAttribute((const void*)dense_stack_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dense_stack_fwd_kernel, dim3(hypel_dense_stack_blocks(n)), dim3(DS_THREADS), lds, ST, x, ldx, n, sh, w,
-                       b, out, ldo);
+                       b, out, ldo, DsApps{1, 0, 0, 0, 0});
     HYPEL_CHECK_LAUNCH("hypel_dense_stack_fwd");
+    return 0;
+}
+
+extern "C" int hypel_dense_stack_fwd_apps(const float* x, int64_t ldx, int64_t n, int32_t n_apps, int64_t w_stride,
+                                          int64_t b_stride, int32_t n_layers, int32_t w0, int32_t w1, int32_t w2, int32_t w3,
+                                          int32_t w4, int32_t act_mask, float alpha, const float* w, const float* b,
+                                          float* out, int64_t ldo, hypel_stream_t stream) {
+    const int32_t widths[DS_MAXL + 1] = {w0, w1, w2, w3, w4};
+    DsShape sh;
+    HYPEL_REQUIRE(x && w && b && out && n > 0 && n_apps >= 1 && n_apps <= 16 && ds_shape(n_layers, widths, act_mask, alpha, sh),
+                  "hypel_dense_stack_fwd_apps");
+    const size_t lds = ds_fwd_lds(sh);
+    HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_dense_stack_fwd_apps");
+    (void)hipFuncSetAttribute((const void*)dense_stack_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dense_stack_fwd_kernel, dim3(hypel_dense_stack_blocks_apps(n, n_apps)), dim3(DS_THREADS), lds, ST, x,
+                       ldx, n, sh, w, b, out, ldo, DsApps{n_apps, w_stride, b_stride, 0, 0});
+    HYPEL_CHECK_LAUNCH("hypel_dense_stack_fwd_apps");
     return 0;
 }
 
@@ -384,7 +437,28 @@ extern "C" int hypel_dense_stack_bwd(const float* x, int64_t ldx, const float* d
     HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_dense_stack_bwd");
     (void)hipFuncSetAttribute((const void*)dense_stack_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dense_stack_bwd_kernel, dim3(hypel_dense_stack_blocks(n)), dim3(DS_THREADS), lds, ST, x, ldx, dout, lddo,
-                       n, sh, w, b, dx, lddx, accumulate_dx, pw, pb);
+                       n, sh, w, b, dx, lddx, accumulate_dx, pw, pb, DsApps{1, 0, 0, 0, 0});
     HYPEL_CHECK_LAUNCH("hypel_dense_stack_bwd");
+    return 0;
+}
+
+extern "C" int hypel_dense_stack_bwd_apps(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n,
+                                          int32_t n_apps, int64_t w_stride, int64_t b_stride, int64_t pw_stride,
+                                          int64_t pb_stride, int32_t n_layers, int32_t w0,
+                                          int32_t w1, int32_t w2, int32_t w3, int32_t w4, int32_t act_mask, float alpha,
+                                          const float* w, const float* b, float* dx, int64_t lddx, int32_t accumulate_dx,
+                                          float* pw, float* pb, hypel_stream_t stream) {
+    const int32_t widths[DS_MAXL + 1] = {w0, w1, w2, w3, w4};
+    DsShape sh;
+    HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && n_apps >= 1 && n_apps <= 16 &&
+                      ds_shape(n_layers, widths, act_mask, alpha, sh),
+                  "hypel_dense_stack_bwd_apps");
+    const size_t lds = ds_bwd_lds(sh);
+    HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_dense_stack_bwd_apps");
+    (void)hipFuncSetAttribute((const void*)dense_stack_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dense_stack_bwd_kernel, dim3(hypel_dense_stack_blocks_apps(n, n_apps)), dim3(DS_THREADS), lds, ST, x,
+                       ldx, dout, lddo, n, sh, w, b, dx, lddx, accumulate_dx, pw, pb,
+                       DsApps{n_apps, w_stride, b_stride, pw_stride, pb_stride});
+    HYPEL_CHECK_LAUNCH("hypel_dense_stack_bwd_apps");
     return 0;
 }

@@ -913,10 +913,11 @@ bool hypel_gm_supported(int bands);
 int64_t hypel_gm_keep_floats(int64_t n, int bands, int only_encoder);
 int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
                  float* out, int64_t ldo, int blocks, hipStream_t st, float* keep, float* enc_out = nullptr,
-                 int64_t ld_enc = 0);
+                 int64_t ld_enc = 0, int n_apps = 1, int64_t w_stride = 0, int64_t b_stride = 0);
 int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
                  const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
-                 int blocks, hipStream_t st, const float* keep, const float* d_enc = nullptr, int64_t ld_denc = 0);
+                 int blocks, hipStream_t st, const float* keep, const float* d_enc = nullptr, int64_t ld_denc = 0,
+                 int n_apps = 1, int64_t w_stride = 0, int64_t b_stride = 0, int64_t pw_stride = 0, int64_t pb_stride = 0);
 
 static bool gan_use_mfma(int bands) {
     static const int on = getenv("HYPEL_GAN_MFMA") ? atoi(getenv("HYPEL_GAN_MFMA")) : 1;
@@ -998,6 +999,43 @@ extern "C" int hypel_gan_generator_bwd_tap(const float* x, int64_t ldx, const fl
     hypel_gm_bwd(x, ldx, dout, lddo, n, bands, w, b, 0, dx, lddx, accumulate_dx, pw, pb, hypel_gan_generator_blocks(n), ST,
                  keep, d_enc, ld_denc);
     HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd_tap");
+    return 0;
+}
+
+/* Several generators of one band count in one launch (include/hypel.h): CycleGAN's G_x2y(x) and G_y2x(y). */
+extern "C" int hypel_gan_generator_blocks_apps(int64_t n, int32_t n_apps) {
+    if (n_apps < 1) n_apps = 1;
+    int64_t t = (n + 15) / 16, per = 512 / n_apps;
+    if (per < 1) per = 1;
+    if (t < 1) t = 1;
+    if (t > per) t = per;
+    return (int)(t * n_apps);
+}
+
+extern "C" int hypel_gan_generator_fwd_apps(const float* x, int64_t ldx, int64_t n, int32_t n_apps, int64_t w_stride,
+                                            int64_t b_stride, int32_t bands, const float* w, const float* b,
+                                            int32_t only_encoder, float* out, int64_t ldo, float* keep,
+                                            hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && w && b && out && n > 0 && n_apps >= 1 && n_apps <= 16 && gan_use_mfma(bands),
+                  "hypel_gan_generator_fwd_apps");
+    hypel_gm_fwd(x, ldx, n, bands, w, b, only_encoder, out, ldo, hypel_gan_generator_blocks_apps(n, n_apps), ST, keep, nullptr,
+                 0, n_apps, w_stride, b_stride);
+    HYPEL_CHECK_LAUNCH("hypel_gan_generator_fwd_apps");
+    return 0;
+}
+
+extern "C" int hypel_gan_generator_bwd_apps(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n,
+                                            int32_t n_apps, int64_t w_stride, int64_t b_stride, int64_t pw_stride,
+                                            int64_t pb_stride, int32_t bands,
+                                            const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
+                                            int32_t accumulate_dx, float* pw, float* pb, const float* keep,
+                                            hypel_stream_t stream) {
+    HYPEL_REQUIRE(x && dout && w && b && pw && pb && n > 0 && n_apps >= 1 && n_apps <= 16 && gan_use_mfma(bands),
+                  "hypel_gan_generator_bwd_apps");
+    hypel_gm_bwd(x, ldx, dout, lddo, n, bands, w, b, only_encoder, dx, lddx, accumulate_dx, pw, pb,
+                 hypel_gan_generator_blocks_apps(n, n_apps), ST, keep, nullptr, 0, n_apps, w_stride, b_stride, pw_stride,
+                 pb_stride);
+    HYPEL_CHECK_LAUNCH("hypel_gan_generator_bwd_apps");
     return 0;
 }
 

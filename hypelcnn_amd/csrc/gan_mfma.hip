@@ -22,6 +22,11 @@
 #include "common.h"
 
 typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
+struct GmApps {
+    int n_apps;
+    int64_t w_stride, b_stride;    // element distance of application g + 1's variables from application g's
+    int64_t pw_stride, pb_stride;  // ... of its first gradient slab (0: the slabs of all applications are consecutive)
+};
 
 namespace {
 
@@ -311,6 +316,11 @@ __device__ __forceinline__ void gm_load_rows(float* img, const GmGeo g, const fl
 // lane-native: float4 (slot, m) of thread `tid` of row tile t at ((t * GM_KEEP_V4(ENC) + slot * GM_MAXT + m) * 512 + tid)
 // float4s, two uint4 of branch bits behind them.  The backward kernel then starts from that copy instead of recomputing
 // the forward (29 % of its time at B = 360): 188 KB per 16 samples written and read once at HBM speed.
+// Several applications of generators of ONE band count in one launch (hypel_gan_generator_*_apps): application g owns rows
+// [g * n, (g + 1) * n) of every row-indexed operand, the variables at w + g * w_stride / bias + g * b_stride -- CycleGAN's
+// G_x2y and G_y2x -- and gridDim.x / n_apps consecutive blocks (and gradient slabs); kept activations are indexed by the
+// global tile number g * tiles + t.  At the Gulfport size (2048 x 64: 128 row tiles) a launch is one block's latency chain:
+// two applications cost what one does.
 // TAP (full generator only): a separate instantiation, so that the plain kernels keep their register counts
 template <bool ENC, bool STASH, bool TAP = false>
 __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(const float* __restrict__ x, int64_t ldx,
@@ -319,10 +329,17 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
                                                                             const float* __restrict__ bias,
                                                                             float* __restrict__ out, int64_t ldo,
                                                                             float* __restrict__ stash,
-                                                                            float* __restrict__ enc_out, int64_t ld_enc) {
+                                                                            float* __restrict__ enc_out, int64_t ld_enc,
+                                                                            GmApps apps) {
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
     const int tid = threadIdx.x;
+    const int bpa = gridDim.x / apps.n_apps, app = blockIdx.x / bpa, blk = blockIdx.x - app * bpa;
+    w += app * apps.w_stride;
+    bias += app * apps.b_stride;
+    x += (int64_t)app * n * ldx;
+    out += (int64_t)app * n * ldo;
+    if constexpr (TAP) enc_out += (int64_t)app * n * ld_enc;
     float* const bufs[3] = {gm_lds, gm_lds + GM_ROWS * g.pitch, gm_lds + 2 * GM_ROWS * g.pitch};
     constexpr bool ONE = GM_FWD_ONE_TABLE != 0;
     float* wz0 = gm_lds + 3 * GM_ROWS * g.pitch;
@@ -334,12 +351,13 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
     float keep[6][GM_MAXT][4];
     unsigned mask[7];
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (int64_t t = blk; t < tiles; t += bpa) {
         const int64_t r0 = t * GM_ROWS;
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
         gm_load_rows(bufs[0], g, x + r0 * ldx, ldx, rows_valid, tid);
         gm_f32x4* sp = nullptr;
-        if constexpr (STASH) sp = reinterpret_cast<gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
+        if constexpr (STASH)
+            sp = reinterpret_cast<gm_f32x4*>(stash) + (size_t)(app * tiles + t) * GmKeep<ENC>::V4 * GM_THREADS + tid;
         gm_forward<ENC, false, GM_FWD_ROLLED != 0, STASH, ONE, TAP>(gm_lds, wz0, wz1, g, raw, raw + gm_woff(bands, 7),
                                                                     out + r0 * ldo, ldo, rows_valid, tid, keep, mask, sp,
                                                                     TAP ? enc_out + r0 * ld_enc : nullptr, ld_enc);
@@ -354,11 +372,18 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dx, int64_t lddx, int accumulate_dx,
     float* __restrict__ pw, float* __restrict__ pb, int wtotal, int slabs, const float* __restrict__ stash,
-    const float* __restrict__ d_enc, int64_t ld_denc) {
+    const float* __restrict__ d_enc, int64_t ld_denc, GmApps apps) {
     constexpr int L = ENC ? 4 : 7;
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bpa = gridDim.x / apps.n_apps, app = blockIdx.x / bpa, blk = blockIdx.x - app * bpa;
+    w += app * apps.w_stride;
+    bias += app * apps.b_stride;
+    x += (int64_t)app * n * ldx;
+    dout += (int64_t)app * n * lddo;
+    if (dx != nullptr) dx += (int64_t)app * n * lddx;
+    if constexpr (TAP) d_enc += (int64_t)app * n * ld_denc;
     const int col = lane & 15, rg = lane >> 4;
     const int img = GM_ROWS * g.pitch;
     float* const bufs[3] = {gm_lds, gm_lds + img, gm_lds + 2 * img};  // forward images, then the gradient ring
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #define GM_MARK(i)
 #endif
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (int64_t t = blk; t < tiles; t += bpa) {
         const int64_t r0 = t * GM_ROWS;
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
         GM_MARK(0)
@@ -395,7 +420,8 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         [[maybe_unused]] float ylast[GM_MAXT][4];  // STASH: the tanh output of this lane's elements
         int res = 0;
         if constexpr (STASH) {  // the forward pass left its activations behind (see GmKeep)
-            const gm_f32x4* sp = reinterpret_cast<const gm_f32x4*>(stash) + (size_t)t * GmKeep<ENC>::V4 * GM_THREADS + tid;
+            const gm_f32x4* sp =
+                reinterpret_cast<const gm_f32x4*>(stash) + (size_t)(app * tiles + t) * GmKeep<ENC>::V4 * GM_THREADS + tid;
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -632,11 +658,14 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         __syncthreads();
     }
     // this block's partials; the slabs of the blocks beyond the grid (the planner's reduce sums `slabs` of them) are zeros
-    for (int sb = blockIdx.x + gridDim.x; sb < slabs; sb += gridDim.x) {
+    for (int sb = blockIdx.x + gridDim.x; sb < slabs; sb += gridDim.x) {  // (single application only: slabs == gridDim.x else)
         for (int i = tid; i < wtotal; i += GM_THREADS) pw[(size_t)sb * wtotal + i] = 0.0f;
         if (tid < 8) pb[(size_t)sb * 8 + tid] = 0.0f;
     }
-    float* pwb = pw + (size_t)blockIdx.x * wtotal;
+    const int64_t slab = apps.pw_stride ? (int64_t)blk : (int64_t)blockIdx.x;
+    pw += app * apps.pw_stride;
+    pb += app * apps.pb_stride;
+    float* pwb = pw + (size_t)slab * wtotal;
     int woff = 0;
 #pragma unroll
     for (int l = 0; l < 7; ++l) {
@@ -644,7 +673,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
         if (tid < ksz) pwb[woff + tid] = l < L ? dwacc[l] : 0.0f;
         woff += ksz;
     }
-    if (tid < 8) pb[(size_t)blockIdx.x * 8 + tid] = tid < L ? red[GM_WAVES + tid] : 0.0f;
+    if (tid < 8) pb[(size_t)slab * 8 + tid] = tid < L ? red[GM_WAVES + tid] : 0.0f;
 #if GM_DIAG == 5
     GM_MARK(7)
     if (tid == 0 && blockIdx.x == 0)
@@ -676,33 +705,38 @@ int64_t hypel_gm_keep_floats(int64_t n, int bands, int only_encoder) {
     } while (0)
 
 int hypel_gm_fwd(const float* x, int64_t ldx, int64_t n, int bands, const float* w, const float* b, int only_encoder,
-                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep, float* enc_out, int64_t ld_enc) {
+                 float* out, int64_t ldo, int blocks, hipStream_t st, float* keep, float* enc_out, int64_t ld_enc,
+                 int n_apps, int64_t w_stride, int64_t b_stride) {
     const size_t lds = gm_fwd_lds(bands);
-    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
-    const int grid = (int)(tiles < blocks ? tiles : blocks);
+    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;  // per application
+    const GmApps apps{n_apps, w_stride, b_stride, 0, 0};
+    // n_apps > 1: `blocks` is the whole grid, a multiple of n_apps (hypel_gan_generator_blocks_apps)
+    const int grid = n_apps > 1 ? blocks : (int)(tiles < blocks ? tiles : blocks);
     if (only_encoder) {
-        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
-        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, false>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc, apps);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<true, false>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc, apps);
     } else if (enc_out) {
-        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
-        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc, apps);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc, apps);
     } else {
-        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
-        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc);
+        if (keep) GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, true>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc, apps);
+        else GM_LAUNCH((gan_generator_fwd_mfma_kernel<false, false>), x, ldx, n, bands, w, b, out, ldo, keep, enc_out, ld_enc, apps);
     }
     return 0;
 }
 
 int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int bands, const float* w,
                  const float* b, int only_encoder, float* dx, int64_t lddx, int accumulate_dx, float* pw, float* pb,
-                 int blocks, hipStream_t st, const float* keep, const float* d_enc, int64_t ld_denc) {
+                 int blocks, hipStream_t st, const float* keep, const float* d_enc, int64_t ld_denc, int n_apps,
+                 int64_t w_stride, int64_t b_stride, int64_t pw_stride, int64_t pb_stride) {
     const size_t lds = gm_bwd_lds(bands);
+    const GmApps apps{n_apps, w_stride, b_stride, pw_stride, pb_stride};
     int wtotal = 0;
     for (int l = 0; l < 7; ++l) wtotal += gm_ksz(bands, l);
     // every one of the `blocks` partial slabs is written (the planner's reduce sums all of them)
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
-    const int grid = (int)(tiles < blocks ? tiles : blocks);
-#define GM_BWD_ARGS x, ldx, dout, lddo, n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks, keep, d_enc, ld_denc
+    const int grid = n_apps > 1 ? blocks : (int)(tiles < blocks ? tiles : blocks);
+#define GM_BWD_ARGS x, ldx, dout, lddo, n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks, keep, d_enc, ld_denc, apps
     if (only_encoder) {
         if (keep) GM_LAUNCH((gan_generator_bwd_mfma_kernel<true, true>), GM_BWD_ARGS);
         else GM_LAUNCH((gan_generator_bwd_mfma_kernel<true, false>), GM_BWD_ARGS);

@@ -2140,6 +2140,10 @@ SLAB_REDUCE_MULTI = os.environ.get("HYPEL_SLAB_REDUCE_MULTI", "1") != "0"
 # the full launch writes it too (hypel_gan_generator_fwd_tap) and its backward takes the gradient that reached it
 # (hypel_gan_generator_bwd_tap) -- the encoder-only launches of those tensors disappear.
 GEN_TAP = os.environ.get("HYPEL_GAN_GEN_TAP", "1") != "0"
+# Two same-shaped networks with DIFFERENT variables (CycleGAN's G_x2y / G_y2x and D_x / D_y, cycle_gan_wrapper.py:82-124) whose
+# applications can run side by side share one launch: each takes its own share of the blocks (hypel_*_apps).  At the
+# Gulfport sizes every one of those applications is a latency chain on a fraction of the chip.
+BATCH_HETERO = os.environ.get("HYPEL_GAN_BATCH_HETERO", "1") != "0"
 
 
 class PhasePlan(TowerPlan):
@@ -2325,6 +2329,32 @@ class PhasePlan(TowerPlan):
                 return ("feat", len(srcs), srcs[0].c)
         return None
 
+    def _shape_signature(self, node):
+        """Hashable identity of "a network of this shape" for the fused kernels that take several variable sets per launch
+        (None: not one of them, or this application cannot join such a launch)."""
+        if not (BATCH_HETERO and SLAB_REDUCE_MULTI and hasattr(self.be, "gan_generator_blocks_apps")):
+            return None
+        if isinstance(node, G.GeneratorNode):
+            if id(node) in self._taps or not self.be.gan_generator_tap_supported(node.src.c):  # (matrix-core shapes only)
+                return None
+            return ("gen", bool(node.only_encoder), node.src.c, self._trains(node.weights))
+        if isinstance(node, G.DenseStackNode):
+            return ("ds", tuple(node.widths), tuple(bool(l[2]) for l in node.layers), float(node.alpha),
+                    self._trains(node.weights))
+        return None
+
+    @staticmethod
+    def _app_runs(unit):
+        """The members of a unit as runs of consecutive same-variable applications: [[(idx, node), ...], ...]."""
+        runs = []
+        for m in unit:
+            w = m[1].weights[0] if isinstance(m[1], (G.GeneratorNode, G.DenseStackNode)) else None
+            if runs and w is not None and runs[-1][0][1].weights[0] is w:
+                runs[-1].append(m)
+            else:
+                runs.append([m])
+        return runs
+
     @staticmethod
     def _node_src(node):
         if isinstance(node, G.FeatStackNode):
@@ -2354,7 +2384,7 @@ class PhasePlan(TowerPlan):
             depth_of(k)
         sigs = [self._batch_signature(n) for _, n in order]
 
-        def attempt(by_depth):
+        def attempt(by_depth, hetero=False):
             groups = {}
             for k, sg in enumerate(sigs):
                 key = (k,) if sg is None else ((sg, depth[k]) if by_depth else (sg,))
@@ -2367,6 +2397,20 @@ class PhasePlan(TowerPlan):
                     continue
                 for c0 in range(0, len(ks), BATCH_APPS_MAX):
                     units.append(ks[c0:c0 + BATCH_APPS_MAX])
+            if hetero:  # pairs of same-shaped units with different variables -> one unit of two variable sets
+                pools, merged, used = {}, [], set()
+                for u, ks in enumerate(units):
+                    sh = self._shape_signature(order[ks[0]][1])
+                    if sh is not None:
+                        pools.setdefault((sh, len(ks), depth[ks[0]] if by_depth else 0), []).append(u)
+                for us in pools.values():
+                    for a, b in zip(us[0::2], us[1::2]):
+                        srcs = [id(self._node_src(order[k][1])) for k in units[a] + units[b]]
+                        if len(set(srcs)) == len(srcs):
+                            merged.append(units[a] + units[b])
+                            used |= {a, b}
+                units = [ks for u, ks in enumerate(units) if u not in used] + merged
+                units.sort(key=lambda ks: ks[0])
             unit_of = {k: u for u, ks in enumerate(units) for k in ks}
             udeps = [sorted({unit_of[d] for k in ks for d in deps[k]} - {u}) for u, ks in enumerate(units)]
             if any(unit_of[d] == u for u, ks in enumerate(units) for k in ks for d in deps[k]):
@@ -2381,7 +2425,11 @@ class PhasePlan(TowerPlan):
                 out.append([order[k] for k in units[u]])
             return out
 
-        return attempt(False) or attempt(True) or [[u] for u in order]
+        tries = [attempt(False), attempt(True)]
+        if BATCH_HETERO:
+            tries += [attempt(False, True), attempt(True, True)]
+        tries = [t for t in tries if t is not None]
+        return min(tries, key=len) if tries else [[u] for u in order]  # fewest units; ties: the plainer grouping
 
     def _concat_inputs(self, tag, srcs):
         """Storage of the row-concatenated inputs [G * nb, c] of a group.  Zero copy when the inputs already are
@@ -2431,6 +2479,10 @@ class PhasePlan(TowerPlan):
         else:
             rep.src = syn_src
         rep.out = G.SymTensor(self.tower, None, n0.out.c, node=rep)
+        runs = self._app_runs(unit)
+        if len(runs) > 1 and isinstance(n0, (G.GeneratorNode, G.DenseStackNode)):
+            assert len(runs) == 2 and len(runs[0]) == len(runs[1]), "two variable sets, equally many applications each"
+            rep.app_nodes = [r[0][1] for r in runs]  # the handlers emit the *_apps form: one variable set per run
         taps = [self._taps.get(id(n)) for _, n in unit]
         syn_tap = None
         if taps[0] is not None:  # (the signature keeps tapped and untapped applications apart)
@@ -2553,6 +2605,23 @@ class PhasePlan(TowerPlan):
         st["apps"].append((launch, pos_w, pos_b, st["blocks"]))
         st["blocks"] += blocks
 
+    def _defer_slab_reduce_apps(self, launch, pos_w, pos_b, pos_ws, pos_bs, bpa, nodes, w_stride, w_count, b_stride, b_count):
+        """The *_apps form: `launch` leaves `bpa` slabs for each of its variable sets (`nodes`: one application node per
+        set).  Every set's slabs still go to that set's own region; the launch reaches set g's first slab by a stride from
+        set 0's (arguments pos_ws / pos_bs), known once the regions are laid out."""
+        sets = self.__dict__.setdefault("_slab_sets", {})
+        where = []
+        for nd in nodes:
+            w0, b0 = nd.weights[0], nd.biases[0]
+            wacc = self._param_acc(w0)
+            for v in nd.weights[1:] + nd.biases:
+                self._param_acc(v)
+            st = sets.setdefault(id(w0), dict(w0=w0, b0=b0, w=(w_stride, w_count), b=(b_stride, b_count), acc=wacc, apps=[],
+                                             blocks=0))
+            where.append((id(w0), st["blocks"]))
+            st["blocks"] += bpa
+        self.__dict__.setdefault("_slab_apps", []).append((launch, pos_w, pos_b, pos_ws, pos_bs, where))
+
     def _flush_slab_reduces(self):
         sets = self.__dict__.get("_slab_sets") or {}
         self._slab_sets = {}
@@ -2572,7 +2641,7 @@ class PhasePlan(TowerPlan):
         for k, st in enumerate(sets.values()):
             fid = self.__dict__.setdefault("_slab_bufs", 0)
             self._slab_bufs = fid + 1
-            names = {}
+            names = st["names"] = {}
             for kind, var in (("w", st["w0"]), ("b", st["b0"])):
                 stride, count = st[kind]
                 names[kind] = f"slabs_{kind}:{fid}"
@@ -2584,9 +2653,23 @@ class PhasePlan(TowerPlan):
                 args[pos_w] = self._ref(names["w"], b0 * st["w"][0])
                 args[pos_b] = self._ref(names["b"], b0 * st["b"][0])
                 launch.args = tuple(args)
+        for launch, pos_w, pos_b, pos_ws, pos_bs, where in self.__dict__.get("_slab_apps") or []:
+            first = [(self._ref(sets[sid]["names"]["w"], b0 * sets[sid]["w"][0]),
+                      self._ref(sets[sid]["names"]["b"], b0 * sets[sid]["b"][0])) for sid, b0 in where]
+            args = list(launch.args)
+            args[pos_w], args[pos_b] = first[0]
+            args[pos_ws] = (first[1][0].ptr() - first[0][0].ptr()) // 4
+            args[pos_bs] = (first[1][1].ptr() - first[0][1].ptr()) // 4
+            launch.args = tuple(args)
+        self._slab_apps = []
         e_t = self.be.upload(np.array(ents, REDUCE_ENTRY_DTYPE))
         self.tables.append(e_t)
         self.bwd.append(Launch("reduce_splits_wave_multi_f32", (base, Ref(e_t), len(ents), total), tag="slab-reduce"))
+
+    @staticmethod
+    def _rel(var0, var1):
+        """element distance of var1 from var0 in the flat parameter buffer"""
+        return int(var1.offset) - int(var0.offset)
 
     # ---- fused generator ----
     def _gen_refs(self, node):
@@ -2600,7 +2683,14 @@ class PhasePlan(TowerPlan):
         st = self._new_value(out, f"z:{idx}")
         w0, b0, _ = self._gen_refs(node)
         tap = self._taps.get(id(node))
-        if tap is not None:
+        apps = getattr(node, "app_nodes", None)
+        if apps is not None:  # two generators of one shape, each on its half of the rows
+            w1, b1, _ = self._gen_refs(apps[1])
+            l = Launch("gan_generator_fwd_apps", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb // len(apps), len(apps),
+                                                  self._rel(w0, w1), self._rel(b0, b1), src.c, self._p(w0), self._p(b0),
+                                                  int(node.only_encoder), self._ref(st.buf), st.ld, None),
+                       nbytes=8 * self.nb * src.c, tag="gen-fwd-apps")
+        elif tap is not None:
             # the encoder-only application on the same input is this launch's n_4
             t_st = self._new_value(tap, f"ztap:{idx}")
             l = Launch("gan_generator_fwd_tap", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb, src.c, self._p(w0),
@@ -2619,14 +2709,17 @@ class PhasePlan(TowerPlan):
         s_st = self.storage_of(src)
         z_st = self.storage[id(out)]
         w0, b0, wtotal = self._gen_refs(node)
-        blocks = self.be.gan_generator_blocks(self.nb)
+        apps = getattr(node, "app_nodes", None)
+        n_apps = len(apps) if apps is not None else 1
+        blocks = self.be.gan_generator_blocks(self.nb) if apps is None else \
+            self.be.gan_generator_blocks_apps(self.nb // n_apps, n_apps)
         dx, lddx, acc = None, 0, 0
         if self._needs_grad(src):
             gst, acc = self._grad_target(src)
             dx, lddx = self._ref(gst.buf, gst.ch_off), gst.ld
         tap = self._taps.get(id(node))
         tap_grad = tap is not None and self.grad_written.get(id(tap), False)
-        keep_n = self.be.gan_generator_keep_floats(self.nb, src.c, int(node.only_encoder)) if GEN_KEEP else 0
+        keep_n = n_apps * self.be.gan_generator_keep_floats(self.nb // n_apps, src.c, int(node.only_encoder)) if GEN_KEEP else 0
         kref = None
         if keep_n > 0:
             # the forward pass of this application leaves its activations for this launch (hypel.h: bit-identical to
@@ -2634,11 +2727,25 @@ class PhasePlan(TowerPlan):
             self._alloc(f"gkeep:{idx}", keep_n)
             kref = self._ref(f"gkeep:{idx}")
             f = self._gen_fwd[idx]
-            if f.name == "gan_generator_fwd_tap":
+            if f.name in ("gan_generator_fwd_tap", "gan_generator_fwd_apps"):
                 f.args = tuple(f.args[:-1]) + (kref,)
             else:
                 f.name, f.args = "gan_generator_fwd_keep", tuple(f.args) + (kref,)
             f.bytes += 4 * keep_n
+        if apps is not None:
+            w1, b1, _ = self._gen_refs(apps[1])
+            l1 = Launch("gan_generator_bwd_apps", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
+                                                   z_st.ld, self.nb // n_apps, n_apps, self._rel(w0, w1), self._rel(b0, b1), 0,
+                                                   0, src.c, self._p(w0), self._p(b0), int(node.only_encoder), dx, lddx, acc,
+                                                   None, None, kref),
+                        nbytes=12 * self.nb * src.c + 4 * keep_n, tag="gen-bwd-apps")
+            self.bwd.append(l1)
+            if self._trains(node.weights):
+                self._defer_slab_reduce_apps(l1, 17, 18, 8, 9, blocks // n_apps, apps, wtotal, wtotal, 8, 7)
+            else:
+                self._scratch(l1, 17, "scratch_gen_w", blocks * wtotal)
+                self._scratch(l1, 18, "scratch_gen_b", blocks * 8)
+            return
         if tap_grad:
             # one backward pass for the full application and the encoder-only one read from it: the gradient that reached
             # the encoder output joins dn_4
@@ -2687,6 +2794,17 @@ class PhasePlan(TowerPlan):
         s_st = self.storage_of(src)
         st = self._new_value(out, f"z:{idx}")
         macs = sum(w.size for w in node.weights)
+        apps = getattr(node, "app_nodes", None)
+        if apps is not None:  # two critics of one shape, each on its half of the rows
+            self._densestack_args(apps[1])
+            self.fwd.append(Launch("dense_stack_fwd_apps", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb // len(apps),
+                                                            len(apps), self._rel(node.weights[0], apps[1].weights[0]),
+                                                            self._rel(node.biases[0], apps[1].biases[0]),
+                                                            *self._densestack_args(node), self._p(node.weights[0]),
+                                                            self._p(node.biases[0]), self._ref(st.buf), st.ld),
+                                   flops=2 * self.nb * macs, nbytes=4 * self.nb * (src.c + out.c),
+                                   tag="dense-stack-fwd-apps"))
+            return
         self.fwd.append(Launch("dense_stack_fwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self.nb,
                                                    *self._densestack_args(node), self._p(node.weights[0]),
                                                    self._p(node.biases[0]), self._ref(st.buf), st.ld),
@@ -2703,6 +2821,24 @@ class PhasePlan(TowerPlan):
         if self._needs_grad(src):
             gst, acc = self._grad_target(src)
             dx, lddx = self._ref(gst.buf, gst.ch_off), gst.ld
+        apps = getattr(node, "app_nodes", None)
+        if apps is not None:
+            n_apps = len(apps)
+            blocks = self.be.dense_stack_blocks_apps(self.nb // n_apps, n_apps)
+            l1 = Launch("dense_stack_bwd_apps", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf),
+                                                 z_st.ld, self.nb // n_apps, n_apps, self._rel(w0, apps[1].weights[0]),
+                                                 self._rel(b0, apps[1].biases[0]), 0, 0, *self._densestack_args(node),
+                                                 self._p(w0), self._p(b0), dx, lddx, acc, None, None),
+                        flops=6 * self.nb * wtotal, nbytes=4 * self.nb * (2 * src.c + out.c), tag="dense-stack-bwd-apps")
+            n_args = len(l1.args)
+            self.bwd.append(l1)
+            if self._trains(node.weights):
+                self._defer_slab_reduce_apps(l1, n_args - 2, n_args - 1, 8, 9, blocks // n_apps, apps, wtotal, wtotal, btotal,
+                                             btotal)
+            else:
+                self._scratch(l1, n_args - 2, "scratch_ds_w", blocks * wtotal)
+                self._scratch(l1, n_args - 1, "scratch_ds_b", blocks * btotal)
+            return
         l1 = Launch("dense_stack_bwd", (self._ref(s_st.buf, s_st.ch_off), s_st.ld, self._ref("g:" + z_st.buf), z_st.ld,
                                         self.nb, *self._densestack_args(node), self._p(w0), self._p(b0), dx, lddx, acc, None,
                                         None), flops=6 * self.nb * wtotal, nbytes=4 * self.nb * (2 * src.c + out.c),

@@ -52,7 +52,9 @@ class CompiledTower:
         nb = self.plan.nb
         own = self.plan.storage[id(sym.owner)]
         if sym.hw is None and st.pixmap is None and sym.owner.npix == 1:
-            v = buf[: nb * own.ld].view(nb, own.ld)[:, st.ch_off:st.ch_off + st.c]
+            # (an application of a row-concatenated batch is a row block of the batch's buffer: its offset holds whole rows)
+            row0, col = divmod(st.ch_off, own.ld)
+            v = buf[: (row0 + nb) * own.ld].view(row0 + nb, own.ld)[row0:, col:col + st.c]
             return v.clone() if copy else v
         full = buf[: sym.owner.npix * nb * own.ld].reshape(sym.owner.npix, nb, own.ld)
         pm = list(range(sym.npix)) if st.pixmap is None else st.pixmap
@@ -67,6 +69,9 @@ class CompiledTower:
         buf = self.plan.buffers[st.buf]
         nb = self.plan.nb
         own = self.plan.storage[id(sym.owner)]
+        if sym.hw is None and st.pixmap is None and sym.owner.npix == 1:
+            row0, col = divmod(st.ch_off, own.ld)
+            return buf[: (row0 + nb) * own.ld].view(row0 + nb, own.ld)[row0:, col:col + st.c].clone()
         full = buf[: sym.owner.npix * nb * own.ld].reshape(sym.owner.npix, nb, own.ld)
         pm = list(range(sym.npix)) if st.pixmap is None else st.pixmap
         v = full[pm][:, :, st.ch_off:st.ch_off + st.c].permute(1, 0, 2)

@@ -491,6 +491,38 @@ int hypel_dense_stack_bwd(const float* x, int64_t ldx, const float* dout, int64_
                           int32_t w0, int32_t w1, int32_t w2, int32_t w3, int32_t w4, int32_t act_mask, float alpha,
                           const float* w, const float* b, float* dx, int64_t lddx, int32_t accumulate_dx, float* pw,
                           float* pb, hypel_stream_t stream);
+
+/* ---- several applications of same-shaped networks with DIFFERENT variables in one launch -----------------------------
+ * CycleGAN applies two generators (x2y, y2x) and two critics (D_x, D_y) of one shape side by side
+ * (gan/wrappers/cycle_gan_wrapper.py:82-124; the DCL-GAN pair of CUT models likewise): at the Gulfport sizes every such
+ * application is a latency chain that leaves most of the chip idle, so application g of `n_apps` runs on its own share of
+ * the blocks of ONE launch.  Rows: application g reads rows [g*n, (g+1)*n) of x / dout / keep and writes the same rows of
+ * out / dx (n rows per application).  Variables: application g's are at w + g*w_stride, b + g*b_stride (elements; any
+ * sign -- the variables of two models lie a fixed distance apart in the flat parameter buffer).  Gradient slabs (bwd):
+ * blocks_apps(n, n_apps) / n_apps slabs per application, application g's first slab at pw + g*pw_stride, pb + g*pb_stride
+ * (pw_stride == 0: all slabs consecutive in application order).  Each application's results are bit-identical to the
+ * single-application entry point's on its rows, and its slabs sum to the same gradients.
+ * Generator: matrix-core shapes only (hypel_gan_generator_tap_supported(bands)); keep (nullable) holds
+ * n_apps * hypel_gan_generator_keep_floats(n) floats, application after application. */
+int hypel_gan_generator_blocks_apps(int64_t n, int32_t n_apps);
+int hypel_gan_generator_fwd_apps(const float* x, int64_t ldx, int64_t n, int32_t n_apps, int64_t w_stride, int64_t b_stride,
+                                 int32_t bands, const float* w, const float* b, int32_t only_encoder, float* out,
+                                 int64_t ldo, float* keep, hypel_stream_t stream);
+int hypel_gan_generator_bwd_apps(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t n_apps,
+                                 int64_t w_stride, int64_t b_stride, int64_t pw_stride, int64_t pb_stride, int32_t bands,
+                                 const float* w, const float* b, int32_t only_encoder, float* dx, int64_t lddx,
+                                 int32_t accumulate_dx, float* pw, float* pb, const float* keep, hypel_stream_t stream);
+int hypel_dense_stack_blocks_apps(int64_t n, int32_t n_apps);
+int hypel_dense_stack_fwd_apps(const float* x, int64_t ldx, int64_t n, int32_t n_apps, int64_t w_stride, int64_t b_stride,
+                               int32_t n_layers, int32_t w0, int32_t w1, int32_t w2, int32_t w3, int32_t w4,
+                               int32_t act_mask, float alpha, const float* w, const float* b, float* out, int64_t ldo,
+                               hypel_stream_t stream);
+int hypel_dense_stack_bwd_apps(const float* x, int64_t ldx, const float* dout, int64_t lddo, int64_t n, int32_t n_apps,
+                               int64_t w_stride, int64_t b_stride, int64_t pw_stride, int64_t pb_stride, int32_t n_layers,
+                               int32_t w0, int32_t w1, int32_t w2, int32_t w3, int32_t w4, int32_t act_mask, float alpha,
+                               const float* w, const float* b, float* dx, int64_t lddx, int32_t accumulate_dx, float* pw,
+                               float* pb, hypel_stream_t stream);
+
 /* tensorflow_gan losses: mode 0: weight*mean((a-target)^2) (least squares, pass weight/2),
  * mode 1: weight*mean(|a-b|) (cycle consistency / absolute_difference), mode 2: weight*mean(a) (Wasserstein).
  * loss[0] (+)= value; da / db (nullable) (+)= gradient.  ws >= 1024 floats. */

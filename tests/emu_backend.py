@@ -18,6 +18,8 @@ def _arr(ref, dtype=np.float32):
     """numpy view of the tensor behind a Ref starting at its offset."""
     if ref is None:
         return None
+    if isinstance(ref, _Addr):  # nominal length: callers slice what they use
+        return np.ctypeslib.as_array((ctypes.c_float * (1 << 26)).from_address(ref.addr)).view(dtype)
     a = ref.t.numpy()
     if a.dtype != dtype:
         a = a.view(dtype) if a.dtype.itemsize == np.dtype(dtype).itemsize else a
@@ -29,6 +31,22 @@ def _at(base_ref, off, count):
     address every operand relative to ONE base pointer, across allocations."""
     addr = base_ref.ptr() + int(off) * 4
     return np.ctypeslib.as_array((ctypes.c_float * int(count)).from_address(addr))
+
+
+class _Addr:
+    """A Ref-like for `base + elems` when the result may lie in another allocation than `base` (the *_apps entry points
+    reach application g's variables and gradient slabs by a stride from application 0's)."""
+    __slots__ = ("addr",)
+
+    def __init__(self, ref, elems):
+        self.addr = ref.ptr() + int(elems) * 4
+
+    def ptr(self):
+        return self.addr
+
+
+def _shift(ref, elems):
+    return None if ref is None else (ref if int(elems) == 0 else _Addr(ref, elems))
 
 
 def _mat(ref, ld, rows, cols, dtype=np.float32):
@@ -1117,3 +1135,75 @@ EmuBackend.k_gan_generator_fwd_keep = lambda self, x, ldx, n, bands, w, b, enc, 
     self, x, ldx, n, bands, w, b, enc, out, ldo)
 EmuBackend.k_gan_generator_bwd_kept = lambda self, x, ldx, dout, lddo, n, bands, w, b, enc, dx, lddx, acc, pw, pb, keep: \
     _k_gan_generator_bwd(self, x, ldx, dout, lddo, n, bands, w, b, enc, dx, lddx, acc, pw, pb)
+
+
+# ---- several same-shaped applications with different variables in one launch (include/hypel.h: *_apps) ----------------
+def _emu_generator_blocks_apps(n, n_apps):
+    return int(max(1, min(max(1, 512 // n_apps), (n + 15) // 16))) * n_apps
+
+
+def _emu_dense_stack_blocks_apps(n, n_apps):
+    return int(max(1, min(max(1, 256 // n_apps), (n + 15) // 16))) * n_apps
+
+
+def _apps_slabs(pw, pb, n_apps, bpa, pw_stride, pb_stride, wtotal, btotal):
+    """per application: Refs of its first slab, after zeroing its bpa slabs"""
+    out = []
+    for g in range(n_apps):
+        rw = _shift(pw, g * (pw_stride if pw_stride else bpa * wtotal))
+        rb = _shift(pb, g * (pb_stride if pw_stride else bpa * btotal))
+        _arr(rw)[: bpa * wtotal] = 0
+        _arr(rb)[: bpa * btotal] = 0
+        out.append((rw, rb))
+    return out
+
+
+def _k_gan_generator_fwd_apps(self, x, ldx, n, n_apps, w_stride, b_stride, bands, w, b, only_encoder, out, ldo, keep):
+    for g in range(n_apps):
+        _k_gan_generator_fwd(self, x + g * n * ldx, ldx, n, bands, _shift(w, g * w_stride), _shift(b, g * b_stride),
+                             only_encoder, out + g * n * ldo, ldo)
+
+
+def _k_gan_generator_bwd_apps(self, x, ldx, dout, lddo, n, n_apps, w_stride, b_stride, pw_stride, pb_stride, bands, w, b,
+                              only_encoder, dx, lddx, acc, pw, pb, keep):
+    _, offs = _gen_layout(bands)
+    bpa = _emu_generator_blocks_apps(n, n_apps) // n_apps
+    one = _emu_generator_blocks(n)
+    tw, tb = torch.zeros(one * offs[7]), torch.zeros(one * 8)
+    for g, (rw, rb) in enumerate(_apps_slabs(pw, pb, n_apps, bpa, pw_stride, pb_stride, offs[7], 8)):
+        _k_gan_generator_bwd(self, x + g * n * ldx, ldx, dout + g * n * lddo, lddo, n, bands, _shift(w, g * w_stride),
+                             _shift(b, g * b_stride), only_encoder, None if dx is None else dx + g * n * lddx, lddx, acc,
+                             Ref(tw), Ref(tb))
+        _arr(rw)[: offs[7]] = tw.numpy()[: offs[7]]
+        _arr(rb)[:8] = tb.numpy()[:8]
+
+
+def _k_dense_stack_fwd_apps(self, x, ldx, n, n_apps, w_stride, b_stride, n_layers, w0, w1, w2, w3, w4, act_mask, alpha, w,
+                            b, out, ldo):
+    for g in range(n_apps):
+        _k_dense_stack_fwd(self, x + g * n * ldx, ldx, n, n_layers, w0, w1, w2, w3, w4, act_mask, alpha,
+                           _shift(w, g * w_stride), _shift(b, g * b_stride), out + g * n * ldo, ldo)
+
+
+def _k_dense_stack_bwd_apps(self, x, ldx, dout, lddo, n, n_apps, w_stride, b_stride, pw_stride, pb_stride, n_layers, w0, w1,
+                            w2, w3, w4, act_mask, alpha, w, b, dx, lddx, acc, pw, pb):
+    widths = [w0, w1, w2, w3, w4]
+    wtotal = sum(widths[l] * widths[l + 1] for l in range(n_layers))
+    btotal = sum(widths[1:n_layers + 1])
+    bpa = _emu_dense_stack_blocks_apps(n, n_apps) // n_apps
+    one = _emu_dense_stack_blocks(n)
+    tw, tb = torch.zeros(one * wtotal), torch.zeros(one * btotal)
+    for g, (rw, rb) in enumerate(_apps_slabs(pw, pb, n_apps, bpa, pw_stride, pb_stride, wtotal, btotal)):
+        _k_dense_stack_bwd(self, x + g * n * ldx, ldx, dout + g * n * lddo, lddo, n, n_layers, w0, w1, w2, w3, w4, act_mask,
+                           alpha, _shift(w, g * w_stride), _shift(b, g * b_stride),
+                           None if dx is None else dx + g * n * lddx, lddx, acc, Ref(tw), Ref(tb))
+        _arr(rw)[:wtotal] = tw.numpy()[:wtotal]
+        _arr(rb)[:btotal] = tb.numpy()[:btotal]
+
+
+EmuBackend.k_gan_generator_fwd_apps = _k_gan_generator_fwd_apps
+EmuBackend.k_gan_generator_bwd_apps = _k_gan_generator_bwd_apps
+EmuBackend.k_dense_stack_fwd_apps = _k_dense_stack_fwd_apps
+EmuBackend.k_dense_stack_bwd_apps = _k_dense_stack_bwd_apps
+EmuBackend.gan_generator_blocks_apps = lambda self, n, n_apps: _emu_generator_blocks_apps(n, n_apps)
+EmuBackend.dense_stack_blocks_apps = lambda self, n, n_apps: _emu_dense_stack_blocks_apps(n, n_apps)

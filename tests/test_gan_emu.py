@@ -130,5 +130,30 @@ def test_same_weight_applications_run_as_one_row_concatenated_application(monkey
         assert "gan_generator_bwd_tap" in counts[True]["gen"] and "gan_generator_fwd_tap" in counts[True]["feat"]
         assert tot[True] * 2 <= tot[False] + 10, tot
     if kind == "cycle_gan":
-        assert len(gen_b) == len(gen_u) == 4  # the four generator applications depend on each other pairwise
+        # the four generator applications depend on each other pairwise: the same-weight ones cannot share a launch, but
+        # G_x2y(x) | G_y2x(y), then G_y2x(fake_y) | G_x2y(fake_x) -- same shape, different variables -- do (hypel.h: *_apps),
+        # and so do the two critics of either phase
+        assert len(gen_u) == 4 and gen_b == ["gan_generator_fwd_apps"] * 2, (gen_u, gen_b)
+        for ph in ("gen", "dis"):
+            assert counts[True][ph].count("dense_stack_bwd_apps") == 1 and "dense_stack_bwd" not in counts[True][ph]
+        assert counts[True]["gen"].count("gan_generator_bwd_apps") == 2
         assert sum(l == "reduce_splits_wave_multi_f32" for v in counts[True].values() for l in v) == 2
+
+
+def test_two_variable_sets_in_one_launch_can_be_switched_off(monkeypatch):
+    """HYPEL_GAN_BATCH_HETERO=0: CycleGAN's generators and critics run one launch per variable set again; both forms give
+    the oracle's phase gradients (the default form is covered by test_phase_gradients_match_oracle)."""
+    from hypelcnn_amd import plan
+    n, bands = 6, 16
+    cfg = OG.GanConfig("cycle_gan", bands, patches=4, max_steps=20)
+    params = U.fp32(OG.init_gan_params("cycle_gan", bands, np.random.default_rng(2), patches=4, dtype=np.float64,
+                                       zero_generator=False))
+    x, y = _data(n, bands, 4)
+    monkeypatch.setattr(plan, "BATCH_HETERO", False)
+    wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
+    sess = ops.ctx.session()
+    U.inject(sess, params)
+    U.check_phase_gradients(cfg, ops, params, x, y, tol=5e-5)
+    names = [l for v in _phase_launches(ops, sess, n).values() for l in v]
+    assert not any(l.endswith("_apps") for l in names)
+    assert names.count("gan_generator_bwd_kept") == 4 and names.count("dense_stack_bwd") == 4, names

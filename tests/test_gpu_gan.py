@@ -46,7 +46,7 @@ def test_phase_gradients_match_oracle(hip, kind, bands, patches, n):
     for phase in ops.loss.phases:
         plan = ops._compiled(sess, phase, n).plan
         names |= {l.name for l in plan.fwd + plan.bwd}
-    assert ("dense_stack_bwd" in names) == (bands <= 128), sorted(names)
+    assert any(n_.startswith("dense_stack_bwd") for n_ in names) == (bands <= 128), sorted(names)  # (plain or *_apps form)
 
 
 def test_cyclegan_graph_replay_and_training_on_dummy_pairs(hip):

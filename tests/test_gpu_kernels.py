@@ -1270,3 +1270,130 @@ def test_gan_generator_encoder_tap(hip, bands, n, kept):
     b.check("dx", rtol=5e-4, atol=5e-5)
     b.check("dw", rtol=5e-4, atol=5e-5)
     b.check("db", rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("bands,n,enc,kept,own_regions", [(64, 2048, 0, True, True), (64, 300, 0, False, False),
+                                                          (360, 100, 1, True, True), (16, 37, 0, True, False),
+                                                          (144, 16 * 300, 0, True, True)])
+def test_gan_generator_two_variable_sets_in_one_launch(hip, bands, n, enc, kept, own_regions):
+    """hypel_gan_generator_{fwd,bwd}_apps: application g on rows [g*n, (g+1)*n) with the variables `w_stride` / `b_stride`
+    behind application 0's.  Per application bit-identical to the single-application entry points (outputs, input
+    gradients); its slabs -- consecutive, or in a region of their own reached by pw_stride / pb_stride, as the planner lays
+    them out -- sum to the same filter / bias gradients."""
+    from tests.emu_backend import generator_knife_edge_rows
+    rng = np.random.default_rng(bands + n)
+    ks = [bands >> s for s in (0, 1, 2, 3, 2, 1, 0)]
+    wt = sum(ks)
+    A, gap_w, gap_b = 2, 40, 24  # variables of the second model: a fixed distance behind the first's
+    w = np.zeros(A * (wt + gap_w), np.float32)
+    bias = np.zeros(A * (8 + gap_b), np.float32)
+    x = rng.random((A * n, bands)).astype(np.float32)
+    for g in range(A):
+        wg = (rng.standard_normal(wt) * 0.4 / np.sqrt(np.repeat(ks, ks))).astype(np.float32)
+        bg = (rng.standard_normal(8) * 0.1).astype(np.float32)
+        w[g * (wt + gap_w): g * (wt + gap_w) + wt] = wg
+        bias[g * (8 + gap_b): g * (8 + gap_b) + 8] = bg
+        xs = x[g * n:(g + 1) * n]
+        for _ in range(20):
+            bad = generator_knife_edge_rows(xs.astype(np.float64), wg.astype(np.float64), bg.astype(np.float64), bands, bool(enc))
+            if not len(bad):
+                break
+            xs[bad] = rng.random((len(bad), bands)).astype(np.float32)
+    blocks = hip.gan_generator_blocks_apps(n, A)
+    bpa, one = blocks // A, hip.gan_generator_blocks(n)
+    assert blocks % A == 0 and blocks <= 512
+    pad = 3 * wt + 5  # (own_regions) other applications' slabs sit between the two sets' regions
+    pws, pbs = (bpa * wt + pad, bpa * 8 + 16) if own_regions else (0, 0)
+    b = Both(hip)
+    for nm, arr in (("x", x), ("w", w), ("b", bias), ("dout", rng.standard_normal((A * n, bands)).astype(np.float32)),
+                    ("out", np.zeros(A * n * bands, np.float32)), ("out1", np.zeros(A * n * bands, np.float32)),
+                    ("dx", np.ones(A * n * bands, np.float32)), ("dx1", np.ones(A * n * bands, np.float32)),
+                    ("pw", np.full(A * (bpa * wt + pad), 7.0, np.float32)), ("pb", np.full(A * (bpa * 8 + 16), 7.0, np.float32)),
+                    ("pw1", np.zeros(one * wt, np.float32)), ("pb1", np.zeros(one * 8, np.float32)),
+                    ("dw", np.zeros(A * wt, np.float32)), ("db", np.zeros(A * 8, np.float32)),
+                    ("dw1", np.zeros(A * wt, np.float32)), ("db1", np.zeros(A * 8, np.float32))):
+        b.arr(nm, arr)
+    keep = keep1 = None
+    if kept:
+        kf = max(16, hip.gan_generator_keep_floats(n, bands, enc))
+        keep, keep1 = b.arr("keep", np.zeros(A * kf, np.float32)), b.arr("keep1", np.zeros(kf, np.float32))
+    b.run("gan_generator_fwd_apps", "x", bands, n, A, wt + gap_w, 8 + gap_b, bands, "w", "b", enc, "out", bands, keep)
+    b.run("gan_generator_bwd_apps", "x", bands, "dout", bands, n, A, wt + gap_w, 8 + gap_b, pws, pbs, bands, "w", "b", enc,
+          "dx", bands, 1, "pw", "pb", keep)
+    for g in range(A):
+        wg, bg, rows = ("w", g * (wt + gap_w)), ("b", g * (8 + gap_b)), g * n * bands
+        b.run("gan_generator_fwd_keep", ("x", rows), bands, n, bands, wg, bg, enc, ("out1", rows), bands, keep1)
+        b.run("gan_generator_bwd_kept" if kept else "gan_generator_bwd", ("x", rows), bands, ("dout", rows), bands, n, bands,
+              wg, bg, enc, ("dx1", rows), bands, 1, "pw1", "pb1", *([keep1] if kept else []))
+        b.run("reduce_splits_pair_f32", "pw1", wt, wt, ("dw1", g * wt), "pb1", 8, 7, ("db1", g * 8), one, 0)
+        b.run("reduce_splits_pair_f32", ("pw", g * (pws if pws else bpa * wt)), wt, wt, ("dw", g * wt),
+              ("pb", g * (pbs if pbs else bpa * 8)), 8, 7, ("db", g * 8), bpa, 0)
+    assert torch.equal(b.h["out"], b.h["out1"]) and torch.equal(b.h["dx"], b.h["dx1"]), "per application: the same kernel work"
+    b.check("out", rtol=2e-4, atol=2e-5)
+    b.check("dx", rtol=5e-4, atol=5e-5)
+    b.check("dw", rtol=5e-4, atol=5e-5)
+    b.check("db", rtol=5e-4, atol=5e-5)
+    for nm in ("dw", "db"):
+        got, ref = b.h[nm].cpu().numpy(), b.h[nm + "1"].cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg=nm)
+    if own_regions:  # nothing outside the two regions' slabs was written
+        pw = b.h["pw"].cpu().numpy()
+        assert (pw[bpa * wt:bpa * wt + pad] == 7.0).all() and (pw[pws + bpa * wt:] == 7.0).all()
+
+
+@pytest.mark.parametrize("widths,n,own_regions", [([64, 64, 64, 64, 32], 2048, True), ([64, 64, 64, 64, 32], 4096, True),
+                                                  ([64, 64, 64, 64, 32], 133, False), ([24, 24, 12], 50, True),
+                                                  ([100, 50, 25, 10], 16 * 200, False)])
+def test_dense_stack_two_variable_sets_in_one_launch(hip, widths, n, own_regions):
+    """hypel_dense_stack_{fwd,bwd}_apps: two critics of one shape (cycle_gan_wrapper.py: D_x, D_y), each on its half of the
+    rows and its share of the blocks -- per application bit-identical to hypel_dense_stack_fwd / _bwd, slabs summing to
+    the same gradients."""
+    rng = np.random.default_rng(n + sum(widths))
+    L = len(widths) - 1
+    wt, bt = sum(a * c for a, c in zip(widths[:-1], widths[1:])), sum(widths[1:])
+    A, gap_w, gap_b = 2, 52, 12
+    w = np.zeros(A * (wt + gap_w), np.float32)
+    bias = np.zeros(A * (bt + gap_b), np.float32)
+    for g in range(A):
+        w[g * (wt + gap_w): g * (wt + gap_w) + wt] = np.concatenate(
+            [(rng.standard_normal(a * c) / np.sqrt(a)).astype(np.float32) for a, c in zip(widths[:-1], widths[1:])])
+        bias[g * (bt + gap_b): g * (bt + gap_b) + bt] = (rng.standard_normal(bt) * 0.1).astype(np.float32)
+    shape = (L, *(widths + [0] * (5 - len(widths))), (1 << min(2, L - 1)) - 1, 0.1)
+    c0, cL = widths[0], widths[-1]
+    blocks = hip.dense_stack_blocks_apps(n, A)
+    bpa, one = blocks // A, hip.dense_stack_blocks(n)
+    assert blocks % A == 0 and blocks <= 256
+    pad = wt + 9
+    pws, pbs = (bpa * wt + pad, bpa * bt + 8) if own_regions else (0, 0)
+    b = Both(hip)
+    for nm, arr in (("x", rng.standard_normal((A * n, c0)).astype(np.float32)), ("w", w), ("b", bias),
+                    ("dout", rng.standard_normal((A * n, cL)).astype(np.float32)),
+                    ("out", np.zeros(A * n * cL, np.float32)), ("out1", np.zeros(A * n * cL, np.float32)),
+                    ("dx", np.ones(A * n * c0, np.float32)), ("dx1", np.ones(A * n * c0, np.float32)),
+                    ("pw", np.full(A * (bpa * wt + pad), 7.0, np.float32)), ("pb", np.full(A * (bpa * bt + 8), 7.0, np.float32)),
+                    ("pw1", np.zeros(one * wt, np.float32)), ("pb1", np.zeros(one * bt, np.float32)),
+                    ("dw", np.zeros(A * wt, np.float32)), ("db", np.zeros(A * bt, np.float32)),
+                    ("dw1", np.zeros(A * wt, np.float32)), ("db1", np.zeros(A * bt, np.float32))):
+        b.arr(nm, arr)
+    b.run("dense_stack_fwd_apps", "x", c0, n, A, wt + gap_w, bt + gap_b, *shape, "w", "b", "out", cL)
+    b.run("dense_stack_bwd_apps", "x", c0, "dout", cL, n, A, wt + gap_w, bt + gap_b, pws, pbs, *shape, "w", "b", "dx", c0, 1,
+          "pw", "pb")
+    for g in range(A):
+        wg, bg = ("w", g * (wt + gap_w)), ("b", g * (bt + gap_b))
+        b.run("dense_stack_fwd", ("x", g * n * c0), c0, n, *shape, wg, bg, ("out1", g * n * cL), cL)
+        b.run("dense_stack_bwd", ("x", g * n * c0), c0, ("dout", g * n * cL), cL, n, *shape, wg, bg, ("dx1", g * n * c0), c0, 1,
+              "pw1", "pb1")
+        b.run("reduce_splits_pair_f32", "pw1", wt, wt, ("dw1", g * wt), "pb1", bt, bt, ("db1", g * bt), one, 0)
+        b.run("reduce_splits_pair_f32", ("pw", g * (pws if pws else bpa * wt)), wt, wt, ("dw", g * wt),
+              ("pb", g * (pbs if pbs else bpa * bt)), bt, bt, ("db", g * bt), bpa, 0)
+    assert torch.equal(b.h["out"], b.h["out1"]) and torch.equal(b.h["dx"], b.h["dx1"]), "per application: the same kernel work"
+    b.check("out", rtol=2e-4, atol=2e-5)
+    b.check("dx", rtol=5e-4, atol=5e-5)
+    b.check("dw", rtol=5e-4, atol=5e-5)
+    b.check("db", rtol=5e-4, atol=5e-5)
+    for nm in ("dw", "db"):
+        got, ref = b.h[nm].cpu().numpy(), b.h[nm + "1"].cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg=nm)
+    if own_regions:
+        pw = b.h["pw"].cpu().numpy()
+        assert (pw[bpa * wt:bpa * wt + pad] == 7.0).all() and (pw[pws + bpa * wt:] == 7.0).all()
