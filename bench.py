@@ -228,7 +228,7 @@ def measure_gan_events(ops, nb, bands, steps):
     sess = ops.ctx.session()
     towers = list(sess._compiled.values())
     lists = [ct.serial_launches() for ct in towers]
-    n_launch = sum(len(l) for l in lists) + sum(len(ph.train_groups) for ph in ops.loss.phases)
+    n_launch = sum(len(l) for l in lists) + sum(len(sess._merged_ranges(ph.train_groups)) for ph in ops.loss.phases)
     ms, flops, n_gen = 0.0, 0.0, 0
     for _ in range(steps):
         evs = []

@@ -133,6 +133,7 @@ SIGNATURES = {
     "gan_generator_bwd_kept": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P],
     "gan_generator_fwd_tap": [_P, _I64, _I64, _I32, _P, _P, _P, _I64, _P, _I64, _P],
     "gan_generator_bwd_tap": [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I64, _I32, _P, _P, _P],
+    "copy_pair_f32": [_P, _P, _I64, _P, _P, _I64],
     "gan_generator_fwd_apps": [_P, _I64, _I64, _I32, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _P],
     "gan_generator_bwd_apps": [_P, _I64, _P, _I64, _I64, _I32, _I64, _I64, _I64, _I64, _I32, _P, _P, _I32, _P, _I64, _I32,
                                _P, _P, _P],

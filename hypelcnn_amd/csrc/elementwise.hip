@@ -1579,6 +1579,34 @@ extern "C" int hypel_copy_blocks_f32(const float* base, const hypel_copy_block_t
     return 0;
 }
 
+// two flat copies in one launch (blockIdx.y = which); float4 when both ends and the count allow
+__global__ __launch_bounds__(256) void copy_pair_kernel(float* dst0, const float* src0, int64_t n0, float* dst1,
+                                                        const float* src1, int64_t n1) {
+    float* dst = blockIdx.y ? dst1 : dst0;
+    const float* src = blockIdx.y ? src1 : src0;
+    const int64_t n = blockIdx.y ? n1 : n0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((n & 3) | (reinterpret_cast<uintptr_t>(dst) & 15) | (reinterpret_cast<uintptr_t>(src) & 15)) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (; i < (n >> 2); i += stride) d4[i] = s4[i];
+    } else {
+        for (; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+extern "C" int hypel_copy_pair_f32(float* dst0, const float* src0, int64_t n0, float* dst1, const float* src1, int64_t n1,
+                                   hypel_stream_t stream) {
+    HYPEL_REQUIRE(dst0 && src0 && n0 >= 0 && (n1 == 0 || (dst1 && src1)) && n1 >= 0, "hypel_copy_pair_f32");
+    const int64_t big = n0 > n1 ? n0 : n1;
+    if (big == 0) return 0;
+    hipLaunchKernelGGL(copy_pair_kernel, dim3(hypel_grid_1d((big + 3) / 4, 256, 2048), n1 > 0 ? 2 : 1), dim3(256), 0, ST, dst0,
+                       src0, n0, dst1, src1, n1);
+    HYPEL_CHECK_LAUNCH("hypel_copy_pair_f32");
+    return 0;
+}
+
 extern "C" int hypel_reduce_splits_pair_f32(const float* partial0, int64_t stride0, int64_t count0, float* out0,
                                             const float* partial1, int64_t stride1, int64_t count1, float* out1,
                                             int32_t n_splits, int32_t accumulate, hypel_stream_t stream) {

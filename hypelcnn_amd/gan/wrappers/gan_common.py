@@ -103,6 +103,8 @@ class GANTrainOps:
         self.loss = loss
         self.lrs = lrs
         self.ctx = ctx
+        if not ctx.group_affinity:  # the variable groups of one train op next to each other in the flat buffers
+            ctx.group_affinity = [list(p.train_groups) for p in loss.phases]
         self.pools = {}
         self.use_pool = use_pool
         self.last_losses = {}
@@ -121,13 +123,15 @@ class GANTrainOps:
         (PhasePlan); `fed` (a set owned by one run_step call) makes only the first phase that reads an input pay for
         the copy."""
         b = ct.plan.buffers
+        todo = []
         for name, t in (("x", x), ("y", y)):
             if "in:" + name in b:
                 key = (name, b["in:" + name].data_ptr())
                 if fed is None or key not in fed:
-                    ct.set_input(name, t)
+                    todo.append((name, t))
                     if fed is not None:
                         fed.add(key)
+        ct.set_inputs(todo)  # (both batches in one launch)
 
     def run_step(self, x, y):
         sess = self.ctx.session()
@@ -141,6 +145,7 @@ class GANTrainOps:
                 gen = sess.compile_phase(self.loss.tower, nb, outputs=[t for _, t in phase.pool], key="generate")
                 self._feed(gen, x, y, fed)
                 gen.forward()
+                pooled = []
                 for name, t in phase.pool:
                     fresh = gen.value(t, copy=False)  # consumed (pool query / set_input copy) before the next forward
                     if self.pool_override is not None:
@@ -149,7 +154,8 @@ class GANTrainOps:
                         val = self.pools.setdefault(name, TensorPool(seed=sess.seed)).query(fresh)
                     else:
                         val = fresh
-                    ct.set_input(name, val)
+                    pooled.append((name, val))
+                ct.set_inputs(pooled)
             ct.forward_backward()
             sess.allreduce_group_gradients(phase.train_groups)
             sess.adam_step_groups(phase.train_groups, self.lrs[phase.lr_key](step), step + 1, beta1=0.5)
@@ -167,6 +173,7 @@ class GanContext:
         self.tower = tower
         self.backend = backend
         self.seed = seed
+        self.group_affinity = []
         self._session = None
 
     def session(self):
@@ -176,7 +183,7 @@ class GanContext:
                 from hypelcnn_amd.backend import HipBackend
                 self.backend = HipBackend()
             self._session = Session(self.tower.store, self.backend, seed=self.seed)
-            self._session.finalize_variables()
+            self._session.finalize_variables(group_affinity=self.group_affinity)
             self._session.init_data_parallel()
         return self._session
 

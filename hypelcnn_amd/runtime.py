@@ -42,6 +42,23 @@ class CompiledTower:
         dst = self.plan.buffers["in:" + name]
         dst.copy_(tensor.reshape(-1).to(dst.dtype), non_blocking=True)
 
+    def set_inputs(self, items):
+        """set_input for several inputs; two fp32 tensors that already live on the device go in ONE launch
+        (hypel_copy_pair_f32): a GAN train op is fed with two batches."""
+        items = list(items)
+        while len(items) >= 2:
+            (n0, t0), (n1, t1) = items[0], items[1]
+            d0, d1 = self.plan.buffers["in:" + n0], self.plan.buffers["in:" + n1]
+            ok = all(t.dtype == d.dtype == torch.float32 and t.device == d.device and t.is_contiguous() and
+                     t.numel() == d.numel() for t, d in ((t0, d0), (t1, d1)))
+            if not ok:
+                break
+            self.be.call("copy_pair_f32", Ref(d0), Ref(t0.reshape(-1)), d0.numel(), Ref(d1), Ref(t1.reshape(-1)),
+                              d1.numel())
+            items = items[2:]
+        for name, t in items:
+            self.set_input(name, t)
+
     def value(self, sym, nhwc=True, copy=True):
         """Fetch a tensor of the tower as [N, H, W, C] / [N, C].  copy=True (default): the caller owns the result.
         copy=False: an [N, C] tensor comes back as a VIEW of the plan buffer (no gather / permute / copy kernels) that the
@@ -200,15 +217,22 @@ class Session:
         self.sync_bn = False
 
     # ---- variables ----
-    def finalize_variables(self, rng=None):
+    def finalize_variables(self, rng=None, group_affinity=()):
         """Lay variables out in the flat buffers (per optimiser group: per-channel vectors first, then the weights,
         each in creation order so that the vectors of a merged level are contiguous and the weights of the layers
-        that finish their backward first form one contiguous tail) and initialise them."""
+        that finish their backward first form one contiguous tail) and initialise them.
+        group_affinity: lists of group names that one train op updates together (a GAN phase's generators, its critics):
+        they are laid out next to each other, so that their optimiser update and their gradient all-reduce are one
+        launch / one collective per train op (adam_step_groups, allreduce_group_gradients merge adjacent ranges)."""
         order = self.store.order
-        groups = []
+        present = []
         for v in order:
-            if v.trainable and v.group not in groups:
-                groups.append(v.group)
+            if v.trainable and v.group not in present:
+                present.append(v.group)
+        groups = []
+        for together in group_affinity:
+            groups += [g for g in together if g in present and g not in groups]
+        groups += [g for g in present if g not in groups]
         self.trainable = []
         self.group_ranges = {}
         off = 0
@@ -329,11 +353,20 @@ class Session:
     def adam_step_groups(self, groups, lr, t, beta1=0.5, beta2=0.999, eps=1e-8):
         """TF1 Adam on the flat ranges of the given optimiser groups (gan_common.py:264-265: beta1 = 0.5)."""
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-        for gname in groups:
-            lo, hi = self.group_ranges[gname]
+        for lo, hi in self._merged_ranges(groups):  # (the groups of one train op are neighbours: finalize_variables)
+            self.backend.call("adam_tf1", Ref(self.params, lo), Ref(self.grads, lo), Ref(self.slot_m, lo),
+                              Ref(self.slot_v, lo), hi - lo, float(lr_t), float(beta1), float(beta2), float(eps))
+
+    def _merged_ranges(self, groups):
+        """the flat ranges of the given groups, adjacent ones merged"""
+        ranges = []
+        for lo, hi in sorted(self.group_ranges[g] for g in groups):
             if hi > lo:
-                self.backend.call("adam_tf1", Ref(self.params, lo), Ref(self.grads, lo), Ref(self.slot_m, lo),
-                                  Ref(self.slot_v, lo), hi - lo, float(lr_t), float(beta1), float(beta2), float(eps))
+                if ranges and ranges[-1][1] == lo:
+                    ranges[-1][1] = hi
+                else:
+                    ranges.append([lo, hi])
+        return ranges
 
     def allreduce_group_gradients(self, groups):
         if self.dist is None:
@@ -342,14 +375,7 @@ class Session:
         # adjacent groups travel in one call.  ONE averaging path on every backend -- SUM, then scale by 1 / world -- so that
         # the 2-rank gloo tests (tests/test_dp_gloo.py) exercise exactly what runs over RCCL (round 3 averaged inside the
         # collective on RCCL only: two code paths, one of them never multi-rank-tested)
-        ranges = []
-        for lo, hi in sorted(self.group_ranges[g] for g in groups):
-            if hi > lo:
-                if ranges and ranges[-1][1] == lo:
-                    ranges[-1][1] = hi
-                else:
-                    ranges.append([lo, hi])
-        for lo, hi in ranges:
+        for lo, hi in self._merged_ranges(groups):
             view = self.grads[lo:hi]
             note_collective()
             dist.all_reduce(view, op=dist.ReduceOp.SUM)

@@ -1207,3 +1207,12 @@ EmuBackend.k_dense_stack_fwd_apps = _k_dense_stack_fwd_apps
 EmuBackend.k_dense_stack_bwd_apps = _k_dense_stack_bwd_apps
 EmuBackend.gan_generator_blocks_apps = lambda self, n, n_apps: _emu_generator_blocks_apps(n, n_apps)
 EmuBackend.dense_stack_blocks_apps = lambda self, n, n_apps: _emu_dense_stack_blocks_apps(n, n_apps)
+
+
+def _k_copy_pair_f32(self, dst0, src0, n0, dst1, src1, n1):
+    _arr(dst0)[:n0] = _arr(src0)[:n0]
+    if n1 > 0:
+        _arr(dst1)[:n1] = _arr(src1)[:n1]
+
+
+EmuBackend.k_copy_pair_f32 = _k_copy_pair_f32

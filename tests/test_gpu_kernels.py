@@ -1397,3 +1397,19 @@ def test_dense_stack_two_variable_sets_in_one_launch(hip, widths, n, own_regions
     if own_regions:
         pw = b.h["pw"].cpu().numpy()
         assert (pw[bpa * wt:bpa * wt + pad] == 7.0).all() and (pw[pws + bpa * wt:] == 7.0).all()
+
+
+@pytest.mark.parametrize("n0,n1,off", [(2048 * 64, 2048 * 64, 0), (1000, 37, 0), (4096, 0, 0), (513, 2052, 1)])
+def test_copy_pair(hip, n0, n1, off):
+    """hypel_copy_pair_f32: two flat copies in one launch (vector path when aligned, scalar otherwise), nothing else touched."""
+    rng = np.random.default_rng(n0 + n1)
+    b = Both(hip)
+    b.arr("s0", rng.standard_normal(n0 + off).astype(np.float32))
+    b.arr("s1", rng.standard_normal(max(n1, 1) + off).astype(np.float32))
+    b.arr("d0", np.full(n0 + 8, 3.0, np.float32))
+    b.arr("d1", np.full(max(n1, 1) + 8, 3.0, np.float32))
+    b.run("copy_pair_f32", "d0", ("s0", off), n0, "d1", ("s1", off), n1)
+    for d, s_, n in (("d0", "s0", n0), ("d1", "s1", n1)):
+        got = b.h[d].cpu().numpy()
+        assert np.array_equal(got[:n], b.h[s_].cpu().numpy()[off:off + n]) and (got[n:] == 3.0).all()
+        assert np.array_equal(got, b.e[d].numpy())
