@@ -31,6 +31,9 @@ class CycleGANWrapper(Wrapper):
                 rec_x = self._generator_fn(m_x2y.generated_data)
             with G.variable_scope(model_forward_generator_name), G.variable_scope("Generator"):
                 rec_y = self._generator_fn(m_y2x.generated_data)
+        # device layout of the four [N, B] inputs: G_x2y(x) | G_y2x(y) share a launch, so do D_x on (pool_fake_x, x) and
+        # D_y on (y, pool_fake_y) -- in this order every such batch is a run of neighbouring row blocks (no gather launch)
+        tower.input_layout = ["pool_fake_x", images_x.name, images_y.name, "pool_fake_y"]
         # identity_x = generator_x2y(data_x) is the SAME tensor as model_x2y.generated_data (reference :303-306)
         return C.CycleGANModel(m_x2y, m_y2x, rec_x, rec_y, m_x2y.generated_data, m_y2x.generated_data)
 

@@ -2236,10 +2236,18 @@ class PhasePlan(TowerPlan):
             if id(t) not in used_inputs:
                 continue
             assert t.hw is None, "GAN inputs are [N, B]"
-            # the phases of one GAN step read the same batch: they share one device buffer per input, fed once per step
-            shared = self.sess.shared_inputs.setdefault((name, nb, t.c), self.be.zeros(nb * t.c))
-            self.buffers["in:" + name] = shared
-            self.storage[id(t)] = Storage("in:" + name, nb, t.c, None, 0, t.c, 1)
+            # the phases of one GAN step read the same batch: they share one device buffer per input, fed once per step.
+            # All [N, c] inputs of the tower are row blocks of ONE slab, in the order the wrapper asks for
+            # (tower.input_layout; default: creation order): applications that run as one row-concatenated batch on
+            # neighbouring inputs then need no gather launch (_concat_inputs)
+            layout = [n_ for n_ in (getattr(self.tower, "input_layout", None) or list(self.tower.inputs))
+                      if self.tower.inputs[n_].hw is None and self.tower.inputs[n_].c == t.c]
+            layout += [n_ for n_, t_ in self.tower.inputs.items() if t_.hw is None and t_.c == t.c and n_ not in layout]
+            slab = self.sess.shared_inputs.setdefault(("slab", nb, t.c), self.be.zeros(len(layout) * nb * t.c))
+            k = layout.index(name)
+            self.buffers[f"in:slab{t.c}"] = slab
+            self.buffers["in:" + name] = slab[k * nb * t.c:(k + 1) * nb * t.c]  # what set_input writes
+            self.storage[id(t)] = Storage(f"in:slab{t.c}", nb, t.c, None, k * nb * t.c, t.c, 1)
         self._alloc("loss", 1)
         units = self._schedule_units()
         for unit in units:
@@ -2431,6 +2439,21 @@ class PhasePlan(TowerPlan):
         tries = [t for t in tries if t is not None]
         return min(tries, key=len) if tries else [[u] for u in order]  # fewest units; ties: the plainer grouping
 
+    def _address_order(self, unit):
+        """Reorder the members of a unit IN PLACE (they are independent of each other) so that inputs which are row
+        blocks of one buffer come in address order -- same-variable runs kept together, runs ordered by their first
+        block: neighbouring inputs (the slab of the tower's placeholders, the outputs of an earlier batch) then
+        concatenate without a copy."""
+        sts = [self.storage_of(self._node_src(n)) for _, n in unit]
+        if len({st.buf for st in sts}) != 1 or any(st.pixmap is not None for st in sts):
+            return
+        addr = {id(m[1]): st.ch_off for m, st in zip(unit, sts)}
+        runs = [sorted(r, key=lambda m: addr[id(m[1])]) for r in self._app_runs(unit)]
+        # (runs of _app_runs are consecutive same-variable members; members of one variable set may be split into several
+        # runs only if the scheduler interleaved them, which it does not)
+        runs.sort(key=lambda r: addr[id(r[0][1])])
+        unit[:] = [m for r in runs for m in r]
+
     def _concat_inputs(self, tag, srcs):
         """Storage of the row-concatenated inputs [G * nb, c] of a group.  Zero copy when the inputs already are
         consecutive row blocks of one buffer (the outputs of the previous batched layer), else one hypel_copy_blocks_f32
@@ -2463,6 +2486,7 @@ class PhasePlan(TowerPlan):
         the ordinary handler with self.nb = G * nb; the members' outputs are row-block views of its output buffer."""
         import copy
         nb0, G_ = self.nb, len(unit)
+        self._address_order(unit)
         idx0, n0 = unit[0]
         srcs = [self._node_src(n) for _, n in unit]
         cat_st, gathered = self._concat_inputs(idx0, srcs)
