@@ -152,8 +152,11 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // VARN (forward 128x64 blocks): the groups of the launch differ in their column count (hypel_tile_t.n, merged levels);
 // the MFMA phase then has one variant per number of active accumulator tiles.  A separate instantiation: as a shared
 // code path the second variant cost the 128x64 forward kernel 20 registers (82 -> 102: 4 instead of 5 waves per SIMD).
+// ACT (plain forward products, a separate instantiation like VARN): C = act(product + bias) with act = leaky-ReLU of the
+// slope HYPEL_GEMM_ACT_* names (bits 16-18 of `accumulate`): the bias + activation launch behind a BN-less
+// tf_slim.fully_connected (the GAN critics' and feature-discriminator layers, gan/shadow_data_models.py:95-149) is gone.
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
-          bool PAIR = false, bool VARN = false>
+          bool PAIR = false, bool VARN = false, bool ACT = false>
 __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
@@ -172,6 +175,12 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int BN = NARROW ? 16 * NT16 : WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
+    static_assert(!ACT || (!TA && !TB && !NARROW && !MULTI && !BNB && !PAIR && !VARN), "activation epilogue: plain forward only");
+    [[maybe_unused]] int act_idx = 0;
+    if constexpr (ACT) {
+        act_idx = accumulate >> 16;
+        accumulate &= 1;
+    }
     static_assert(!NARROW || (WM == 4 && TM == 1 && (TN == 1 || (TN == 4 && !TA && !TB && !MULTI))),
                   "narrow variant: 4 x 1 waves of 32 x 16 (forward: 32 x 64)");
     // LDS images (rows x pitch), global row order preserved
@@ -787,6 +796,31 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             }
         }
     }
+    if constexpr (ACT) {
+        // act(product + bias): the bias joins the accumulators here (the stores below then add none); no read-modify-write,
+        // no shortcut gather, no statistics with this epilogue (the dispatcher checks)
+        const float alpha = act_idx == 1 ? 0.1f : act_idx == 2 ? 0.18f : act_idx == 3 ? 0.2f : act_idx == 4 ? 0.01f : 0.0f;
+        const int bc0 = bias ? (int)(grp.c_off % ldc) + n0 : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = (wn * TN + j) * 32 + l31;
+            float bv = 0.0f;
+            if constexpr (HOIST) {
+                bv = h_bv[j];
+                h_bv[j] = 0.0f;
+            } else {
+                bv = bias && col < cols_left ? bias[bc0 + col] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][j][e] + bv;
+                    acc[i][j][e] = v > 0.0f ? v : alpha * v;
+                }
+        }
+        bias = nullptr;
+    }
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
     float* cbase = C + grp.c_off + (int64_t)m0 * ldc + n0;
     // bias is indexed by the absolute output column: groups of a merged level start at channel offsets
@@ -1109,9 +1143,9 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                                          : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : (TA && TM * TN == 2 ? HYPEL_OCC_BN64_TA : 3))))
 
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
-          bool PAIR = false, bool VARN = false>
+          bool PAIR = false, bool VARN = false, bool ACT = false>
 __global__ HYPEL_SGPR_ATTR HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PARAMS) {
-    seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, BNB, PAIR, VARN>(HYPEL_GEMM_ARGS);
+    seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, BNB, PAIR, VARN, ACT>(HYPEL_GEMM_ARGS);
 }
 
 // The same code under a cap of 96 scalar registers: 7 instead of 6 resident 128x32 blocks per CU (hipcc uses all 106
@@ -1226,8 +1260,26 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const bool cap96 = cap_on && (accumulate & HYPEL_GEMM_SINGLE_SEG) != 0;  // every group has one segment
     const bool mfma16x4 = (accumulate & HYPEL_GEMM_MFMA16X4) != 0;  // merged level with <= 16 filters per branch
     const bool var_n = (accumulate & HYPEL_GEMM_VAR_N) != 0;        // groups differ in their column count
+    const int act_idx = (accumulate >> 16) & 7;                     // HYPEL_GEMM_ACT_*: leaky-ReLU of (product + bias)
     accumulate &= 1;
     const bool plain_fwd = !trans_a && !trans_b && !split_tail && !pairs && !bnb.partial && !stats && !res;
+    if (act_idx) {
+        HYPEL_REQUIRE(plain_fwd && !accumulate && !mfma16x4 && !var_n && act_idx <= 4,
+                      "hypel_seg_gemm_f32: HYPEL_GEMM_ACT_* needs a plain forward product (no accumulate / shortcut / statistics)");
+        const bool narrow_a = hint == 1 || n <= 32 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < 1000);
+        const int bn = narrow_a ? 32 : 64;
+        const int n_nt = (n + bn - 1) / bn;
+        if (narrow_a)
+            hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 1, false, false, false, false, false, false, false, true>),
+                               dim3(n_tiles * n_nt), dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles,
+                               n_nt, bias, act_idx << 16, res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
+        else
+            hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 2, false, false, false, false, false, false, false, true>),
+                               dim3(n_tiles * n_nt), dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles,
+                               n_nt, bias, act_idx << 16, res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
+        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
+        return 0;
+    }
     if (mfma16x4 && n <= 64 && plain_fwd) {
         launch_cfg<4, 1, 1, 4, true>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st);

@@ -72,6 +72,8 @@ SIDE_STREAMS = max(1, int(os.environ.get("HYPEL_SIDE_STREAMS", "0") or 0))
 FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
 # layers without batch norm: the bias-gradient reduction also writes dY (no separate activation-backward launch)
 ACT_BIAS_BWD = os.environ.get("HYPEL_ACT_BIAS_BWD", "1") != "0"
+# bias + leaky-ReLU of a normaliser-less fully-connected layer in the product's epilogue (HYPEL_GEMM_ACT_*): no post-op launch
+ACT_IN_GEMM = os.environ.get("HYPEL_ACT_IN_GEMM", "1") != "0"
 # GAN loss terms and regularisers leave weighted partials in slots; one finaliser launch per train op sums them
 LOSS_SLOTS = os.environ.get("HYPEL_LOSS_SLOTS", "1") != "0"
 GEN_KEEP = os.environ.get("HYPEL_GEN_KEEP", "1") != "0"  # generator backward starts from the forward pass's kept activations
@@ -1111,9 +1113,11 @@ class TowerPlan:
             tb = GemmTables()
             for pi, (off, width) in enumerate(node.in_slices):
                 tb.add_group(pi * cout, [(s_st.pix_off(0) + off, node.branches[pi].w.offset, width)], nb)
+            act_flag = self._act_in_gemm(node, cout)
+            aux["act_in_gemm"] = bool(act_flag)
             self._emit_gemm(self.fwd, tb, cout, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), cout, 0,
                             self._ref(ybuf), c, bias_ref, 0, f"fwd:{node.branches[0].scope}+{len(node.branches) - 1}",
-                            allow_split=False)
+                            allow_split=False, flags=act_flag)
         else:  # dense
             b = node.branches[0]
             rowbase = 0
@@ -1127,10 +1131,14 @@ class TowerPlan:
                 gemm_stats = (STATS_EPILOGUE and len(node.sources) == 1 and c > 16 and self._chunk_bn(node, nb)
                               and self._split_k(tb, c, s_st.ld, 0, c, 0, c) is None)
                 aux["stats_in_gemm"] = gemm_stats
+                act_flag = 0
+                if len(node.sources) == 1 and self._split_k(tb, c, s_st.ld, 0, c, 0, c) is None:
+                    act_flag = self._act_in_gemm(node, c)
+                aux["act_in_gemm"] = bool(act_flag)
                 self._emit_gemm(self.fwd, tb, c, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), c, 0,
                                 self._ref(ybuf), c, bias_ref if si == 0 else None, 1 if si > 0 else 0,
                                 f"fwd:{b.scope}",
-                                stats=((nb + GEMM_BM - 1) // GEMM_BM) * 2 * c if gemm_stats else None)
+                                stats=((nb + GEMM_BM - 1) // GEMM_BM) * 2 * c if gemm_stats else None, flags=act_flag)
                 rowbase += src.npix * src.c
 
         rows = out.npix * nb
@@ -1183,13 +1191,30 @@ class TowerPlan:
             aux["rstd"] = self._ref(f"rstd:{idx}")
             aux["beta_ref"] = self._p(aux["beta"])
         # ---- fused post-op ----
-        if node.has_post:
+        if node.has_post and aux.get("act_in_gemm"):
+            # the product's epilogue already applied bias + leaky-ReLU: the "pre-activation" buffer holds the layer output
+            # (the backward kernels take act' from its sign, which a positive slope preserves)
+            self.storage[id(out)] = y_st
+        elif node.has_post:
             zbuf = f"z:{idx}"
             self._alloc(zbuf, rows * c)
             self.storage[id(out)] = Storage(zbuf, nb, c, None, 0, c, out.npix)
             self._emit_post_fwd(idx, node, self._ref(ybuf), c, rows, c, aux, self._ref(zbuf))
         else:
             self.storage[id(out)] = y_st
+
+    def _act_in_gemm(self, node, n):
+        """HYPEL_GEMM_ACT_* code when this layer's post-op is nothing but (bias +) leaky-ReLU of a slope the library names
+        (include/hypel.h) and its product runs on the 32-wide matrix-core tiles: a tf_slim.fully_connected without a
+        normaliser then is ONE launch.  0: keep the separate post-op launch."""
+        act = node.act
+        if not (ACT_IN_GEMM and node.has_post and not node.has_bn and not node.residuals and node.dropout_keep is None
+                and act is not None and act.code == 1 and n > 16 and not self.sync_bn):
+            return 0
+        for code, slope in ((1, 0.1), (2, 0.18), (3, 0.2), (4, 0.01)):
+            if np.float32(act.alpha) == np.float32(slope):
+                return code << 16
+        return 0
 
     def _emit_bn_finalize(self, idx, node, aux, n_chunks, chunk, rows, c):
         """Chunk partials (in scratch_partial) -> mean / rstd / moving averages.  Synchronised batch norm: the rank's

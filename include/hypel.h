@@ -115,6 +115,15 @@ typedef struct {
  * on neither (a launch without them computes the unused tiles on zeros). */
 #define HYPEL_GEMM_MFMA16X4 0x2000
 #define HYPEL_GEMM_VAR_N 0x4000
+/* Activation in the product's epilogue (hypel_seg_gemm_f32, trans_a = trans_b = 0, no accumulate): C = lrelu(product + bias)
+ * with the slope the code names -- a tf_slim.fully_connected(activation_fn=leaky_relu) WITHOUT a normaliser in one launch
+ * (gan/shadow_data_models.py:95-149: the critics' and feature-discriminator layers, slope 0.1).  The slopes are a closed
+ * list so that the constant is exact fp32 (no float travels in `accumulate`).  Backward passes take act' from the sign of
+ * the OUTPUT, which a positive slope preserves. */
+#define HYPEL_GEMM_ACT_LRELU_0_1 0x10000
+#define HYPEL_GEMM_ACT_LRELU_0_18 0x20000
+#define HYPEL_GEMM_ACT_LRELU_0_2 0x30000
+#define HYPEL_GEMM_ACT_LRELU_0_01 0x40000
 
 /* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint
  * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks, 3 = 128x96 blocks for n > 64) -- results do not

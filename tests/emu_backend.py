@@ -356,6 +356,12 @@ class EmuBackend:
             if bv is not None:
                 col0 = co % ldc
                 acc += bv[col0:col0 + n]
+            act_idx = (accumulate_raw >> 16) & 7  # HYPEL_GEMM_ACT_*: leaky-ReLU of (product + bias)
+            if act_idx:
+                assert not ta and not tb and not accumulate and not any_split and act_idx <= 4 and \
+                    not (accumulate_raw & 0x6000), "HYPEL_GEMM_ACT_*: plain forward products only"
+                alpha = np.float32([0.0, 0.1, 0.18, 0.2, 0.01][act_idx]).astype(np.float64)
+                acc = np.where(acc > 0, acc, alpha * acc)
             if accumulate:
                 cm += acc.astype(np.float32)
             else:

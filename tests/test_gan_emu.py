@@ -157,3 +157,28 @@ def test_two_variable_sets_in_one_launch_can_be_switched_off(monkeypatch):
     names = [l for v in _phase_launches(ops, sess, n).values() for l in v]
     assert not any(l.endswith("_apps") for l in names)
     assert names.count("gan_generator_bwd_kept") == 4 and names.count("dense_stack_bwd") == 4, names
+
+
+def test_bias_and_leaky_relu_ride_in_the_product(monkeypatch):
+    """A tf_slim.fully_connected without a normaliser (the feature-discriminator layers, the wide critic:
+    shadow_data_models.py:95-149) is ONE launch: the product's epilogue applies bias + leaky-ReLU (HYPEL_GEMM_ACT_*), the
+    backward pass reads act' from the sign of the layer output.  HYPEL_ACT_IN_GEMM=0 restores product -> post-op; both
+    forms give the oracle's phase gradients."""
+    from hypelcnn_amd import plan
+    n, bands = 6, 144  # (wide critic: the 144-band stack runs layer by layer)
+    cfg = OG.GanConfig("cut_x2y", bands, patches=6, max_steps=20)
+    params = U.fp32(OG.init_gan_params("cut_x2y", bands, np.random.default_rng(2), patches=6, dtype=np.float64,
+                                       zero_generator=False))
+    x, y = _data(n, bands, 4)
+    posts = {}
+    for fused in (True, False):
+        monkeypatch.setattr(plan, "ACT_IN_GEMM", fused)
+        wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
+        sess = ops.ctx.session()
+        U.inject(sess, params)
+        U.check_phase_gradients(cfg, ops, params, x, y, tol=5e-5)
+        plans = [ops._compiled(sess, ph, n).plan for ph in ops.loss.phases]
+        posts[fused] = sum(l.name == "bn_act_fwd" for p in plans for l in p.fwd)
+        flagged = sum(l.name == "seg_gemm_f32" and (int(l.args[14]) >> 16) & 7 == 1 for p in plans for l in p.fwd)
+        assert (flagged > 0) == fused
+    assert posts[True] < posts[False], posts

@@ -1413,3 +1413,37 @@ def test_copy_pair(hip, n0, n1, off):
         got = b.h[d].cpu().numpy()
         assert np.array_equal(got[:n], b.h[s_].cpu().numpy()[off:off + n]) and (got[n:] == 3.0).all()
         assert np.array_equal(got, b.e[d].numpy())
+
+
+@pytest.mark.parametrize("rows,k,n,groups,bias,code,hint", [
+    (16384, 60, 60, 6, True, 1, 0),    # CUT feature discriminator, first layer: six band slices, slope 0.1
+    (8192, 360, 360, 1, True, 1, 0),   # the 360-band critic's first layer
+    (300, 77, 33, 2, False, 2, 1),     # ragged, no bias, slope 0.18, 128x32 blocks
+    (129, 19, 70, 1, True, 4, 2),      # slope 0.01, 128x64 blocks
+    (4096, 180, 90, 1, True, 3, 0),
+])
+def test_seg_gemm_leaky_relu_epilogue(hip, rows, k, n, groups, bias, code, hint):
+    """HYPEL_GEMM_ACT_*: C = leaky_relu(product + bias) straight from the accumulators -- a normaliser-less
+    tf_slim.fully_connected (gan/shadow_data_models.py:95-149) in one launch.  Equal, bit for bit, to the plain product
+    followed by the element-wise activation kernel; columns outside the groups stay untouched."""
+    rng = np.random.default_rng(rows + k + n)
+    ldc = groups * n + 3
+    a = rng.standard_normal((rows, groups * k)).astype(np.float32)
+    w = (rng.standard_normal(groups * k * n) / np.sqrt(k)).astype(np.float32)
+    bv = rng.standard_normal(ldc).astype(np.float32)
+    slope = [0.0, 0.1, 0.18, 0.2, 0.01][code]
+    b = Both(hip)
+    garr, sarr, tarr, _ = _tables(b, [(g * n, [(g * k, g * k * n, k)], rows) for g in range(groups)]).finalize(n)
+    for nm, arr in (("a", a), ("w", w), ("c", np.full((rows, ldc), 5.0, np.float32)), ("c2", np.full((rows, ldc), 5.0, np.float32)),
+                    ("z2", np.zeros((rows, ldc), np.float32)), ("bias", bv), ("g", garr), ("s", sarr), ("t", tarr)):
+        b.arr(nm, arr)
+    b.run("seg_gemm_f32", "a", groups * k, 0, "w", n, 0, "c", ldc, n, "g", "s", "t", len(tarr), "bias" if bias else None,
+          (code << 16) | (hint << 8))
+    b.check("c", rtol=2e-4, atol=2e-5)
+    # the two-launch form on the device
+    b.run("seg_gemm_f32", "a", groups * k, 0, "w", n, 0, "c2", ldc, n, "g", "s", "t", len(tarr), "bias" if bias else None,
+          hint << 8)
+    b.run("bn_act_fwd", "c2", ldc, rows, groups * n, None, None, None, 1, slope, None, 0, None, 0, None, None, 0, None, "z2", ldc)
+    got, two = b.h["c"].cpu().numpy().reshape(rows, ldc), b.h["z2"].cpu().numpy().reshape(rows, ldc)
+    assert np.array_equal(got[:, :groups * n], two[:, :groups * n]), "same arithmetic as product -> activation kernel"
+    assert (got[:, groups * n:] == 5.0).all()
