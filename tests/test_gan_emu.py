@@ -137,6 +137,8 @@ def test_same_weight_applications_run_as_one_row_concatenated_application(monkey
         for ph in ("gen", "dis"):
             assert counts[True][ph].count("dense_stack_bwd_apps") == 1 and "dense_stack_bwd" not in counts[True][ph]
         assert counts[True]["gen"].count("gan_generator_bwd_apps") == 2
+        # the batched inputs are neighbouring row blocks of the tower's input slab (tower.input_layout): nothing to gather
+        assert not any(l == "copy_blocks_f32" for v in counts[True].values() for l in v), counts[True]
         assert sum(l == "reduce_splits_wave_multi_f32" for v in counts[True].values() for l in v) == 2
 
 
