@@ -166,3 +166,32 @@ def test_cfg5_joint_loop_at_avon_shape_on_gpu(tmp_path):
                                scene="avon:h=40:w=50:bands=360:samples=0.6", neighborhood=3, alg=alg, batch=64,
                                gan_batch=64)
     assert np.isfinite(res.loss) and res.test_accuracy > 0.6, (res.loss, res.test_accuracy)
+
+
+@pytest.mark.parametrize("kind,bands,n", [("cycle_gan", 64, 96), ("cut_x2y", 64, 64), ("dcl_gan", 64, 48)])
+def test_training_steps_track_oracle_trainer_on_gpu(hip, kind, bands, n):
+    """Six whole GAN steps on the MI355X (every train op replayed as a HIP graph: two-variable-set launches, slab inputs,
+    one Adam launch per train op, the LR decay from step 4 on) against oracle/gan.py::GanTrainer on the same batches:
+    losses of every train op and every variable after the last step."""
+    steps = 6
+    cfg = OG.GanConfig(kind, bands, patches=6, max_steps=8)
+    params = U.fp32(OG.init_gan_params(kind, bands, np.random.default_rng(3), patches=6, dtype=np.float64,
+                                       zero_generator=False))
+    wrapper, model, loss, ops = U.build(cfg, n, hip)
+    ops.capture_graphs = True
+    ops.pool_override = lambda name, fresh: fresh  # pass-through pool (the oracle trainer does the same)
+    sess = ops.ctx.session()
+    U.inject(sess, params)
+    trainer = OG.GanTrainer(cfg, {k: v.copy() for k, v in params.items()})
+    for s in range(steps):
+        x, y = _data(n, bands, 100 + s)
+        ops.run_step(torch.as_tensor(x.reshape(n, -1), dtype=torch.float32).cuda(),
+                     torch.as_tensor(y.reshape(n, -1), dtype=torch.float32).cuda())
+        ref_losses = trainer.step(x, y)
+        got = ops.losses()
+        for ph, v in ref_losses.items():
+            assert abs(got[ph] - v) < 2e-3 * max(1.0, abs(v)), (s, ph, got[ph], v)
+    assert sess.global_step == steps
+    for k, v in trainer.params.items():
+        got = sess.get_variable(k)
+        assert np.abs(got - v).max() < 2e-3 * max(np.abs(v).max(), 1e-3), k
