@@ -257,6 +257,110 @@ __global__ __launch_bounds__(256, 2) void split_gemm_v2(const float* __restrict_
             }
 }
 
+// v3: the B operand (weights: small, constant over a step) arrives PRE-SPLIT -- three bf16 planes [n][k] written once by
+// presplit_b -- so that its share of the staging is six 16-byte copies per thread and k-tile (no conversion, no scattered
+// 4-byte loads); A as in v1.
+__global__ void presplit_b(const float* __restrict__ B, int ldb, unsigned short* __restrict__ P, int N, int K) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, k2 = blockIdx.y;  // one (n, pair of k) per thread
+    if (n >= N) return;
+    unsigned h, m, l;
+    split2(B[(size_t)(2 * k2) * ldb + n], B[(size_t)(2 * k2 + 1) * ldb + n], h, m, l);
+    const size_t plane = (size_t)N * K;
+    reinterpret_cast<unsigned*>(P)[((size_t)n * K + 2 * k2) / 2] = h;
+    reinterpret_cast<unsigned*>(P + plane)[((size_t)n * K + 2 * k2) / 2] = m;
+    reinterpret_cast<unsigned*>(P + 2 * plane)[((size_t)n * K + 2 * k2) / 2] = l;
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 2) void split_gemm_v3(const float* __restrict__ A, int lda,
+                                                        const unsigned short* __restrict__ Bp, float* __restrict__ C,
+                                                        int ldc, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * PLANE], Bs[3 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+    const int n_nt = (N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / n_nt) * BM, n0 = (blockIdx.x % n_nt) * BN;
+    const size_t plane = (size_t)N * K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    float4 ra[4];
+    uint4 rb[3][2];  // [plane][half]: 8 bf16 of row b_n0 + 64 h, k chunk b_kc
+    const int a_kq = tid & 7, a_r0 = tid >> 3;
+    const int b_kc = tid & 3, b_n0 = tid >> 2;  // 4 chunks of 8 k per row, rows b_n0, b_n0 + 64
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = m0 + a_r0 + 32 * i;
+            ra[i] = r < M ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + k0 + 4 * a_kq) : float4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n0 + b_n0 + 64 * h;
+                rb[p][h] = n < N ? *reinterpret_cast<const uint4*>(Bp + p * plane + (size_t)n * K + k0 + 8 * b_kc) : uint4{0, 0, 0, 0};
+            }
+    };
+    load(0);
+    const int a_rd = (wm * 64 + l31) * PITCH + 8 * lhi, b_rd = (wn * 64 + l31) * PITCH + 8 * lhi;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 h, m, l;
+            split2(ra[i].x, ra[i].y, h.x, m.x, l.x);
+            split2(ra[i].z, ra[i].w, h.y, m.y, l.y);
+            const int o = (a_r0 + 32 * i) * PITCH + 4 * a_kq;
+            *reinterpret_cast<uint2*>(&As[o]) = h;
+            *reinterpret_cast<uint2*>(&As[PLANE + o]) = m;
+            *reinterpret_cast<uint2*>(&As[2 * PLANE + o]) = l;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                *reinterpret_cast<uint4*>(&Bs[p * PLANE + (b_n0 + 64 * h) * PITCH + 8 * b_kc]) = rb[p][h];
+        __syncthreads();
+        if (k0 + BK < K) load(k0 + BK);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i][p] = *reinterpret_cast<const bf16x8*>(&As[p * PLANE + a_rd + i * 32 * PITCH + 16 * s]);
+                    b[i][p] = *reinterpret_cast<const bf16x8*>(&Bs[p * PLANE + b_rd + i * 32 * PITCH + 16 * s]);
+                }
+            constexpr int PA[9] = {2, 1, 2, 1, 2, 0, 1, 0, 0};
+            constexpr int PB[9] = {2, 2, 1, 1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int q = 9 - NPROD; q < 9; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = m0 + wm * 64 + i * 32 + (e >> 2) * 8 + lhi * 4 + (e & 3), c = n0 + wn * 64 + j * 32 + l31;
+                if (r < M && c < N) C[(size_t)r * ldc + c] = acc[i][j][e];
+            }
+}
+
 template <int NPROD, int VER>
 static void run(const float* dA, const float* dB, float* dC, int M, int N, int K, const std::vector<float>& hA,
                 const std::vector<float>& hB) {
@@ -264,8 +368,14 @@ static void run(const float* dA, const float* dB, float* dC, int M, int N, int K
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
+    static unsigned short* dBp = nullptr;
+    if (VER == 3 && !dBp) {
+        CHECK(hipMalloc(&dBp, (size_t)3 * N * K * 2));
+        presplit_b<<<dim3((N + 255) / 256, K / 2), 256>>>(dB, N, dBp, N, K);
+    }
     auto go = [&]() {
-        if (VER == 2) split_gemm_v2<NPROD><<<blocks, 256>>>(dA, K, dB, N, dC, N, M, N, K);
+        if (VER == 3) split_gemm_v3<NPROD><<<blocks, 256>>>(dA, K, dBp, dC, N, M, N, K);
+        else if (VER == 2) split_gemm_v2<NPROD><<<blocks, 256>>>(dA, K, dB, N, dC, N, M, N, K);
         else split_gemm<NPROD><<<blocks, 256>>>(dA, K, dB, N, dC, N, M, N, K);
     };
     for (int i = 0; i < 3; ++i) go();
@@ -318,6 +428,9 @@ int main(int argc, char** argv) {
     run<3, 1>(dA, dB, dC, M, N, K, hA, hB);
     run<6, 1>(dA, dB, dC, M, N, K, hA, hB);
     run<9, 1>(dA, dB, dC, M, N, K, hA, hB);
+    run<3, 3>(dA, dB, dC, M, N, K, hA, hB);
+    run<6, 3>(dA, dB, dC, M, N, K, hA, hB);
+    run<9, 3>(dA, dB, dC, M, N, K, hA, hB);
     run<3, 2>(dA, dB, dC, M, N, K, hA, hB);
     run<6, 2>(dA, dB, dC, M, N, K, hA, hB);
     run<9, 2>(dA, dB, dC, M, N, K, hA, hB);
