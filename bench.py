@@ -310,6 +310,22 @@ def pmc_traffic(workload, nb, launches_per_step):
     return None, None
 
 
+def pmc_mfma_busy(workload):
+    """Matrix-pipe busy share of the seg_gemm launches from the committed SQ-counter pass of this same command
+    (tools/pmc_sq_per_launch.py: SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; its own rocprofv3 run).  Returns
+    ({"busy": ..., "useful": ...} or None, source label)."""
+    import re
+    name = f"r4_mfma_busy_per_launch_{workload}.txt"
+    try:
+        last = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
+    except OSError:
+        return None, None
+    m = re.search(r"mfma busy ([0-9.]+) % .* useful ([0-9.]+) %", last)
+    if not m:
+        return None, None
+    return {"busy": float(m.group(1)) / 100, "useful": float(m.group(2)) / 100}, f"profiles/{name} (committed PMC pass)"
+
+
 def input_pipeline_iterator(be, nb, patch, chans, classes, rank, pool=8192):
     """The reference's tf.data stage (common/common_nn_ops.py:188-201,376-440) for the timed loop: a resident pool
     of `pool` synthetic patches, per-epoch permutation, per-sample rot90 / flips / spectral shift drawn on the device
@@ -548,6 +564,9 @@ def main():
                 "algorithmic_gflop_per_step": flops / ev_steps / 1e9,
                 "algorithmic_bytes_per_launch": measure_gemm_events.bytes_per_launch,
                 "kernel_launches_per_step": len(ct.serial_launches()) + 1}  # every launch of the step + the optimiser
+        busy, busy_source = pmc_mfma_busy(args.workload)
+        if busy is not None:  # share of SIMD-cycles with the matrix pipe executing / executing exact-tap work (PMC)
+            roof["mfma_busy_pmc"], roof["mfma_useful_pmc"], roof["mfma_busy_source"] = busy["busy"], busy["useful"], busy_source
         if world == 1 and not args.no_cpu_baseline and args.workload == "hypelcnn":
             cpu = cpu_baseline()
     if rank == 0 and not classifier:

@@ -6,6 +6,7 @@
 #   bench line (driver contract)                        -> bench_<wl>.json
 #   rocprofv3 --kernel-trace --stats of the same cmd    -> kernel_stats_<wl>.csv (+ per_launch_<wl>.txt for classifiers)
 #   classifiers: PMC passes FETCH_SIZE / WRITE_SIZE     -> hbm_traffic_<wl>.{txt,json}, hbm_traffic_per_launch_<wl>.txt
+#   headline: PMC pass of the SQ counters               -> mfma_busy_per_launch_hypelcnn.txt
 set -u
 TAG=${1:-r4}
 WLS=${2:-"hypelcnn dualcnn cut cyclegan"}
@@ -36,6 +37,14 @@ for WL in $WLS; do
     [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W --workload $WL --batch $NB --known-bytes $KNOWN --json $OUT/hbm_traffic_$WL.json --source "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py $EXTRA --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-input-pipeline (every step of the run incl. pre-warm and event replay), tools/pmc_traffic.py" > $OUT/hbm_traffic_$WL.txt 2>&1
     [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic_per_launch.py $F $W --workload $WL > $OUT/hbm_traffic_per_launch_$WL.txt 2>&1
     rm -rf $OUT/pmc_f_$WL $OUT/pmc_w_$WL
+    if [ $WL = hypelcnn ]; then   # matrix-core utilisation per launch from the SQ counters (own pass, no tracing)
+      cd /tmp
+      rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_sq_$WL -o q -- python $ROOT/bench.py $EXTRA --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-input-pipeline > /dev/null 2> $ROOT/$OUT/pmc_sq_$WL.err
+      cd $ROOT
+      Q=$(find $OUT/pmc_sq_$WL -name "*counter_collection.csv" | head -1)
+      [ -n "$Q" ] && python tools/pmc_sq_per_launch.py $Q --workload $WL > $OUT/mfma_busy_per_launch_$WL.txt 2>&1
+      rm -rf $OUT/pmc_sq_$WL
+    fi
   else
     [ -n "$S" ] && python tools/kstats.py $S 30 > $OUT/kernel_top_$WL.txt 2>&1
   fi
