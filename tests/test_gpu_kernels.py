@@ -1447,3 +1447,31 @@ def test_seg_gemm_leaky_relu_epilogue(hip, rows, k, n, groups, bias, code, hint)
     got, two = b.h["c"].cpu().numpy().reshape(rows, ldc), b.h["z2"].cpu().numpy().reshape(rows, ldc)
     assert np.array_equal(got[:, :groups * n], two[:, :groups * n]), "same arithmetic as product -> activation kernel"
     assert (got[:, groups * n:] == 5.0).all()
+
+
+def test_loss_terms_slots(hip):
+    """hypel_loss_terms_slots + hypel_loss_finalize_slots: four terms (least squares, L1 with two gradients, Wasserstein
+    mean, l2 regulariser) in one launch, base-relative operands, accumulate flags on known gradient contents; three rounds."""
+    from hypelcnn_amd.backend import LOSS_NONE, LOSS_TERM_DTYPE
+    rng = np.random.default_rng(5)
+    rows, c, nw = 300, 37, 5000
+    # one arena: a0 | a1 | b1 | a2 | w | da0 | da1 | db1 | dw
+    sizes = [rows * c] * 4 + [nw] + [rows * c] * 3 + [nw]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    arena = rng.standard_normal(int(offs[-1])).astype(np.float32)
+    arena[offs[5]:] = 1.5
+    N = LOSS_NONE
+    terms = np.array([
+        (offs[0], N, offs[5], N, c, 0, c, 0, rows, 0, c, 0, 0, 1.0, 0.5 / (rows * c), 0.5 / (rows * c), 0),
+        (offs[1], offs[2], offs[6], offs[7], c, c, c, c, rows, 1, c, 1, 0, 0.0, 10.0 / (rows * c), 10.0 / (rows * c), 1),
+        (offs[3], N, N, N, c, 0, 0, 0, rows, 2, c, 0, 0, 0.0, 1.0 / (rows * c), 1.0 / (rows * c), 2),
+        (offs[4], N, offs[8], N, 0, 0, 0, 0, nw, 3, 1, 1, 0, 0.0, 1e-3, 0.5e-3, 3)], LOSS_TERM_DTYPE)
+    b = Both(hip)
+    for nm, arr in (("arena", arena), ("terms", terms), ("slots", np.zeros(4 * 1024, np.float32)),
+                    ("loss", np.full(1, 3.0, np.float32))):
+        b.arr(nm, arr)
+    for acc in (0, 1, 1):
+        b.run("loss_terms_slots", "arena", "terms", 4, "slots")
+        b.run("loss_finalize_slots", "slots", 4, "loss", acc)
+    b.check("arena", rtol=1e-5, atol=1e-6)
+    b.check("loss", rtol=2e-5, atol=1e-6)
