@@ -21,6 +21,10 @@
 
 #include "common.h"
 
+// No fused multiply-adds outside the MFMAs: whether hipcc contracts `gd * f` into a neighbouring sum depends on the code
+// around it, and the two backward kernels (LDS ring / register ring) must round alike (they are tested bit for bit).
+#pragma clang fp contract(off)
+
 typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
 struct GmApps {
     int n_apps;
@@ -93,7 +97,7 @@ __host__ __device__ inline size_t gm_fwd_lds(int bands) {
 __host__ __device__ inline int gm_atiles(int bands) { return (bands + 30) / 16 + 2; }  // upper bound of the tile offsets a
 __host__ __device__ inline size_t gm_bwd_lds(int bands) {
     const GmGeo g = gm_geo(bands);
-    return sizeof(float) * (5 * (size_t)GM_ROWS * g.pitch + 6 * (size_t)g.bp + (size_t)gm_atiles(bands) * 16 * GM_GP + 64 +
+    return sizeof(float) * (5 * (size_t)GM_ROWS * g.pitch + 6 * (size_t)g.bp + (size_t)gm_atiles(bands) * 16 * GM_GP + 128 +
                             gm_raw(bands));
 }
 
@@ -365,6 +369,281 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
     }
 }
 
+// ---- filter gradient of one layer (step B of the backward kernels) ---------------------------------------------------
+// G_a = sum_j X_{j+a}^T . Z_j for every tile offset a in [a_lo, a_hi] (X_t, Z_t: the 16-column tiles of the [16 x B] LDS
+// images; tap t = d + pad is the sum of diagonal d of the G_a that contain it).  Work items are (offset, half of the
+// column tiles) -- layers with fewer offsets than waves (k <= B / 4 at 360 bands: 5 - 7 offsets) cut the j axis at nt / 2,
+// so that they still feed 8 waves -- in half-major, offset-minor order; the list is cut into GM_WAVES contiguous runs of
+// nearly equal work (gm_wgrad_schedule, once per block) and a wave sweeps its run in sub-runs of <= GM_RUN CONSECUTIVE
+// offsets: at column tile j the offsets a0 .. a0 + C - 1 multiply X tiles j + a0 .. j + a0 + C - 1 by the SAME Z tile, and
+// the next j needs one new X tile and one new Z tile -- 8 fragment words for 4 C MFMAs where one (offset, j) pair at a
+// time took 8 for 4 (round-4 phase stamps: this step 112 k cycles per row tile against 64 k of MFMA issue on its busiest
+// SIMD).  An X tile outside [0, nt) enters as zeros (the ragged ends of a sub-run: C (C - 1) / 2 idle tile pairs).  Fixed
+// order of the sums: j ascending inside an item, k-steps 0..3 (two chains 0,2 / 1,3 when C <= 2), halves added in order
+// by gm_diag_sum.
+#ifndef GM_RUN
+#define GM_RUN 4
+#endif
+#ifndef GM_BSTEP
+#define GM_BSTEP 0  // 0: round-3 form (gm_wgrad_tiles_v0), measured faster (NOTES 4.J); 1: balanced runs of consecutive offsets
+#endif
+#ifndef GM_BSCHED
+#define GM_BSCHED 1
+#endif
+#ifndef GM_BDIAG
+#define GM_BDIAG 0  // timing diagnostics of the filter-gradient step (results garbage): 1 = no fragment reads in the j loop,
+                    // 2 = no MFMAs
+#endif
+struct GmItems {
+    int a_lo, n_off, halves, n_items, jmid;  // half 0: column tiles [0, jmid], half 1: (jmid, nt)
+};
+__device__ __forceinline__ GmItems gm_items(const GmGeo g, int ksz, int pad) {
+    GmItems it;
+    it.a_lo = -((pad + 15) / 16);
+    const int a_hi = (ksz - 1 - pad + 15) / 16;
+    it.n_off = a_hi - it.a_lo + 1;
+    it.halves = (GM_BSTEP && it.n_off < GM_WAVES && 2 * it.n_off <= gm_atiles(g.bands) && g.nt >= 2) ? 2 : 1;
+    it.n_items = it.n_off * it.halves;
+    it.jmid = it.halves == 2 ? (g.nt - 1) / 2 : g.nt - 1;
+    return it;
+}
+// column tiles [lo, hi] of item i (empty: lo > hi)
+__device__ __forceinline__ void gm_item_range(const GmItems& it, int nt, int i, int& a, int& lo, int& hi) {
+    const int h = i >= it.n_off ? 1 : 0;
+    a = it.a_lo + (i - h * it.n_off);
+    lo = max(h ? it.jmid + 1 : 0, -a);
+    hi = min(h || it.halves == 1 ? nt - 1 : it.jmid, nt - 1 - a);
+}
+// sched[l * GM_WAVES + w] = first | last << 8: the items [first, last) of layer l that wave w sweeps.  Item i goes to wave
+// floor((work before i + work_i / 2) * GM_WAVES / total) -- a running comparison, no division.
+__device__ __forceinline__ void gm_wgrad_schedule(int* sched, const GmGeo g, int L, int tid) {
+    if (tid >= L * GM_WAVES) return;
+    const int l = tid / GM_WAVES, w = tid % GM_WAVES;
+    const int ksz = gm_ksz(g.bands, l), pad = (ksz - 1) / 2;
+    const GmItems it = gm_items(g, ksz, pad);
+    int total = 0;
+    for (int i = 0; i < it.n_items; ++i) {
+        int a, lo, hi;
+        gm_item_range(it, g.nt, i, a, lo, hi);
+        total += max(0, hi - lo + 1);
+    }
+    int first = it.n_items, last = 0, cum = 0, owner = 0;
+    for (int i = 0; i < it.n_items; ++i) {
+        int a, lo, hi;
+        gm_item_range(it, g.nt, i, a, lo, hi);
+        const int wk = max(0, hi - lo + 1);
+        if (total > 0) {
+            while (owner < GM_WAVES - 1 && (owner + 1) * 2 * total <= (2 * cum + wk) * GM_WAVES) ++owner;
+        } else {
+            owner = i % GM_WAVES;
+        }
+        if (owner == w) {
+            first = min(first, i);
+            last = max(last, i + 1);
+        }
+        cum += wk;
+    }
+    if (first > last) first = last = 0;
+    sched[tid] = first | (last << 8);
+}
+
+template <int C>
+__device__ __forceinline__ void gm_wgrad_run(const float* __restrict__ X, const float* __restrict__ Z, float* __restrict__ G,
+                                             const GmGeo g, const GmItems& it, int i0, int lane) {
+    constexpr int NCH = C <= 2 ? 2 : 1;
+    const int col = lane & 15, rg = lane >> 4;
+    int a0, jA, jB;
+    gm_item_range(it, g.nt, i0, a0, jA, jB);
+    {
+        int a, lo, hi;
+        gm_item_range(it, g.nt, i0 + C - 1, a, lo, hi);
+        jA = min(jA, lo);  // the union of the items' ranges: they differ only by the clipping of j + a to [0, nt)
+        jB = max(jB, hi);
+    }
+    gm_f32x4 acc[C][NCH];
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[i][c] = gm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (jA <= jB) {
+        const float* xp = X + rg * g.pitch + col;
+        const float* zp = Z + rg * g.pitch + col;
+        // raw fragment of X tile t (address clamped); the caller replaces it by zeros where `ok` is false (wave-uniform)
+        auto xtile = [&](int t, float (&f)[4]) -> bool {
+            const bool ok = t >= 0 && t < g.nt;
+            const int tc = ok ? t : 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f[s] = xp[16 * tc + 4 * s * g.pitch];
+            return ok;
+        };
+        float xf[C][4], zf[4], xn[4], zn[4];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const bool ok = xtile(jA + a0 + i, xf[i]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xf[i][s] = ok ? xf[i][s] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zf[s] = zp[16 * jA + 4 * s * g.pitch];
+        for (int j = jA; j <= jB; ++j) {
+            // the next column tile's two new fragments, requested ahead of this tile's products (the last trip
+            // re-reads tile jB: no branch in the loop body)
+            const int jn = min(j + 1, jB);
+#if GM_BDIAG == 1
+            const bool okn = true;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { xn[s] = xf[0][s] + 1.0f; zn[s] = zf[s] + 1.0f; }
+#else
+            const bool okn = xtile(jn + a0 + C - 1, xn);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) zn[s] = zp[16 * jn + 4 * s * g.pitch];
+#endif
+#if GM_BSCHED
+            __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the eight reads below the MFMAs, right in front of their wait
+#endif
+#if GM_BDIAG == 2
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < C; ++i) acc[i][s % NCH][0] += xf[i][s] * zf[s];
+#else
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < C; ++i)
+                    acc[i][s % NCH] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[i][s], zf[s], acc[i][s % NCH], 0, 0, 0);
+#endif
+#if GM_BSCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i + 1 < C; ++i) xf[i][s] = xf[i + 1][s];
+                xf[C - 1][s] = okn ? xn[s] : 0.0f;
+                zf[s] = zn[s];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        if constexpr (NCH == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][0][e] += acc[i][1][e];
+        }
+        float* gt = G + (i0 + i) * 16 * GM_GP;  // [i_local = 4 rg + e][j_local = col]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gt[(4 * rg + e) * GM_GP + col] = acc[i][0][e];
+    }
+}
+
+__device__ __forceinline__ void gm_wgrad_tiles(const float* __restrict__ X, const float* __restrict__ Z, float* __restrict__ G,
+                                               const GmGeo g, int ksz, int pad, int run, int lane) {
+    const GmItems it = gm_items(g, ksz, pad);
+    int i0 = __builtin_amdgcn_readfirstlane(run & 0xff);
+    const int last = __builtin_amdgcn_readfirstlane(run >> 8);
+    while (i0 < last) {
+        // a sub-run: <= GM_RUN consecutive offsets of ONE half
+        const int h_end = i0 >= it.n_off ? it.n_items : it.n_off;
+        const int c = min(GM_RUN, min(last, h_end) - i0);
+        if (GM_RUN >= 4 && c >= 4) gm_wgrad_run<4>(X, Z, G, g, it, i0, lane);
+        else if (GM_RUN >= 3 && c == 3) gm_wgrad_run<3>(X, Z, G, g, it, i0, lane);
+        else if (c == 2) gm_wgrad_run<2>(X, Z, G, g, it, i0, lane);
+        else gm_wgrad_run<1>(X, Z, G, g, it, i0, lane);
+        i0 += c;
+    }
+}
+
+// GM_BSTEP=0: the round-3 form of the step (one (offset, column tile) pair at a time, offsets dealt to the waves round
+// robin), kept for A/B runs
+__device__ __forceinline__ void gm_wgrad_tiles_v0(const float* __restrict__ X, const float* __restrict__ Z,
+                                                  float* __restrict__ G, const GmGeo g, int ksz, int pad, int wave, int lane) {
+    const int col = lane & 15, rg = lane >> 4;
+    const int a_lo = -((pad + 15) / 16), a_hi = (ksz - 1 - pad + 15) / 16;
+    for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
+        gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};  // two chains (see gm_conv_tile)
+        const int j_lo = max(0, -a), j_hi = min(g.nt - 1, g.nt - 1 - a);
+        // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; n = 4 s + kq
+        const float* ap = X + rg * g.pitch + 16 * a + col;
+        const float* bp = Z + rg * g.pitch + col;
+        float fa[4], fb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            fa[s] = ap[16 * j_lo + 4 * s * g.pitch];
+            fb[s] = bp[16 * j_lo + 4 * s * g.pitch];
+        }
+        for (int jt = j_lo; jt < j_hi; ++jt) {
+            float na[4], nb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                na[s] = ap[16 * (jt + 1) + 4 * s * g.pitch];
+                nb[s] = bp[16 * (jt + 1) + 4 * s * g.pitch];
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                fa[s] = na[s];
+                fb[s] = nb[s];
+            }
+        }
+        if (j_lo <= j_hi) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += accb[e];
+        float* gt = G + (a - a_lo) * 16 * GM_GP;  // [i_local = 4 rg + e][j_local = col]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gt[(4 * rg + e) * GM_GP + col] = acc[e];
+    }
+}
+
+// tap `tap` of the layer: the sum of diagonal d = tap - pad of G, halves ascending, tiles ascending, rows ascending
+__device__ __forceinline__ float gm_diag_sum(const float* __restrict__ G, const GmGeo g, int ksz, int pad, int tap) {
+    const GmItems it = gm_items(g, ksz, pad);
+    const int a_hi = it.a_lo + it.n_off - 1;
+    const int d = tap - pad;
+    const int a0 = (d + 15 >= 0 ? (d + 15) / 16 : -((-(d + 15) + 15) / 16));  // floor((d + 15) / 16)
+    float total = 0.0f;
+#pragma unroll 1
+    for (int h = 0; h < it.halves; ++h) {
+        // every candidate element is fetched (absent ones from G[0], then replaced by 0) before the first add: as
+        // two nested loops with data-dependent bounds this was <= 32 dependent LDS round trips per thread and layer
+        float v[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int a = a0 - 1 + t;
+            const int dl = d - 16 * a;  // i_local - j_local
+            const bool tile_ok = a >= it.a_lo && a <= a_hi;
+            // element il of the diagonal sits at gt[il * (GM_GP + 1) - dl]: one base per tile, immediate offsets;
+            // an absent element is read from wherever that lands inside the block's LDS and replaced by 0
+            // (volatile: hipcc otherwise sinks every load under its predicate -- 32 branches, each with its own
+            // LDS round trip)
+            typedef const volatile __attribute__((address_space(3))) float* gm_lds_vptr;
+            const gm_lds_vptr bp =
+                (gm_lds_vptr)(G + (tile_ok ? h * it.n_off + a - it.a_lo : 0) * 16 * GM_GP - (tile_ok ? dl : 0));
+            const int lo = tile_ok ? max(0, dl) : 16, hi = min(15, 15 + dl);
+#pragma unroll
+            for (int il = 0; il < 16; ++il) {
+                const float x = bp[il * (GM_GP + 1)];
+                v[t][il] = (il >= lo && il <= hi) ? x : 0.0f;
+            }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int il = 0; il < 16; ++il) s += v[t][il];  // tiles ascending, rows ascending
+        total = h == 0 ? s : total + s;
+    }
+    return total;
+}
+
 // ---- backward ------------------------------------------------------------------------------------------------------
 // pw[blocks][sum k], pb[blocks][8]: this block's partial filter / bias gradients (summed over its row tiles).
 template <bool ENC, bool STASH, bool TAP = false>
@@ -393,9 +672,11 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     float* wz2 = wz + 3 * g.bp;    // second tap table of the forward recompute
     float* G = wz2 + 3 * g.bp;     // [a][16][GM_GP]
     float* red = G + gm_atiles(bands) * 16 * GM_GP;  // [GM_WAVES] bias-gradient partials, [GM_WAVES + l] their sums
-    float* raw = red + 64;                            // LDS copy of every layer's taps + biases
+    int* sched = reinterpret_cast<int*>(red + 64);    // [L][GM_WAVES] filter-gradient runs (gm_wgrad_schedule)
+    float* raw = red + 128;                           // LDS copy of every layer's taps + biases
     gm_zero(gm_lds, 5 * img + 6 * g.bp, tid);
     gm_stage_raw(raw, bands, w, bias, tid);
+    gm_wgrad_schedule(sched, g, L, tid);
     __syncthreads();
 
     float dwacc[7];  // thread t owns tap t of every layer; red[GM_WAVES + l] collects the bias gradients
@@ -539,86 +820,19 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
                 red[GM_WAVES + l] += s;
             }
             GM_MARK(3)  // step A
-            // ---- step B: filter gradient.  Tile offset a: diagonals d = i - j in [16 a - 15, 16 a + 15] ----
-            const int a_lo = -((pad + 15) / 16), a_hi = (ksz - 1 - pad + 15) / 16;
-            for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
-                gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};  // two chains (see gm_conv_tile)
-                const int j_lo = max(0, -a), j_hi = min(g.nt - 1, g.nt - 1 - a);
-                // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; n = 4 s + kq
-                const float* ap = X + rg * g.pitch + 16 * a + col;
-                const float* bp = Z + rg * g.pitch + col;
-                // the next tile pair's fragments are requested ahead of this pair's MFMAs (here the hand-written prefetch
-                // pays: backward 167 vs 190 us at N = 4096 -- unlike in gm_conv_tile, GM_PIPE)
-                float fa[4], fb[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    fa[s] = ap[16 * j_lo + 4 * s * g.pitch];
-                    fb[s] = bp[16 * j_lo + 4 * s * g.pitch];
-                }
-                for (int jt = j_lo; jt < j_hi; ++jt) {
-                    float na[4], nb[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        na[s] = ap[16 * (jt + 1) + 4 * s * g.pitch];
-                        nb[s] = bp[16 * (jt + 1) + 4 * s * g.pitch];
-                    }
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        fa[s] = na[s];
-                        fb[s] = nb[s];
-                    }
-                }
-                if (j_lo <= j_hi) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += accb[e];
-                float* gt = G + (a - a_lo) * 16 * GM_GP;  // [i_local = 4 rg + e][j_local = col]
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gt[(4 * rg + e) * GM_GP + col] = acc[e];
-            }
+            // ---- step B: filter gradient (gm_wgrad_tiles: balanced runs of consecutive tile offsets) ----
+#if GM_BSTEP
+            gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane);
+#else
+            gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane);
+#endif
             __syncthreads();
             GM_MARK(4)  // step B products
 #ifndef GM_NO_DIAGSUM
 #define GM_NO_DIAGSUM 0
 #endif
-            if (!GM_NO_DIAGSUM && tid < ksz) {  // tap t = d + pad: sum the diagonal d of G, tiles ascending, rows ascending
-                const int d = tid - pad;
-                float s = 0.0f;
-                const int a0 = (d + 15 >= 0 ? (d + 15) / 16 : -((-(d + 15) + 15) / 16));  // floor((d + 15) / 16)
-                // every candidate element is fetched (absent ones from G[0], then replaced by 0) before the first add: as
-                // two nested loops with data-dependent bounds this was <= 32 dependent LDS round trips per thread and layer
-                // -- 28 % of the kernel at 64 bands, 9 % at 360
-                float v[2][16];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int a = a0 - 1 + t;
-                    const int dl = d - 16 * a;  // i_local - j_local
-                    const bool tile_ok = a >= a_lo && a <= a_hi;
-                    // element il of the diagonal sits at gt[il * (GM_GP + 1) - dl]: one base per tile, immediate offsets;
-                    // an absent element is read from wherever that lands inside the block's LDS and replaced by 0
-                    // (volatile: hipcc otherwise sinks every load under its predicate -- 32 branches, each with its own
-                    // LDS round trip)
-                    typedef const volatile __attribute__((address_space(3))) float* gm_lds_vptr;
-                    const gm_lds_vptr bp = (gm_lds_vptr)(G + (tile_ok ? a - a_lo : 0) * 16 * GM_GP - (tile_ok ? dl : 0));
-                    const int lo = tile_ok ? max(0, dl) : 16, hi = min(15, 15 + dl);
-#pragma unroll
-                    for (int il = 0; il < 16; ++il) {
-                        const float x = bp[il * (GM_GP + 1)];
-                        v[t][il] = (il >= lo && il <= hi) ? x : 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int il = 0; il < 16; ++il) s += v[t][il];  // tiles ascending, rows ascending
+            if (!GM_NO_DIAGSUM && tid < ksz) {  // thread t owns tap t
+                const float s = gm_diag_sum(G, g, ksz, pad, tid);
 #pragma unroll
                 for (int q = 0; q < 7; ++q)
                     if (q == l) dwacc[q] += s;
@@ -681,6 +895,251 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #endif
 }
 
+// ---- backward from kept activations, two resident blocks per CU (round 4) -----------------------------------------------
+// The round-3 kernel above keeps five [16 x B] images (three of them the gradient ring dn_l / dn_{l-1} / dn_{l-2}), two tap
+// tables and every layer's taps in LDS: 161 KB at 360 bands, ONE block per CU, and its per-layer bookkeeping (step A: 12
+// elements per lane, each an LDS read-modify-write chain inside a divergent branch; the sub-run set-up of step B; the
+// diagonal sums) is ~60 % of its cycles with the matrix pipe idle (phase stamps, NOTES 4.J).  This kernel serves the form
+// the train ops run (activations kept by the forward pass) with the ring in REGISTERS: a lane owns the same 12 elements
+// (MFMA C layout) in every layer -- step A reads dn_l from registers, step C adds the data-gradient tile to registers --
+// and of the kept activations only the layer at hand is resident (12 floats, requested one layer ahead, like the taps and
+// the branch bits).  LDS: dz_l, n_{l-1}, ONE tap table, the G tiles = 80.6 KB at 360 bands, <= 128 registers: two
+// blocks per CU, the bookkeeping of one under the products of the other.  Same sums in the same order as the kernel
+// above (dn_{l-1} = (dn_{l-1} + dn_l) + dz_l . T^T), so the two stay bit-identical.
+__host__ __device__ inline size_t gm_bwd2_lds(int bands) {
+    const GmGeo g = gm_geo(bands);
+    return sizeof(float) * (2 * (size_t)GM_ROWS * g.pitch + 3 * (size_t)g.bp + (size_t)gm_atiles(bands) * 16 * GM_GP + 128);
+}
+
+template <bool ENC, bool TAP = false>
+__global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gan_generator_bwd2_mfma_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, int bands,
+    const float* __restrict__ w, float* __restrict__ dx, int64_t lddx, int accumulate_dx, float* __restrict__ pw,
+    float* __restrict__ pb, int wtotal, int slabs, const float* __restrict__ stash, const float* __restrict__ d_enc,
+    int64_t ld_denc, GmApps apps) {
+    constexpr int L = ENC ? 4 : 7;
+    extern __shared__ __attribute__((aligned(16))) float gm_lds[];
+    const GmGeo g = gm_geo(bands);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bpa = gridDim.x / apps.n_apps, app = blockIdx.x / bpa, blk = blockIdx.x - app * bpa;
+    w += app * apps.w_stride;
+    x += (int64_t)app * n * ldx;
+    dout += (int64_t)app * n * lddo;
+    if (dx != nullptr) dx += (int64_t)app * n * lddx;
+    if constexpr (TAP) d_enc += (int64_t)app * n * ld_denc;
+    const int col = lane & 15, rg = lane >> 4;
+    const int img = GM_ROWS * g.pitch;
+    float* Z = gm_lds;        // dz_l
+    float* X = gm_lds + img;  // n_{l-1}
+    float* wz = gm_lds + 2 * img;
+    float* G = wz + 3 * g.bp;  // [item][16][GM_GP]
+    float* red = G + gm_atiles(bands) * 16 * GM_GP;  // [GM_WAVES] bias-gradient partials, [GM_WAVES + l] their sums
+    int* sched = reinterpret_cast<int*>(red + 64);   // [L][GM_WAVES] filter-gradient runs
+    gm_zero(gm_lds, 2 * img + 3 * g.bp, tid);  // image padding and tap margins stay zero
+    gm_wgrad_schedule(sched, g, L, tid);
+    if (tid < 7) red[GM_WAVES + tid] = 0.0f;
+    __syncthreads();
+
+    float dwacc[7];  // thread t owns tap t of every layer
+#pragma unroll
+    for (int l = 0; l < 7; ++l) dwacc[l] = 0.0f;
+    const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
+    constexpr int kOOB = 0x7fffffff;
+    for (int64_t t = blk; t < tiles; t += bpa) {
+        const int64_t r0 = t * GM_ROWS;
+        const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
+        // (opaque copies: hipcc otherwise hoists the ~50 element addresses of the tile and layer loops out of them and
+        // spills them)
+        int colt = col, rgt = rg, tidt = tid;
+        asm volatile("" : "+v"(colt), "+v"(rgt), "+v"(tidt));
+        // Row-indexed operands through raw buffer accesses (scalar descriptor per tile, one 32-bit offset per element, rows
+        // beyond the batch and columns beyond the bands out of range: loads return 0, stores are dropped) -- with 64-bit
+        // addresses for 12 elements per lane the kernel does not fit 128 registers.
+        auto tile_rsrc = [&](const float* base, int64_t ld) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(base + r0 * ld), 0,
+                                                     __builtin_amdgcn_readfirstlane(((rows_valid - 1) * (int)ld + g.bands) * 4),
+                                                     0x00020000);
+        };
+        auto elem_off = [&](int m, int e, int ld) {  // byte offset of element (row 4 rg + e, column tile wave + 8 m)
+            const int c = 16 * (wave + GM_WAVES * m) + colt;
+            return c < g.bands ? ((4 * rgt + e) * ld + c) * 4 : kOOB;
+        };
+        // kept activations of this row tile: float4 (slot q, m) of thread tid at ((q * GM_MAXT + m) * 512 + tid) * 16 bytes
+        const __amdgpu_buffer_rsrc_t keep_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(stash + (size_t)(app * tiles + t) * GmKeep<ENC>::V4 * GM_THREADS * 4), 0,
+            GmKeep<ENC>::V4 * GM_THREADS * 16, 0x00020000);
+        auto load_slot = [&](int q, float (&v)[GM_MAXT][4]) {  // tiles beyond nt hold nothing
+            // (dword loads: a dwordx4 raw buffer load under this dword descriptor returned only its first component)
+            const int so = __builtin_amdgcn_readfirstlane(q * GM_MAXT * GM_THREADS * 16);
+#pragma unroll
+            for (int m = 0; m < GM_MAXT; ++m) {
+                const int vo = wave + GM_WAVES * m < g.nt ? tidt * 16 + m * GM_THREADS * 16 : kOOB;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[m][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(keep_rsrc, vo + 4 * e, so, 0));
+            }
+        };
+        auto load_mask = [&](int l) {  // branch bits of layer l: word l of the two uint4 behind the slots
+            return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
+                keep_rsrc, tid * 16 + (l & 3) * 4,
+                __builtin_amdgcn_readfirstlane((GmKeep<ENC>::SLOTS * GM_MAXT + (l >> 2)) * GM_THREADS * 16), 0);
+        };
+        float da[GM_MAXT][4], db[GM_MAXT][4], xin[GM_MAXT][4];
+        {  // dn_L = dout, straight into the lanes that own it; zero outside the real rows / bands
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(dout, lddo);
+#pragma unroll
+            for (int m = 0; m < GM_MAXT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    da[m][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, elem_off(m, e, (int)lddo), 0, 0));
+                    db[m][e] = 0.0f;
+                }
+        }
+        load_slot(ENC ? 2 : 6, xin);  // the top layer's operand: n_3's input n_2 (encoder) / the tanh output (full stack)
+        int woff = gm_woff(bands, L);
+        float wreg = 0.0f;  // tap `tid` of the layer at hand, requested one layer ahead
+        {
+            const int k0 = gm_ksz(bands, L - 1);
+            if (tid < k0) wreg = w[woff - k0 + tid];
+        }
+        unsigned mk = ENC ? load_mask(3) : 0u;  // branch bits of the layer at hand (the tanh layer has none)
+#pragma unroll 1
+        for (int l = L - 1; l >= 0; --l) {
+            const int ksz = gm_ksz(bands, l), pad = (ksz - 1) / 2;
+            woff -= ksz;
+            const bool top_tanh = !ENC && l == 6;
+            const bool init_b = l == L - 1 || (!ENC && l == 5);  // the top skip layer initialises dn_{l-1}
+            int lbase = 4 * rg * g.pitch + 16 * wave + col;  // this lane's element (m = 0, e = 0) in a [16 x pitch] image
+            asm volatile("" : "+v"(lbase));
+            if constexpr (TAP && !ENC) {
+                // encoder tap: the gradient that reached the encoder-only application's output joins dn_4
+                if (l == 3) {
+                    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(d_enc, ld_denc);
+#pragma unroll
+                    for (int m = 0; m < GM_MAXT; ++m)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            da[m][e] += __builtin_bit_cast(
+                                float, __builtin_amdgcn_raw_buffer_load_b32(rs, elem_off(m, e, (int)ld_denc), 0, 0));
+                }
+            }
+            // ---- step A: dz_l and n_{l-1} into LDS, skip gradients in registers, bias gradient ----
+            for (int i = tid; i < g.bands; i += GM_THREADS) wz[g.bp + i] = i < ksz ? wreg : 0.0f;
+            float dbl = 0.0f;
+#pragma unroll
+            for (int m = 0; m < GM_MAXT; ++m) {
+                const int jt = wave + GM_WAVES * m;
+                if (jt >= g.nt) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = lbase + e * g.pitch + 16 * GM_WAVES * m;
+                    const float gd = da[m][e];
+                    float f;
+                    if (top_tanh) {
+                        const float y = xin[m][e];
+                        f = 1.0f - y * y;
+                    } else {
+                        f = ((mk >> (4 * m + e)) & 1u) ? 1.0f : 0.1f;
+                    }
+                    const float z = gd * f;
+                    Z[o] = z;
+                    dbl += z;
+                    // n_l = c_l + n_{l-1} (+ n_{l-2}); n_6 only feeds the last convolution
+                    const float nb = top_tanh ? 0.0f : (init_b ? gd : db[m][e] + gd);
+                    db[m][e] = gd;     // dn_{l-2} starts from dn_l (unused below layer 1 and under the tanh layer)
+                    da[m][e] = nb;     // dn_{l-1} so far; step C adds dz_l . T^T
+                    if (l >= 1 && !top_tanh) X[o] = xin[m][e];
+                }
+            }
+            if (top_tanh) {  // the tanh layer's input is n_5: its own slot, requested only now (the registers held y)
+                load_slot(5, xin);
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m) {
+                    const int jt = wave + GM_WAVES * m;
+                    if (jt >= g.nt) break;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[lbase + e * g.pitch + 16 * GM_WAVES * m] = xin[m][e];
+                }
+            }
+            if (l == 0) gm_load_rows(X, g, x + r0 * ldx, ldx, rows_valid, tid);
+            // next layer's operands: its input n_{l-2}, its taps, its branch bits
+            if (l >= 2) load_slot(l - 2, xin);
+            if (l >= 1) {
+                const int k1 = gm_ksz(bands, l - 1);
+                wreg = tid < k1 ? w[woff - k1 + tid] : 0.0f;
+                mk = load_mask(l - 1);
+            }
+            // bias gradient: lanes -> wave -> block, fixed order
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dbl += __shfl_xor(dbl, off, 64);
+            if (lane == 0) red[wave] = dbl;
+            __syncthreads();
+            if (tid == 0) {
+                float s = 0.0f;
+#pragma unroll
+                for (int wv = 0; wv < GM_WAVES; ++wv) s += red[wv];
+                red[GM_WAVES + l] += s;
+            }
+            // ---- step B: filter gradient ----
+#if GM_BSTEP
+            gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane);
+#else
+            gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane);
+#endif
+            __syncthreads();
+            if (tid < ksz) {
+                const float s = gm_diag_sum(G, g, ksz, pad, tid);
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q == l) dwacc[q] += s;
+            }
+            // ---- step C: data gradient dn_{l-1} += dz_l . T^T ----
+            if (l > 0 || dx != nullptr) {
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m) {
+                    const int jt = wave + GM_WAVES * m;
+                    if (jt >= g.nt) break;
+                    const gm_f32x4 acc = gm_conv_tile<true>(Z, wz, g, 16 * jt, ksz, pad, lane);
+                    if (16 * jt + col < g.bands) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) da[m][e] += acc[e];
+                    }
+                }
+            }
+            __syncthreads();  // every wave has left Z / X / wz / G
+        }
+        if (dx != nullptr) {
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(dx, lddx);
+#pragma unroll
+            for (int m = 0; m < GM_MAXT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = elem_off(m, e, (int)lddx);
+                    float v = da[m][e];
+                    if (accumulate_dx) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, o, 0, 0);
+                }
+        }
+    }
+    // this block's partials; the slabs of the blocks beyond the grid (the planner's reduce sums `slabs` of them) are zeros
+    for (int sb = blockIdx.x + gridDim.x; sb < slabs; sb += gridDim.x) {  // (single application only: slabs == gridDim.x else)
+        for (int i = tid; i < wtotal; i += GM_THREADS) pw[(size_t)sb * wtotal + i] = 0.0f;
+        if (tid < 8) pb[(size_t)sb * 8 + tid] = 0.0f;
+    }
+    const int64_t slab = apps.pw_stride ? (int64_t)blk : (int64_t)blockIdx.x;
+    pw += app * apps.pw_stride;
+    pb += app * apps.pb_stride;
+    float* pwb = pw + (size_t)slab * wtotal;
+    int woff = 0;
+#pragma unroll
+    for (int l = 0; l < 7; ++l) {
+        const int ksz = gm_ksz(bands, l);
+        if (tid < ksz) pwb[woff + tid] = l < L ? dwacc[l] : 0.0f;
+        woff += ksz;
+    }
+    if (tid < 8) pb[(size_t)slab * 8 + tid] = tid < L ? red[GM_WAVES + tid] : 0.0f;
+}
+
 }  // namespace
 
 // Entry points used by gan.hip's dispatch (same contracts as the VALU kernels there).
@@ -736,6 +1195,22 @@ int hypel_gm_bwd(const float* x, int64_t ldx, const float* dout, int64_t lddo, i
     // every one of the `blocks` partial slabs is written (the planner's reduce sums all of them)
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     const int grid = n_apps > 1 ? blocks : (int)(tiles < blocks ? tiles : blocks);
+    // from kept activations: the register-ring kernel (two resident blocks per CU); HYPEL_GAN_BWD2=0 = the round-3 kernel
+    static const int use_bwd2 = getenv("HYPEL_GAN_BWD2") ? atoi(getenv("HYPEL_GAN_BWD2")) : 1;
+    if (keep && use_bwd2) {
+        const size_t lds2 = gm_bwd2_lds(bands);
+#define GM_BWD2(K)                                                                                                     \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);              \
+        hipLaunchKernelGGL(K, dim3(grid), dim3(GM_THREADS), lds2, st, x, ldx, dout, lddo, n, bands, w, dx, lddx,       \
+                           accumulate_dx, pw, pb, wtotal, blocks, keep, d_enc, ld_denc, apps);                         \
+    } while (0)
+        if (only_encoder) GM_BWD2((gan_generator_bwd2_mfma_kernel<true, false>));
+        else if (d_enc) GM_BWD2((gan_generator_bwd2_mfma_kernel<false, true>));
+        else GM_BWD2((gan_generator_bwd2_mfma_kernel<false, false>));
+#undef GM_BWD2
+        return 0;
+    }
 #define GM_BWD_ARGS x, ldx, dout, lddo, n, bands, w, b, dx, lddx, accumulate_dx, pw, pb, wtotal, blocks, keep, d_enc, ld_denc, apps
     if (only_encoder) {
         if (keep) GM_LAUNCH((gan_generator_bwd_mfma_kernel<true, true>), GM_BWD_ARGS);
