@@ -369,6 +369,15 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
     }
 }
 
+// Sample rows of the filter-gradient products: k-step s, k-slot kq multiply row gm_brow(kq) + s of the X and Z images.  The
+// two k-slots a ds_read_b32 lane group serves (kq = 0, 1 / 2, 3) are 8 rows apart: with the images' pitch of 18 mod 32
+// (chosen for the convolution tiles' fragments) that is a bank distance of 16, so the 2 x 16 consecutive columns of a
+// group hit 32 banks (rows 4 s + kq collided in two banks per group: every fragment read took two LDS cycles more).
+#ifndef GM_BROW
+#define GM_BROW 1
+#endif
+__device__ __forceinline__ int gm_brow(int kq) { return GM_BROW ? 4 * (kq >> 1) + 8 * (kq & 1) : 4 * kq; }
+
 // ---- filter gradient of one layer (step B of the backward kernels) ---------------------------------------------------
 // G_a = sum_j X_{j+a}^T . Z_j for every tile offset a in [a_lo, a_hi] (X_t, Z_t: the 16-column tiles of the [16 x B] LDS
 // images; tap t = d + pad is the sum of diagonal d of the G_a that contain it).  Work items are (offset, half of the
@@ -466,14 +475,14 @@ __device__ __forceinline__ void gm_wgrad_run(const float* __restrict__ X, const 
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[i][c] = gm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (jA <= jB) {
-        const float* xp = X + rg * g.pitch + col;
-        const float* zp = Z + rg * g.pitch + col;
+        const float* xp = X + gm_brow(rg) * g.pitch + col;
+        const float* zp = Z + gm_brow(rg) * g.pitch + col;
         // raw fragment of X tile t (address clamped); the caller replaces it by zeros where `ok` is false (wave-uniform)
         auto xtile = [&](int t, float (&f)[4]) -> bool {
             const bool ok = t >= 0 && t < g.nt;
             const int tc = ok ? t : 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) f[s] = xp[16 * tc + 4 * s * g.pitch];
+            for (int s = 0; s < 4; ++s) f[s] = xp[16 * tc + s * g.pitch];
             return ok;
         };
         float xf[C][4], zf[4], xn[4], zn[4];
@@ -484,7 +493,7 @@ __device__ __forceinline__ void gm_wgrad_run(const float* __restrict__ X, const 
             for (int s = 0; s < 4; ++s) xf[i][s] = ok ? xf[i][s] : 0.0f;
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) zf[s] = zp[16 * jA + 4 * s * g.pitch];
+        for (int s = 0; s < 4; ++s) zf[s] = zp[16 * jA + s * g.pitch];
         for (int j = jA; j <= jB; ++j) {
             // the next column tile's two new fragments, requested ahead of this tile's products (the last trip
             // re-reads tile jB: no branch in the loop body)
@@ -496,7 +505,7 @@ __device__ __forceinline__ void gm_wgrad_run(const float* __restrict__ X, const 
 #else
             const bool okn = xtile(jn + a0 + C - 1, xn);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) zn[s] = zp[16 * jn + 4 * s * g.pitch];
+            for (int s = 0; s < 4; ++s) zn[s] = zp[16 * jn + s * g.pitch];
 #endif
 #if GM_BSCHED
             __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the eight reads below the MFMAs, right in front of their wait
@@ -563,26 +572,37 @@ __device__ __forceinline__ void gm_wgrad_tiles_v0(const float* __restrict__ X, c
     for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
         gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};  // two chains (see gm_conv_tile)
         const int j_lo = max(0, -a), j_hi = min(g.nt - 1, g.nt - 1 - a);
-        // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; n = 4 s + kq
-        const float* ap = X + rg * g.pitch + 16 * a + col;
-        const float* bp = Z + rg * g.pitch + col;
+        // A[i_local][n] = X[n][16 (jt + a) + i_local], B[n][j_local] = Z[n][16 jt + j_local]; sample row n of k-step s,
+        // k-slot kq: gm_brow(kq) + s
+        const float* ap = X + gm_brow(rg) * g.pitch + 16 * a + col;
+        const float* bp = Z + gm_brow(rg) * g.pitch + col;
         float fa[4], fb[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            fa[s] = ap[16 * j_lo + 4 * s * g.pitch];
-            fb[s] = bp[16 * j_lo + 4 * s * g.pitch];
+            fa[s] = ap[16 * j_lo + s * g.pitch];
+            fb[s] = bp[16 * j_lo + s * g.pitch];
         }
         for (int jt = j_lo; jt < j_hi; ++jt) {
             float na[4], nb[4];
+#if GM_BDIAG == 1
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { na[s] = fa[s] + 1.0f; nb[s] = fb[s] + 1.0f; }
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                na[s] = ap[16 * (jt + 1) + 4 * s * g.pitch];
-                nb[s] = bp[16 * (jt + 1) + 4 * s * g.pitch];
+                na[s] = ap[16 * (jt + 1) + s * g.pitch];
+                nb[s] = bp[16 * (jt + 1) + s * g.pitch];
             }
+#endif
+#if GM_BDIAG == 2
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] += fa[s] * fb[s];
+#else
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
             accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
             accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 fa[s] = na[s];
@@ -895,6 +915,20 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #endif
 }
 
+// Block barrier of the register-ring backward kernel's layer loop: every wave's LDS accesses are complete, its global
+// loads (the next layer's kept activations, taps and branch bits, requested a layer ahead) stay in flight --
+// __syncthreads() waits for vmcnt(0) too, which put one exposed HBM round trip into every layer.
+#ifndef GM_LDS_BARRIER
+#define GM_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void gm_lds_barrier() {
+#if GM_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // ---- backward from kept activations, two resident blocks per CU (round 4) -----------------------------------------------
 // The round-3 kernel above keeps five [16 x B] images (three of them the gradient ring dn_l / dn_{l-1} / dn_{l-2}), two tap
 // tables and every layer's taps in LDS: 161 KB at 360 bands, ONE block per CU, and its per-layer bookkeeping (step A: 12
@@ -945,8 +979,16 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int l = 0; l < 7; ++l) dwacc[l] = 0.0f;
     const int64_t tiles = (n + GM_ROWS - 1) / GM_ROWS;
     constexpr int kOOB = 0x7fffffff;
+#if GM_DIAG == 5
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tmark = clock64();
+#endif
+#if GM_DIAG == 6  // occupancy timeline: every block reports its start / end (100 MHz wall clock) and where it ran
+    const long long wall0 = wall_clock64();
+#endif
     for (int64_t t = blk; t < tiles; t += bpa) {
         const int64_t r0 = t * GM_ROWS;
+        GM_MARK(0)
         const int rows_valid = (int)min((int64_t)GM_ROWS, n - r0);
         // (opaque copies: hipcc otherwise hoists the ~50 element addresses of the tile and layer loops out of them and
         // spills them)
@@ -1003,6 +1045,7 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             if (tid < k0) wreg = w[woff - k0 + tid];
         }
         unsigned mk = ENC ? load_mask(3) : 0u;  // branch bits of the layer at hand (the tanh layer has none)
+        GM_MARK(2)  // tile set-up: dout and the top layer's operands requested
 #pragma unroll 1
         for (int l = L - 1; l >= 0; --l) {
             const int ksz = gm_ksz(bands, l), pad = (ksz - 1) / 2;
@@ -1061,10 +1104,14 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     for (int e = 0; e < 4; ++e) X[lbase + e * g.pitch + 16 * GM_WAVES * m] = xin[m][e];
                 }
             }
+            GM_MARK(1)  // (diagnostics) step A up to the element loop's end
             if (l == 0) gm_load_rows(X, g, x + r0 * ldx, ldx, rows_valid, tid);
             // next layer's operands: its input n_{l-2}, its taps, its branch bits
-            if (l >= 2) load_slot(l - 2, xin);
-            if (l >= 1) {
+#ifndef GM_ADIAG
+#define GM_ADIAG 0  // timing diagnostics (results garbage): 1 = no requests for the next layer's operands
+#endif
+            if (!GM_ADIAG && l >= 2) load_slot(l - 2, xin);
+            if (!GM_ADIAG && l >= 1) {
                 const int k1 = gm_ksz(bands, l - 1);
                 wreg = tid < k1 ? w[woff - k1 + tid] : 0.0f;
                 mk = load_mask(l - 1);
@@ -1073,26 +1120,30 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) dbl += __shfl_xor(dbl, off, 64);
             if (lane == 0) red[wave] = dbl;
-            __syncthreads();
+            gm_lds_barrier();
             if (tid == 0) {
                 float s = 0.0f;
 #pragma unroll
                 for (int wv = 0; wv < GM_WAVES; ++wv) s += red[wv];
                 red[GM_WAVES + l] += s;
             }
+            GM_MARK(3)  // step A
             // ---- step B: filter gradient ----
 #if GM_BSTEP
             gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane);
 #else
             gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane);
 #endif
-            __syncthreads();
+            GM_MARK(7)  // (diagnostics) step B: wave 0's own products
+            gm_lds_barrier();
+            GM_MARK(4)  // step B products
             if (tid < ksz) {
                 const float s = gm_diag_sum(G, g, ksz, pad, tid);
 #pragma unroll
                 for (int q = 0; q < 7; ++q)
                     if (q == l) dwacc[q] += s;
             }
+            GM_MARK(5)  // diagonal sums
             // ---- step C: data gradient dn_{l-1} += dz_l . T^T ----
             if (l > 0 || dx != nullptr) {
 #pragma unroll
@@ -1106,7 +1157,8 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     }
                 }
             }
-            __syncthreads();  // every wave has left Z / X / wz / G
+            gm_lds_barrier();  // every wave has left Z / X / wz / G
+            GM_MARK(6)  // step C
         }
         if (dx != nullptr) {
             const __amdgpu_buffer_rsrc_t rs = tile_rsrc(dx, lddx);
@@ -1138,6 +1190,21 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         woff += ksz;
     }
     if (tid < 8) pb[(size_t)slab * 8 + tid] = tid < L ? red[GM_WAVES + tid] : 0.0f;
+#if GM_DIAG == 5
+    GM_MARK(7)
+    if (tid == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 8; ++i) pb[i] = (float)dbg[i];
+#endif
+#if GM_DIAG == 6
+    __syncthreads();
+    if (tid == 0) {
+        int* o = reinterpret_cast<int*>(pb + (size_t)slab * 8);
+        o[0] = (int)(unsigned)wall0;
+        o[1] = (int)(unsigned)wall_clock64();
+        o[2] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+        o[3] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+#endif
 }
 
 }  // namespace
