@@ -369,6 +369,21 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(cons
     }
 }
 
+// Sum over the 64 lanes of a wave in registers (row_shr 1 / 2 / 4 / 8 inside the rows of 16, row_bcast15 / 31 across them:
+// lane 63 ends up with the total), returned wave-uniform.  Six ds_bpermute round trips (__shfl_xor) per layer otherwise.
+__device__ __forceinline__ float gm_wave_sum(float v) {
+#define GM_DPP_ADD(ctrl, rows)                                                                                        \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rows, 0xf, false))
+    GM_DPP_ADD(0x111, 0xf);
+    GM_DPP_ADD(0x112, 0xf);
+    GM_DPP_ADD(0x114, 0xf);
+    GM_DPP_ADD(0x118, 0xf);
+    GM_DPP_ADD(0x142, 0xa);
+    GM_DPP_ADD(0x143, 0xc);
+#undef GM_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Sample rows of the filter-gradient products: k-step s, k-slot kq multiply row gm_brow(kq) + s of the X and Z images.  The
 // two k-slots a ds_read_b32 lane group serves (kq = 0, 1 / 2, 3) are 8 rows apart: with the images' pitch of 18 mod 32
 // (chosen for the convolution tiles' fragments) that is a bank distance of 16, so the 2 x 16 consecutive columns of a
@@ -829,8 +844,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
             }
             if (l == 0) gm_load_rows(X, g, x + r0 * ldx, ldx, rows_valid, tid);
             // bias gradient: lanes -> wave -> block, fixed order
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) dbl += __shfl_xor(dbl, off, 64);
+            dbl = gm_wave_sum(dbl);
             if (lane == 0) red[wave] = dbl;
             __syncthreads();
             if (tid == 0) {
@@ -1053,7 +1067,8 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             const bool top_tanh = !ENC && l == 6;
             const bool init_b = l == L - 1 || (!ENC && l == 5);  // the top skip layer initialises dn_{l-1}
             int lbase = 4 * rg * g.pitch + 16 * wave + col;  // this lane's element (m = 0, e = 0) in a [16 x pitch] image
-            asm volatile("" : "+v"(lbase));
+            int lane_l = lane, tid_l = tid;  // (opaque per layer: nothing derived from them is hoisted out of the layer loop)
+            asm volatile("" : "+v"(lbase), "+v"(lane_l), "+v"(tid_l));
             if constexpr (TAP && !ENC) {
                 // encoder tap: the gradient that reached the encoder-only application's output joins dn_4
                 if (l == 3) {
@@ -1117,8 +1132,7 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 mk = load_mask(l - 1);
             }
             // bias gradient: lanes -> wave -> block, fixed order
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) dbl += __shfl_xor(dbl, off, 64);
+            dbl = gm_wave_sum(dbl);
             if (lane == 0) red[wave] = dbl;
             gm_lds_barrier();
             if (tid == 0) {
@@ -1130,15 +1144,15 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             GM_MARK(3)  // step A
             // ---- step B: filter gradient ----
 #if GM_BSTEP
-            gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane);
+            gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane_l);
 #else
-            gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane);
+            gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane_l);
 #endif
             GM_MARK(7)  // (diagnostics) step B: wave 0's own products
             gm_lds_barrier();
             GM_MARK(4)  // step B products
-            if (tid < ksz) {
-                const float s = gm_diag_sum(G, g, ksz, pad, tid);
+            if (tid_l < ksz) {
+                const float s = gm_diag_sum(G, g, ksz, pad, tid_l);
 #pragma unroll
                 for (int q = 0; q < 7; ++q)
                     if (q == l) dwacc[q] += s;
@@ -1150,8 +1164,8 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 for (int m = 0; m < GM_MAXT; ++m) {
                     const int jt = wave + GM_WAVES * m;
                     if (jt >= g.nt) break;
-                    const gm_f32x4 acc = gm_conv_tile<true>(Z, wz, g, 16 * jt, ksz, pad, lane);
-                    if (16 * jt + col < g.bands) {
+                    const gm_f32x4 acc = gm_conv_tile<true>(Z, wz, g, 16 * jt, ksz, pad, lane_l);
+                    if (16 * jt + (lane_l & 15) < g.bands) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) da[m][e] += acc[e];
                     }
