@@ -647,33 +647,27 @@ __device__ __forceinline__ float gm_diag_sum(const float* __restrict__ G, const 
     float total = 0.0f;
 #pragma unroll 1
     for (int h = 0; h < it.halves; ++h) {
-        // every candidate element is fetched (absent ones from G[0], then replaced by 0) before the first add: as
-        // two nested loops with data-dependent bounds this was <= 32 dependent LDS round trips per thread and layer
-        float v[2][16];
+        // Diagonal d crosses the tiles a0 - 1 (rows dl0 .. 15, dl0 = d - 16 (a0 - 1) in [1, 16]) and a0 (rows 0 .. dl0 - 1):
+        // 16 elements, row il from tile a0 when il < dl0.  All 16 are fetched before the first add (as nested loops with
+        // data-dependent bounds this was <= 32 dependent LDS round trips per thread and layer); an element of an absent
+        // tile is read from G's first tile and replaced by 0 (volatile: hipcc otherwise sinks every load under its
+        // predicate -- a branch and an LDS round trip each).
+        const int dl0 = d - 16 * (a0 - 1);
+        const bool ok0 = a0 - 1 >= it.a_lo && a0 - 1 <= a_hi, ok1 = a0 >= it.a_lo && a0 <= a_hi;
+        // element il of tile t sits at gt_t[il * (GM_GP + 1) - dl_t]
+        const float* b0 = G + (ok0 ? h * it.n_off + a0 - 1 - it.a_lo : 0) * 16 * GM_GP - (ok0 ? dl0 : 0);
+        const float* b1 = G + (ok1 ? h * it.n_off + a0 - it.a_lo : 0) * 16 * GM_GP - (ok1 ? dl0 - 16 : 0);
+        typedef const volatile __attribute__((address_space(3))) float* gm_lds_vptr;
+        float v[16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int a = a0 - 1 + t;
-            const int dl = d - 16 * a;  // i_local - j_local
-            const bool tile_ok = a >= it.a_lo && a <= a_hi;
-            // element il of the diagonal sits at gt[il * (GM_GP + 1) - dl]: one base per tile, immediate offsets;
-            // an absent element is read from wherever that lands inside the block's LDS and replaced by 0
-            // (volatile: hipcc otherwise sinks every load under its predicate -- 32 branches, each with its own
-            // LDS round trip)
-            typedef const volatile __attribute__((address_space(3))) float* gm_lds_vptr;
-            const gm_lds_vptr bp =
-                (gm_lds_vptr)(G + (tile_ok ? h * it.n_off + a - it.a_lo : 0) * 16 * GM_GP - (tile_ok ? dl : 0));
-            const int lo = tile_ok ? max(0, dl) : 16, hi = min(15, 15 + dl);
-#pragma unroll
-            for (int il = 0; il < 16; ++il) {
-                const float x = bp[il * (GM_GP + 1)];
-                v[t][il] = (il >= lo && il <= hi) ? x : 0.0f;
-            }
+        for (int il = 0; il < 16; ++il) {
+            const bool from1 = il < dl0;
+            const float x = ((gm_lds_vptr)(from1 ? b1 : b0))[il * (GM_GP + 1)];
+            v[il] = (from1 ? ok1 : ok0) ? x : 0.0f;
         }
         float s = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int il = 0; il < 16; ++il) s += v[t][il];  // tiles ascending, rows ascending
+        for (int il = 0; il < 16; ++il) s += v[il];  // rows ascending
         total = h == 0 ? s : total + s;
     }
     return total;
@@ -935,6 +929,9 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
 #ifndef GM_LDS_BARRIER
 #define GM_LDS_BARRIER 1
 #endif
+#ifndef GM_KEEP_B128
+#define GM_KEEP_B128 1  // 16-byte loads of the kept activations (0: four dword buffer loads; 3 % slower)
+#endif
 __device__ __forceinline__ void gm_lds_barrier() {
 #if GM_LDS_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1025,6 +1022,20 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             (void*)(stash + (size_t)(app * tiles + t) * GmKeep<ENC>::V4 * GM_THREADS * 4), 0,
             GmKeep<ENC>::V4 * GM_THREADS * 16, 0x00020000);
         auto load_slot = [&](int q, float (&v)[GM_MAXT][4]) {  // tiles beyond nt hold nothing
+#if GM_KEEP_B128
+            // one 16-byte load per column tile: scalar base + a 32-bit lane offset (a dwordx4 RAW BUFFER load under the
+            // dword descriptor returned only its first component)
+            const char* kb = reinterpret_cast<const char*>(stash) +
+                             ((size_t)(app * tiles + t) * GmKeep<ENC>::V4 + (size_t)q * GM_MAXT) * GM_THREADS * 16;
+#pragma unroll
+            for (int m = 0; m < GM_MAXT; ++m) {
+                gm_f32x4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (wave + GM_WAVES * m < g.nt)
+                    f = *reinterpret_cast<const gm_f32x4*>(kb + (unsigned)(tidt * 16 + m * GM_THREADS * 16));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[m][e] = f[e];
+            }
+#else
             // (dword loads: a dwordx4 raw buffer load under this dword descriptor returned only its first component)
             const int so = __builtin_amdgcn_readfirstlane(q * GM_MAXT * GM_THREADS * 16);
 #pragma unroll
@@ -1034,6 +1045,7 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 for (int e = 0; e < 4; ++e)
                     v[m][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(keep_rsrc, vo + 4 * e, so, 0));
             }
+#endif
         };
         auto load_mask = [&](int l) {  // branch bits of layer l: word l of the two uint4 behind the slots
             return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
