@@ -219,10 +219,15 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
                                           gm_f32x4* __restrict__ stash = nullptr, float* __restrict__ enc_out = nullptr,
                                           int64_t ld_enc = 0) {
     constexpr int L = ENC ? 4 : 7;
+#ifndef GM_FWD_REGSKIP
+#define GM_FWD_REGSKIP 1
+#endif
+    constexpr bool REGSKIP = GM_FWD_REGSKIP && !KEEP;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile loops are wave-uniform
     const int col = lane & 15, rg = lane >> 4;
     const int img = GM_ROWS * g.pitch;
     int woff = 0;
+    [[maybe_unused]] float nr1[GM_MAXT][4], nr2[GM_MAXT][4];
     if constexpr (KEEP) {
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -249,6 +254,21 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
         const float bl = bias[l];
         const bool last_tanh = !ENC && l == 6;
         unsigned mk = 0;
+        // REGSKIP (the forward kernels): the skip operands n_{l-1}, n_{l-2} of a lane's 12 elements are the outputs it wrote
+        // in the two layers before -- kept in registers (nr1, nr2) instead of read back from LDS, and the columns beyond
+        // the bands are zeroed by a select: no divergent branch around 12 dependent LDS round trips per layer
+        if constexpr (REGSKIP) {
+            if (l == 0) {  // n_{-1} = x: this lane's elements of the input image
+#pragma unroll
+                for (int m = 0; m < GM_MAXT; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int jt = wave + GM_WAVES * m;
+                        nr1[m][e] = jt < g.nt ? src[(4 * rg + e) * g.pitch + 16 * jt + col] : 0.0f;
+                        nr2[m][e] = 0.0f;
+                    }
+            }
+        }
 #pragma unroll
         for (int m = 0; m < GM_MAXT; ++m) {
             const int jt = wave + GM_WAVES * m;
@@ -267,18 +287,36 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
                 } else {
                     if (v > 0.0f) mk |= 1u << (4 * m + e);
                     y = v > 0.0f ? v : 0.1f * v;
-                    y += src[row * g.pitch + c];                // + n_{l-1}
-                    if (l >= 1) y += skip2[row * g.pitch + c];  // + n_{l-2}
+                    if constexpr (REGSKIP) {
+                        y += nr1[m][e];              // + n_{l-1}
+                        if (l >= 1) y += nr2[m][e];  // + n_{l-2}
+                    } else {
+                        y += src[row * g.pitch + c];                // + n_{l-1}
+                        if (l >= 1) y += skip2[row * g.pitch + c];  // + n_{l-2}
+                    }
                 }
-                if (c < g.bands) {
-                    dst[row * g.pitch + c] = y;
-                    if (out != nullptr && l == L - 1 && row < rows_valid) out[(int64_t)row * ldo + c] = y;
-                    // encoder tap: n_4 IS the output of the encoder-only application on the same input
-                    if constexpr (TAP && !ENC) {
-                        if (l == 3 && row < rows_valid) enc_out[(int64_t)row * ld_enc + c] = y;
+                if constexpr (REGSKIP) {
+                    y = c < g.bands ? y : 0.0f;
+                    dst[row * g.pitch + c] = y;  // c < bp: inside the image, the padding columns keep their zeros
+                    nr2[m][e] = nr1[m][e];
+                    nr1[m][e] = y;
+                    if (c < g.bands && row < rows_valid) {
+                        if (out != nullptr && l == L - 1) out[(int64_t)row * ldo + c] = y;
+                        if constexpr (TAP && !ENC) {
+                            if (l == 3) enc_out[(int64_t)row * ld_enc + c] = y;
+                        }
                     }
                 } else {
-                    y = 0.0f;
+                    if (c < g.bands) {
+                        dst[row * g.pitch + c] = y;
+                        if (out != nullptr && l == L - 1 && row < rows_valid) out[(int64_t)row * ldo + c] = y;
+                        // encoder tap: n_4 IS the output of the encoder-only application on the same input
+                        if constexpr (TAP && !ENC) {
+                            if (l == 3 && row < rows_valid) enc_out[(int64_t)row * ld_enc + c] = y;
+                        }
+                    } else {
+                        y = 0.0f;
+                    }
                 }
                 if constexpr (KEEP) {
 #pragma unroll
@@ -327,7 +365,7 @@ __device__ __forceinline__ void gm_load_rows(float* img, const GmGeo g, const fl
 // two applications cost what one does.
 // TAP (full generator only): a separate instantiation, so that the plain kernels keep their register counts
 template <bool ENC, bool STASH, bool TAP = false>
-__global__ __launch_bounds__(GM_THREADS) void gan_generator_fwd_mfma_kernel(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gan_generator_fwd_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                                             int64_t n, int bands,
                                                                             const float* __restrict__ w,
                                                                             const float* __restrict__ bias,

@@ -1,7 +1,9 @@
 {
 timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "generator or gan" 2>&1 | tail -3
+for r in 1 2; do
 python tools/exp/gen_time.py
+HYPEL_LIB_PATH=$PWD/hypelcnn_amd/csrc/alt/libhypel_regskip0.so python tools/exp/gen_time.py
+done
 GP_B=64 GP_N=2048 python tools/exp/gen_time.py
-python bench.py --workload cut --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('cut bwd2 ms', d['ms_per_step'], d['roofline']['frac'], d['roofline']['generator_ms_per_step'])"
-python bench.py --workload cyclegan --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('cyc bwd2 ms', d['ms_per_step'])"
+HYPEL_LIB_PATH=$PWD/hypelcnn_amd/csrc/alt/libhypel_regskip0.so GP_B=64 GP_N=2048 python tools/exp/gen_time.py
 } 2>&1 | grep -v amdgpu.ids
