@@ -819,10 +819,12 @@ def test_dense_stack_fwd_bwd(hip, widths, n, act_mask, want_dx):
 
 
 @pytest.mark.parametrize("bands,n,only_enc", [(360, 4096, 0), (360, 70, 1), (64, 2048, 0), (144, 37, 0), (16, 5, 1),
-                                              (200, 1000, 1)])
+                                              (200, 1000, 1), (32, 9000, 0), (48, 8300, 1)])
 def test_gan_generator_kept_activations_bit_identical(hip, bands, n, only_enc):
     """hypel_gan_generator_fwd_keep + _bwd_kept (the backward pass starts from the activations the forward pass left
-    behind) == hypel_gan_generator_fwd + _bwd (it recomputes them), bit for bit: out, dx and every partial slab."""
+    behind; round 4: the register-ring kernel gan_generator_bwd2_mfma_kernel) == hypel_gan_generator_fwd + _bwd (the LDS-ring
+    kernel, which recomputes them), bit for bit: out, dx and every partial slab.  The last two cases have more row tiles
+    than blocks (a block walks two tiles: its filter / bias gradient sums carry over)."""
     rng = np.random.default_rng(bands + n)
     ks = [bands, bands // 2, bands // 4, bands // 8, bands // 4, bands // 2, bands]
     wtot = sum(ks)
