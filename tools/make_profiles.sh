@@ -21,7 +21,6 @@ for WL in $WLS; do
     *)        STEPS=100; TSTEPS=30; KNOWN=0; NB=0;;
   esac
   EXTRA=""; [ $WL = hypelcnn ] || EXTRA="--workload $WL"
-  python bench.py $EXTRA --steps $STEPS > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$WL -o t -- python $ROOT/bench.py $EXTRA --steps $TSTEPS --warmup 3 --no-cpu-baseline --no-input-pipeline > $ROOT/$OUT/trace_bench_$WL.json 2> $ROOT/$OUT/trace_$WL.err
   cd $ROOT
@@ -37,18 +36,25 @@ for WL in $WLS; do
     [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W --workload $WL --batch $NB --known-bytes $KNOWN --json $OUT/hbm_traffic_$WL.json --source "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py $EXTRA --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-input-pipeline (every step of the run incl. pre-warm and event replay), tools/pmc_traffic.py" > $OUT/hbm_traffic_$WL.txt 2>&1
     [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic_per_launch.py $F $W --workload $WL > $OUT/hbm_traffic_per_launch_$WL.txt 2>&1
     rm -rf $OUT/pmc_f_$WL $OUT/pmc_w_$WL
+    # the bench line below quotes roofline.traffic from profiles/<tag>_hbm_traffic*.json: put THIS call's passes there first
+    if [ -s $OUT/hbm_traffic_$WL.json ]; then
+      if [ $WL = hypelcnn ]; then cp $OUT/hbm_traffic_$WL.json profiles/${TAG}_hbm_traffic.json; else cp $OUT/hbm_traffic_$WL.json profiles/${TAG}_hbm_traffic_$WL.json; fi
+    fi
     if [ $WL = hypelcnn ]; then   # matrix-core utilisation per launch from the SQ counters (own pass, no tracing)
       cd /tmp
       rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_sq_$WL -o q -- python $ROOT/bench.py $EXTRA --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-input-pipeline > /dev/null 2> $ROOT/$OUT/pmc_sq_$WL.err
       cd $ROOT
       Q=$(find $OUT/pmc_sq_$WL -name "*counter_collection.csv" | head -1)
       [ -n "$Q" ] && python tools/pmc_sq_per_launch.py $Q --workload $WL > $OUT/mfma_busy_per_launch_$WL.txt 2>&1
+      [ -s $OUT/mfma_busy_per_launch_$WL.txt ] && cp $OUT/mfma_busy_per_launch_$WL.txt profiles/${TAG}_mfma_busy_per_launch_$WL.txt
       rm -rf $OUT/pmc_sq_$WL
     fi
   else
     [ -n "$S" ] && python tools/kstats.py $S 30 > $OUT/kernel_top_$WL.txt 2>&1
   fi
   rm -rf $OUT/trace_$WL   # raw traces are large; the summaries above are what gets committed
+  # the driver-contract line, after the PMC passes (its roofline.traffic is this call's)
+  python bench.py $EXTRA --steps $STEPS > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
   # the same step with the RCCL path active on a 1-rank communicator (the only multi-process check a 1-GPU box allows):
   # what the data-parallel machinery itself costs (sync-point graph cuts, all-reduce launches, the flag exchange)
   HYPEL_DP_SELFTEST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
