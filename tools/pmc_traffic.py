@@ -57,9 +57,13 @@ def main():
     print(f"{'kernel':34s} {'launches':>8s} {'read MB/launch':>15s} {'write MB/launch':>16s} {'total MB':>10s}")
     tot = 0.0
     for k in sorted(set(f) | set(w), key=lambda k: -(cal_f * sum(f.get(k, [0])) + cal_w * sum(w.get(k, [0])))):
-        n = max(len(f.get(k, [])), len(w.get(k, [])))
-        rd = cal_f * sum(f.get(k, [0])) / n
-        wr = cal_w * sum(w.get(k, [0])) / n
+        # the two passes are separate runs of a bench whose pre-warm is time based: they need not hold the same number of
+        # steps, so each counter is averaged over ITS pass's launches (dividing both by the larger count under-reported
+        # the reads by 1/13 whenever the write pass had one step more: the 160 vs 170 MB of rounds 3-4)
+        nf, nw = len(f.get(k, [])), len(w.get(k, []))
+        n = max(nf, nw)
+        rd = cal_f * sum(f.get(k, [0])) / max(nf, 1)
+        wr = cal_w * sum(w.get(k, [0])) / max(nw, 1)
         tot += (rd + wr) * n
         out[k] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr}
         if (rd + wr) * n > 1e6:
