@@ -1247,23 +1247,11 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 red[GM_WAVES + l] += s;
             }
             GM_MARK(3)  // step A
-            // ---- step B: filter gradient ----
-#if GM_BSTEP
-            gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane_l);
-#else
-            gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane_l);
-#endif
-            GM_MARK(7)  // (diagnostics) step B: wave 0's own products
-            gm_lds_barrier();
-            GM_MARK(4)  // step B products
-            if (tid_l < ksz) {
-                const float s = gm_diag_sum(G, g, ksz, pad, tid_l);
-#pragma unroll
-                for (int q = 0; q < 7; ++q)
-                    if (q == l) dwacc[q] += s;
-            }
-            GM_MARK(5)  // diagonal sums
-            // ---- step C: data gradient dn_{l-1} += dz_l . T^T ----
+            // ---- step C: data gradient dn_{l-1} += dz_l . T^T (this wave's column tiles, into its registers) ----
+            // Steps C and B only READ dz_l / n_{l-1} / the tap table and are independent of each other: no barrier between
+            // them (a wave's MFMA-dense data-gradient tiles run beside other waves' latency-bound filter-gradient items);
+            // the diagonal sums behind the barrier read G only, so the next layer's step A may overwrite the images beside
+            // them -- two block barriers per layer
             if (l > 0 || dx != nullptr) {
 #pragma unroll
                 for (int m = 0; m < GM_MAXT; ++m) {
@@ -1276,8 +1264,23 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     }
                 }
             }
-            gm_lds_barrier();  // every wave has left Z / X / wz / G
             GM_MARK(6)  // step C
+            // ---- step B: filter gradient ----
+#if GM_BSTEP
+            gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane_l);
+#else
+            gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane_l);
+#endif
+            GM_MARK(7)  // (diagnostics) step B: wave 0's own products
+            gm_lds_barrier();  // every wave has left Z / X / wz; G is complete
+            GM_MARK(4)  // step B products
+            if (tid_l < ksz) {
+                const float s = gm_diag_sum(G, g, ksz, pad, tid_l);
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q == l) dwacc[q] += s;
+            }
+            GM_MARK(5)  // diagonal sums
         }
         if (dx != nullptr) {
             const __amdgpu_buffer_rsrc_t rs = tile_rsrc(dx, lddx);
