@@ -502,7 +502,8 @@ __device__ __forceinline__ int gm_brow(int kq) { return GM_BROW ? 4 * (kq >> 1) 
 #define GM_RUN 4
 #endif
 #ifndef GM_BSTEP
-#define GM_BSTEP 0  // 0: round-3 form (gm_wgrad_tiles_v0), measured faster (NOTES 4.J); 1: balanced runs of consecutive offsets
+#define GM_BSTEP 2  // 2: pair at a time with gm_conv_tile's loop shape (gm_wgrad_tiles_v2, adopted: 186 -> 180 us at 8192 x 360);
+                    // 0: the round-3 loop (gm_wgrad_tiles_v0, same sums bit for bit); 1: balanced runs of consecutive offsets (slower)
 #endif
 #ifndef GM_BSCHED
 #define GM_BSCHED 1
@@ -519,7 +520,7 @@ __device__ __forceinline__ GmItems gm_items(const GmGeo g, int ksz, int pad) {
     it.a_lo = -((pad + 15) / 16);
     const int a_hi = (ksz - 1 - pad + 15) / 16;
     it.n_off = a_hi - it.a_lo + 1;
-    it.halves = (GM_BSTEP && it.n_off < GM_WAVES && 2 * it.n_off <= gm_atiles(g.bands) && g.nt >= 2) ? 2 : 1;
+    it.halves = (GM_BSTEP == 1 && it.n_off < GM_WAVES && 2 * it.n_off <= gm_atiles(g.bands) && g.nt >= 2) ? 2 : 1;
     it.n_items = it.n_off * it.halves;
     it.jmid = it.halves == 2 ? (g.nt - 1) / 2 : g.nt - 1;
     return it;
@@ -731,6 +732,60 @@ __device__ __forceinline__ void gm_wgrad_tiles_v0(const float* __restrict__ X, c
     }
 }
 
+// GM_BSTEP=2: the same products in the same order as gm_wgrad_tiles_v0 (bit-identical), with the loop shape of gm_conv_tile:
+// two fragment sets used alternately (no register copies), the next pair's eight reads requested ahead of this pair's MFMAs
+// by a scalar two-pair software pipeline, one LDS base per sample-row step
+__device__ __forceinline__ void gm_wgrad_tiles_v2(const float* __restrict__ X, const float* __restrict__ Z,
+                                                  float* __restrict__ G, const GmGeo g, int ksz, int pad, int wave, int lane) {
+    const int col = lane & 15, rg = lane >> 4;
+    const int a_lo = -((pad + 15) / 16), a_hi = (ksz - 1 - pad + 15) / 16;
+    const float* xb = X + gm_brow(rg) * g.pitch + col;
+    const float* zb = Z + gm_brow(rg) * g.pitch + col;
+    for (int a = a_lo + wave; a <= a_hi; a += GM_WAVES) {
+        gm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int j_lo = max(0, -a), j_hi = min(g.nt - 1, g.nt - 1 - a);
+        const int nch = j_hi - j_lo + 1;
+        if (nch > 0) {
+            const float* ap = xb + 16 * (a + j_lo);
+            const float* bp = zb + 16 * j_lo;
+            float a0[4], b0[4], a1[4], b1[4];
+            auto fetch = [&](int c, float (&fa)[4], float (&fb)[4]) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    fa[s] = ap[16 * c + s * g.pitch];
+                    fb[s] = bp[16 * c + s * g.pitch];
+                }
+            };
+            auto mac = [&](const float (&fa)[4], const float (&fb)[4]) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], accb, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], accb, 0, 0, 0);
+            };
+            fetch(0, a0, b0);
+            int c = 0;
+            for (; c + 2 < nch; c += 2) {
+                fetch(c + 1, a1, b1);
+                mac(a0, b0);
+                fetch(c + 2, a0, b0);
+                mac(a1, b1);
+            }
+            if (c + 1 < nch) {  // two pairs left
+                fetch(c + 1, a1, b1);
+                mac(a0, b0);
+                mac(a1, b1);
+            } else {
+                mac(a0, b0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += accb[e];
+        float* gt = G + (a - a_lo) * 16 * GM_GP;  // [i_local = 4 rg + e][j_local = col]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gt[(4 * rg + e) * GM_GP + col] = acc[e];
+    }
+}
+
 // tap `tap` of the layer: the sum of diagonal d = tap - pad of G, halves ascending, tiles ascending, rows ascending
 __device__ __forceinline__ float gm_diag_sum(const float* __restrict__ G, const GmGeo g, int ksz, int pad, int tap) {
     const GmItems it = gm_items(g, ksz, pad);
@@ -798,7 +853,7 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
     float* raw = red + 128;                           // LDS copy of every layer's taps + biases
     gm_zero(gm_lds, 5 * img + 6 * g.bp, tid);
     gm_stage_raw(raw, bands, w, bias, tid);
-    gm_wgrad_schedule(sched, g, L, tid);
+    if (GM_BSTEP == 1) gm_wgrad_schedule(sched, g, L, tid);
     __syncthreads();
 
     float dwacc[7];  // thread t owns tap t of every layer; red[GM_WAVES + l] collects the bias gradients
@@ -942,8 +997,10 @@ __global__ __launch_bounds__(GM_THREADS) void gan_generator_bwd_mfma_kernel(
             }
             GM_MARK(3)  // step A
             // ---- step B: filter gradient (gm_wgrad_tiles: balanced runs of consecutive tile offsets) ----
-#if GM_BSTEP
+#if GM_BSTEP == 1
             gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane);
+#elif GM_BSTEP == 2
+            gm_wgrad_tiles_v2(X, Z, G, g, ksz, pad, wave, lane);
 #else
             gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane);
 #endif
@@ -1074,7 +1131,7 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     float* red = G + gm_atiles(bands) * 16 * GM_GP;  // [GM_WAVES] bias-gradient partials, [GM_WAVES + l] their sums
     int* sched = reinterpret_cast<int*>(red + 64);   // [L][GM_WAVES] filter-gradient runs
     gm_zero(gm_lds, 2 * img + 3 * g.bp, tid);  // image padding and tap margins stay zero
-    gm_wgrad_schedule(sched, g, L, tid);
+    if (GM_BSTEP == 1) gm_wgrad_schedule(sched, g, L, tid);
     if (tid < 7) red[GM_WAVES + tid] = 0.0f;
     __syncthreads();
 
@@ -1266,8 +1323,10 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             }
             GM_MARK(6)  // step C
             // ---- step B: filter gradient ----
-#if GM_BSTEP
+#if GM_BSTEP == 1
             gm_wgrad_tiles(X, Z, G, g, ksz, pad, sched[l * GM_WAVES + wave], lane_l);
+#elif GM_BSTEP == 2
+            gm_wgrad_tiles_v2(X, Z, G, g, ksz, pad, wave, lane_l);
 #else
             gm_wgrad_tiles_v0(X, Z, G, g, ksz, pad, wave, lane_l);
 #endif
