@@ -806,16 +806,14 @@ __device__ __forceinline__ float gm_diag_sum(const float* __restrict__ G, const 
         const float* b0 = G + (ok0 ? h * it.n_off + a0 - 1 - it.a_lo : 0) * 16 * GM_GP - (ok0 ? dl0 : 0);
         const float* b1 = G + (ok1 ? h * it.n_off + a0 - it.a_lo : 0) * 16 * GM_GP - (ok1 ? dl0 - 16 : 0);
         typedef const volatile __attribute__((address_space(3))) float* gm_lds_vptr;
+        // (two loops: with the select next to its load hipcc waited for every load before it issued the next one -- 16
+        // serial LDS round trips, 1.8 k cycles per layer whatever the band count)
         float v[16];
 #pragma unroll
-        for (int il = 0; il < 16; ++il) {
-            const bool from1 = il < dl0;
-            const float x = ((gm_lds_vptr)(from1 ? b1 : b0))[il * (GM_GP + 1)];
-            v[il] = (from1 ? ok1 : ok0) ? x : 0.0f;
-        }
+        for (int il = 0; il < 16; ++il) v[il] = ((gm_lds_vptr)(il < dl0 ? b1 : b0))[il * (GM_GP + 1)];
         float s = 0.0f;
 #pragma unroll
-        for (int il = 0; il < 16; ++il) s += v[il];  // rows ascending
+        for (int il = 0; il < 16; ++il) s += ((il < dl0 ? ok1 : ok0) ? v[il] : 0.0f);  // rows ascending
         total = h == 0 ? s : total + s;
     }
     return total;
