@@ -59,6 +59,13 @@ constexpr int GM_MAX_BANDS = 16 * GM_WAVES * GM_MAXT;
 #define GM_FWD_ROLLED 0  // forward kernel: 1 = rolled layer loop (54 vs 51 us); the backward kernel's recompute is always
                          // rolled (unrolled it spills > 200 registers)
 #endif
+#if GM_DIAG == 7  // forward phase stamps: cycles of thread 0 of block 0 per phase, reported through out[0..7]
+__device__ long long gm_fdbg[8];
+__device__ long long gm_fmark;
+#define GM_FMARK(i) { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long now_ = clock64(); gm_fdbg[i] += now_ - gm_fmark; gm_fmark = now_; } }
+#else
+#define GM_FMARK(i)
+#endif
 constexpr int GM_GP = 17;       // pitch of a 16 x 16 filter-gradient tile in LDS (diagonal reads hit distinct banks)
 
 struct GmGeo {
@@ -245,9 +252,11 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
         if constexpr (ONE_TABLE) {  // wz0 == wz1: every wave must have left layer l - 1's products before its taps go
             if (l > 0) __syncthreads();
         }
+        GM_FMARK(4)  // end of the previous layer's epilogue .. (ONE_TABLE barrier)
         gm_fill_taps(wz, g, w + woff, ksz, tid);
         woff += ksz;
         __syncthreads();  // taps of layer l and the outputs of layer l - 1 are in LDS
+        GM_FMARK(1)  // tap table + barrier
         const float* src = lds0 + (l % 3) * img;          // n_l (x for l = 0)
         const float* skip2 = lds0 + ((l + 2) % 3) * img;  // n_{l-1}
         float* dst = lds0 + ((l + 1) % 3) * img;
@@ -275,6 +284,7 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
             if (jt >= g.nt) break;
             const int j0 = 16 * jt;
             const gm_f32x4 acc = gm_conv_tile<false>(src, wz, g, j0, ksz, pad, lane);
+            GM_FMARK(2)  // products
             const int c = j0 + col;
             [[maybe_unused]] gm_f32x4 kept = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -327,6 +337,7 @@ __device__ __forceinline__ int gm_forward(float* lds0, float* wz0, float* wz1, c
             if constexpr (STASH) {  // slots n_1..n_3 (encoder) / n_1..n_6 + the tanh output
                 if (ENC ? l < 3 : true) stash[(l * GM_MAXT + m) * GM_THREADS] = kept;
             }
+            GM_FMARK(3)  // epilogue
         }
         if constexpr (KEEP) {
 #pragma unroll
@@ -402,6 +413,12 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     extern __shared__ __attribute__((aligned(16))) float gm_lds[];
     const GmGeo g = gm_geo(bands);
     const int tid = threadIdx.x;
+#if GM_DIAG == 7
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 8; ++i) gm_fdbg[i] = 0;
+        gm_fmark = clock64();
+    }
+#endif
     const int bpa = gridDim.x / apps.n_apps, app = blockIdx.x / bpa, blk = blockIdx.x - app * bpa;
     w += app * apps.w_stride;
     bias += app * apps.b_stride;
@@ -446,6 +463,7 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         __syncthreads();
         if (blk < tiles) gm_load_rows(bufs[0], g, x + (int64_t)blk * GM_ROWS * ldx, ldx, (int)min((int64_t)GM_ROWS, n - (int64_t)blk * GM_ROWS), tid);
     }
+    GM_FMARK(0)  // block set-up
     float keep[6][GM_MAXT][4];
     unsigned mask[7];
     for (int64_t t = blk; t < tiles; t += bpa) {
@@ -459,7 +477,12 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                                                                     out + r0 * ldo, ldo, rows_valid, tid, keep, mask, sp,
                                                                     TAP ? enc_out + r0 * ld_enc : nullptr, ld_enc);
         __syncthreads();  // the next row tile overwrites bufs[0]
+        GM_FMARK(5)  // last epilogue .. tile end
     }
+#if GM_DIAG == 7
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 8; ++i) out[i] = (float)gm_fdbg[i];
+#endif
 }
 
 // Sum over the 64 lanes of a wave in registers (row_shr 1 / 2 / 4 / 8 inside the rows of 16, row_bcast15 / 31 across them:
