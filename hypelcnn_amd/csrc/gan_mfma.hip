@@ -1266,6 +1266,8 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             }
             // ---- step A: dz_l and n_{l-1} into LDS, skip gradients in registers, bias gradient ----
             for (int i = tid; i < g.bands; i += GM_THREADS) wz[g.bp + i] = i < ksz ? wreg : 0.0f;
+            // (branch-free element loop: as per-element `if (top_tanh) / if (init_b) / if (l >= 1)` hipcc compiled three to four
+            // scalar branches and a vmcnt(0) wait around every one of the 12 elements)
             float dbl = 0.0f;
 #pragma unroll
             for (int m = 0; m < GM_MAXT; ++m) {
@@ -1275,25 +1277,20 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 for (int e = 0; e < 4; ++e) {
                     const int o = lbase + e * g.pitch + 16 * GM_WAVES * m;
                     const float gd = da[m][e];
-                    float f;
-                    if (top_tanh) {
-                        const float y = xin[m][e];
-                        f = 1.0f - y * y;
-                    } else {
-                        f = ((mk >> (4 * m + e)) & 1u) ? 1.0f : 0.1f;
-                    }
-                    const float z = gd * f;
+                    const float y = xin[m][e];  // the tanh output under the top layer (else n_{l-1}, unused here)
+                    const float ft = 1.0f - y * y;
+                    const float fl = ((mk >> (4 * m + e)) & 1u) ? 1.0f : 0.1f;
+                    const float z = gd * (top_tanh ? ft : fl);
                     Z[o] = z;
                     dbl += z;
                     // n_l = c_l + n_{l-1} (+ n_{l-2}); n_6 only feeds the last convolution
-                    const float nb = top_tanh ? 0.0f : (init_b ? gd : db[m][e] + gd);
-                    db[m][e] = gd;     // dn_{l-2} starts from dn_l (unused below layer 1 and under the tanh layer)
-                    da[m][e] = nb;     // dn_{l-1} so far; step C adds dz_l . T^T
-                    if (l >= 1 && !top_tanh) X[o] = xin[m][e];
+                    const float nb = init_b ? gd : db[m][e] + gd;
+                    db[m][e] = gd;                     // dn_{l-2} starts from dn_l (unused below layer 1 and under the tanh layer)
+                    da[m][e] = top_tanh ? 0.0f : nb;   // dn_{l-1} so far; step C adds dz_l . T^T
                 }
             }
-            if (top_tanh) {  // the tanh layer's input is n_5: its own slot, requested only now (the registers held y)
-                load_slot(5, xin);
+            if (top_tanh) load_slot(5, xin);  // the tanh layer's input is n_5: its own slot, requested only now (the registers held y)
+            if (l >= 1) {
 #pragma unroll
                 for (int m = 0; m < GM_MAXT; ++m) {
                     const int jt = wave + GM_WAVES * m;
