@@ -113,6 +113,14 @@ __host__ __device__ inline size_t gm_bwd_lds(int bands) {
 // pitch = 18 mod 32 the 32 lanes of a ds_read_b32 group (16 rows x 2 k-slots) hit 32 banks.  B fragment: lane
 // (c = lane & 15, kq) supplies T[k][j0 + c] = w[k - (j0 + c) + pad] (mirrored: w[(j0 + c) - k + pad]) from the
 // zero-margined tap table wz (taps at [bp, bp + ksz)).
+#ifndef GM_CONV_SCHED
+#define GM_CONV_SCHED 0  // 1: the fetch / mac / fetch / mac order of the loop below pinned with sched_barrier
+#endif
+#if GM_CONV_SCHED
+#define GM_CONV_PIN __builtin_amdgcn_sched_barrier(0);
+#else
+#define GM_CONV_PIN
+#endif
 template <bool MIRROR>
 __device__ __forceinline__ gm_f32x4 gm_conv_tile(const float* __restrict__ src, const float* __restrict__ wz, const GmGeo g,
                                                  int j0, int ksz, int pad, int lane) {
@@ -171,9 +179,13 @@ __device__ __forceinline__ gm_f32x4 gm_conv_tile(const float* __restrict__ src, 
     int c = 0;
     for (; c + 2 < nch; c += 2) {
         fetch(c + 1, a1, b1);
+        GM_CONV_PIN
         mac(a0, b0);
+        GM_CONV_PIN
         fetch(c + 2, a0, b0);
+        GM_CONV_PIN
         mac(a1, b1);
+        GM_CONV_PIN
     }
     if (c + 1 < nch) {  // two chunks left
         fetch(c + 1, a1, b1);
@@ -755,6 +767,14 @@ __device__ __forceinline__ void gm_wgrad_tiles_v0(const float* __restrict__ X, c
     }
 }
 
+#ifndef GM_V2_SCHED
+#define GM_V2_SCHED 1  // the order fetch / mac / fetch / mac pinned (hipcc otherwise merges both fetches behind the first MFMAs
+#endif                 // and waits for the second right in front of its use)
+#if GM_V2_SCHED
+#define GM_V2_PIN __builtin_amdgcn_sched_barrier(0);
+#else
+#define GM_V2_PIN
+#endif
 // GM_BSTEP=2: the same products in the same order as gm_wgrad_tiles_v0 (bit-identical), with the loop shape of gm_conv_tile:
 // two fragment sets used alternately (no register copies), the next pair's eight reads requested ahead of this pair's MFMAs
 // by a scalar two-pair software pipeline, one LDS base per sample-row step
@@ -789,9 +809,13 @@ __device__ __forceinline__ void gm_wgrad_tiles_v2(const float* __restrict__ X, c
             int c = 0;
             for (; c + 2 < nch; c += 2) {
                 fetch(c + 1, a1, b1);
+                GM_V2_PIN
                 mac(a0, b0);
+                GM_V2_PIN
                 fetch(c + 2, a0, b0);
+                GM_V2_PIN
                 mac(a1, b1);
+                GM_V2_PIN
             }
             if (c + 1 < nch) {  // two pairs left
                 fetch(c + 1, a1, b1);
