@@ -284,8 +284,16 @@ __global__ __launch_bounds__(DS_THREADS) void dense_stack_bwd_kernel(
                 ds_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
                 const float* ap = Ain + kq * pa + 16 * it + r;  // A^T fragment: element (i = r, n = 4 s + kq)
                 const float* bp = D + kq * pa + 16 * jt + r;    // dZ fragment:  element (n = 4 s + kq, j = r)
+                // all eight fragment words before the first MFMA (hipcc otherwise reads two, waits, multiplies, four times over)
+                float fa[4], fb[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * pa], bp[4 * s * pa], acc, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    fa[s] = ap[4 * s * pa];
+                    fb[s] = bp[4 * s * pa];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], acc, 0, 0, 0);
                 const int j = 16 * jt + r;
                 if (j < cout) {
 #pragma unroll
