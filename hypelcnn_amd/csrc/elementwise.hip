@@ -173,28 +173,50 @@ __global__ void reduce_splits_wave_pair_kernel(const float* __restrict__ p0, int
 // bias gradient slabs of the fused generator and dense-stack kernels of a whole GAN phase): the outputs of all entries are
 // numbered consecutively, a wave finds its entry by walking the (short) table; per output the same lanes-over-slabs
 // butterfly as reduce_splits_wave_kernel, the old value added last.
-__global__ void reduce_splits_wave_multi_kernel(const float* __restrict__ base,
-                                                const hypel_reduce_entry_t* __restrict__ entries, int n_entries,
-                                                int64_t total) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < total; i += n_waves) {
+// (round 4, second form) One block = 64 consecutive outputs x 16 slab groups: the 64 lanes of a wave read 64 CONSECUTIVE
+// outputs of one slab (one 256-byte row segment per load; with a wave per output every lane touched its own cache line --
+// 64 sectors per load instruction), thread (tx, ty) sums the slabs ty, ty + 16, .. of output tx in ascending order, the 16
+// group sums are added in group order through LDS, the old value last (two contributions that are exact negatives of each
+// other still cancel before it is added).  Deterministic; 10.9 -> ~7 us for the 256 x 10.5 k slabs of a CycleGAN train op.
+constexpr int RSW_TX = 64, RSW_TY = 16;
+__global__ __launch_bounds__(RSW_TX * RSW_TY) void reduce_splits_wave_multi_kernel(
+    const float* __restrict__ base, const hypel_reduce_entry_t* __restrict__ entries, int n_entries, int64_t total) {
+    __shared__ float sh[RSW_TY][RSW_TX];
+    const int tx = threadIdx.x & (RSW_TX - 1), ty = threadIdx.x / RSW_TX;
+    for (int64_t c0 = (int64_t)blockIdx.x * RSW_TX; c0 < total; c0 += (int64_t)gridDim.x * RSW_TX) {
+        const int64_t i = c0 + tx;
+        float s = 0.0f;
         int64_t o = i;
         int e = 0;
-        while (e + 1 < n_entries && o >= entries[e].count) {
-            o -= entries[e].count;
-            ++e;
+        const bool live = i < total;
+        if (live) {
+            while (e + 1 < n_entries && o >= entries[e].count) {
+                o -= entries[e].count;
+                ++e;
+            }
+            const hypel_reduce_entry_t en = entries[e];
+            const float* __restrict__ p = base + en.partial_off + o;
+            int k = ty;
+            for (; k + 7 * RSW_TY < en.n_splits; k += 8 * RSW_TY) {  // eight slabs in flight
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(k + q * RSW_TY) * en.stride];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += v[q];
+            }
+            for (; k < en.n_splits; k += RSW_TY) s += p[(int64_t)k * en.stride];
         }
-        const hypel_reduce_entry_t en = entries[e];
-        const float* __restrict__ p = base + en.partial_off + o;
-        float s = 0.0f;
-        for (int k = lane; k < en.n_splits; k += 64) s += p[(int64_t)k * en.stride];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) {
+        sh[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && live) {
+            float t = sh[0][tx];
+#pragma unroll
+            for (int g = 1; g < RSW_TY; ++g) t += sh[g][tx];
+            const hypel_reduce_entry_t en = entries[e];
             float* out = const_cast<float*>(base) + en.out_off + o;
-            *out = (en.flags & 1) ? *out + s : s;
+            *out = (en.flags & 1) ? *out + t : t;
         }
+        __syncthreads();
     }
 }
 
@@ -1561,8 +1583,9 @@ extern "C" int hypel_reduce_splits_wave_multi_f32(const float* base, const hypel
                                                   int32_t n_entries, int64_t total_count, hypel_stream_t stream) {
     HYPEL_REQUIRE(base && entries && n_entries >= 0 && total_count >= 0, "hypel_reduce_splits_wave_multi_f32");
     if (n_entries == 0 || total_count == 0) return 0;
-    hipLaunchKernelGGL(reduce_splits_wave_multi_kernel, dim3(hypel_grid_1d(total_count * 64, 256)), dim3(256), 0, ST, base,
-                       entries, n_entries, total_count);
+    const int64_t chunks = (total_count + RSW_TX - 1) / RSW_TX;
+    hipLaunchKernelGGL(reduce_splits_wave_multi_kernel, dim3((unsigned)(chunks < 4096 ? chunks : 4096)), dim3(RSW_TX * RSW_TY), 0, ST,
+                       base, entries, n_entries, total_count);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_wave_multi_f32");
     return 0;
 }
