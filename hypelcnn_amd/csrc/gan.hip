@@ -578,18 +578,34 @@ __global__ __launch_bounds__(256) void gan_loss_partial_kernel(int mode, const f
     if (threadIdx.x == 0) ws[blockIdx.x] = t * pscale;
 }
 
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ ws, int n, double scale,
-                                                             float* __restrict__ loss, int accumulate) {
-    __shared__ double sh[256];
+// One block of 1024 threads: eight partials per thread requested before the first add (as `for (i = tid; i < n; i += 256)`
+// the ~7 k slot values of a train op were 28 dependent global round trips per thread: 7.2 us), fp64 sums -- lanes by
+// shuffles, the 16 waves through LDS in wave order.
+constexpr int LOSS_FIN_THREADS = 1024;
+__global__ __launch_bounds__(LOSS_FIN_THREADS) void loss_finalize_kernel(const float* __restrict__ ws, int n, double scale,
+                                                                          float* __restrict__ loss, int accumulate) {
+    __shared__ double sh[LOSS_FIN_THREADS / 64];
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)ws[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * LOSS_FIN_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + q * LOSS_FIN_THREADS;
+            v[q] = i < n ? ws[i] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += (double)v[q];
     }
-    if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.0f) + (float)(sh[0] * scale);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < LOSS_FIN_THREADS / 64; ++k) t += sh[k];
+        loss[0] = (accumulate ? loss[0] : 0.0f) + (float)(t * scale);
+    }
 }
 
 // l2 regulariser: loss += scale/2 * sum w^2, dw += scale * w
@@ -1098,7 +1114,7 @@ extern "C" int hypel_gan_loss(int32_t mode, const float* a, int64_t lda, const f
     const double count = (double)rows * c;
     hipLaunchKernelGGL(gan_loss_partial_kernel, dim3(grid), dim3(256), 0, ST, mode, a, lda, b, ldb, rows, c, target,
                        (float)(weight / count), da, ldda, acc_da, db, lddb, acc_db, ws, 1.0f);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, grid, (double)weight / count, loss,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LOSS_FIN_THREADS), 0, ST, ws, grid, (double)weight / count, loss,
                        accumulate_loss);
     HYPEL_CHECK_LAUNCH("hypel_gan_loss");
     return 0;
@@ -1173,7 +1189,7 @@ extern "C" int hypel_loss_terms_slots(const float* base, const hypel_loss_term_t
 extern "C" int hypel_loss_finalize_slots(const float* slots, int32_t n_slots, float* loss, int32_t accumulate_loss,
                                          hypel_stream_t stream) {
     HYPEL_REQUIRE(slots && loss && n_slots > 0, "hypel_loss_finalize_slots");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, slots, n_slots * LOSS_SLOT, 1.0, loss,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LOSS_FIN_THREADS), 0, ST, slots, n_slots * LOSS_SLOT, 1.0, loss,
                        accumulate_loss);
     HYPEL_CHECK_LAUNCH("hypel_loss_finalize_slots");
     return 0;
@@ -1184,7 +1200,7 @@ extern "C" int hypel_l2_reg(const float* w, int64_t count, float scale, float* l
     HYPEL_REQUIRE(w && loss && ws && count > 0, "hypel_l2_reg");
     const int grid = hypel_grid_1d(count, 256, 1024);
     hipLaunchKernelGGL(l2_reg_kernel, dim3(grid), dim3(256), 0, ST, w, count, scale, dw, ws, 1.0f);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, grid, 0.5 * (double)scale, loss,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LOSS_FIN_THREADS), 0, ST, ws, grid, 0.5 * (double)scale, loss,
                        accumulate_loss);
     HYPEL_CHECK_LAUNCH("hypel_l2_reg");
     return 0;
@@ -1257,7 +1273,7 @@ extern "C" int hypel_nce_loss(const float* g, int64_t ldg, const float* r, int64
         hipLaunchKernelGGL(nce_kernel, grid, dim3(64), 0, ST, g, ldg, r, ldr, n, p, e, 1.0f / tau, gcoef, ws, dg, lddg,
                            acc_dg, dr, lddr, acc_dr);
 #undef HYPEL_NCE
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, ST, ws, (int)n, (double)weight / (double)n, loss,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LOSS_FIN_THREADS), 0, ST, ws, (int)n, (double)weight / (double)n, loss,
                        accumulate_loss);
     HYPEL_CHECK_LAUNCH("hypel_nce_loss");
     return 0;
