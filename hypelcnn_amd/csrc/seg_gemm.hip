@@ -22,29 +22,6 @@
 
 #include "common.h"
 
-// regs[i] -> LDS dword (image_base + tid + 256 * i), i < N: the staging layout of every UNPADDED image (thread t holds
-// element t + 256 i of the row-major tile).  ds_write_addtid_b32 takes its address from M0 + offset + 4 * lane, so a
-// wave stores 64 consecutive dwords without an address register.  m0 = byte address of the wave's first dword.
-template <int N, int I = 0>
-__device__ __forceinline__ void lds_store_addtid(unsigned m0, const float (&regs)[N]) {
-    if constexpr (I + 4 <= N) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-                     "ds_write_addtid_b32 %1 offset:%5\n\tds_write_addtid_b32 %2 offset:%6\n\t"
-                     "ds_write_addtid_b32 %3 offset:%7\n\tds_write_addtid_b32 %4 offset:%8"
-                     :
-                     : "s"(m0), "v"(regs[I]), "v"(regs[I + 1]), "v"(regs[I + 2]), "v"(regs[I + 3]), "i"(1024 * I),
-                       "i"(1024 * (I + 1)), "i"(1024 * (I + 2)), "i"(1024 * (I + 3))
-                     : "memory");
-        lds_store_addtid<N, I + 4>(m0, regs);
-    } else if constexpr (I < N) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%2"
-                     :
-                     : "s"(m0), "v"(regs[I]), "i"(1024 * I)
-                     : "memory");
-        lds_store_addtid<N, I + 1>(m0, regs);
-    }
-}
-
 // Batch-norm backward reduction riding in a data-gradient epilogue (see the kernel's epilogue): the layer whose
 // output gradient dZ this launch finishes.  partial == nullptr: off.
 struct BnBwdEpi {
@@ -60,6 +37,29 @@ struct BnBwdEpi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// SPLIT variants (HYPEL_GEMM_SPLIT6): an fp32 value is EXACTLY hi + mid + lo with three round-to-nearest bf16 parts
+// (8 + 8 + 8 significand bits, the exponent range of fp32); every part x part product is exact in the fp32 accumulator
+// of v_mfma_f32_32x32x16_bf16, and the three smallest of the nine partial products (mid lo, lo mid, lo lo) are below
+// 2^-24 |a b|, i.e. below the rounding unit of the fp32 accumulate that follows.  Six bf16 MFMAs per k-step therefore
+// give an fp32-grade product (tests/test_gpu_kernels.py measures it against the fp32 MFMA chain per launch shape) at
+// 16 / 6 = 2.67x the rate of v_mfma_f32_32x32x2_f32.
+// two floats -> their (hi, mid, lo) bf16 parts, element 0 in the low half of each word
+__device__ __forceinline__ void hypel_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    bf16x2 p = {(__bf16)x0, (__bf16)x1};
+    h = __builtin_bit_cast(unsigned, p);
+    float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    p = bf16x2{(__bf16)r0, (__bf16)r1};
+    m = __builtin_bit_cast(unsigned, p);
+    r0 -= __builtin_bit_cast(float, m << 16);
+    r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+    p = bf16x2{(__bf16)r0, (__bf16)r1};
+    l = __builtin_bit_cast(unsigned, p);
+}
 
 namespace {
 
@@ -71,9 +71,6 @@ constexpr int BK_WIDE = HYPEL_GEMM_BK;
 #define HYPEL_GEMM_BK_NARROW 32  // reduction columns per LDS tile of the 128x16 variant (experiments: 64)
 #endif
 constexpr int BK_NARROW = HYPEL_GEMM_BK_NARROW;
-#ifndef HYPEL_GEMM_SETPRIO
-#define HYPEL_GEMM_SETPRIO 1
-#endif
 #ifndef HYPEL_GEMM_CLK
 #define HYPEL_GEMM_CLK 0  // tools/gemm_quantisation.py: 1 = --clk (shader clock the kernel ran at), 2 = --timeline
 #endif
@@ -92,19 +89,6 @@ constexpr int BK_NARROW = HYPEL_GEMM_BK_NARROW;
 #ifndef HYPEL_GEMM_HOIST_EPI
 #define HYPEL_GEMM_HOIST_EPI 1  // bias / shortcut column ranges requested before the k loop
 #endif
-#ifndef HYPEL_GEMM_EARLY_SEG
-#define HYPEL_GEMM_EARLY_SEG 1  // next segment record requested before the LDS hand-over of the current k-tile
-#endif
-#ifndef HYPEL_ASTAGE_PROBE
-#define HYPEL_ASTAGE_PROBE 0  // TIMING PROBE (results are garbage), NOTES 4.C: what a consumer-side batch-norm + activation
-                              // + shortcut fusion would cost the forward 1x1 GEMMs (launches of hypel_seg_gemm_stats_f32
-                              // only): 1 = per-column scalars + (x - mu) * r + b -> leaky-ReLU while the A tile goes to LDS;
-                              // 2 = + a second gathered operand per element (the shortcut); 3 = + the column-tile-0 block
-                              // stores the transformed tile (the activation the backward pass needs)
-#endif
-#ifndef HYPEL_GEMM_ADDTID
-#define HYPEL_GEMM_ADDTID 0  // 1: unpadded LDS images are written with ds_write_addtid_b32 (no address VGPR: 2 cycles
-#endif                       // per wave-store instead of 4, MI355X_MICROARCH.md LDS table)
 constexpr int CHUNK = HYPEL_GEMM_CHUNK;
 static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, "chunk of k2 / k4 steps");
 #ifndef HYPEL_OCC_BN32
@@ -130,21 +114,6 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // A = B = C.
 // BNB: instantiate the batch-norm backward epilogue (16 more live registers at the end of the block: a separate
 // instantiation keeps the register allocation -- 6 waves per SIMD -- of every other launch).
-#ifndef HYPEL_GEMM_RUNNING_SOFFSET
-#define HYPEL_GEMM_RUNNING_SOFFSET 1  // row step of the staging loads as one running scalar (see stage()); 0 = precomputed
-#endif
-#ifndef HYPEL_GEMM_SGPR_CAP
-#define HYPEL_GEMM_SGPR_CAP 0  // > 0: cap the scalar registers of every variant (experiments on blocks per CU)
-#endif
-#if HYPEL_GEMM_SGPR_CAP > 0
-// (r2 experiment, -DHYPEL_GEMM_SGPR_CAP=96: hipcc honours it for the 128x32 variants only -- 94 scalar registers, 7
-// instead of 6 blocks per CU -- the 1x1 data gradients gain 3 %, the multi-segment level gradients lose 3 % to the
-// extra scalar spills in the segment loop; step 7.03 vs 7.08 ms.  Not adopted: a template-dependent cap is not
-// accepted by the attribute.)
-#define HYPEL_SGPR_ATTR __attribute__((amdgpu_num_sgpr(HYPEL_GEMM_SGPR_CAP)))
-#else
-#define HYPEL_SGPR_ATTR
-#endif
 // PAIR (data gradients, !TA && TB): two consecutive segments of at most 16 reduction columns each share ONE k-tile
 // (columns 0-15 from the first, 16-31 from the second).  A data gradient through a convolution with 15 filters (the
 // narrowest HYPELCNN level, DUALCNN's last levels) otherwise stages, synchronises and walks a whole 32-column k-tile
@@ -155,8 +124,10 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // ACT (plain forward products, a separate instantiation like VARN): C = act(product + bias) with act = leaky-ReLU of the
 // slope HYPEL_GEMM_ACT_* names (bits 16-18 of `accumulate`): the bias + activation launch behind a BN-less
 // tf_slim.fully_connected (the GAN critics' and feature-discriminator layers, gan/shadow_data_models.py:95-149) is gone.
+// SPLIT: operands split three ways on their way into LDS (three bf16 planes per operand, reduction dimension
+// contiguous), six v_mfma_f32_32x32x16_bf16 per 32x32x16 step; prologue, segment walk and epilogues are shared.
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
-          bool PAIR = false, bool VARN = false, bool ACT = false>
+          bool PAIR = false, bool VARN = false, bool ACT = false, bool SPLIT = false>
 __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
@@ -176,6 +147,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
     static_assert(!ACT || (!TA && !TB && !NARROW && !MULTI && !BNB && !PAIR && !VARN), "activation epilogue: plain forward only");
+    static_assert(!SPLIT || (!NARROW && !BNB && !PAIR && !VARN && !ACT && !(TA && TB)), "split variants: plain NN / NT / TN products");
     [[maybe_unused]] int act_idx = 0;
     if constexpr (ACT) {
         act_idx = accumulate >> 16;
@@ -217,9 +189,15 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int A_RSTEP = 256 / A_COLS;
     constexpr int B_RSTEP = 256 / B_COLS;
     static_assert(!RD64 || (A_RSTEP % 2 == 0 && B_RSTEP % 2 == 0 && (A_ROWS * A_PITCH) % 2 == 0), "RD64 staging layout");
-    __shared__ __attribute__((aligned(16))) float lds[A_ROWS * A_PITCH + B_ROWS * B_PITCH];
+    // SPLIT: three bf16 planes per operand, each [rows][BK] with the reduction dimension contiguous and rows of
+    // 80 bytes (BK + 8 halves): the 16 lanes that a ds_read_b128 services per LDS cycle then start in 16 different
+    // 4-bank groups (20 r mod 64, r = 0-3, 12-15, 20-27) -- conflict-free fragment reads; so are the staging stores
+    // (8 consecutive rows x 16 bytes, and 2 rows x 8 quads x 8 bytes up to a 2-way overlap on four banks).
+    constexpr int SP_PITCH = 20;           // floats (80 bytes) per plane row
+    constexpr int SP_PLANE_A = BM * SP_PITCH, SP_PLANE_B = BN * SP_PITCH;  // floats per plane
+    __shared__ __attribute__((aligned(16))) float lds[SPLIT ? 3 * (SP_PLANE_A + SP_PLANE_B) : A_ROWS * A_PITCH + B_ROWS * B_PITCH];
     float* As = lds;
-    float* Bs = lds + A_ROWS * A_PITCH;
+    float* Bs = lds + (SPLIT ? 3 * SP_PLANE_A : A_ROWS * A_PITCH);
 
     // ---- block -> (row tile, column tile), XCD-aware (bijective remap, guide §5 T1) ----
     const int nblk = gridDim.x;
@@ -231,8 +209,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     struct { int64_t a_off0, b_off0; int k0; } tile;
     int m0, n0;
     int tile_index = 0;  // position in the tile table (non-MULTI): the chunk index of the epilogue reductions
-    int split_info = 0;  // K-slice record: count | index << 8 (include/hypel.h, tail splitting)
-    uint64_t slab_addr = 0, ticket_addr = 0;
     if constexpr (MULTI) {
         if (lid >= n_tiles) return;
         const hypel_mtile_t rec = reinterpret_cast<const hypel_mtile_t*>(tiles_v)[lid];
@@ -257,9 +233,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         tile = {t.a_off0, t.b_off0, t.k0};
         m0 = t.m0;
         if (t.n > 0) n = t.n;  // this tile's group has its own column count (merged multi-kernel levels)
-        split_info = t.split;
-        slab_addr = t.slab;
-        ticket_addr = t.ticket;
     }
     const int rows_left = grp.rows - m0;  // valid rows in this tile (may exceed BM)
     if (rows_left <= 0) return;           // empty record (padding of an XCD's share of the table)
@@ -341,16 +314,17 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int B_KSTEP = TB ? 2 : 2 * B_PITCH;
     constexpr int B_TILE = TB ? 32 * B_PITCH : 32;
 
-    float ra[A_PER_THREAD], rb[B_PER_THREAD];
-#if HYPEL_ASTAGE_PROBE
-    [[maybe_unused]] float ra2[A_PER_THREAD];
-    [[maybe_unused]] float pmu = 0.0f, prs = 1.0f, pbe = 0.0f;
-    [[maybe_unused]] float* pz = nullptr;
-    constexpr bool PROBE = !TA && !TB && !MULTI && !NARROW && !BNB && !PAIR && !VARN;
-#endif
-    // byte address of this wave's first dword inside an unpadded LDS image (dword index tid = 64 * wave + lane)
-    const unsigned lds_m0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + 256u * (unsigned)wave;
-
+    float ra[SPLIT ? 1 : A_PER_THREAD], rb[SPLIT ? 1 : B_PER_THREAD];
+    // SPLIT staging registers.  An operand stored with its reduction dimension contiguous ([x][k]: A of a forward / data
+    // gradient, B = W^T of a data gradient) is fetched as 16-byte quads: thread -> quad tid & 7 of rows (tid >> 3) + 32 i;
+    // one stored with k strided ([k][x]: both operands of a filter gradient, the weights of a forward product) by dword
+    // loads along x, a thread keeping KR consecutive k of ONE x -- the transpose happens in the registers.
+    constexpr int SA_N = BM / 32;                         // A, k-contiguous: quads per thread
+    constexpr int SB_N = BN / 32;                         // B, k-contiguous
+    constexpr int SA_KR = 8, SA_U = BM / 64;              // A, k-strided: 8 k per (x, octet) unit, units per wave
+    constexpr int SB_KR = BN >= 64 ? 8 : 4, SB_U = BN >= 64 ? BN / 64 : 1;
+    [[maybe_unused]] f32x4 qa[SPLIT && !TA ? SA_N : 1], qb[SPLIT && TB ? SB_N : 1];
+    [[maybe_unused]] float sa[SPLIT && TA ? SA_U : 1][SA_KR], sb[SPLIT && !TB ? SB_U : 1][SB_KR];
     int ls = grp.seg_begin;
     const int s_end = grp.seg_begin + grp.seg_count;
     int lk = 0;
@@ -384,7 +358,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
         const int kOOB = 0x7fffffff;
         const int voff = col < cols_valid ? (row0 * (int)ld + col) * 4 : kOOB;
-#if HYPEL_GEMM_RUNNING_SOFFSET
         // the row step as ONE running scalar (an opaque s_add between the loads) instead of COUNT precomputed soffsets
         // that stay live across the whole staging burst: up to 20 scalar registers less, the scalar spills of the
         // 128x32 data-gradient variant drop from 11 to 2 (step 6.87 -> 6.81 ms, same-box A/B)
@@ -404,19 +377,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                 asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
             }
         }
-#else
-        if (rows_valid >= COUNT * RSTEP) {  // uniform: every staged row exists
-#pragma unroll
-            for (int i = 0; i < COUNT; ++i)
-                regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, i * RSTEP * ld4, 0));
-        } else {
-#pragma unroll
-            for (int i = 0; i < COUNT; ++i) {
-                const int v = (row0 + i * RSTEP) < rows_valid ? voff : kOOB;
-                regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, i * RSTEP * ld4, 0));
-            }
-        }
-#endif
     };
 
     // PAIR: the k columns [0, 16) of the tile come from (offX, kx), [16, 32) from (offY, ky): ONE descriptor based at
@@ -435,7 +395,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         const int c2 = col - 16;
         const int voff = col < 16 ? (col < kx ? dx + (row0 * (int)ld + col) * 4 : kOOB)
                                   : (c2 < ky ? dy + (row0 * (int)ld + c2) * 4 : kOOB);
-#if HYPEL_GEMM_RUNNING_SOFFSET
         const int step = RSTEP * ld4;
         int so = 0;
 #pragma unroll
@@ -444,16 +403,90 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, so, 0));
             asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
         }
-#else
+    };
+
+    // SPLIT, operand with its reduction dimension contiguous: [rows][32 k] as 16-byte quads (dword-aligned addresses
+    // suffice for buffer_load_dwordx4); a k-tile that ends inside a quad (segment k not a multiple of 4) takes the
+    // per-element path -- wave-uniform choice
+    [[maybe_unused]] auto stage_q = [&](const float* base, int64_t ld, int rows_valid, int k_valid, auto& regs, auto count_c) {
+        constexpr int COUNT = decltype(count_c)::value;
+        const int ld4 = __builtin_amdgcn_readfirstlane((int)ld * 4);
+        const int span = __builtin_amdgcn_readfirstlane(
+            rows_valid > 0 && k_valid > 0 ? ((rows_valid - 1) * (int)ld + k_valid) * 4 : 0);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
+        const int kOOB = 0x7fffffff;
+        const int row0 = tid >> 3, q4 = (tid & 7) * 4;
+        const int step = 32 * ld4;
+        int so = 0;
+        if ((k_valid & 3) == 0) {
+            const int voff = q4 < k_valid ? (row0 * (int)ld + q4) * 4 : kOOB;
 #pragma unroll
-        for (int i = 0; i < COUNT; ++i) {
-            const int v = (row0 + i * RSTEP) < rows_valid ? voff : kOOB;
-            regs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, i * RSTEP * ld4, 0));
+            for (int i = 0; i < COUNT; ++i) {
+                const int v = (row0 + 32 * i) < rows_valid ? voff : kOOB;
+                regs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, v, so, 0));
+                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < COUNT; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = (row0 + 32 * i) < rows_valid && q4 + e < k_valid ? (row0 * (int)ld + q4 + e) * 4 : kOOB;
+                    regs[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, so, 0));
+                }
+                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
+            }
         }
-#endif
+    };
+    // SPLIT, operand with its reduction dimension strided: [32 k][XW x], dword loads along x (fully coalesced), a thread
+    // keeps KR consecutive k of one x.  XW >= 64: unit = wave * U + u -> x = (unit % (XW / 64)) * 64 + lane, k = 8 * (unit /
+    // (XW / 64)) + r; XW = 32: x = tid & 31, k = 4 * (tid >> 5) + r
+    [[maybe_unused]] auto stage_s = [&](const float* base, int64_t ld, int k_valid, int x_valid, auto& regs, auto xw_c,
+                                        auto kr_c, auto u_c) {
+        constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
+        const int ld4 = __builtin_amdgcn_readfirstlane((int)ld * 4);
+        const int span = __builtin_amdgcn_readfirstlane(
+            k_valid > 0 && x_valid > 0 ? ((k_valid - 1) * (int)ld + x_valid) * 4 : 0);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
+        const int kOOB = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int x, kr0;
+            if constexpr (XW >= 64) {
+                const int unit = wave * U + u;
+                x = (unit % (XW / 64)) * 64 + lane;
+                kr0 = (unit / (XW / 64)) * 8;
+            } else {
+                x = tid & 31;
+                kr0 = (tid >> 5) * 4;
+            }
+            const int voff = x < x_valid ? (kr0 * (int)ld + x) * 4 : kOOB;
+            int so = 0;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int v = (kr0 + r) < k_valid ? voff : kOOB;
+                regs[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, so, 0));
+                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(ld4) : "scc");
+            }
+        }
     };
 
     auto load_tiles = [&](const hypel_seg_t& sg, int k0) {
+        if constexpr (SPLIT) {
+            const int k_left = min(BK, sg.k - k0);
+            const int m_left = min(BM, rows_left);
+            const int n_left = min(BN, cols_left);
+            if constexpr (!TA)
+                stage_q(A + sg.a_off + (int64_t)m0 * lda + k0, lda, m_left, k_left, qa, std::integral_constant<int, SA_N>{});
+            else
+                stage_s(A + sg.a_off + (int64_t)k0 * lda + m0, lda, k_left, m_left, sa, std::integral_constant<int, BM>{},
+                        std::integral_constant<int, SA_KR>{}, std::integral_constant<int, SA_U>{});
+            if constexpr (TB)
+                stage_q(B + sg.b_off + (int64_t)n0 * ldb + k0, ldb, n_left, k_left, qb, std::integral_constant<int, SB_N>{});
+            else
+                stage_s(B + sg.b_off + (int64_t)k0 * ldb + n0, ldb, k_left, n_left, sb, std::integral_constant<int, BN>{},
+                        std::integral_constant<int, SB_KR>{}, std::integral_constant<int, SB_U>{});
+        } else {
         if constexpr (PAIR) {
             if (sg.k & HYPEL_SEG_PAIR_FLAG) {
                 const int kx = sg.k & ~HYPEL_SEG_PAIR_FLAG, ky = seg2.k;
@@ -470,21 +503,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         if (!TA)  // rows = output rows (m), cols = k
             stage(A + sg.a_off + (int64_t)m0 * lda + k0, lda, a_row0, a_col, m_left, k_left, ra,
                   std::integral_constant<int, A_RSTEP>{}, std::integral_constant<int, A_PER_THREAD>{});
-#if HYPEL_ASTAGE_PROBE
-        if constexpr (PROBE) {
-            if (stats) {
-                const float* cs = A + sg.a_off + k0 + min(a_col, k_left - 1);
-                pmu = cs[0];
-                prs = cs[lda];
-                pbe = cs[2 * lda];
-#if HYPEL_ASTAGE_PROBE >= 2
-                stage(A + sg.a_off + (int64_t)(m0 + 64) * lda + k0, lda, a_row0, a_col, m_left, k_left, ra2,
-                      std::integral_constant<int, A_RSTEP>{}, std::integral_constant<int, A_PER_THREAD>{});
-#endif
-                pz = const_cast<float*>(A) + sg.a_off + (int64_t)m0 * lda + k0;
-            }
-        }
-#endif
         else  // rows = k (reduction rows), cols = output rows (m)
             stage(A + sg.a_off + (int64_t)k0 * lda + m0, lda, a_row0, a_col, k_left, m_left, ra,
                   std::integral_constant<int, A_RSTEP>{}, std::integral_constant<int, A_PER_THREAD>{});
@@ -494,6 +512,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         else  // rows = n, cols = k
             stage(B + sg.b_off + (int64_t)n0 * ldb + k0, ldb, b_row0, b_col, n_left, k_left, rb,
                   std::integral_constant<int, B_RSTEP>{}, std::integral_constant<int, B_PER_THREAD>{});
+        }
     };
 
     // Epilogue operands that only depend on the block's position -- the shortcut gradient's column ranges and the bias --
@@ -522,7 +541,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     while (have) {
         const bool paired = PAIR && (seg.k & HYPEL_SEG_PAIR_FLAG);
         const int kvalid = paired ? 16 + seg2.k : min(BK, seg.k - lk);
-#if HYPEL_GEMM_EARLY_SEG
         // advance the (segment, k) cursor NOW and request the next segment record before the LDS hand-over below: behind
         // the second barrier the scalar load sat directly in front of the address arithmetic of the next tile's loads
         // -- one exposed round trip per segment, i.e. per k-tile in the data gradients of the multi-kernel levels
@@ -538,34 +556,55 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             }
         }
         have = ls < s_end;
-#endif
         __syncthreads();  // previous tile's MFMAs are done reading LDS
-        constexpr bool A_TID = HYPEL_GEMM_ADDTID && !RD64 && A_PITCH == A_COLS;
-        constexpr bool B_TID = HYPEL_GEMM_ADDTID && !RD64 && B_PITCH == B_COLS && B_THREADS == 256;
-        if constexpr (A_TID) {
-            lds_store_addtid<A_PER_THREAD>(lds_m0, ra);
-        } else if constexpr (LIN && !TA) {  // [m][k] tile transposed into the pair-interleaved image
-#if HYPEL_ASTAGE_PROBE
-            if constexpr (PROBE) {
-                if (stats) {
+        if constexpr (SPLIT) {
+            // three-way split on the way into LDS: plane p of element (x, k) at p * PLANE + x * 80 + 2 k bytes
+            auto put_q = [&](float* img, int plane, const auto& regs, auto count_c) {
+                constexpr int COUNT = decltype(count_c)::value;
 #pragma unroll
-                    for (int i = 0; i < A_PER_THREAD; ++i) {
-                        const float t = (ra[i] - pmu) * prs + pbe;
-                        ra[i] = fmaxf(t, 0.18f * t);
-#if HYPEL_ASTAGE_PROBE >= 2
-                        ra[i] += ra2[i];
-#endif
-                    }
-#if HYPEL_ASTAGE_PROBE >= 3
-                    if (n0 == 0 && a_col < 24) {
-#pragma unroll
-                        for (int i = 0; i < A_PER_THREAD; ++i)
-                            if (a_row0 + i * A_RSTEP < rows_left) pz[(int64_t)(a_row0 + i * A_RSTEP) * lda + a_col] = ra[i];
-                    }
-#endif
+                for (int i = 0; i < COUNT; ++i) {
+                    unsigned h[2], m[2], l[2];
+                    hypel_split2(regs[i][0], regs[i][1], h[0], m[0], l[0]);
+                    hypel_split2(regs[i][2], regs[i][3], h[1], m[1], l[1]);
+                    float* o = img + ((tid >> 3) + 32 * i) * SP_PITCH + 2 * (tid & 7);
+                    *reinterpret_cast<u32x2*>(o) = u32x2{h[0], h[1]};
+                    *reinterpret_cast<u32x2*>(o + plane) = u32x2{m[0], m[1]};
+                    *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l[0], l[1]};
                 }
-            }
-#endif
+            };
+            auto put_s = [&](float* img, int plane, const auto& regs, auto xw_c, auto kr_c, auto u_c) {
+                constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if constexpr (KR == 8) {
+                        const int unit = wave * U + u;
+                        const int x = (unit % (XW / 64)) * 64 + lane, oct = unit / (XW / 64);
+                        unsigned h[4], m[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hypel_split2(regs[u][2 * e], regs[u][2 * e + 1], h[e], m[e], l[e]);
+                        float* o = img + x * SP_PITCH + 4 * oct;
+                        *reinterpret_cast<u32x4*>(o) = u32x4{h[0], h[1], h[2], h[3]};
+                        *reinterpret_cast<u32x4*>(o + plane) = u32x4{m[0], m[1], m[2], m[3]};
+                        *reinterpret_cast<u32x4*>(o + 2 * plane) = u32x4{l[0], l[1], l[2], l[3]};
+                    } else {
+                        unsigned h[2], m[2], l[2];
+                        hypel_split2(regs[u][0], regs[u][1], h[0], m[0], l[0]);
+                        hypel_split2(regs[u][2], regs[u][3], h[1], m[1], l[1]);
+                        float* o = img + (tid & 31) * SP_PITCH + 2 * (tid >> 5);
+                        *reinterpret_cast<u32x2*>(o) = u32x2{h[0], h[1]};
+                        *reinterpret_cast<u32x2*>(o + plane) = u32x2{m[0], m[1]};
+                        *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l[0], l[1]};
+                    }
+                }
+            };
+            if constexpr (!TA) put_q(As, SP_PLANE_A, qa, std::integral_constant<int, SA_N>{});
+            else put_s(As, SP_PLANE_A, sa, std::integral_constant<int, BM>{}, std::integral_constant<int, SA_KR>{},
+                       std::integral_constant<int, SA_U>{});
+            if constexpr (TB) put_q(Bs, SP_PLANE_B, qb, std::integral_constant<int, SB_N>{});
+            else put_s(Bs, SP_PLANE_B, sb, std::integral_constant<int, BN>{}, std::integral_constant<int, SB_KR>{},
+                       std::integral_constant<int, SB_U>{});
+        } else {
+        if constexpr (LIN && !TA) {  // [m][k] tile transposed into the pair-interleaved image
 #pragma unroll
             for (int i = 0; i < A_PER_THREAD; ++i)
                 As[(a_col >> 1) * PPA + 2 * (a_row0 + i * A_RSTEP) + (a_col & 1)] = ra[i];
@@ -577,9 +616,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 #pragma unroll
             for (int i = 0; i < A_PER_THREAD; ++i) As[(a_row0 + i * A_RSTEP) * A_PITCH + a_col] = ra[i];
         }
-        if constexpr (B_TID) {
-            lds_store_addtid<B_PER_THREAD>(lds_m0 + 4u * A_ROWS * A_PITCH, rb);
-        } else if constexpr (LIN && TB) {
+        if constexpr (LIN && TB) {
 #pragma unroll
             for (int i = 0; i < B_PER_THREAD; ++i)
                 Bs[(b_col >> 1) * PPB + 2 * (b_row0 + i * B_RSTEP) + (b_col & 1)] = rb[i];
@@ -593,33 +630,48 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             for (int i = 0; i < B_PER_THREAD; ++i)
                 if (B_THREADS == 256 || b_stager) Bs[(b_row0 + i * B_RSTEP) * B_PITCH + b_col] = rb[i];
         }
-        if constexpr (A_TID || B_TID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // invisible to hipcc's counter
+        }
         __syncthreads();
 
         // put the next tile's loads in flight
-#if !HYPEL_GEMM_EARLY_SEG
-        lk += BK;
-        if (paired || lk >= seg.k) {
-            ls += paired ? 2 : 1;
-            lk = 0;
-            if (ls < s_end) {
-                seg = segs[ls];
-                if constexpr (PAIR)
-                    if (seg.k & HYPEL_SEG_PAIR_FLAG) seg2 = segs[ls + 1];
-            }
-        }
-        have = ls < s_end;
-#endif
         if (have) load_tiles(seg, lk);
 
         // One straight-line path (no per-tile branches, so the accumulators stay put and the compiler
         // pipelines the ds_reads under the MFMAs).  Ragged shapes rely on the zero-filled LDS image; the
         // only skips are wave-uniform: a wave with no active tile, and the second half of a short k-tile.
         if (any_act) {
-#if HYPEL_GEMM_SETPRIO
             __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
-#endif
-            if constexpr (NARROW && NT16 > 1) {
+            if constexpr (SPLIT) {
+                // 16 reduction columns per step: lane half h supplies k = 16 s + 8 h .. + 7 of its row (column) from each
+                // plane with one ds_read_b128; six products per accumulator tile, smallest first
+                const int sa_rd = (wm * TM * 32 + l31) * SP_PITCH + 4 * lhi;
+                const int sb_rd = (wn * TN * 32 + l31) * SP_PITCH + 4 * lhi;
+#pragma unroll
+                for (int st = 0; st < BK / 16; ++st) {
+                    if (st > 0 && kvalid <= 16 * st) break;
+                    bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            a[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                                                                      &As[p * SP_PLANE_A + sa_rd + i * 32 * SP_PITCH + 8 * st]));
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            b[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                                                                      &Bs[p * SP_PLANE_B + sb_rd + j * 32 * SP_PITCH + 8 * st]));
+                    }
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+                }
+            } else if constexpr (NARROW && NT16 > 1) {
                 // one straight-line variant per number of active 16-column tiles (a wave-uniform switch: the
                 // accumulators stay where they are, no MFMA is exec-masked)
                 auto phase = [&](auto nact_c) {
@@ -719,9 +771,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                     }
                 }
             }
-#if HYPEL_GEMM_SETPRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
         }
     }
 
@@ -738,64 +788,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     }
     bias = nullptr;
 #endif
-    // ---- tail splitting: a K-slice block hands its accumulators over; the last arriver sums the slices ----
-    if constexpr (!MULTI) {
-        const int s_cnt = split_info & 0xff;
-        if (s_cnt > 1) {
-            constexpr int NV4 = NARROW ? 2 * NT16 : TM * TN * 4;  // float4 per lane
-            const int s_idx = (split_info >> 8) & 0xff;
-            const int jn = n0 / BN;
-            float* slab0 = reinterpret_cast<float*>(slab_addr) + (size_t)jn * s_cnt * (BM * BN);
-            // register order: float4 q of lane `tid` at ((q * 256 + tid) * 4); write-through (sc1) 16-byte stores, so that
-            // no release fence is needed (cdna_hip_programming.md Guideline 16, recipe R1)
-            __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)slab0, 0, s_cnt * BM * BN * 4, 0x00020000);
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const int own = s_idx * BM * BN * 4;
-#pragma unroll
-            for (int q = 0; q < NV4; ++q) {
-                f32x4 v;
-                if constexpr (NARROW) {
-                    v = acc16[q];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[(q >> 2) / TN][(q >> 2) % TN][(q & 3) * 4 + e];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, (q * 256 + tid) * 16, own, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the ticket is drawn
-            __syncthreads();                                   // (also: every wave has left its last MFMA phase)
-            unsigned* tk = reinterpret_cast<unsigned*>(ticket_addr) + jn;
-            unsigned* flag = reinterpret_cast<unsigned*>(lds);
-            if (tid == 0) flag[0] = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const unsigned drawn = flag[0];
-            if (drawn != (unsigned)(s_cnt - 1)) return;
-            if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            // all slices, this block's own included, in index order: every load is issued before the first add
-            f32x4 part[NV4];
-#pragma unroll
-            for (int q = 0; q < NV4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part[q][e] = 0.0f;
-            for (int i = 0; i < s_cnt; ++i) {
-                u32x4 raw[NV4];
-#pragma unroll
-                for (int q = 0; q < NV4; ++q)
-                    raw[q] = __builtin_amdgcn_raw_buffer_load_b128(srs, (q * 256 + tid) * 16, i * BM * BN * 4, 16);
-#pragma unroll
-                for (int q = 0; q < NV4; ++q) part[q] += __builtin_bit_cast(f32x4, raw[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < NV4; ++q) {
-                if constexpr (NARROW) {
-                    acc16[q] = part[q];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[(q >> 2) / TN][(q >> 2) % TN][(q & 3) * 4 + e] = part[q][e];
-                }
-            }
-        }
-    }
     if constexpr (ACT) {
         // act(product + bias): the bias joins the accumulators here (the stores below then add none); no read-modify-write,
         // no shortcut gather, no statistics with this epilogue (the dispatcher checks)
@@ -1144,7 +1136,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
           bool PAIR = false, bool VARN = false, bool ACT = false>
-__global__ HYPEL_SGPR_ATTR HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PARAMS) {
+__global__ HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PARAMS) {
     seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, BNB, PAIR, VARN, ACT>(HYPEL_GEMM_ARGS);
 }
 
@@ -1157,6 +1149,13 @@ __global__ HYPEL_SGPR_ATTR HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PAR
 template <int WM, int WN, int TM, int TN, bool TA, bool TB>
 __global__ __attribute__((amdgpu_num_sgpr(96))) HYPEL_GEMM_BOUNDS void seg_gemm_kernel_s96(HYPEL_GEMM_PARAMS) {
     seg_gemm_body<WM, WN, TM, TN, TA, TB, false, false, false, false>(HYPEL_GEMM_ARGS);
+}
+
+// Split-operand variants (HYPEL_GEMM_SPLIT6): 128x128 blocks (2 x 2 waves of 64x64: 60 KB of LDS, two blocks per CU),
+// 128x64 (4 x 1 waves of 32x64: 45 KB, three) and 128x32 (4 x 1 waves of 32x32: 37.5 KB, four)
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool MULTI = false>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4))) void seg_gemm_split_kernel(HYPEL_GEMM_PARAMS) {
+    seg_gemm_body<WM, WN, TM, TN, TA, TB, false, MULTI, false, false, false, false, true>(HYPEL_GEMM_ARGS);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -1212,10 +1211,8 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
             return 0;
         }
     }
-    // diagnostic: unused dynamic LDS lowers the number of resident blocks per CU (occupancy experiments)
-    static const int lds_pad = getenv("HYPEL_GEMM_LDS_PAD") ? atoi(getenv("HYPEL_GEMM_LDS_PAD")) : 0;
 #define HYPEL_GO(TA_, TB_)                                                                                         \
-    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW, MULTI>), dim3(grid), dim3(256), lds_pad, st, a, \
+    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW, MULTI>), dim3(grid), dim3(256), 0, st, a,  \
                        lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,     \
                        res_start, stats, BnBwdEpi{})
     if constexpr (MULTI) {  // filter gradients only: A transposed, B as stored
@@ -1223,12 +1220,33 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
     } else {
         if (!ta && !tb) HYPEL_GO(false, false);
         else if (!ta && tb) HYPEL_GO(false, true);
-        else if (ta && !tb) HYPEL_GO(true, false);
-        else HYPEL_GO(true, true);
+        else HYPEL_GO(true, false);
     }
 #undef HYPEL_GO
     return 0;
     }
+}
+
+template <int WM, int WN, int TM, int TN, bool MULTI = false>
+int launch_split(const float* a, int64_t lda, int ta, const float* b, int64_t ldb, int tb, float* c, int64_t ldc, int n,
+                 const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles, const float* bias,
+                 int accumulate, const float* res, int64_t ldr, const int32_t* res_start, hipStream_t st, float* stats) {
+    constexpr int BN = WN * TN * 32;
+    const int n_nt = MULTI ? 1 : (n + BN - 1) / BN;
+    const int grid = n_tiles * n_nt;
+#define HYPEL_GO(TA_, TB_)                                                                                           \
+    hipLaunchKernelGGL((seg_gemm_split_kernel<WM, WN, TM, TN, TA_, TB_, MULTI>), dim3(grid), dim3(256), 0, st, a, lda, b, \
+                       ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr, res_start, stats, \
+                       BnBwdEpi{})
+    if constexpr (MULTI) {
+        HYPEL_GO(true, false);
+    } else {
+        if (!ta && !tb) HYPEL_GO(false, false);
+        else if (!ta && tb) HYPEL_GO(false, true);
+        else HYPEL_GO(true, false);
+    }
+#undef HYPEL_GO
+    return 0;
 }
 
 }  // namespace
@@ -1240,29 +1258,42 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
                              hypel_stream_t stream, float* stats = nullptr, BnBwdEpi bnb = BnBwdEpi{}) {
     HYPEL_REQUIRE(a && b && c && groups && segs && tiles, "hypel_seg_gemm_f32");
     HYPEL_REQUIRE(n > 0 && n_tiles >= 0, "hypel_seg_gemm_f32");
+    HYPEL_REQUIRE(!(trans_a && trans_b), "hypel_seg_gemm_f32: A^T B^T products are not part of the path");
     if (n_tiles == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // Tile choice (measured, profiles/r1_*): 128x64 blocks (4 waves/SIMD -> 1024 resident blocks) beat 128x128
     // (3 waves/SIMD -> 768) on every layer of the model by 1.1-1.7x: the grids here are only 1-4 "waves" of blocks,
-    // so the finer grain wastes less of the last wave.  HYPEL_GEMM_BN128=1 restores 128x128 for n > 64.
-    static const int bn128 = getenv("HYPEL_GEMM_BN128") ? atoi(getenv("HYPEL_GEMM_BN128")) : 0;
-    // launches with fewer than ~one round of 128x64 blocks (level data gradients: 784) balance better as 128x32
-    static const int bn32_below = getenv("HYPEL_GEMM_BN32_BELOW") ? atoi(getenv("HYPEL_GEMM_BN32_BELOW")) : 1000;
-    // bits 8-9 of `accumulate`: tile-width hint of the caller (1 = 128x32, 2 = 128x64), measured per launch class
-    // (profiles/r1_gemm_tile_choice.txt): data gradients with >= 48 reduction columns per segment and launches with
-    // few blocks run faster on the narrow tile, wide filter gradients on the wide one
+    // so the finer grain wastes less of the last wave.
+    // bits 8-9 of `accumulate`: tile-width hint of the caller (1 = 128x32, 2 = 128x64, 3 = 128x96), measured per launch
+    // class (profiles/r1_gemm_tile_choice.txt): data gradients with >= 48 reduction columns per segment and launches with
+    // few blocks run faster on the narrow tile, wide filter gradients on the wide one; without a hint: launches with
+    // fewer than ~one round of 128x64 blocks (level data gradients: 784) balance better as 128x32
     int hint = (accumulate >> 8) & 3;
-    // a table with K-slice records (tail splitting) was built for ONE tile width: the hint is binding then
-    const bool split_tail = (accumulate & HYPEL_GEMM_SPLIT_TAIL) != 0;
-    HYPEL_REQUIRE(!split_tail || (hint != 0 && !bnb.partial), "hypel_seg_gemm_f32: HYPEL_GEMM_SPLIT_TAIL needs a tile width");
     const bool pairs = (accumulate & HYPEL_GEMM_PAIRED_SEGS) != 0;  // segments carry HYPEL_SEG_PAIR_FLAG
-    static const int cap_on = getenv("HYPEL_GEMM_S96") ? atoi(getenv("HYPEL_GEMM_S96")) : 1;
-    const bool cap96 = cap_on && (accumulate & HYPEL_GEMM_SINGLE_SEG) != 0;  // every group has one segment
+    const bool cap96 = (accumulate & HYPEL_GEMM_SINGLE_SEG) != 0;   // every group has one segment
     const bool mfma16x4 = (accumulate & HYPEL_GEMM_MFMA16X4) != 0;  // merged level with <= 16 filters per branch
     const bool var_n = (accumulate & HYPEL_GEMM_VAR_N) != 0;        // groups differ in their column count
+    const bool split6 = (accumulate & HYPEL_GEMM_SPLIT6) != 0;      // three-way split operands on the bf16 matrix cores
     const int act_idx = (accumulate >> 16) & 7;                     // HYPEL_GEMM_ACT_*: leaky-ReLU of (product + bias)
     accumulate &= 1;
-    const bool plain_fwd = !trans_a && !trans_b && !split_tail && !pairs && !bnb.partial && !stats && !res;
+    if (split6) {
+        HYPEL_REQUIRE(!pairs && !bnb.partial && !mfma16x4 && !var_n && !act_idx && n > 16,
+                      "hypel_seg_gemm_f32: HYPEL_GEMM_SPLIT6 needs a plain product with n > 16");
+        // hint: 1 = 128x32, 2 = 128x64, 3 = 128x128 blocks; 0 = by n
+        const int w = hint == 1 || n <= 32 ? 32 : (hint == 2 || n <= 64 ? 64 : (hint == 3 || n > 96 ? 128 : 64));
+        if (w == 32)
+            launch_split<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                                     accumulate, res, ldr, res_start, st, stats);
+        else if (w == 64)
+            launch_split<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                                     accumulate, res, ldr, res_start, st, stats);
+        else
+            launch_split<2, 2, 2, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+                                     accumulate, res, ldr, res_start, st, stats);
+        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
+        return 0;
+    }
+    const bool plain_fwd = !trans_a && !trans_b && !pairs && !bnb.partial && !stats && !res;
     if (act_idx) {
         HYPEL_REQUIRE(plain_fwd && !accumulate && !mfma16x4 && !var_n && act_idx <= 4,
                       "hypel_seg_gemm_f32: HYPEL_GEMM_ACT_* needs a plain forward product (no accumulate / shortcut / statistics)");
@@ -1296,12 +1327,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     }
     // hint 3 = 128x96 blocks (three 32x32 accumulators per wave, 5 resident blocks per CU): N = 240 / 480 tile without
     // padding (5 x 96, 96 + 96 + 48) and a layer's 392 row tiles x 3 or 5 column tiles fit the resident capacity where
-    // 392 x 4 / x 8 of the 64-wide tiling overflow it by 2 %.  HYPEL_GEMM_FORCE_WIDTH=32|64|96: experiments.
-    static const int force_w = getenv("HYPEL_GEMM_FORCE_WIDTH") ? atoi(getenv("HYPEL_GEMM_FORCE_WIDTH")) : 0;
-    if (force_w == 32 && !split_tail) hint = 1;
-    if (force_w == 64 && !split_tail) hint = 2;
-    if (force_w == 96 && !split_tail) hint = 3;
-    HYPEL_REQUIRE(!split_tail || hint != 3 || n > 64, "hypel_seg_gemm_f32: 96-wide slabs need n > 64");
+    // 392 x 4 / x 8 of the 64-wide tiling overflow it by 2 %.
     if (hint == 3 && n > 64 && !bnb.partial) {
         launch_cfg<4, 1, 1, 3>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats);
@@ -1309,13 +1335,10 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
         return 0;
     }
     if (hint == 3) hint = 2;
-    const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
-    // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (HYPEL_GEMM_MFMA16=0: 128x32)
-    static const int mfma16 = getenv("HYPEL_GEMM_MFMA16") ? atoi(getenv("HYPEL_GEMM_MFMA16")) : 1;
+    const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < 1000);
     if (pairs) {  // data gradients only: A as stored, B transposed; n > 16
         HYPEL_REQUIRE(!trans_a && trans_b && n > 16 && !stats && !bnb.partial, "hypel_seg_gemm_f32: paired segments");
-        const bool narrow_p = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < bn32_below);
-        if (n <= 32 || narrow_p)
+        if (n <= 32 || narrow)
             launch_cfg_pair<4, 1, 1, 1>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
                                         ldr, res_start, st);
         else
@@ -1335,17 +1358,15 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_bnbwd_f32");
         return 0;
     }
-    if (n <= 16 && (mfma16 || split_tail) && !stats)  // the 16-wide variant has no reduction epilogues
+    // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (no reduction epilogues there)
+    if (n <= 16 && !stats)
         launch_cfg<4, 1, 1, 1, true>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st);
     else if (n <= 32 || narrow)
         launch_cfg<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats, cap96);
-    else if (n <= 64 || !bn128 || split_tail)
-        launch_cfg<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                               accumulate, res, ldr, res_start, st, stats);
     else
-        launch_cfg<2, 2, 2, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+        launch_cfg<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats);
     HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
     return 0;
@@ -1398,11 +1419,25 @@ extern "C" int hypel_seg_gemm_multi_f32(const float* base, int32_t trans_a, int3
                                         hypel_stream_t stream) {
     HYPEL_REQUIRE(base && segs && blocks && n_blocks >= 0, "hypel_seg_gemm_multi_f32");
     HYPEL_REQUIRE(trans_a == 1 && trans_b == 0, "hypel_seg_gemm_multi_f32: only A^T B products (filter gradients)");
-    HYPEL_REQUIRE(tile_width == 16 || tile_width == 32 || tile_width == 64, "hypel_seg_gemm_multi_f32");
+    const bool split6 = (tile_width & HYPEL_GEMM_MULTI_SPLIT6) != 0;
+    tile_width &= ~HYPEL_GEMM_MULTI_SPLIT6;
+    HYPEL_REQUIRE(tile_width == 16 || tile_width == 32 || tile_width == 64 || (split6 && tile_width == 128),
+                  "hypel_seg_gemm_multi_f32");
+    HYPEL_REQUIRE(!split6 || tile_width >= 32, "hypel_seg_gemm_multi_f32: split operands need 32- / 64- / 128-wide blocks");
     if (n_blocks == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     float* c = const_cast<float*>(base);
-    if (tile_width == 16)
+    if (split6) {
+        if (tile_width == 32)
+            launch_split<4, 1, 1, 1, true>(base, 0, 1, base, 0, 0, c, 0, 32, nullptr, segs, blocks, n_blocks, nullptr, 0,
+                                           nullptr, 0, nullptr, st, nullptr);
+        else if (tile_width == 64)
+            launch_split<4, 1, 1, 2, true>(base, 0, 1, base, 0, 0, c, 0, 64, nullptr, segs, blocks, n_blocks, nullptr, 0,
+                                           nullptr, 0, nullptr, st, nullptr);
+        else
+            launch_split<2, 2, 2, 2, true>(base, 0, 1, base, 0, 0, c, 0, 128, nullptr, segs, blocks, n_blocks, nullptr, 0,
+                                           nullptr, 0, nullptr, st, nullptr);
+    } else if (tile_width == 16)
         launch_cfg<4, 1, 1, 1, true, true>(base, 0, 1, base, 0, 0, c, 0, 16, nullptr, segs, blocks, n_blocks, nullptr, 0,
                                            nullptr, 0, nullptr, st);
     else if (tile_width == 32)

@@ -163,17 +163,18 @@ RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the dev
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
 SINGLE_SEG_HINT = os.environ.get("HYPEL_SINGLE_SEG_HINT", "1") != "0"
 GEMM_PAIRED_SEGS = 0x400    # ... HYPEL_GEMM_PAIRED_SEGS (bit of `accumulate`)
-GEMM_SPLIT_TAIL = 0x1000    # ... HYPEL_GEMM_SPLIT_TAIL: the tile table holds K-slice records, the width hint is binding
-# Tail splitting (include/hypel.h): the last tiles of every XCD's share of a forward / data-gradient launch are cut along
-# K so that the launch ends on short blocks.  HYPEL_TAIL_SPLIT = fraction of the resident blocks the slice records of a
-# launch should amount to (0 = off); HYPEL_TAIL_SLICES = slices per tile (0 = by the tile's length: 4 from 12 k-tiles,
-# 2 from 4).
-TAIL_SPLIT = float(os.environ.get("HYPEL_TAIL_SPLIT", "0"))  # measured neutral (NOTES.md): off by default
-TAIL_SLICES = int(os.environ.get("HYPEL_TAIL_SLICES", "0"))
-TAIL_MIN_TILES = int(os.environ.get("HYPEL_TAIL_MIN_TILES", "64"))  # launches with fewer row tiles are left alone
-TAIL_SLICE_KTILES = int(os.environ.get("HYPEL_TAIL_SLICE_KTILES", "8"))  # k-tiles a slice must keep
-TAIL_MAX_SLICES = int(os.environ.get("HYPEL_TAIL_MAX_SLICES", "4"))
-GEMM_BK = 32  # reduction columns per k-tile of the kernel (slices are cut at multiples of it)
+GEMM_BK = 32  # reduction columns per k-tile of the kernel
+# fp32 products on the bf16 matrix cores with three-way split operands and six partial products (include/hypel.h
+# HYPEL_GEMM_SPLIT6): "0" = never, "6" = wherever the launch is eligible and large enough (widths by column count),
+# "6:W" = the same with the tile width forced to hint W (1 = 128x32, 2 = 128x64, 3 = 128x128; per-launch A/B).
+# HYPEL_SPLIT_OVERRIDE="fwd:conv_dec_0=3,dgrad:conv_dec_0=0": per launch tag, 0 = fp32 MFMA kernel.
+GEMM_SPLIT6 = 0x8000        # include/hypel.h HYPEL_GEMM_SPLIT6 (bit of `accumulate`)
+GEMM_MULTI_SPLIT6 = 0x100   # ... HYPEL_GEMM_MULTI_SPLIT6 (bit of hypel_seg_gemm_multi_f32's tile_width)
+_gs = os.environ.get("HYPEL_GEMM_SPLIT", "0").split(":")
+GEMM_SPLIT = int(_gs[0] or 0)
+GEMM_SPLIT_WIDTH = int(_gs[1]) if len(_gs) > 1 else 0
+GEMM_SPLIT_MIN_FLOPS = float(os.environ.get("HYPEL_GEMM_SPLIT_MIN_GFLOP", "2")) * 1e9
+SPLIT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_SPLIT_OVERRIDE", "").split(",") if kv)}
 PAIR_SEGS = os.environ.get("HYPEL_PAIR_SEGS", "1") != "0"  # short data-gradient segments (k <= 16) share k-tiles
 GEMM_MFMA16X4 = 0x2000  # include/hypel.h HYPEL_GEMM_MFMA16X4: 128x64 blocks on the 16x16x4 MFMA (merged level, <= 16 filters)
 GEMM_VAR_N = 0x4000     # ... HYPEL_GEMM_VAR_N: tile records carry their group's column count
@@ -213,33 +214,10 @@ class GemmTables:
     def n_of(self, gi, n):
         return self.ns[gi] or n
 
-    @staticmethod
-    def _slice_segments(gs, S, a_ks, b_ks):
-        """Cut a tile's segment list into S parts of (nearly) equal k-tile counts, at multiples of the kernel's k-tile
-        inside a segment.  a_ks / b_ks: element distance of one reduction step in A / B."""
-        kts = [(k + GEMM_BK - 1) // GEMM_BK for _, _, k in gs]
-        total = sum(kts)
-        cuts = [total * i // S for i in range(S + 1)]
-        parts = [[] for _ in range(S)]
-        base = 0
-        for (a_off, b_off, k), kt in zip(gs, kts):
-            for i in range(S):
-                lo, hi = max(cuts[i], base), min(cuts[i + 1], base + kt)
-                if hi > lo:
-                    k_lo, k_hi = (lo - base) * GEMM_BK, min(k, (hi - base) * GEMM_BK)
-                    parts[i].append((a_off + k_lo * a_ks, b_off + k_lo * b_ks, k_hi - k_lo))
-            base += kt
-        return parts
-
-    def finalize(self, n, pair=False, split=None):
+    def finalize(self, n, pair=False):
         """pair: consecutive segments of a group with k <= 16 each are marked to share one k-tile (SEG_PAIR_FLAG on
-        the first; the kernel's data-gradient variant for short segments).  self.paired = number of pairs made.
-        split = dict(width, resident, a_ks, b_ks): tail splitting (include/hypel.h) -- the table is laid out as 8 equal
-        shares (one per XCD, what the kernel's block remap hands each XCD), the last tiles of every share are replaced
-        by K-slice records; self.split_need = (slab floats, ticket words) of scratch the launch needs, the records'
-        slab / ticket fields hold byte offsets into those two regions until _patch_split_tables adds the addresses."""
+        the first; the kernel's data-gradient variant for short segments).  self.paired = number of pairs made."""
         self.paired = 0
-        self.split_need = None
         segs = []
         garr = np.zeros(len(self.groups), GROUP_DTYPE)
         tiles = []
@@ -271,79 +249,16 @@ class GemmTables:
         # Filter-gradient launches pass key = split index (= batch-row range), for the same reason.
         tiles.sort(key=lambda t: (t[3], -t[0]))
 
-        def record(g, m0, seg_begin=None, seg_count=None, split_word=0, slab=0, ticket=0):
+        def record(g, m0):
             c_off, gs, rows = self.groups[g]
-            sb = int(garr[g]["seg_begin"]) if seg_begin is None else seg_begin
-            sc = len(gs) if seg_count is None else seg_count
+            sb, sc = int(garr[g]["seg_begin"]), len(gs)
             a0, b0, k0 = segs[sb][:3] if sc else (0, 0, 0)  # incl. the pair flag
-            return (g, m0, rows, sb, sc, k0, c_off, a0, b0, split_word, self.ns[g], slab, ticket)
+            return (g, m0, rows, sb, sc, k0, c_off, a0, b0, 0, self.ns[g])
 
-        recs = None
-        if split is not None and not self.paired and len(tiles) >= TAIL_MIN_TILES and TAIL_SPLIT > 0:
-            recs = self._tail_split(tiles, segs, n, split, record)
-        if recs is None:
-            recs = [record(g, m0) for (_, g, m0, _) in tiles]
+        recs = [record(g, m0) for (_, g, m0, _) in tiles]
         sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
         tarr = np.array(recs, TILE_DTYPE) if recs else np.zeros(0, TILE_DTYPE)
         return garr, sarr, tarr, macs
-
-    def _tail_split(self, tiles, segs, n, split, record):
-        width, resident = split["width"], split["resident"]
-        n_nt = (n + width - 1) // width
-        T = len(tiles)
-
-        def slices_of(g):
-            # a slice pays ~15 us of fixed block cost (record, first loads, slab hand-over) whatever its length: only
-            # tiles whose slices keep TAIL_SLICE_KTILES k-tiles are cut (the multi-kernel levels: up to 72 k-tiles per
-            # tile; the K <= 480 products of the 1x1 stack lost 4-10 us per launch when their tails were cut)
-            kt = sum((k + GEMM_BK - 1) // GEMM_BK for _, _, k in self.groups[g][1])
-            want = TAIL_SLICES if TAIL_SLICES else min(TAIL_MAX_SLICES, kt // TAIL_SLICE_KTILES)
-            return max(1, min(want, kt))
-
-        s_typ = max(slices_of(g) for _, g, _, _ in tiles[-64:])
-        if s_typ < 2:
-            return None
-        if T * n_nt <= resident // 2:
-            per_share = T  # the launch does not fill the device: every tile is cut
-        else:
-            t_total = min(T // 2, int(TAIL_SPLIT * resident / (s_typ * n_nt) + 0.5))
-            per_share = t_total // 8
-        if per_share < 1:
-            return None
-        shares = [tiles[T * x // 8: T * (x + 1) // 8] for x in range(8)]
-        out, slab_pos, ticket_pos, n_split = [], 0, 0, 0
-        lists = []
-        for sh in shares:
-            keep = max(0, len(sh) - per_share)
-            lst = [record(g, m0) for (_, g, m0, _) in sh[:keep]]
-            for (_, g, m0, _) in sh[keep:]:
-                S = slices_of(g)
-                if S < 2:
-                    lst.append(record(g, m0))
-                    continue
-                parts = self._slice_segments(self.groups[g][1], S, split["a_ks"], split["b_ks"])
-                parts = [p for p in parts if p]
-                S = len(parts)
-                if S < 2:
-                    lst.append(record(g, m0))
-                    continue
-                for i, part in enumerate(parts):
-                    sb = len(segs)
-                    segs.extend((int(a), int(b), int(k), 0) for a, b, k in part)
-                    lst.append(record(g, m0, sb, len(part), S | (i << 8), slab_pos * 4, ticket_pos * 4))
-                slab_pos += n_nt * S * GEMM_BM * width
-                ticket_pos += n_nt
-                n_split += 1
-            lists.append(lst)
-        if not n_split:
-            return None
-        L = max(len(l) for l in lists)
-        empty = (0,) * len(TILE_DTYPE.names)
-        for lst in lists:  # equal shares: block b runs on XCD b % 8 and takes the records of share b % 8 in order
-            out += lst + [empty] * (L - len(lst))
-        self.split_need = (slab_pos, ticket_pos)
-        self.split_tiles = n_split
-        return out
 
     def compulsory_bytes(self, n, lda, ta, ldb, tb):
         """Algorithmic HBM bytes of the launch: every DISTINCT operand element read once, every output element
@@ -591,6 +506,28 @@ class TowerPlan:
             return 1
         return 1 if blocks64 < 768 else 2
 
+    @staticmethod
+    def _split6_width(n):
+        """Tile-width hint of a split-operand launch by its column count: 128x128 blocks unless the last column tile
+        would be more than half empty."""
+        if GEMM_SPLIT_WIDTH:
+            return GEMM_SPLIT_WIDTH
+        if n <= 32:
+            return 1
+        rem = n % 128
+        return 2 if n <= 64 or 0 < rem <= 64 and n < 256 else 3
+
+    def _split6(self, tag, tables, n, ta, tb, flags, bnbwd, paired):
+        """0 = fp32 MFMA kernel, else the tile-width hint of the split-operand kernel for this launch."""
+        if tag in SPLIT_OVERRIDE:
+            return SPLIT_OVERRIDE[tag]
+        if GEMM_SPLIT != 6 or n <= 16 or (ta and tb) or flags or bnbwd is not None or paired:
+            return 0
+        macs = sum(rows * sum(k for _, _, k in gs) * tables.n_of(gi, n) for gi, (_, gs, rows) in enumerate(tables.groups))
+        if 2 * macs < GEMM_SPLIT_MIN_FLOPS:
+            return 0
+        return self._split6_width(n)
+
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
                    allow_split=True, res=None, stats=None, bnbwd=None, pair=False, hint=None, flags=0):
         """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32).
@@ -617,33 +554,18 @@ class TowerPlan:
             hint = HINT_OVERRIDE[tag]
         single_seg = bool(SINGLE_SEG_HINT and not ta and bnbwd is None and
                           all(len(segs) == 1 for _, segs, _ in tables.groups))
-        # tail splitting (forward and data-gradient launches on the main stream): the planner fixes the tile width the
-        # library would otherwise be free to choose, because the slab layout of the K-slice records depends on it
-        split = None
-        if TAIL_SPLIT > 0 and not ta and bnbwd is None and not USE_SIDE_STREAM and TILE_HINTS:
-            n_tiles_est = sum((rows + GEMM_BM - 1) // GEMM_BM for _, _, rows in tables.groups)
-            if n <= 16 and stats is None:
-                width, hint_b, bpc = 16, max(hint, 1), 7
-            elif n <= 32 or hint == 1 or (hint == 0 and n_tiles_est * ((n + 63) // 64) < 1000):
-                width, hint_b, bpc = 32, 1, (7 if single_seg and not pair else 6)
-            elif hint == 3 and n > 64:
-                width, hint_b, bpc = 96, 3, (5 if tb else 4)
-            else:
-                width, hint_b, bpc = 64, 2, (6 if tb else 5)
-            split = dict(width=width, resident=bpc * 256, a_ks=1, b_ks=(1 if tb else int(ldb)))
-        garr, sarr, tarr, macs = tables.finalize(n, pair=pair, split=split)
+        sp6 = self._split6(tag, tables, n, ta, tb, flags, bnbwd,
+                           pair and any(k <= 16 for _, gs, _ in tables.groups for _, _, k in gs))
+        if sp6:
+            pair, hint, single_seg = False, sp6, False
+            accumulate = int(accumulate) | GEMM_SPLIT6
+        garr, sarr, tarr, macs = tables.finalize(n, pair=pair)
         if len(tarr) == 0:
             return
         if pair and tables.paired:
             accumulate = int(accumulate) | GEMM_PAIRED_SEGS
         g_t, s_t, t_t = self.be.upload(garr), self.be.upload(sarr), self.be.upload(tarr)
         self.tables += [g_t, s_t, t_t]
-        if tables.split_need is not None:
-            hint = hint_b
-            accumulate = int(accumulate) | GEMM_SPLIT_TAIL
-            self.__dict__.setdefault("_split_tables", []).append((tarr, t_t))
-            self.scratch_sizes["ksplit_slabs"] = max(self.scratch_sizes.get("ksplit_slabs", 1), tables.split_need[0])
-            self.scratch_sizes["ksplit_tickets"] = max(self.scratch_sizes.get("ksplit_tickets", 1), tables.split_need[1])
         if single_seg and not flags:
             accumulate = int(accumulate) | GEMM_SINGLE_SEG
         accumulate = int(accumulate) | int(flags)
@@ -670,9 +592,6 @@ class TowerPlan:
             name = "seg_gemm_stats_f32"
             args = args + (None,)
         l = Launch(name, args, flops=2 * macs, nbytes=tables.compulsory_bytes(n, lda, ta, ldb, tb), tag=tag)
-        if tables.split_need is not None:
-            l.meta = {"tail_split_tiles": int(tables.split_tiles), "records": int(len(tarr)),
-                      "slab_mb": tables.split_need[0] * 4 / 1e6}
         if stats is not None:
             self._scratch(l, len(args) - 1, "scratch_partial", stats)
         lst.append(l)
@@ -836,23 +755,13 @@ class TowerPlan:
 
     def _finish_scratch(self):
         """Shared scratch (stream order makes reuse safe): allocate every region at its largest request, resolve the
-        launches' scratch arguments, and give the K-slice records of the tail-split tables their device addresses."""
+        launches' scratch arguments."""
         for name, size in self.scratch_sizes.items():
             self._alloc(name, size)
         for launch, pos, name in self._pending_scratch:
             args = list(launch.args)
             args[pos] = self._ref(name)
             launch.args = tuple(args)
-        if getattr(self, "_split_tables", None) and getattr(self.be, "name", "") == "hip":
-            import torch
-            slab0 = self.buffers["ksplit_slabs"].data_ptr()
-            tick0 = self.buffers["ksplit_tickets"].data_ptr()
-            for tarr, t_t in self._split_tables:
-                sel = (tarr["split"] & 0xff) > 1
-                tarr["slab"][sel] += np.uint64(slab0)
-                tarr["ticket"][sel] += np.uint64(tick0)
-                t_t.copy_(torch.from_numpy(np.ascontiguousarray(tarr).view(np.uint8).reshape(-1)))
-            self._split_tables = []
 
     def _scratch(self, launch, pos, name, size=0):
         self.scratch_sizes[name] = max(self.scratch_sizes.get(name, 1), int(size))
@@ -1841,9 +1750,13 @@ class TowerPlan:
         entries = []
         unpacks = []  # block copies packed gradient image -> TF-layout gradient slots (merged levels)
 
-        def col_tiles(n, merged):
+        def col_tiles(n, merged, split6=0):
             """[(n0, tile width)] of a product with n output columns.  Ordinary products: one width per product.  The
-            per-offset products of a merged level (n = 15 .. 240): 64-wide tiles while >= 48 columns remain, then 32, 16."""
+            per-offset products of a merged level (n = 15 .. 240): 64-wide tiles while >= 48 columns remain, then 32, 16.
+            split6 = tile-width hint of the split-operand kernel (widths | GEMM_MULTI_SPLIT6: their own launches)."""
+            if split6:
+                wdt = {1: 32, 2: 64, 3: 128}[split6]
+                return [(n0, wdt | GEMM_MULTI_SPLIT6) for n0 in range(0, n, wdt)]
             if not merged:
                 wdt = 16 if n <= 16 else (32 if n <= 32 else 64)
                 return [(n0, wdt) for n0 in range(0, n, wdt)]
@@ -1878,11 +1791,12 @@ class TowerPlan:
                 flags = 0 if up is not None else e["acc"]
             a0, b0 = rel(e["a_ref"]), rel(e["b_ref"])
             tb = e["tb"]
+            sp6 = 0 if up is not None else self._split6(e["tag"], tb, n, 1, 0, 0, None, False)
             first_width = None
             loc_groups = {}  # (width, locality key) -> [work, [(work, record)]]
             for gi, (c_off, gs, rows) in enumerate(tb.groups):
                 gn = tb.n_of(gi, n)
-                tiles = col_tiles(gn, up is not None)
+                tiles = col_tiles(gn, up is not None, sp6)
                 ksum = sum(k for _, _, k in gs)
                 key = tb.keys[gi] if tb.keys[gi] is not None else 0
                 seg_begin = {}
@@ -1899,7 +1813,7 @@ class TowerPlan:
                 for m0 in range(0, rows, GEMM_BM):
                     work = ksum * min(GEMM_BM, rows - m0)
                     for n0, wdt in tiles:
-                        per_width[wdt]["macs"] += min(GEMM_BM, rows - m0) * ksum * min(wdt, gn - n0)
+                        per_width[wdt]["macs"] += min(GEMM_BM, rows - m0) * ksum * min(wdt & 0xff, gn - n0)
                         recs = loc_groups.setdefault((wdt, key), [0, []])
                         recs[1].append((work, (c_base + int(c_off), first[0], first[1], m0, rows, n0, gn,
                                                seg_begin[wdt], len(gs), first[2], flags, e["lda"], e["ldb"], gn, 0)))
@@ -1928,7 +1842,8 @@ class TowerPlan:
             s_t, r_t = self.be.upload(sarr), self.be.upload(arr)
             self.tables += [s_t, r_t]
             l = Launch("seg_gemm_multi_f32", (base, 1, 0, width, Ref(s_t), Ref(r_t), int(len(arr))),
-                       flops=2 * pw["macs"], nbytes=pw["nbytes"], tag=f"wgrad-merged/{width}")
+                       flops=2 * pw["macs"], nbytes=pw["nbytes"],
+                       tag=f"wgrad-merged/{'s' if width & GEMM_MULTI_SPLIT6 else ''}{width & 0xff}")
             l.meta = {"products": pw["tags"], "blocks": int(sum(len(r) for r in xcd_recs)),
                       "xcd_work": [int(w) for w in xcd_work]}
             if WGRAD_PARALLEL and width != max(per_width):

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* hypel_stream_t; /* hipStream_t */
 
-#define HYPEL_ABI_VERSION 4  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
+#define HYPEL_ABI_VERSION 5  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
 
 /* activation codes (leaky_relu: HYPELCNNModel.py:39, DUALCNNModel.py:18, shadow_data_models.py:53;
  * relu: tf_slim default, CONCNNModel.py; sigmoid: HYPELCNNModel.py:93; tanh: shadow_data_models.py:86) */
@@ -73,24 +73,11 @@ typedef struct { int64_t a_off; int64_t b_off; int32_t k; int32_t reserved; } hy
 typedef struct { int64_t c_off; int32_t seg_begin; int32_t seg_count; int32_t rows; int32_t reserved; } hypel_group_t;
 typedef struct {
     int32_t group; int32_t m0;                         /* output rows [m0, min(m0 + 128, rows)) of groups[group] */
-    int32_t rows; int32_t seg_begin; int32_t seg_count; /* copies of groups[group] (a K-slice record: its own segments) */
+    int32_t rows; int32_t seg_begin; int32_t seg_count; /* copies of groups[group] */
     int32_t k0; int64_t c_off; int64_t a_off0; int64_t b_off0; /* c_off copy; segs[seg_begin] copy (0 if none) */
-    int32_t split; int32_t n;                          /* K-slice record: count | index << 8 (0 = whole tile), see below;
-                                                          n > 0: THIS tile's group has n output columns (<= the launch's n) */
-    uint64_t slab; uint64_t ticket;                    /* device addresses of the tile's partial slabs / ticket words */
+    int32_t reserved; int32_t n;                       /* n > 0: THIS tile's group has n output columns (<= the launch's n) */
 } hypel_tile_t;
 #define HYPEL_GEMM_BM 128
-/* Tail splitting.  The blocks of a launch start together and live 60-80 us each, so a launch ends in a long decay
- * while the last round drains (15-20 % of its time at the sizes of this model).  The LAST tiles of every XCD's share
- * of the tile table may therefore be cut along K into `count` slice records (same group / m0 / c_off, each with its own
- * segment range that covers one part of the reduction): every slice block writes its accumulators to
- * slab + ((column_tile * count + index) * 128 * tile_width) floats (write-through stores), draws a ticket from
- * ticket[column_tile] (zero before the first launch; the last arriver resets it), and the block that draws
- * count - 1 sums the `count` slabs IN INDEX ORDER (deterministic, no float atomics) and runs the ordinary epilogue
- * (bias, accumulate, shortcut gradient, statistics).  A table with slice records must be launched with
- * HYPEL_GEMM_SPLIT_TAIL in `accumulate` and a binding tile width in bits 8-9 (1 = 32, 2 = 64, 3 = 96; n <= 16: 16),
- * because the slab layout depends on it.  An all-zero record is an empty block (padding of an XCD's share). */
-#define HYPEL_GEMM_SPLIT_TAIL 0x1000
 /* Short segments (data gradients through convolutions with <= 16 filters: K = 15 in the narrowest HYPELCNN level):
  * a segment whose `k` has HYPEL_SEG_PAIR_FLAG set (real k = k & ~flag, <= 16) shares ONE 32-column k-tile with the
  * NEXT segment of its group (k <= 16, flag clear); the tile record's k0 copy carries the flag too.  Launches whose
@@ -124,11 +111,24 @@ typedef struct {
 #define HYPEL_GEMM_ACT_LRELU_0_18 0x20000
 #define HYPEL_GEMM_ACT_LRELU_0_2 0x30000
 #define HYPEL_GEMM_ACT_LRELU_0_01 0x40000
+/* fp32 products on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the rate of v_mfma_f32_32x32x2_f32).  Every
+ * fp32 operand element is split EXACTLY into three round-to-nearest bf16 parts (x = hi + mid + lo: 8 + 8 + 8 significand
+ * bits, fp32's exponent range) on its way into LDS; each k-step issues the six partial products hi hi, hi mid, mid hi,
+ * hi lo, lo hi, mid mid (every one exact in the fp32 accumulator) and drops mid lo, lo mid, lo lo, which are below
+ * 2^-24 |a b| -- the rounding unit of the fp32 accumulate itself.  Inputs, outputs, tables and epilogues (bias,
+ * accumulate, shortcut gather, statistics) are those of the plain launch; the result is as accurate as the fp32 MFMA
+ * chain (tests/test_gpu_kernels.py::test_seg_gemm_split6_error_vs_fp32_chain measures max |c - fp64| / sum |a b| of
+ * both on every launch shape of the benchmark step) but not bit-identical to it.  Plain products only (no paired
+ * segments, MFMA16X4, VAR_N, ACT), n > 16, not trans_a = trans_b = 1.  With this flag the tile-width hint reads
+ * 1 = 128x32, 2 = 128x64, 3 = 128x128 blocks.  hypel_seg_gemm_multi_f32: OR HYPEL_GEMM_MULTI_SPLIT6 into tile_width
+ * (32, 64 or 128 then). */
+#define HYPEL_GEMM_SPLIT6 0x8000
+#define HYPEL_GEMM_MULTI_SPLIT6 0x100
 
 /* `accumulate`: bit 0 = add to C instead of overwriting it; bits 8-9 = optional tile-width hint
  * (0 = library heuristic, 1 = 128x32 blocks, 2 = 128x64 blocks, 3 = 128x96 blocks for n > 64) -- results do not
- * depend on it; bit 10 = HYPEL_GEMM_PAIRED_SEGS; bit 11 = HYPEL_GEMM_SINGLE_SEG; bit 12 = HYPEL_GEMM_SPLIT_TAIL;
- * bit 13 = HYPEL_GEMM_MFMA16X4; bit 14 = HYPEL_GEMM_VAR_N. */
+ * depend on it; bit 10 = HYPEL_GEMM_PAIRED_SEGS; bit 11 = HYPEL_GEMM_SINGLE_SEG;
+ * bit 13 = HYPEL_GEMM_MFMA16X4; bit 14 = HYPEL_GEMM_VAR_N; bit 15 = HYPEL_GEMM_SPLIT6; bits 16-18 = HYPEL_GEMM_ACT_*. */
 int hypel_seg_gemm_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb, int32_t trans_b,
                        float* c, int64_t ldc, int32_t n, const hypel_group_t* groups, const hypel_seg_t* segs,
                        const hypel_tile_t* tiles, int32_t n_tiles, const float* bias, int32_t accumulate,
@@ -177,7 +177,8 @@ int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans_a, const f
  * first segment, as in hypel_tile_t) plus what used to be per-launch arguments -- column tile n0, the product's n,
  * lda, ldb, ldc -- and flags (bit 0 = accumulate into C).  Every offset (records and `segs`) is in elements relative
  * to `base`, one pointer for A, B and C (the operands live in different allocations; differences of device
- * addresses are exact in int64).  tile_width in {16, 32, 64}; trans_a = 1, trans_b = 0 only. */
+ * addresses are exact in int64).  tile_width in {16, 32, 64} (| HYPEL_GEMM_MULTI_SPLIT6: {32, 64, 128}, the width of
+ * the column tiles n0 the records were built for); trans_a = 1, trans_b = 0 only. */
 typedef struct {
     int64_t c_off; int64_t a_off0; int64_t b_off0;      /* output offset of the group; segs[seg_begin] copy */
     int32_t m0; int32_t rows; int32_t n0; int32_t n;      /* output rows [m0, m0+128) x columns [n0, n0+tile_width) */

@@ -264,10 +264,9 @@ class EmuBackend:
         g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
         s = segs.t.numpy()[segs.off:].view(SEG_DTYPE)
         t = tiles.t.numpy()[tiles.off:].view(TILE_DTYPE)[:n_tiles]
-        # tiles must cover every group's rows exactly once.  Tail splitting (include/hypel.h): a tile may instead appear
-        # as `count` K-slice records whose segment ranges together cover the group's reduction exactly once; all-zero
-        # records are empty blocks.  The result is specified per group, from the group's own segment list.
-        seen, slices = {}, {}
+        # tiles must cover every group's rows exactly once; all-zero records are empty blocks.  The result is specified
+        # per group, from the group's own segment list.
+        seen = {}
         any_split = False
         group_n = {}  # hypel_tile_t.n: a group's own column count (merged levels); every tile of a group agrees
         for tt in t:
@@ -278,43 +277,21 @@ class EmuBackend:
             assert accumulate_raw & 0x4000, "tile records with their own n need HYPEL_GEMM_VAR_N"
         if accumulate_raw & 0x2000:
             assert n <= 64 and not ta and not tb, "HYPEL_GEMM_MFMA16X4: forward products with n <= 64"
+        if accumulate_raw & 0x8000:  # HYPEL_GEMM_SPLIT6: same result to fp32 rounding, plain products only
+            assert n > 16 and not (ta and tb) and not (accumulate_raw & 0x6400) and not ((accumulate_raw >> 16) & 7), \
+                "HYPEL_GEMM_SPLIT6: plain NN / NT / TN products with n > 16"
+        assert not (ta and tb), "A^T B^T products are not part of the path"
         n_launch = n
         for tt in t:
             if int(tt["rows"]) == 0:
-                assert not any(int(tt[f]) for f in ("group", "m0", "seg_count", "split")), "malformed empty record"
+                assert not any(int(tt[f]) for f in ("group", "m0", "seg_count")), "malformed empty record"
                 continue
-            cnt = int(tt["split"]) & 0xff
-            if cnt > 1:
-                any_split = True
-                slices.setdefault((int(tt["group"]), int(tt["m0"])), []).append(tt)
-            else:
-                seen.setdefault(int(tt["group"]), []).append(int(tt["m0"]))
-        if any_split:
-            assert accumulate_raw & 0x1000 and (accumulate_raw >> 8) & 3, "K-slice records without HYPEL_GEMM_SPLIT_TAIL + width"
-        for (gi, m0), recs in slices.items():
-            seen.setdefault(gi, []).append(m0)
-            cnt = int(recs[0]["split"]) & 0xff
-            assert sorted((int(r["split"]) >> 8) & 0xff for r in recs) == list(range(cnt)), "slice indices"
-            gg = g[gi]
-            full = []  # (a_off, b_off) of every reduction step of the group / of the slices, in k-tile units
-            for si in range(int(gg["seg_begin"]), int(gg["seg_begin"]) + int(gg["seg_count"])):
-                full += [(int(s[si]["a_off"]), int(s[si]["b_off"]), int(s[si]["k"]))]
-            a_ks, b_ks = (lda if ta else 1), (1 if tb else ldb)
-            steps_full = sorted((ao + j * a_ks, bo + j * b_ks) for ao, bo, k in full for j in range(k))
-            steps = []
-            for r in sorted(recs, key=lambda r: (int(r["split"]) >> 8) & 0xff):
-                assert (int(r["rows"]), int(r["c_off"])) == (int(gg["rows"]), int(gg["c_off"]))
-                sb, sc = int(r["seg_begin"]), int(r["seg_count"])
-                assert sc > 0 and (int(r["a_off0"]), int(r["b_off0"]), int(r["k0"])) == \
-                    (int(s[sb]["a_off"]), int(s[sb]["b_off"]), int(s[sb]["k"]))
-                steps += [(int(s[si]["a_off"]) + j * a_ks, int(s[si]["b_off"]) + j * b_ks)
-                          for si in range(sb, sb + sc) for j in range(int(s[si]["k"]))]
-            assert sorted(steps) == steps_full, "the K slices of a tile must cover its reduction exactly once"
+            seen.setdefault(int(tt["group"]), []).append(int(tt["m0"]))
         for gi, m0s in seen.items():
             rows = int(g[gi]["rows"])
             assert sorted(m0s) == list(range(0, rows, 128)), (gi, m0s, rows)
-        for tt in t:  # every whole-tile record repeats its group and first segment (include/hypel.h)
-            if int(tt["rows"]) == 0 or (int(tt["split"]) & 0xff) > 1:
+        for tt in t:  # every tile record repeats its group and first segment (include/hypel.h)
+            if int(tt["rows"]) == 0:
                 continue
             gg = g[int(tt["group"])]
             assert (int(tt["rows"]), int(tt["seg_begin"]), int(tt["seg_count"]), int(tt["c_off"])) == \
@@ -385,7 +362,9 @@ class EmuBackend:
     def k_seg_gemm_multi_f32(self, base, ta, tb, tile_width, segs, blocks, n_blocks):
         """Specification of the merged filter-gradient launch: every block record is one 128 x tile_width output
         block of its own product C = A^T B (+ C when flagged), all offsets relative to `base`."""
-        assert ta == 1 and tb == 0 and tile_width in (16, 32, 64)
+        split6 = bool(tile_width & 0x100)  # HYPEL_GEMM_MULTI_SPLIT6: same result to fp32 rounding
+        tile_width &= ~0x100
+        assert ta == 1 and tb == 0 and tile_width in ((32, 64, 128) if split6 else (16, 32, 64))
         s = segs.t.numpy()[segs.off:].view(SEG_DTYPE)
         recs = blocks.t.numpy()[blocks.off:].view(MTILE_DTYPE)[:n_blocks]
         seen = set()

@@ -60,7 +60,7 @@ def test_signature_table_matches_header():
 def test_table_struct_layouts_match_header():
     from hypelcnn_amd.backend import GROUP_DTYPE, LOSS_TERM_DTYPE, SEG_DTYPE, TILE_DTYPE
     assert LOSS_TERM_DTYPE.itemsize == 104 and LOSS_TERM_DTYPE.fields["mode"][1] == 72 and LOSS_TERM_DTYPE.fields["slot"][1] == 100
-    assert SEG_DTYPE.itemsize == 24 and GROUP_DTYPE.itemsize == 24 and TILE_DTYPE.itemsize == 72
+    assert SEG_DTYPE.itemsize == 24 and GROUP_DTYPE.itemsize == 24 and TILE_DTYPE.itemsize == 56
     assert TILE_DTYPE.fields["n"][1] == 52  # hypel_tile_t.n (ABI 4) sits where `reserved` was
     from hypelcnn_amd.backend import COPY_BLOCK_DTYPE
     assert COPY_BLOCK_DTYPE.itemsize == 40 and COPY_BLOCK_DTYPE.fields["rows"][1] == 16

@@ -128,21 +128,26 @@ def test_channel_part_split_with_batch_norm_matches_oracle(monkeypatch):
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 
-def test_tail_split_tables_match_oracle(monkeypatch):
-    """Tail splitting (include/hypel.h): with the thresholds forced down, the forward and data-gradient tables of a toy
-    HYPELCNN carry K-slice records; the emulation checks that the slices of a tile cover its reduction exactly once,
-    and the whole step still equals the oracle."""
+def test_split6_plan_matches_oracle(monkeypatch):
+    """HYPEL_GEMM_SPLIT=6 (include/hypel.h HYPEL_GEMM_SPLIT6): with the size threshold forced down the planner marks the
+    eligible forward, data-gradient and merged filter-gradient launches of a toy HYPELCNN; the emulation checks the
+    eligibility rules of the flag, and the whole step still equals the oracle."""
     from hypelcnn_amd import plan
-    monkeypatch.setattr(plan, "TAIL_MIN_TILES", 1)
-    monkeypatch.setattr(plan, "TAIL_SLICES", 3)
-    monkeypatch.setattr(plan, "TAIL_SPLIT", 1.0)  # off by default (measured neutral)
+    monkeypatch.setattr(plan, "GEMM_SPLIT", 6)
+    monkeypatch.setattr(plan, "GEMM_SPLIT_MIN_FLOPS", 0.0)
     alg = dict(ALG_H, filter_count=96)
     built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 5, 40, 4, alg, 70, 29)
     ct = U.run_train_step(built, x, onehot, masks)
-    split = [l for l in ct.plan.fwd + ct.plan.bwd if l.meta.get("tail_split_tiles")]
+    launches = ct.plan.fwd + ct.plan.bwd
+    split = [l for l in launches if l.name.startswith("seg_gemm") and l.name != "seg_gemm_multi_f32" and l.args[14] & 0x8000]
     assert any(l.tag.startswith("fwd:") for l in split) and any(l.tag.startswith("dgrad:") for l in split), \
         [l.tag for l in split]
-    assert all(l.args[14] & 0x1000 and (l.args[14] >> 8) & 3 for l in split)
+    assert all((l.args[14] >> 8) & 3 for l in split)
+    multi = [l for l in launches if l.name == "seg_gemm_multi_f32"]
+    assert any(l.args[3] & 0x100 for l in multi), [l.tag for l in multi]
+    # launches the flag does not apply to stay on the fp32 kernel: n <= 16, paired short segments
+    assert any(l.name.startswith("seg_gemm") and l.name != "seg_gemm_multi_f32" and not (l.args[14] & 0x8000)
+               for l in launches)
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 

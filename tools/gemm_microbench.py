@@ -78,7 +78,7 @@ def main():
             a = l.args
             shape = f"  n={a[8]} tiles={a[12]} ta={a[2]} tb={a[5]}" if len(a) > 12 else f"  blocks={a[6]}"
             print(f"{l.tag:34s} {l.flops / 1e9:7.2f} GF  med {med:8.1f} us  min {t.min():8.1f} us  {l.flops / med / 1e6:6.1f} TF/s"
-                  + shape + (f"  split_tiles={l.meta['tail_split_tiles']}" if l.meta.get("tail_split_tiles") else ""))
+                  + shape + ("  SPLIT6" if (len(a) > 12 and a[14] & 0x8000) or (len(a) <= 12 and a[3] & 0x100) else ""))
     flops = sum(l.flops for l, _ in items)
     print(f"TOTAL {tot / 1e3:.3f} ms  {flops / tot / 1e6:.1f} TF/s")
 
