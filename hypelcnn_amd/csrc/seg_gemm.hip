@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -48,6 +49,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 2^-24 |a b|, i.e. below the rounding unit of the fp32 accumulate that follows.  Six bf16 MFMAs per k-step therefore
 // give an fp32-grade product (tests/test_gpu_kernels.py measures it against the fp32 MFMA chain per launch shape) at
 // 16 / 6 = 2.67x the rate of v_mfma_f32_32x32x2_f32.
+// (a, b) -> bf16(a) | bf16(b) << 16, round to nearest even.  Inline assembly: as a C++ cast pair hipcc re-converts element 0
+// alone wherever `word << 16` is needed (5 instead of 3 conversions per pair).
+__device__ __forceinline__ unsigned hypel_cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // two floats -> their (hi, mid, lo) bf16 parts, element 0 in the low half of each word
 __device__ __forceinline__ void hypel_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     bf16x2 p = {(__bf16)x0, (__bf16)x1};
@@ -62,6 +70,12 @@ __device__ __forceinline__ void hypel_split2(float x0, float x1, unsigned& h, un
 }
 
 namespace {
+
+// f(integral_constant<int, LO>), ..., f(integral_constant<int, LO + N - 1>)
+template <int LO, class F, int... Is>
+__device__ __forceinline__ void hypel_for_range(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, LO + Is>{}), ...);
+}
 
 #ifndef HYPEL_GEMM_BK
 #define HYPEL_GEMM_BK 32  // reduction columns per LDS tile (a multiple of 16)
@@ -144,7 +158,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     // hypel_tile_t.n): the A tile is staged once for up to four branches and the MFMA work stays exact to 16 columns
     constexpr int NT16 = NARROW ? TN : 1;  // 16-column accumulator tiles per wave
     constexpr int BN = NARROW ? 16 * NT16 : WN * TN * 32;
-    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int NT = 64 * WM * WN;  // threads per block
+    static_assert(WM * WN == 4 || (SPLIT && WM * WN == 8), "4 waves per block (split variants: 4 or 8)");
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
     static_assert(!ACT || (!TA && !TB && !NARROW && !MULTI && !BNB && !PAIR && !VARN), "activation epilogue: plain forward only");
     static_assert(!SPLIT || (!NARROW && !BNB && !PAIR && !VARN && !ACT && !(TA && TB)), "split variants: plain NN / NT / TN products");
@@ -189,13 +204,15 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int A_RSTEP = 256 / A_COLS;
     constexpr int B_RSTEP = 256 / B_COLS;
     static_assert(!RD64 || (A_RSTEP % 2 == 0 && B_RSTEP % 2 == 0 && (A_ROWS * A_PITCH) % 2 == 0), "RD64 staging layout");
-    // SPLIT: three bf16 planes per operand, each [rows][BK] with the reduction dimension contiguous and rows of
-    // 80 bytes (BK + 8 halves): the 16 lanes that a ds_read_b128 services per LDS cycle then start in 16 different
-    // 4-bank groups (20 r mod 64, r = 0-3, 12-15, 20-27) -- conflict-free fragment reads; so are the staging stores
-    // (8 consecutive rows x 16 bytes, and 2 rows x 8 quads x 8 bytes up to a 2-way overlap on four banks).
-    constexpr int SP_PITCH = 20;           // floats (80 bytes) per plane row
+    // SPLIT: k-tiles of SP_BK = 16 reduction columns (one 32x32x16 step); three bf16 planes per operand, each [rows][16]
+    // with the reduction dimension contiguous and rows of 48 bytes (16 + 8 halves): the 16 lanes that a ds_read_b128
+    // services per LDS cycle (rows 0-3, 12-15, 20-27 of a 32-row fragment) then start in 16 different 4-bank groups
+    // (12 r mod 64) -- conflict-free fragment reads; so are the 16-byte staging stores of eight consecutive rows.
+    constexpr int SP_BK = 16;
+    constexpr int SP_PITCH = (SP_BK + 8) / 2;  // floats (48 bytes) per plane row
     constexpr int SP_PLANE_A = BM * SP_PITCH, SP_PLANE_B = BN * SP_PITCH;  // floats per plane
-    __shared__ __attribute__((aligned(16))) float lds[SPLIT ? 3 * (SP_PLANE_A + SP_PLANE_B) : A_ROWS * A_PITCH + B_ROWS * B_PITCH];
+    constexpr int SP_BUF = 3 * (SP_PLANE_A + SP_PLANE_B);                  // floats per buffer; the split variants keep TWO
+    __shared__ __attribute__((aligned(16))) float lds[SPLIT ? 2 * SP_BUF : A_ROWS * A_PITCH + B_ROWS * B_PITCH];
     float* As = lds;
     float* Bs = lds + (SPLIT ? 3 * SP_PLANE_A : A_ROWS * A_PITCH);
 
@@ -315,16 +332,22 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int B_TILE = TB ? 32 * B_PITCH : 32;
 
     float ra[SPLIT ? 1 : A_PER_THREAD], rb[SPLIT ? 1 : B_PER_THREAD];
-    // SPLIT staging registers.  An operand stored with its reduction dimension contiguous ([x][k]: A of a forward / data
-    // gradient, B = W^T of a data gradient) is fetched as 16-byte quads: thread -> quad tid & 7 of rows (tid >> 3) + 32 i;
-    // one stored with k strided ([k][x]: both operands of a filter gradient, the weights of a forward product) by dword
-    // loads along x, a thread keeping KR consecutive k of ONE x -- the transpose happens in the registers.
-    constexpr int SA_N = BM / 32;                         // A, k-contiguous: quads per thread
-    constexpr int SB_N = BN / 32;                         // B, k-contiguous
-    constexpr int SA_KR = 8, SA_U = BM / 64;              // A, k-strided: 8 k per (x, octet) unit, units per wave
-    constexpr int SB_KR = BN >= 64 ? 8 : 4, SB_U = BN >= 64 ? BN / 64 : 1;
-    [[maybe_unused]] f32x4 qa[SPLIT && !TA ? SA_N : 1], qb[SPLIT && TB ? SB_N : 1];
-    [[maybe_unused]] float sa[SPLIT && TA ? SA_U : 1][SA_KR], sb[SPLIT && !TB ? SB_U : 1][SB_KR];
+    // SPLIT staging.  An operand stored with its reduction dimension contiguous ([x][k]: A of a forward / data gradient,
+    // B = W^T of a data gradient) is fetched as 16-byte quads: thread -> quad tid & 7 of rows (tid >> 3) + 32 i; one stored
+    // with k strided ([k][x]: both operands of a filter gradient, the weights of a forward product) by dword loads along
+    // x, a thread keeping KR consecutive k of ONE x -- the transpose happens in the registers.  Either way a thread ends
+    // up with PAIRS of k-adjacent elements: SP_NPA + SP_NPB pairs per k-tile.
+    constexpr int SP_QPR = SP_BK / 4;                     // quads per row of a k-contiguous operand tile
+    constexpr int SP_RP = NT / SP_QPR;                    // rows one pass of quad loads covers
+    constexpr int SA_N = BM / SP_RP, SB_N = BN >= SP_RP ? BN / SP_RP : 1;  // k-contiguous operand: quads per thread (BN <
+                                                                          // rows per pass: the threads beyond BN rows idle)
+    // k-strided operand of X columns: KR consecutive k per thread (all of the thread's share of the tile, at most 8),
+    // (X / 64) * (SP_BK / KR) wave-wide units dealt to the waves; X = 32: 32 x per 32 lanes, 2 k each
+    constexpr int SA_KR = SP_BK * BM / NT >= 8 ? 8 : SP_BK * BM / NT, SA_U = (BM / 64) * (SP_BK / SA_KR) / (NT / 64);
+    constexpr int SB_KR = SP_BK * BN / NT >= 8 ? 8 : SP_BK * BN / NT;
+    constexpr int SB_U = BN >= 64 ? (BN / 64) * (SP_BK / SB_KR) / (NT / 64) : 1;
+    static_assert(!SPLIT || (SA_N >= 1 && SB_N >= 1 && SA_U >= 1 && SB_U >= 1 && SA_KR >= 2 && SB_KR >= 2 &&
+                             (BN >= 64 || (NT == 256 && SB_KR == 2))), "split staging geometry");
     int ls = grp.seg_begin;
     const int s_end = grp.seg_begin + grp.seg_count;
     int lk = 0;
@@ -405,42 +428,33 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         }
     };
 
-    // SPLIT, operand with its reduction dimension contiguous: [rows][32 k] as 16-byte quads (dword-aligned addresses
-    // suffice for buffer_load_dwordx4); a k-tile that ends inside a quad (segment k not a multiple of 4) takes the
-    // per-element path -- wave-uniform choice
+    // SPLIT staging loads are branch-free: every fetch issues the SAME number of buffer loads on every path, so that hipcc's
+    // s_waitcnt insertion can count exactly how many younger loads may stay in flight (any branch that changes the count
+    // makes it fall back to vmcnt(0), which empties the whole prefetch ring).  Validity rides in the descriptor: rows at or
+    // beyond rows_valid (and everything, when the stream has ended: rows_valid = 0) lie beyond `span` and come back as 0;
+    // columns at or beyond the valid count are fetched at an out-of-range per-lane offset.
+    // Operand with its reduction dimension contiguous: [rows][16 k] as 16-byte quads (dword-aligned addresses suffice for
+    // buffer_load_dwordx4; each dword is range-checked on its own).  A k-tile that ends inside a quad (segment k not a
+    // multiple of 4) reads the row's next columns with it: split_quad() masks them.
     [[maybe_unused]] auto stage_q = [&](const float* base, int64_t ld, int rows_valid, int k_valid, auto& regs, auto count_c) {
         constexpr int COUNT = decltype(count_c)::value;
         const int ld4 = __builtin_amdgcn_readfirstlane((int)ld * 4);
         const int span = __builtin_amdgcn_readfirstlane(
             rows_valid > 0 && k_valid > 0 ? ((rows_valid - 1) * (int)ld + k_valid) * 4 : 0);
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
-        const int kOOB = 0x7fffffff;
-        const int row0 = tid >> 3, q4 = (tid & 7) * 4;
-        const int step = 32 * ld4;
+        const int q4 = (tid % SP_QPR) * 4;
+        const int voff = q4 < k_valid ? ((tid / SP_QPR) * (int)ld + q4) * 4 : 0x7fffffff;
+        const int step = SP_RP * ld4;
         int so = 0;
-        if ((k_valid & 3) == 0) {
-            const int voff = q4 < k_valid ? (row0 * (int)ld + q4) * 4 : kOOB;
 #pragma unroll
-            for (int i = 0; i < COUNT; ++i) {
-                const int v = (row0 + 32 * i) < rows_valid ? voff : kOOB;
-                regs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, v, so, 0));
-                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < COUNT; ++i) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int v = (row0 + 32 * i) < rows_valid && q4 + e < k_valid ? (row0 * (int)ld + q4 + e) * 4 : kOOB;
-                    regs[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, so, 0));
-                }
-                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
-            }
+        for (int i = 0; i < COUNT; ++i) {
+            regs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so, 0));
+            asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
         }
     };
-    // SPLIT, operand with its reduction dimension strided: [32 k][XW x], dword loads along x (fully coalesced), a thread
-    // keeps KR consecutive k of one x.  XW >= 64: unit = wave * U + u -> x = (unit % (XW / 64)) * 64 + lane, k = 8 * (unit /
-    // (XW / 64)) + r; XW = 32: x = tid & 31, k = 4 * (tid >> 5) + r
+    // Operand with its reduction dimension strided: [16 k][XW x], dword loads along x (fully coalesced), a thread keeps KR
+    // consecutive k of one x.  XW >= 64: unit = wave * U + u -> x = (unit % (XW / 64)) * 64 + lane, k = KR * (unit /
+    // (XW / 64)) + r; XW = 32 (256 threads): x = tid & 31, k = 2 * (tid >> 5) + r
     [[maybe_unused]] auto stage_s = [&](const float* base, int64_t ld, int k_valid, int x_valid, auto& regs, auto xw_c,
                                         auto kr_c, auto u_c) {
         constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
@@ -448,45 +462,28 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         const int span = __builtin_amdgcn_readfirstlane(
             k_valid > 0 && x_valid > 0 ? ((k_valid - 1) * (int)ld + x_valid) * 4 : 0);
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
-        const int kOOB = 0x7fffffff;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int x, kr0;
             if constexpr (XW >= 64) {
                 const int unit = wave * U + u;
                 x = (unit % (XW / 64)) * 64 + lane;
-                kr0 = (unit / (XW / 64)) * 8;
+                kr0 = (unit / (XW / 64)) * KR;
             } else {
                 x = tid & 31;
-                kr0 = (tid >> 5) * 4;
+                kr0 = (tid >> 5) * KR;
             }
-            const int voff = x < x_valid ? (kr0 * (int)ld + x) * 4 : kOOB;
+            const int voff = x < x_valid ? (kr0 * (int)ld + x) * 4 : 0x7fffffff;
             int so = 0;
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
-                const int v = (kr0 + r) < k_valid ? voff : kOOB;
-                regs[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, so, 0));
+                regs[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
                 asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(ld4) : "scc");
             }
         }
     };
 
     auto load_tiles = [&](const hypel_seg_t& sg, int k0) {
-        if constexpr (SPLIT) {
-            const int k_left = min(BK, sg.k - k0);
-            const int m_left = min(BM, rows_left);
-            const int n_left = min(BN, cols_left);
-            if constexpr (!TA)
-                stage_q(A + sg.a_off + (int64_t)m0 * lda + k0, lda, m_left, k_left, qa, std::integral_constant<int, SA_N>{});
-            else
-                stage_s(A + sg.a_off + (int64_t)k0 * lda + m0, lda, k_left, m_left, sa, std::integral_constant<int, BM>{},
-                        std::integral_constant<int, SA_KR>{}, std::integral_constant<int, SA_U>{});
-            if constexpr (TB)
-                stage_q(B + sg.b_off + (int64_t)n0 * ldb + k0, ldb, n_left, k_left, qb, std::integral_constant<int, SB_N>{});
-            else
-                stage_s(B + sg.b_off + (int64_t)k0 * ldb + n0, ldb, k_left, n_left, sb, std::integral_constant<int, BN>{},
-                        std::integral_constant<int, SB_KR>{}, std::integral_constant<int, SB_U>{});
-        } else {
         if constexpr (PAIR) {
             if (sg.k & HYPEL_SEG_PAIR_FLAG) {
                 const int kx = sg.k & ~HYPEL_SEG_PAIR_FLAG, ky = seg2.k;
@@ -512,7 +509,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         else  // rows = n, cols = k
             stage(B + sg.b_off + (int64_t)n0 * ldb + k0, ldb, b_row0, b_col, n_left, k_left, rb,
                   std::integral_constant<int, B_RSTEP>{}, std::integral_constant<int, B_PER_THREAD>{});
-        }
     };
 
     // Epilogue operands that only depend on the block's position -- the shortcut gradient's column ranges and the bias --
@@ -536,242 +532,379 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             }
         }
     }
-    if (have) load_tiles(seg, lk);
-
-    while (have) {
-        const bool paired = PAIR && (seg.k & HYPEL_SEG_PAIR_FLAG);
-        const int kvalid = paired ? 16 + seg2.k : min(BK, seg.k - lk);
-        // advance the (segment, k) cursor NOW and request the next segment record before the LDS hand-over below: behind
-        // the second barrier the scalar load sat directly in front of the address arithmetic of the next tile's loads
-        // -- one exposed round trip per segment, i.e. per k-tile in the data gradients of the multi-kernel levels
-        // (segments of 15-60 reduction columns)
-        lk += BK;
-        if (paired || lk >= seg.k) {
-            ls += paired ? 2 : 1;
-            lk = 0;
-            if (ls < s_end) {
-                seg = segs[ls];
-                if constexpr (PAIR)
-                    if (seg.k & HYPEL_SEG_PAIR_FLAG) seg2 = segs[ls + 1];
+    if constexpr (SPLIT) {
+        // ---- split-operand pipeline ----
+        // The fp32 -> 3 x bf16 split costs ~5 VALU operations per element.  Done between two barriers (load -> split -> LDS
+        // -> MFMA, as the fp32 kernel stages) it serialises with an MFMA phase that is 2.67x shorter here: that form ran at
+        // the fp32 kernel's own speed (round-5 notes).  And with two or three blocks per CU little but a block's own loads
+        // covers the memory latency: at the MFMA rate a CU consumes ~21 bytes per cycle, i.e. ~90 KB must be in flight
+        // across ~2 us.  So the k-tiles (16 reduction columns each) run through a software pipeline inside every wave:
+        //     LDS[t & 1]             tile t feeds the MFMAs
+        //     raw[(t + 1) % 4]       tile t + 1 is split and stored into LDS[(t + 1) & 1] UNDER those MFMAs, chunk by chunk
+        //     raw[(t + 2 .. 4) % 4]  the loads of tiles t + 2 .. t + 4 are in flight (tile t + 4 goes out at the phase start)
+        // One barrier per k-tile.
+        struct Raw {
+            f32x4 qa[!TA ? SA_N : 1], qb[TB ? SB_N : 1];
+            float sa[TA ? SA_U : 1][SA_KR], sb[!TB ? SB_U : 1][SB_KR];
+            int kv;  // valid reduction columns of the tile (scalar)
+        };
+        Raw raw0, raw1, raw2, raw3;
+        auto raw_of = [&](auto i_c) -> Raw& {
+            constexpr int I = decltype(i_c)::value & 3;
+            if constexpr (I == 0) return raw0;
+            else if constexpr (I == 1) return raw1;
+            else if constexpr (I == 2) return raw2;
+            else return raw3;
+        };
+        const int m_left = min(BM, rows_left), n_left = min(BN, cols_left);
+        // cursor of the load stream: (seg, lk) = the next k-tile, nseg = the record behind seg (always requested one fetch
+        // ahead, clamped at the group's last); have = the stream has not ended.  No branches (see stage_q).
+        hypel_seg_t nseg = segs[min(ls + 1, s_end - 1)];
+        int n_fetched = 0;  // real k-tiles requested so far: tile t + 1 exists iff t + 1 < n_fetched
+        auto fetch = [&](Raw& r) {
+            const int k_left = have ? min(SP_BK, seg.k - lk) : 0;  // 0: every load of this fetch is out of range
+            r.kv = k_left;
+            if constexpr (!TA)
+                stage_q(A + seg.a_off + (int64_t)m0 * lda + lk, lda, m_left, k_left, r.qa, std::integral_constant<int, SA_N>{});
+            else
+                stage_s(A + seg.a_off + (int64_t)lk * lda + m0, lda, k_left, m_left, r.sa, std::integral_constant<int, BM>{},
+                        std::integral_constant<int, SA_KR>{}, std::integral_constant<int, SA_U>{});
+            if constexpr (TB)
+                stage_q(B + seg.b_off + (int64_t)n0 * ldb + lk, ldb, n_left, k_left, r.qb, std::integral_constant<int, SB_N>{});
+            else
+                stage_s(B + seg.b_off + (int64_t)lk * ldb + n0, ldb, k_left, n_left, r.sb, std::integral_constant<int, BN>{},
+                        std::integral_constant<int, SB_KR>{}, std::integral_constant<int, SB_U>{});
+            n_fetched += have ? 1 : 0;
+            lk += SP_BK;
+            const bool adv = have && lk >= seg.k;
+            ls += adv ? 1 : 0;
+            lk = adv ? 0 : lk;
+            seg.a_off = adv ? nseg.a_off : seg.a_off;
+            seg.b_off = adv ? nseg.b_off : seg.b_off;
+            seg.k = adv ? nseg.k : seg.k;
+            have = ls < s_end;
+            nseg = segs[min(ls + 1, s_end - 1)];
+        };
+        // chunk c of an operand's raw registers (a quad of a k-contiguous operand, a KR-run of a k-strided one) -> split
+        // -> the three planes of LDS buffer `buf`: plane p of element (x, k) at p * PLANE + x * 80 + 2 k bytes
+        constexpr int SP_NCA = !TA ? SA_N : SA_U, SP_NCB = TB ? SB_N : SB_U;
+        auto chunk_q = [&](f32x4 v, int kv, float* img, int plane, int i, auto rows_c) {
+            constexpr int ROWS = decltype(rows_c)::value;
+            if (ROWS < SP_RP && tid / SP_QPR >= ROWS) return;  // (an operand with fewer rows than one pass of the block covers)
+            if (kv & 3) {  // the tile ends inside a quad: the elements behind its end are the row's next columns, not zeros
+                const int q4 = (tid % SP_QPR) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = q4 + e < kv ? v[e] : 0.0f;
             }
-        }
-        have = ls < s_end;
-        __syncthreads();  // previous tile's MFMAs are done reading LDS
-        if constexpr (SPLIT) {
-            // three-way split on the way into LDS: plane p of element (x, k) at p * PLANE + x * 80 + 2 k bytes
-            auto put_q = [&](float* img, int plane, const auto& regs, auto count_c) {
-                constexpr int COUNT = decltype(count_c)::value;
+            const unsigned h0 = hypel_cvt_pk_bf16(v[0], v[1]), h1 = hypel_cvt_pk_bf16(v[2], v[3]);
+            float r0 = v[0] - __builtin_bit_cast(float, h0 << 16), r1 = v[1] - __builtin_bit_cast(float, h0 & 0xffff0000u);
+            float r2 = v[2] - __builtin_bit_cast(float, h1 << 16), r3 = v[3] - __builtin_bit_cast(float, h1 & 0xffff0000u);
+            const unsigned m0_ = hypel_cvt_pk_bf16(r0, r1), m1_ = hypel_cvt_pk_bf16(r2, r3);
+            r0 -= __builtin_bit_cast(float, m0_ << 16);
+            r1 -= __builtin_bit_cast(float, m0_ & 0xffff0000u);
+            r2 -= __builtin_bit_cast(float, m1_ << 16);
+            r3 -= __builtin_bit_cast(float, m1_ & 0xffff0000u);
+            float* o = img + (tid / SP_QPR + SP_RP * i) * SP_PITCH + 2 * (tid % SP_QPR);
+            *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(o + plane) = u32x2{m0_, m1_};
+            *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{hypel_cvt_pk_bf16(r0, r1), hypel_cvt_pk_bf16(r2, r3)};
+        };
+        auto chunk_s = [&](const auto& v, float* img, int plane, int u, auto xw_c, auto kr_c, auto u_c) {
+            constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
+            int x, kg;
+            if constexpr (XW >= 64) {
+                const int unit = wave * U + u;
+                x = (unit % (XW / 64)) * 64 + lane;
+                kg = unit / (XW / 64);
+            } else {
+                x = tid & 31;
+                kg = tid >> 5;
+            }
+            unsigned h[KR / 2], m[KR / 2], l[KR / 2];
 #pragma unroll
-                for (int i = 0; i < COUNT; ++i) {
-                    unsigned h[2], m[2], l[2];
-                    hypel_split2(regs[i][0], regs[i][1], h[0], m[0], l[0]);
-                    hypel_split2(regs[i][2], regs[i][3], h[1], m[1], l[1]);
-                    float* o = img + ((tid >> 3) + 32 * i) * SP_PITCH + 2 * (tid & 7);
-                    *reinterpret_cast<u32x2*>(o) = u32x2{h[0], h[1]};
-                    *reinterpret_cast<u32x2*>(o + plane) = u32x2{m[0], m[1]};
-                    *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l[0], l[1]};
+            for (int e = 0; e < KR / 2; ++e) {
+                h[e] = hypel_cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+                float r0 = v[2 * e] - __builtin_bit_cast(float, h[e] << 16);
+                float r1 = v[2 * e + 1] - __builtin_bit_cast(float, h[e] & 0xffff0000u);
+                m[e] = hypel_cvt_pk_bf16(r0, r1);
+                r0 -= __builtin_bit_cast(float, m[e] << 16);
+                r1 -= __builtin_bit_cast(float, m[e] & 0xffff0000u);
+                l[e] = hypel_cvt_pk_bf16(r0, r1);
+            }
+            if constexpr (KR == 8) {
+                float* o = img + x * SP_PITCH + 4 * kg;
+                *reinterpret_cast<u32x4*>(o) = u32x4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<u32x4*>(o + plane) = u32x4{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<u32x4*>(o + 2 * plane) = u32x4{l[0], l[1], l[2], l[3]};
+            } else if constexpr (KR == 2) {
+                unsigned* o = reinterpret_cast<unsigned*>(img + x * SP_PITCH + kg);
+                o[0] = h[0];
+                o[plane] = m[0];
+                o[2 * plane] = l[0];
+            } else {
+                float* o = img + x * SP_PITCH + 2 * kg;
+                *reinterpret_cast<u32x2*>(o) = u32x2{h[0], h[1]};
+                *reinterpret_cast<u32x2*>(o + plane) = u32x2{m[0], m[1]};
+                *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l[0], l[1]};
+            }
+        };
+        auto chunk_a = [&](const Raw& r, int c, int buf) {
+            if constexpr (!TA) chunk_q(r.qa[c], r.kv, As + buf * SP_BUF, SP_PLANE_A, c, std::integral_constant<int, BM>{});
+            else chunk_s(r.sa[c], As + buf * SP_BUF, SP_PLANE_A, c, std::integral_constant<int, BM>{},
+                         std::integral_constant<int, SA_KR>{}, std::integral_constant<int, SA_U>{});
+        };
+        auto chunk_b = [&](const Raw& r, int c, int buf) {
+            if constexpr (TB) chunk_q(r.qb[c], r.kv, Bs + buf * SP_BUF, SP_PLANE_B, c, std::integral_constant<int, BN>{});
+            else chunk_s(r.sb[c], Bs + buf * SP_BUF, SP_PLANE_B, c, std::integral_constant<int, BN>{},
+                         std::integral_constant<int, SB_KR>{}, std::integral_constant<int, SB_U>{});
+        };
+        // One 32x32x16 step per k-tile: lane half h supplies k = 8 h .. 8 h + 7 of its row (column) from each plane with one
+        // ds_read_b128; six products per accumulator tile, smallest first.  WITH: the chunks of the next tile (raw set
+        // P + 1) are split and stored in between, spread over the six groups of MFMAs
+        const int sa_rd = (wm * TM * 32 + l31) * SP_PITCH + 4 * lhi;
+        const int sb_rd = (wn * TN * 32 + l31) * SP_PITCH + 4 * lhi;
+        auto phase = [&](auto p_c, auto with_c, auto mfma_c) {
+            constexpr int P = decltype(p_c)::value, CUR = P & 1;
+            constexpr bool WITH = decltype(with_c)::value, MF = decltype(mfma_c)::value;
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int NC = SP_NCA + SP_NCB;
+            const Raw& rs = raw_of(std::integral_constant<int, P + 1>{});
+            bf16x8 a[TM][3], b[TN][3];
+            if constexpr (MF) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        a[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                            &As[CUR * SP_BUF + p * SP_PLANE_A + sa_rd + i * 32 * SP_PITCH]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        b[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                            &Bs[CUR * SP_BUF + p * SP_PLANE_B + sb_rd + j * 32 * SP_PITCH]));
                 }
-            };
-            auto put_s = [&](float* img, int plane, const auto& regs, auto xw_c, auto kr_c, auto u_c) {
-                constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
+            }
+            hypel_for_range<0>([&](auto g_c) {
+                constexpr int Gi = decltype(g_c)::value;
+                if constexpr (MF) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if constexpr (KR == 8) {
-                        const int unit = wave * U + u;
-                        const int x = (unit % (XW / 64)) * 64 + lane, oct = unit / (XW / 64);
-                        unsigned h[4], m[4], l[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hypel_split2(regs[u][2 * e], regs[u][2 * e + 1], h[e], m[e], l[e]);
-                        float* o = img + x * SP_PITCH + 4 * oct;
-                        *reinterpret_cast<u32x4*>(o) = u32x4{h[0], h[1], h[2], h[3]};
-                        *reinterpret_cast<u32x4*>(o + plane) = u32x4{m[0], m[1], m[2], m[3]};
-                        *reinterpret_cast<u32x4*>(o + 2 * plane) = u32x4{l[0], l[1], l[2], l[3]};
-                    } else {
-                        unsigned h[2], m[2], l[2];
-                        hypel_split2(regs[u][0], regs[u][1], h[0], m[0], l[0]);
-                        hypel_split2(regs[u][2], regs[u][3], h[1], m[1], l[1]);
-                        float* o = img + (tid & 31) * SP_PITCH + 2 * (tid >> 5);
-                        *reinterpret_cast<u32x2*>(o) = u32x2{h[0], h[1]};
-                        *reinterpret_cast<u32x2*>(o + plane) = u32x2{m[0], m[1]};
-                        *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l[0], l[1]};
-                    }
-                }
-            };
-            if constexpr (!TA) put_q(As, SP_PLANE_A, qa, std::integral_constant<int, SA_N>{});
-            else put_s(As, SP_PLANE_A, sa, std::integral_constant<int, BM>{}, std::integral_constant<int, SA_KR>{},
-                       std::integral_constant<int, SA_U>{});
-            if constexpr (TB) put_q(Bs, SP_PLANE_B, qb, std::integral_constant<int, SB_N>{});
-            else put_s(Bs, SP_PLANE_B, sb, std::integral_constant<int, BN>{}, std::integral_constant<int, SB_KR>{},
-                       std::integral_constant<int, SB_U>{});
-        } else {
-        if constexpr (LIN && !TA) {  // [m][k] tile transposed into the pair-interleaved image
-#pragma unroll
-            for (int i = 0; i < A_PER_THREAD; ++i)
-                As[(a_col >> 1) * PPA + 2 * (a_row0 + i * A_RSTEP) + (a_col & 1)] = ra[i];
-        } else if constexpr (RD64 && TA) {  // [k][m] image, column pairs interleaved; the row step is even
-#pragma unroll
-            for (int i = 0; i < A_PER_THREAD; ++i)
-                As[(((a_row0 >> 1) + i * (A_RSTEP / 2)) * BM + a_col) * 2 + (a_row0 & 1)] = ra[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_PER_THREAD; ++i) As[(a_row0 + i * A_RSTEP) * A_PITCH + a_col] = ra[i];
-        }
-        if constexpr (LIN && TB) {
-#pragma unroll
-            for (int i = 0; i < B_PER_THREAD; ++i)
-                Bs[(b_col >> 1) * PPB + 2 * (b_row0 + i * B_RSTEP) + (b_col & 1)] = rb[i];
-        } else if constexpr (RD64 && !TB) {  // [k][n] image, column pairs interleaved
-#pragma unroll
-            for (int i = 0; i < B_PER_THREAD; ++i)
-                if (B_THREADS == 256 || b_stager)
-                    Bs[(((b_row0 >> 1) + i * (B_RSTEP / 2)) * BN + b_col) * 2 + (b_row0 & 1)] = rb[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_PER_THREAD; ++i)
-                if (B_THREADS == 256 || b_stager) Bs[(b_row0 + i * B_RSTEP) * B_PITCH + b_col] = rb[i];
-        }
-        }
-        __syncthreads();
-
-        // put the next tile's loads in flight
-        if (have) load_tiles(seg, lk);
-
-        // One straight-line path (no per-tile branches, so the accumulators stay put and the compiler
-        // pipelines the ds_reads under the MFMAs).  Ragged shapes rely on the zero-filled LDS image; the
-        // only skips are wave-uniform: a wave with no active tile, and the second half of a short k-tile.
-        if (any_act) {
-            __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
-            if constexpr (SPLIT) {
-                // 16 reduction columns per step: lane half h supplies k = 16 s + 8 h .. + 7 of its row (column) from each
-                // plane with one ds_read_b128; six products per accumulator tile, smallest first
-                const int sa_rd = (wm * TM * 32 + l31) * SP_PITCH + 4 * lhi;
-                const int sb_rd = (wn * TN * 32 + l31) * SP_PITCH + 4 * lhi;
-#pragma unroll
-                for (int st = 0; st < BK / 16; ++st) {
-                    if (st > 0 && kvalid <= 16 * st) break;
-                    bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            a[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
-                                                                      &As[p * SP_PLANE_A + sa_rd + i * 32 * SP_PITCH + 8 * st]));
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            b[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
-                                                                      &Bs[p * SP_PLANE_B + sb_rd + j * 32 * SP_PITCH + 8 * st]));
-                    }
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[Gi]], b[j][PB[Gi]], acc[i][j], 0, 0, 0);
                 }
-            } else if constexpr (NARROW && NT16 > 1) {
-                // one straight-line variant per number of active 16-column tiles (a wave-uniform switch: the
-                // accumulators stay where they are, no MFMA is exec-masked)
-                auto phase = [&](auto nact_c) {
-                    constexpr int NACT = decltype(nact_c)::value;
+                if constexpr (WITH) {
+#pragma unroll
+                    for (int c = Gi * NC / 6; c < (Gi + 1) * NC / 6; ++c) {
+                        if (c < SP_NCA) chunk_a(rs, c, CUR ^ 1);
+                        else chunk_b(rs, c - SP_NCA, CUR ^ 1);
+                    }
+                }
+            }, std::make_integer_sequence<int, 6>{});
+        };
+        // pipeline stage P (= t mod 4) of a tile that HAS a successor: fetch tile t + 4 into the set tile t left, run the
+        // phase, one barrier (tile t is done with, tile t + 1 is complete in the other buffer)
+        auto stage_of = [&](auto p_c) {
+            constexpr int P = decltype(p_c)::value;
+            fetch(raw_of(std::integral_constant<int, P>{}));
+            if (any_act) {
+                __builtin_amdgcn_s_setprio(1);
+                phase(p_c, std::true_type{}, std::true_type{});
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                phase(p_c, std::true_type{}, std::false_type{});
+            }
+            __syncthreads();
+        };
+        if (have) {
+            fetch(raw0);
+            fetch(raw1);
+            fetch(raw2);
+            fetch(raw3);
+#pragma unroll
+            for (int c = 0; c < SP_NCA; ++c) chunk_a(raw0, c, 0);
+#pragma unroll
+            for (int c = 0; c < SP_NCB; ++c) chunk_b(raw0, c, 0);
+            __syncthreads();
+            int t = 0;
+            while (true) {
+                if (!(t + 1 < n_fetched)) break;
+                stage_of(std::integral_constant<int, 0>{});
+                if (!(t + 2 < n_fetched)) { t += 1; break; }
+                stage_of(std::integral_constant<int, 1>{});
+                if (!(t + 3 < n_fetched)) { t += 2; break; }
+                stage_of(std::integral_constant<int, 2>{});
+                if (!(t + 4 < n_fetched)) { t += 3; break; }
+                stage_of(std::integral_constant<int, 3>{});
+                t += 4;
+            }
+            if (any_act) {  // the last tile: nothing left to split
+                __builtin_amdgcn_s_setprio(1);
+                if (t & 1) phase(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
+                else phase(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+    } else {
+        if (have) load_tiles(seg, lk);
+
+        while (have) {
+            const bool paired = PAIR && (seg.k & HYPEL_SEG_PAIR_FLAG);
+            const int kvalid = paired ? 16 + seg2.k : min(BK, seg.k - lk);
+            // advance the (segment, k) cursor NOW and request the next segment record before the LDS hand-over below: behind
+            // the second barrier the scalar load sat directly in front of the address arithmetic of the next tile's loads
+            // -- one exposed round trip per segment, i.e. per k-tile in the data gradients of the multi-kernel levels
+            // (segments of 15-60 reduction columns)
+            lk += BK;
+            if (paired || lk >= seg.k) {
+                ls += paired ? 2 : 1;
+                lk = 0;
+                if (ls < s_end) {
+                    seg = segs[ls];
+                    if constexpr (PAIR)
+                        if (seg.k & HYPEL_SEG_PAIR_FLAG) seg2 = segs[ls + 1];
+                }
+            }
+            have = ls < s_end;
+            __syncthreads();  // previous tile's MFMAs are done reading LDS
+            if constexpr (LIN && !TA) {  // [m][k] tile transposed into the pair-interleaved image
+#pragma unroll
+                for (int i = 0; i < A_PER_THREAD; ++i)
+                    As[(a_col >> 1) * PPA + 2 * (a_row0 + i * A_RSTEP) + (a_col & 1)] = ra[i];
+            } else if constexpr (RD64 && TA) {  // [k][m] image, column pairs interleaved; the row step is even
+#pragma unroll
+                for (int i = 0; i < A_PER_THREAD; ++i)
+                    As[(((a_row0 >> 1) + i * (A_RSTEP / 2)) * BM + a_col) * 2 + (a_row0 & 1)] = ra[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_PER_THREAD; ++i) As[(a_row0 + i * A_RSTEP) * A_PITCH + a_col] = ra[i];
+            }
+            if constexpr (LIN && TB) {
+#pragma unroll
+                for (int i = 0; i < B_PER_THREAD; ++i)
+                    Bs[(b_col >> 1) * PPB + 2 * (b_row0 + i * B_RSTEP) + (b_col & 1)] = rb[i];
+            } else if constexpr (RD64 && !TB) {  // [k][n] image, column pairs interleaved
+#pragma unroll
+                for (int i = 0; i < B_PER_THREAD; ++i)
+                    if (B_THREADS == 256 || b_stager)
+                        Bs[(((b_row0 >> 1) + i * (B_RSTEP / 2)) * BN + b_col) * 2 + (b_row0 & 1)] = rb[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER_THREAD; ++i)
+                    if (B_THREADS == 256 || b_stager) Bs[(b_row0 + i * B_RSTEP) * B_PITCH + b_col] = rb[i];
+            }
+            __syncthreads();
+
+            // put the next tile's loads in flight
+            if (have) load_tiles(seg, lk);
+
+            // One straight-line path (no per-tile branches, so the accumulators stay put and the compiler
+            // pipelines the ds_reads under the MFMAs).  Ragged shapes rely on the zero-filled LDS image; the
+            // only skips are wave-uniform: a wave with no active tile, and the second half of a short k-tile.
+            if (any_act) {
+                __builtin_amdgcn_s_setprio(1);  // favour the wave that is in its MFMA phase over the ones staging tiles
+                if constexpr (NARROW && NT16 > 1) {
+                    // one straight-line variant per number of active 16-column tiles (a wave-uniform switch: the
+                    // accumulators stay where they are, no MFMA is exec-masked)
+                    auto phase = [&](auto nact_c) {
+                        constexpr int NACT = decltype(nact_c)::value;
+#pragma unroll
+                        for (int q = 0; q < BK / CHUNK; ++q) {
+                            if (q > 0 && kvalid <= q * CHUNK) break;
+#pragma unroll
+                            for (int k4 = q * (CHUNK / 4); k4 < (q + 1) * (CHUNK / 4); ++k4) {
+                                const float a0 = As[a_rd + k4 * A_K4STEP];
+                                const float a1 = As[a_rd + A_TILE16 + k4 * A_K4STEP];
+                                float b[NACT];
+#pragma unroll
+                                for (int j = 0; j < NACT; ++j) b[j] = Bs[b_rd + 16 * j + k4 * B_K4STEP];
+#pragma unroll
+                                for (int j = 0; j < NACT; ++j) {
+                                    acc16[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], acc16[j], 0, 0, 0);
+                                    acc16[NT16 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j], acc16[NT16 + j], 0, 0, 0);
+                                }
+                            }
+                        }
+                    };
+                    if (tn_act >= 4) phase(std::integral_constant<int, 4>{});
+                    else if (tn_act == 3) phase(std::integral_constant<int, 3>{});
+                    else if (tn_act == 2) phase(std::integral_constant<int, 2>{});
+                    else phase(std::integral_constant<int, 1>{});
+                } else if constexpr (NARROW) {
+                    // CHUNK reduction columns at a time, as below
 #pragma unroll
                     for (int q = 0; q < BK / CHUNK; ++q) {
                         if (q > 0 && kvalid <= q * CHUNK) break;
 #pragma unroll
                         for (int k4 = q * (CHUNK / 4); k4 < (q + 1) * (CHUNK / 4); ++k4) {
+                            const float b = Bs[b_rd + k4 * B_K4STEP];
                             const float a0 = As[a_rd + k4 * A_K4STEP];
                             const float a1 = As[a_rd + A_TILE16 + k4 * A_K4STEP];
-                            float b[NACT];
+                            acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc16[0], 0, 0, 0);
+                            acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc16[1], 0, 0, 0);
+                        }
+                    }
+                } else if constexpr (RD64) {
+                    // CHUNK reduction columns (CHUNK / 4 step pairs) at a time, skipped beyond kvalid as below.  NACT = active
+                    // 32-column accumulator tiles (a prefix): forward 128x64 blocks of a merged level serve groups of 30 - 120
+                    // columns and run the one-tile variant where the second tile lies outside the group (wave-uniform switch)
+                    auto phase = [&](auto nact_c) {
+                        constexpr int NACT = decltype(nact_c)::value;
 #pragma unroll
-                            for (int j = 0; j < NACT; ++j) b[j] = Bs[b_rd + 16 * j + k4 * B_K4STEP];
+                        for (int q = 0; q < BK / CHUNK; ++q) {
+                            if (q > 0 && kvalid <= q * CHUNK) break;
 #pragma unroll
-                            for (int j = 0; j < NACT; ++j) {
-                                acc16[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], acc16[j], 0, 0, 0);
-                                acc16[NT16 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j], acc16[NT16 + j], 0, 0, 0);
+                            for (int t = q * (CHUNK / 4); t < (q + 1) * (CHUNK / 4); ++t) {
+                                float2 a[TM], b[NACT];
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+                                    a[i] = *reinterpret_cast<const float2*>(&As[a_rd + i * A_PTILE + t * A_PSTEP]);
+#pragma unroll
+                                for (int j = 0; j < NACT; ++j)
+                                    b[j] = *reinterpret_cast<const float2*>(&Bs[b_rd + j * B_PTILE + t * B_PSTEP]);
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                    for (int j = 0; j < NACT; ++j)
+                                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                    for (int j = 0; j < NACT; ++j)
+                                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                             }
                         }
+                    };
+                    constexpr bool PREFIX = VARN && TN == 2 && TM == 1 && !TA && !TB && !MULTI && !BNB && !PAIR;
+                    if constexpr (PREFIX) {
+                        if (tn_act >= 2) phase(std::integral_constant<int, 2>{});
+                        else phase(std::integral_constant<int, 1>{});
+                    } else {
+                        phase(std::integral_constant<int, TN>{});
                     }
-                };
-                if (tn_act >= 4) phase(std::integral_constant<int, 4>{});
-                else if (tn_act == 3) phase(std::integral_constant<int, 3>{});
-                else if (tn_act == 2) phase(std::integral_constant<int, 2>{});
-                else phase(std::integral_constant<int, 1>{});
-            } else if constexpr (NARROW) {
-                // CHUNK reduction columns at a time, as below
-#pragma unroll
-                for (int q = 0; q < BK / CHUNK; ++q) {
-                    if (q > 0 && kvalid <= q * CHUNK) break;
-#pragma unroll
-                    for (int k4 = q * (CHUNK / 4); k4 < (q + 1) * (CHUNK / 4); ++k4) {
-                        const float b = Bs[b_rd + k4 * B_K4STEP];
-                        const float a0 = As[a_rd + k4 * A_K4STEP];
-                        const float a1 = As[a_rd + A_TILE16 + k4 * A_K4STEP];
-                        acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc16[0], 0, 0, 0);
-                        acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc16[1], 0, 0, 0);
-                    }
-                }
-            } else if constexpr (RD64) {
-                // CHUNK reduction columns (CHUNK / 4 step pairs) at a time, skipped beyond kvalid as below.  NACT = active
-                // 32-column accumulator tiles (a prefix): forward 128x64 blocks of a merged level serve groups of 30 - 120
-                // columns and run the one-tile variant where the second tile lies outside the group (wave-uniform switch)
-                auto phase = [&](auto nact_c) {
-                    constexpr int NACT = decltype(nact_c)::value;
-#pragma unroll
+                } else {
+                // 16 reduction columns (8 MFMA k-steps) at a time; the chunks of a short k-tile beyond kvalid are skipped
+                    // by a wave-uniform branch
+        #pragma unroll
                     for (int q = 0; q < BK / CHUNK; ++q) {
                         if (q > 0 && kvalid <= q * CHUNK) break;
-#pragma unroll
-                        for (int t = q * (CHUNK / 4); t < (q + 1) * (CHUNK / 4); ++t) {
-                            float2 a[TM], b[NACT];
-#pragma unroll
+        #pragma unroll
+                        for (int k2 = q * (CHUNK / 2); k2 < (q + 1) * (CHUNK / 2); ++k2) {
+                            float a[TM], b[TN];
+        #pragma unroll
+                            for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
+        #pragma unroll
+                            for (int j = 0; j < TN; ++j) b[j] = Bs[b_rd + j * B_TILE + k2 * B_KSTEP];
+        #pragma unroll
                             for (int i = 0; i < TM; ++i)
-                                a[i] = *reinterpret_cast<const float2*>(&As[a_rd + i * A_PTILE + t * A_PSTEP]);
-#pragma unroll
-                            for (int j = 0; j < NACT; ++j)
-                                b[j] = *reinterpret_cast<const float2*>(&Bs[b_rd + j * B_PTILE + t * B_PSTEP]);
-#pragma unroll
-                            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                for (int j = 0; j < NACT; ++j)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-                            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                for (int j = 0; j < NACT; ++j)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+        #pragma unroll
+                                for (int j = 0; j < TN; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
                         }
                     }
-                };
-                constexpr bool PREFIX = VARN && TN == 2 && TM == 1 && !TA && !TB && !MULTI && !BNB && !PAIR;
-                if constexpr (PREFIX) {
-                    if (tn_act >= 2) phase(std::integral_constant<int, 2>{});
-                    else phase(std::integral_constant<int, 1>{});
-                } else {
-                    phase(std::integral_constant<int, TN>{});
                 }
-            } else {
-            // 16 reduction columns (8 MFMA k-steps) at a time; the chunks of a short k-tile beyond kvalid are skipped
-                // by a wave-uniform branch
-    #pragma unroll
-                for (int q = 0; q < BK / CHUNK; ++q) {
-                    if (q > 0 && kvalid <= q * CHUNK) break;
-    #pragma unroll
-                    for (int k2 = q * (CHUNK / 2); k2 < (q + 1) * (CHUNK / 2); ++k2) {
-                        float a[TM], b[TN];
-    #pragma unroll
-                        for (int i = 0; i < TM; ++i) a[i] = As[a_rd + i * A_TILE + k2 * A_KSTEP];
-    #pragma unroll
-                        for (int j = 0; j < TN; ++j) b[j] = Bs[b_rd + j * B_TILE + k2 * B_KSTEP];
-    #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-    #pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                    }
-                }
+                __builtin_amdgcn_s_setprio(0);
             }
-            __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -1151,10 +1284,10 @@ __global__ __attribute__((amdgpu_num_sgpr(96))) HYPEL_GEMM_BOUNDS void seg_gemm_
     seg_gemm_body<WM, WN, TM, TN, TA, TB, false, false, false, false>(HYPEL_GEMM_ARGS);
 }
 
-// Split-operand variants (HYPEL_GEMM_SPLIT6): 128x128 blocks (2 x 2 waves of 64x64: 60 KB of LDS, two blocks per CU),
-// 128x64 (4 x 1 waves of 32x64: 45 KB, three) and 128x32 (4 x 1 waves of 32x32: 37.5 KB, four)
+// Split-operand variants (HYPEL_GEMM_SPLIT6): 128x128 blocks of 512 threads (2 x 4 waves of 64x32: 60 KB of LDS, two
+// blocks = 16 waves per CU), 128x64 (4 x 1 waves of 32x64: 45 KB, three blocks) and 128x32 (4 x 1 waves of 32x32: 37.5 KB, four)
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool MULTI = false>
-__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4))) void seg_gemm_split_kernel(HYPEL_GEMM_PARAMS) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 2 : 3)))) void seg_gemm_split_kernel(HYPEL_GEMM_PARAMS) {
     seg_gemm_body<WM, WN, TM, TN, TA, TB, false, MULTI, false, false, false, false, true>(HYPEL_GEMM_ARGS);
 }
 
@@ -1235,7 +1368,7 @@ int launch_split(const float* a, int64_t lda, int ta, const float* b, int64_t ld
     const int n_nt = MULTI ? 1 : (n + BN - 1) / BN;
     const int grid = n_tiles * n_nt;
 #define HYPEL_GO(TA_, TB_)                                                                                           \
-    hipLaunchKernelGGL((seg_gemm_split_kernel<WM, WN, TM, TN, TA_, TB_, MULTI>), dim3(grid), dim3(256), 0, st, a, lda, b, \
+    hipLaunchKernelGGL((seg_gemm_split_kernel<WM, WN, TM, TN, TA_, TB_, MULTI>), dim3(grid), dim3(64 * WM * WN), 0, st, a, lda, b, \
                        ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr, res_start, stats, \
                        BnBwdEpi{})
     if constexpr (MULTI) {

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/split_ab
 o=gpurun_out/split_ab
 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "split6" -s > $o/tests.txt 2>&1
 tail -5 $o/tests.txt
-for v in 0 6:1 6:2 6:3 6; do
+for v in ${VARIANTS:-0 6:2 6:3 6}; do
   HYPEL_GEMM_SPLIT=$v HYPEL_GEMM_SPLIT_MIN_GFLOP=${MINGF:-0} python tools/gemm_microbench.py --rounds ${ROUNDS:-12} > $o/mb_$v.txt 2>&1
   tail -1 $o/mb_$v.txt
 done
