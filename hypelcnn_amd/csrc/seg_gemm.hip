@@ -592,6 +592,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             constexpr int ROWS = decltype(rows_c)::value;
             if (ROWS < SP_RP && tid / SP_QPR >= ROWS) return;  // (an operand with fewer rows than one pass of the block covers)
             if (kv & 3) {  // the tile ends inside a quad: the elements behind its end are the row's next columns, not zeros
+                asm volatile("" ::: "memory");  // (keeps this a rare uniform branch: if-converted it is 4 selects per quad)
                 const int q4 = (tid % SP_QPR) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = q4 + e < kv ? v[e] : 0.0f;
@@ -1410,8 +1411,9 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const int act_idx = (accumulate >> 16) & 7;                     // HYPEL_GEMM_ACT_*: leaky-ReLU of (product + bias)
     accumulate &= 1;
     if (split6) {
-        HYPEL_REQUIRE(!pairs && !bnb.partial && !mfma16x4 && !var_n && !act_idx && n > 16,
+        HYPEL_REQUIRE(!pairs && !bnb.partial && !mfma16x4 && !act_idx && n > 16,
                       "hypel_seg_gemm_f32: HYPEL_GEMM_SPLIT6 needs a plain product with n > 16");
+        (void)var_n;  // tile records with their own column count are honoured by every variant (blocks beyond them exit)
         // hint: 1 = 128x32, 2 = 128x64, 3 = 128x128 blocks; 0 = by n
         const int w = hint == 1 || n <= 32 ? 32 : (hint == 2 || n <= 64 ? 64 : (hint == 3 || n > 96 ? 128 : 64));
         if (w == 32)

@@ -170,7 +170,7 @@ GEMM_BK = 32  # reduction columns per k-tile of the kernel
 # HYPEL_SPLIT_OVERRIDE="fwd:conv_dec_0=3,dgrad:conv_dec_0=0": per launch tag, 0 = fp32 MFMA kernel.
 GEMM_SPLIT6 = 0x8000        # include/hypel.h HYPEL_GEMM_SPLIT6 (bit of `accumulate`)
 GEMM_MULTI_SPLIT6 = 0x100   # ... HYPEL_GEMM_MULTI_SPLIT6 (bit of hypel_seg_gemm_multi_f32's tile_width)
-_gs = os.environ.get("HYPEL_GEMM_SPLIT", "0").split(":")
+_gs = os.environ.get("HYPEL_GEMM_SPLIT", "6").split(":")
 GEMM_SPLIT = int(_gs[0] or 0)
 GEMM_SPLIT_WIDTH = int(_gs[1]) if len(_gs) > 1 else 0
 GEMM_SPLIT_MIN_FLOPS = float(os.environ.get("HYPEL_GEMM_SPLIT_MIN_GFLOP", "2")) * 1e9
@@ -192,6 +192,9 @@ MERGE_LEVELS_MAX_COUT = int(os.environ.get("HYPEL_MERGE_LEVELS_MAX_COUT", "32"))
 # per pass: widest branch (filters) the pass is merged for, taps per merged forward tile, forward tile-width hint
 MERGE_PASS_MAX_COUT = {k: int(os.environ.get(f"HYPEL_MERGE_{k.upper()}_MAX_COUT", d))
                        for k, d in (("fwd", "16"), ("dgrad", "1048576"), ("wgrad", "1048576"))}
+# ... and for the split-operand kernels, whose cost is dominated by staging A: sharing one staged A tile between the
+# branches of a ring pays for wider branches too
+MERGE_FWD_MAX_COUT_SPLIT = int(os.environ.get("HYPEL_MERGE_FWD_MAX_COUT_SPLIT", "16"))
 MERGE_MAX_TAPS = int(os.environ.get("HYPEL_MERGE_MAX_TAPS", "0"))  # 0 = MAX_TAPS_PER_TILE
 MERGE_FWD_HINT = int(os.environ.get("HYPEL_MERGE_FWD_HINT", "2"))
 
@@ -521,7 +524,7 @@ class TowerPlan:
         """0 = fp32 MFMA kernel, else the tile-width hint of the split-operand kernel for this launch."""
         if tag in SPLIT_OVERRIDE:
             return SPLIT_OVERRIDE[tag]
-        if GEMM_SPLIT != 6 or n <= 16 or (ta and tb) or flags or bnbwd is not None or paired:
+        if GEMM_SPLIT != 6 or n <= 16 or (ta and tb) or (flags & ~GEMM_VAR_N) or bnbwd is not None or paired:
             return 0
         macs = sum(rows * sum(k for _, _, k in gs) * tables.n_of(gi, n) for gi, (_, gs, rows) in enumerate(tables.groups))
         if 2 * macs < GEMM_SPLIT_MIN_FLOPS:
@@ -822,7 +825,8 @@ class TowerPlan:
                     pos += src.c * (C - lay["col0"][r])
                 lay["dense_size"] = pos
                 assert pos == sum(b.w.size for b in brs)
-                if any(w_ in MERGE_LEVELS and co <= MERGE_PASS_MAX_COUT[w_] for w_ in ("fwd", "dgrad")):
+                if any(w_ in MERGE_LEVELS and co <= max(MERGE_PASS_MAX_COUT[w_], MERGE_FWD_MAX_COUT_SPLIT if GEMM_SPLIT == 6 else 0)
+                       for w_ in ("fwd", "dgrad")):
                     # these passes read the packed image (the filter gradient does not)
                     lay["packed"] = True
                     self._alloc(lay["buf"], len(offs) * src.c * C)
@@ -832,7 +836,10 @@ class TowerPlan:
     def _level_pass(self, idx, node, what):
         """The level's packed layout if pass `what` ("fwd" / "dgrad" / "wgrad") uses the merged form, else None."""
         lay = self._level_layout(idx, node)
-        if lay is None or what not in MERGE_LEVELS or lay["co"] > MERGE_PASS_MAX_COUT[what]:
+        cap = MERGE_PASS_MAX_COUT[what]
+        if what == "fwd" and GEMM_SPLIT == 6:
+            cap = max(cap, MERGE_FWD_MAX_COUT_SPLIT)
+        if lay is None or what not in MERGE_LEVELS or lay["co"] > cap:
             return None
         return lay
 
@@ -900,7 +907,7 @@ class TowerPlan:
         pos = len(self.fwd)
         self._emit_gemm(self.fwd, tb, C, self._ref(s_st.buf), s_st.ld, 0, self._ref(lay["buf"]), C, 0, self._ref(ybuf), c,
                         None, 0, f"fwd:{node.branches[0].scope}/merged", allow_split=False, hint=MERGE_FWD_HINT,
-                        flags=flags)
+                        flags=flags)  # (a split-operand launch takes its own width, _split6_width)
         if len(self.fwd) > pos:
             self.fwd[pos].kparts = kp_n
         choff = 0

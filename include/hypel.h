@@ -119,7 +119,7 @@ typedef struct {
  * accumulate, shortcut gather, statistics) are those of the plain launch; the result is as accurate as the fp32 MFMA
  * chain (tests/test_gpu_kernels.py::test_seg_gemm_split6_error_vs_fp32_chain measures max |c - fp64| / sum |a b| of
  * both on every launch shape of the benchmark step) but not bit-identical to it.  Plain products only (no paired
- * segments, MFMA16X4, VAR_N, ACT), n > 16, not trans_a = trans_b = 1.  With this flag the tile-width hint reads
+ * segments, MFMA16X4, ACT; HYPEL_GEMM_VAR_N is fine), n > 16, not trans_a = trans_b = 1.  With this flag the tile-width hint reads
  * 1 = 128x32, 2 = 128x64, 3 = 128x128 blocks.  hypel_seg_gemm_multi_f32: OR HYPEL_GEMM_MULTI_SPLIT6 into tile_width
  * (32, 64 or 128 then). */
 #define HYPEL_GEMM_SPLIT6 0x8000

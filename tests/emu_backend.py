@@ -278,7 +278,7 @@ class EmuBackend:
         if accumulate_raw & 0x2000:
             assert n <= 64 and not ta and not tb, "HYPEL_GEMM_MFMA16X4: forward products with n <= 64"
         if accumulate_raw & 0x8000:  # HYPEL_GEMM_SPLIT6: same result to fp32 rounding, plain products only
-            assert n > 16 and not (ta and tb) and not (accumulate_raw & 0x6400) and not ((accumulate_raw >> 16) & 7), \
+            assert n > 16 and not (ta and tb) and not (accumulate_raw & 0x2400) and not ((accumulate_raw >> 16) & 7), \
                 "HYPEL_GEMM_SPLIT6: plain NN / NT / TN products with n > 16"
         assert not (ta and tb), "A^T B^T products are not part of the path"
         n_launch = n

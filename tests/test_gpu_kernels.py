@@ -72,12 +72,10 @@ def _tables(b, groups):  # (b: unused, kept for the call sites)
     (145, 333, 120, 1, 0, 0, False),   # wgrad: A transposed, M = Cin = 145
     (60, 1000, 60, 1, 0, 0, False),
     (15, 77, 45, 1, 0, 1, False),
-    (130, 33, 70, 1, 1, 0, False),
-    # n <= 16: the 128x16 blocks on the 16x16x4 MFMA, all four operand layouts, ragged K / rows, k-tile halves
+    # n <= 16: the 128x16 blocks on the 16x16x4 MFMA, the three operand layouts of the path, ragged K / rows, k-tile halves
     (300, 120, 15, 0, 0, 0, True),
     (120, 1085, 15, 1, 0, 0, False),   # level-2 filter gradient: M = Cin = 120, n = 15
     (257, 49, 16, 0, 1, 1, False),
-    (40, 17, 9, 1, 1, 0, True),
     (129, 7, 1, 0, 0, 1, False),
 ])
 def test_seg_gemm_single_segment(hip, rows, k, n, ta, tb_, acc, bias):
@@ -253,6 +251,28 @@ def test_seg_gemm_split6_multi_segment_levels(hip):
     for hint in (1, 2):
         b.run("seg_gemm_f32", "x", cin, 0, "w", cout, 0, "y", c_total, cout, "g", "s", "t", len(tarr), None, SPLIT6 | (hint << 8))
         b.check("y", rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,nbr,hint", [(320, 128, 128, 3), (320, 128, 96, 2), (145, 60, 200, 2), (120, 30, 64, 1),
+                                               (480, 480, 256, 3)])
+def test_seg_gemm_split6_filter_gradient_pixel_pairs(hip, cin, cout, nbr, hint):
+    """A filter gradient as the planner emits it: dW[tap] = sum over (input pixel, output pixel) pairs of X[p_in]^T dY[p_out]
+    -- groups whose segments are batch-row blocks of DIFFERENT pixel pairs (k = rows per block, not a multiple of 16 for
+    one case), X contiguous, dY at a channel offset of a wider tensor, ragged Cin tiles; two groups, three to five pairs."""
+    rng = np.random.default_rng(cin + cout)
+    P, c_tot, ch0 = 6, cout * 2 + 8, cout + 8
+    x = rng.standard_normal(P * nbr * cin).astype(np.float32)
+    dy = rng.standard_normal(P * nbr * c_tot).astype(np.float32)
+    groups = []
+    for gi, pairs in enumerate(([(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)], [(5, 0), (4, 2), (1, 1)])):
+        segs = [(pi * nbr * cin, po * nbr * c_tot + ch0, nbr) for pi, po in pairs]
+        groups.append((gi * cin * cout, segs, cin))
+    b = Both(hip)
+    garr, sarr, tarr, _ = _tables(b, groups).finalize(cout)
+    for nm, arr in (("x", x), ("dy", dy), ("w", np.zeros(2 * cin * cout, np.float32)), ("g", garr), ("s", sarr), ("t", tarr)):
+        b.arr(nm, arr)
+    b.run("seg_gemm_f32", "x", cin, 1, "dy", c_tot, 0, "w", cout, cout, "g", "s", "t", len(tarr), None, SPLIT6 | (hint << 8))
+    b.check("w", rtol=2e-4, atol=2e-5)
 
 
 def _gemm_errors(hip, rows, k, n, ta, tb_, hint, seed):
