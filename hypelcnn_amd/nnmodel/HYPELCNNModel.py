@@ -23,6 +23,9 @@ class HYPELCNNModel(NNModel):
         bn_params = {"is_training": training, "decay": p["bn_decay"]}
         with g.arg_scope([g.conv2d, g.fully_connected],
                          weights_initializer=g.variance_scaling_init(scale=2.0),
+                         # recorded on the convolution weights as the reference does (:42); the classifier's loss never
+                         # collects regularisation losses (common_nn_ops.py:214), the dense layers pass None (:80-93,121)
+                         weights_regularizer=g.l2_regularizer(p["l2regularizer_scale"]),
                          normalizer_fn=g.batch_norm, normalizer_params=bn_params,
                          activation_fn=g.leaky_relu(p["lrelu_alpha"])):
             net0 = model_input_params.x
@@ -42,15 +45,16 @@ class HYPELCNNModel(NNModel):
 
             net5 = self._fc_pyramid(g.flatten(net3), class_count, p["degradation_coeff"], 1 - p["drop_out_ratio"],
                                     training)
-            logits = g.fully_connected(net5, class_count, activation_fn=None, scope="fc_final")
+            logits = g.fully_connected(net5, class_count, weights_regularizer=None, activation_fn=None, scope="fc_final")
 
             image_out = None
             if training:
                 patch_elems = net0.hw[0] * net0.hw[1] * net0.c
                 head = logits
                 for i, mult in enumerate((3, 9, 27), start=1):
-                    head = g.fully_connected(head, class_count * mult, scope=f"image_gen_net_{i}")
-                image_out = g.fully_connected(head, patch_elems, activation_fn=g.sigmoid, scope="image_gen_net_4")
+                    head = g.fully_connected(head, class_count * mult, weights_regularizer=None, scope=f"image_gen_net_{i}")
+                image_out = g.fully_connected(head, patch_elems, weights_regularizer=None, activation_fn=g.sigmoid,
+                                              scope="image_gen_net_4")
         return ModelOutputTensors(y_conv=logits, image_output=image_out, image_original=net0,
                                   histogram_tensors=[HistogramTensorPair(net1, "spectral_expansion"),
                                                      HistogramTensorPair(net2, "spectral_reduction"),
@@ -97,6 +101,6 @@ class HYPELCNNModel(NNModel):
         net = flat
         for i in range(stages - 1):
             size //= shrink
-            net = g.fully_connected(net, size, scope=f"fc_{i}")
+            net = g.fully_connected(net, size, weights_regularizer=None, scope=f"fc_{i}")
             net = g.dropout(net, keep_prob=keep_prob, is_training=training)
         return net
