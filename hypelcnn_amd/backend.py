@@ -20,7 +20,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HYPEL_LIB_PATH: an alternative build of the same ABI (A/B experiments on one GPU box)
 LIB_PATH = os.environ.get("HYPEL_LIB_PATH") or os.path.join(_HERE, "csrc", "libhypel_hip.so")
 
-MAX_SIDE_STREAMS = 4  # side streams a plan may fork filter gradients onto (plan.SIDE_STREAMS <= this)
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 GEMM_BM = 128
 ABI_VERSION = 5  # include/hypel.h HYPEL_ABI_VERSION: a library built from other headers is refused at load time
@@ -173,8 +172,6 @@ def load_library(path=LIB_PATH):
             continue  # optional entry points (checked by tests/test_abi.py against the header)
         fn.argtypes = list(sig) + [_P]
         fn.restype = ctypes.c_int
-    lib.hypel_stream_fork.argtypes = [_P, _P]
-    lib.hypel_stream_join.argtypes = [_P, _P]
     lib.hypel_graph_begin_capture.argtypes = [_P]
     lib.hypel_graph_end_capture.argtypes = [_P, ctypes.POINTER(_P)]
     lib.hypel_graph_launch.argtypes = [_P, _P]
@@ -264,17 +261,13 @@ class HipBackend:
             raise HypelError(f"libhypel_hip.so ABI version {self.lib.hypel_version()} != {ABI_VERSION} (stale build or HYPEL_LIB_PATH)")
         # All hypel launches (and the torch plumbing ops around them) run on ONE dedicated non-default
         # stream: HIP cannot capture the legacy null stream into a graph, and a private stream keeps the
-        # step ordered without device-wide syncs.  The stream pair is per DEVICE, not per backend object: torch's
+        # step ordered without device-wide syncs.  The stream is per DEVICE, not per backend object: torch's
         # "current stream" is process-global state, so a second HipBackend with streams of its own would silently
         # move the first one's copies (set_input, .cpu()) onto a stream its kernels are not ordered with.
         key = self.device.index if self.device.index is not None else torch.cuda.current_device()
         if key not in HipBackend._streams:
-            # side stream: independent kernels of the backward pass (filter gradients) run there and fill the grid
-            # tails of the data-gradient kernels on the main stream
-            HipBackend._streams[key] = (torch.cuda.Stream(self.device),
-                                        [torch.cuda.Stream(self.device) for _ in range(MAX_SIDE_STREAMS)])
-        self.stream, self.side_streams = HipBackend._streams[key]
-        self.side_stream = self.side_streams[0]
+            HipBackend._streams[key] = torch.cuda.Stream(self.device)
+        self.stream = HipBackend._streams[key]
         torch.cuda.set_stream(self.stream)
 
     # -- memory (PyTorch is the allocator: plumbing only) --
@@ -325,24 +318,8 @@ class HipBackend:
     def bind(self, name, args, stream=None):
         if name in COLLECTIVES:
             return bind_collective(name, args)
-        if name == "_fork" or name == "_join":
-            # _fork (k,): side stream k waits for the main stream; _join (k1, k2, ..): the main stream waits for them
-            fn = self.lib.hypel_stream_fork if name == "_fork" else self.lib.hypel_stream_join
-            main, lib = self.stream.cuda_stream, self.lib
-            ks = [int(k) for k in args] if args else [1]
-            sides = [self.side_streams[k - 1].cuda_stream for k in ks]
-
-            def sync_call():
-                for side in sides:
-                    if fn(main, side) != 0:
-                        raise HypelError(lib.hypel_last_error().decode())
-
-            return sync_call
         fn = getattr(self.lib, "hypel_" + name)
-        if isinstance(stream, int) and 1 <= stream <= MAX_SIDE_STREAMS:
-            st = self.side_streams[stream - 1].cuda_stream
-        else:
-            st = self.stream_handle() if stream is None or stream == 0 else stream
+        st = self.stream_handle() if stream is None or stream == 0 else stream
         cargs = []
         for a in args:
             if isinstance(a, Ref):

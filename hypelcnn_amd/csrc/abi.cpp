@@ -70,27 +70,6 @@ extern "C" uint32_t hypel_crc32c(uint32_t crc, const void* data, uint64_t n) {
     return c ^ 0xffffffffu;
 }
 
-static int dep(hipStream_t from, hipStream_t to, const char* what) {
-    hipEvent_t ev = nullptr;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(ev, from);
-    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
-    if (ev) (void)hipEventDestroy(ev);  // destruction is deferred until the event completes
-    if (e != hipSuccess) {
-        hypel_set_error("%s: %s", what, hipGetErrorString(e));
-        return -2;
-    }
-    return 0;
-}
-
-extern "C" int hypel_stream_fork(hypel_stream_t main_stream, hypel_stream_t side_stream) {
-    return dep((hipStream_t)main_stream, (hipStream_t)side_stream, "hypel_stream_fork");
-}
-
-extern "C" int hypel_stream_join(hypel_stream_t main_stream, hypel_stream_t side_stream) {
-    return dep((hipStream_t)side_stream, (hipStream_t)main_stream, "hypel_stream_join");
-}
-
 extern "C" int hypel_graph_begin_capture(hypel_stream_t stream) {
     // HYPEL_CAPTURE_MODE=relaxed|global: experiments (default thread-local)
     static const char* mode_env = getenv("HYPEL_CAPTURE_MODE");

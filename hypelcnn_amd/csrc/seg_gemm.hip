@@ -1285,10 +1285,13 @@ __global__ __attribute__((amdgpu_num_sgpr(96))) HYPEL_GEMM_BOUNDS void seg_gemm_
     seg_gemm_body<WM, WN, TM, TN, TA, TB, false, false, false, false>(HYPEL_GEMM_ARGS);
 }
 
-// Split-operand variants (HYPEL_GEMM_SPLIT6): 128x128 blocks of 512 threads (2 x 4 waves of 64x32: 60 KB of LDS, two
-// blocks = 16 waves per CU), 128x64 (4 x 1 waves of 32x64: 45 KB, three blocks) and 128x32 (4 x 1 waves of 32x32: 37.5 KB, four)
+// Split-operand variants (HYPEL_GEMM_SPLIT6): 128x128 blocks of 512 threads (2 x 4 waves of 64x32; 72 KB of LDS: two
+// blocks = 16 waves per CU, <= 128 registers), 128x64 blocks of 512 threads (4 x 2 waves of 32x32; 54 KB: two blocks) and
+// 128x32 blocks of 256 threads (4 x 1 waves of 32x32; 45 KB: three).  Same-box A/B against 256-thread blocks with
+// 64x64 / 32x64 wave tiles (round 5): 155 vs 164 us on M = 50176, K = n = 480 -- four waves per SIMD hide the barrier of
+// every 16-column k-tile and the split's VALU work better than two.
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool MULTI = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 2 : 3)))) void seg_gemm_split_kernel(HYPEL_GEMM_PARAMS) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void seg_gemm_split_kernel(HYPEL_GEMM_PARAMS) {
     seg_gemm_body<WM, WN, TM, TN, TA, TB, false, MULTI, false, false, false, false, true>(HYPEL_GEMM_ARGS);
 }
 
@@ -1420,10 +1423,10 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
             launch_split<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st, stats);
         else if (w == 64)
-            launch_split<4, 1, 1, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+            launch_split<4, 2, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st, stats);
         else
-            launch_split<2, 2, 2, 2>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
+            launch_split<2, 4, 2, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st, stats);
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
         return 0;
@@ -1567,10 +1570,10 @@ extern "C" int hypel_seg_gemm_multi_f32(const float* base, int32_t trans_a, int3
             launch_split<4, 1, 1, 1, true>(base, 0, 1, base, 0, 0, c, 0, 32, nullptr, segs, blocks, n_blocks, nullptr, 0,
                                            nullptr, 0, nullptr, st, nullptr);
         else if (tile_width == 64)
-            launch_split<4, 1, 1, 2, true>(base, 0, 1, base, 0, 0, c, 0, 64, nullptr, segs, blocks, n_blocks, nullptr, 0,
+            launch_split<4, 2, 1, 1, true>(base, 0, 1, base, 0, 0, c, 0, 64, nullptr, segs, blocks, n_blocks, nullptr, 0,
                                            nullptr, 0, nullptr, st, nullptr);
         else
-            launch_split<2, 2, 2, 2, true>(base, 0, 1, base, 0, 0, c, 0, 128, nullptr, segs, blocks, n_blocks, nullptr, 0,
+            launch_split<2, 4, 2, 1, true>(base, 0, 1, base, 0, 0, c, 0, 128, nullptr, segs, blocks, n_blocks, nullptr, 0,
                                            nullptr, 0, nullptr, st, nullptr);
     } else if (tile_width == 16)
         launch_cfg<4, 1, 1, 1, true, true>(base, 0, 1, base, 0, 0, c, 0, 16, nullptr, segs, blocks, n_blocks, nullptr, 0,

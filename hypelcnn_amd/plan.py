@@ -46,26 +46,18 @@ TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitt
 
 
 class Launch:
-    __slots__ = ("name", "args", "flops", "bytes", "tag", "stream", "kparts", "meta")
+    __slots__ = ("name", "args", "flops", "bytes", "tag", "kparts", "meta")
 
-    def __init__(self, name, args, flops=0, nbytes=0, tag="", stream=0):
+    def __init__(self, name, args, flops=0, nbytes=0, tag=""):
         self.name = name
         self.args = args
         self.flops = flops
         self.bytes = nbytes
         self.tag = tag
-        self.stream = stream  # 0 = main, 1 = side (concurrent filter gradients)
         self.kparts = 1  # channel parts the reduction dimension of a level forward was cut into (diagnostic)
         self.meta = {}  # diagnostics (e.g. the products a merged filter-gradient launch contains)
 
 
-# Side streams for work that only READS a layer's finished dY / X (un-merged filter gradients, HYPEL_MERGE_WGRAD=0).
-# Default 0 = everything on the main stream: measured on MI355X (round 2, same box A/B, 100 steps each) the forked
-# step is 2 % SLOWER (7.49 vs 7.35 ms; 2, 3, 4 side streams: 7.58 / 7.53 / 7.30) -- kernels of two HIP streams
-# hardly ever run side by side here (rocprofv3 timeline: two GEMMs concurrently active for < 2 % of a step), so the
-# fork/join edges cost more than the overlap returns.
-USE_SIDE_STREAM = os.environ.get("HYPEL_SIDE_STREAMS", "0") != "0"
-SIDE_STREAMS = max(1, int(os.environ.get("HYPEL_SIDE_STREAMS", "0") or 0))
 # Statistics kernels that finalise themselves (last block of a channel stripe, ticket counter): correct and tested,
 # but measured SLOWER on MI355X (8.65 vs 7.88 ms/step): every block pays the round trip of a device-scope atomic
 # through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
@@ -93,7 +85,6 @@ FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 # collected and go out as ONE hypel_seg_gemm_multi_f32 per tile width (+ ONE hypel_reduce_splits_multi_f32) at the end
 # of the backward pass (and at every data-parallel sync point).  A step's twenty ~25 us launch ramps/drains become three.
 MERGE_WGRAD = os.environ.get("HYPEL_MERGE_WGRAD", "1") != "0"
-WGRAD_PARALLEL = os.environ.get("HYPEL_WGRAD_PARALLEL", "0") != "0"  # measured: NOTES 4.E
 # Batch-norm statistics of a 1x1 convolution's output in the GEMM epilogue (hypel_seg_gemm_stats_f32) instead of a
 # separate pass over Y (hypel_col_stats_partial)
 STATS_EPILOGUE = os.environ.get("HYPEL_STATS_EPILOGUE", "1") != "0"
@@ -174,6 +165,9 @@ _gs = os.environ.get("HYPEL_GEMM_SPLIT", "6").split(":")
 GEMM_SPLIT = int(_gs[0] or 0)
 GEMM_SPLIT_WIDTH = int(_gs[1]) if len(_gs) > 1 else 0
 GEMM_SPLIT_MIN_FLOPS = float(os.environ.get("HYPEL_GEMM_SPLIT_MIN_GFLOP", "2")) * 1e9
+# narrow products stage a whole 128-row A tile per 32 output columns: the split costs more than the matrix rate returns
+# (H13 level 1, 30 filters per branch: 382 -> 397 us forward, 103 -> 95 TFLOP/s filter gradient; per-launch A/B, round 5)
+GEMM_SPLIT_MIN_N = int(os.environ.get("HYPEL_GEMM_SPLIT_MIN_N", "32"))
 SPLIT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_SPLIT_OVERRIDE", "").split(",") if kv)}
 PAIR_SEGS = os.environ.get("HYPEL_PAIR_SEGS", "1") != "0"  # short data-gradient segments (k <= 16) share k-tiles
 GEMM_MFMA16X4 = 0x2000  # include/hypel.h HYPEL_GEMM_MFMA16X4: 128x64 blocks on the 16x16x4 MFMA (merged level, <= 16 filters)
@@ -312,10 +306,6 @@ class TowerPlan:
         self.world = dist_[0] if dist_ is not None else 1
         if self.sync_bn and FUSED_STATS:
             raise RuntimeError("HYPEL_FUSED_STATS and synchronised batch norm exclude each other")
-        if self.sync_bn and USE_SIDE_STREAM:
-            # the host collectives cut the HIP-graph segments in the middle of the backward pass, where a fork onto a
-            # side stream may still be open: the segment would end with unjoined work
-            raise RuntimeError("HYPEL_SIDE_STREAMS and synchronised batch norm exclude each other")
         self.sess = session
         self.be = session.backend
         self.training = tower.is_training
@@ -524,7 +514,7 @@ class TowerPlan:
         """0 = fp32 MFMA kernel, else the tile-width hint of the split-operand kernel for this launch."""
         if tag in SPLIT_OVERRIDE:
             return SPLIT_OVERRIDE[tag]
-        if GEMM_SPLIT != 6 or n <= 16 or (ta and tb) or (flags & ~GEMM_VAR_N) or bnbwd is not None or paired:
+        if GEMM_SPLIT != 6 or n <= GEMM_SPLIT_MIN_N or (ta and tb) or (flags & ~GEMM_VAR_N) or bnbwd is not None or paired:
             return 0
         macs = sum(rows * sum(k for _, _, k in gs) * tables.n_of(gi, n) for gi, (_, gs, rows) in enumerate(tables.groups))
         if 2 * macs < GEMM_SPLIT_MIN_FLOPS:
@@ -745,12 +735,8 @@ class TowerPlan:
                     # starts the all-reduce of what no earlier point covered here, under the rest of the backward pass
                     sync_at = sync_map[idx]
                     self._flush_wgrads()
-                    if getattr(self, "_side_open", False):
-                        self.bwd.append(self._join_sides())
                     self.sync_points.append((len(self.bwd), sync_at[1], sync_at[2]))
             self._flush_wgrads()
-            if getattr(self, "_side_open", False):
-                self.bwd.append(self._join_sides())
             if tw.n_dropout and not self.external_masks and not getattr(self, "_step_in_loss", False):
                 self.bwd.append(Launch("step_inc", (self._ref("step_ctr"),), tag="rng"))
         # shared scratch (stream order makes reuse safe)
@@ -1486,7 +1472,7 @@ class TowerPlan:
                     acc = 1
             # ---- filter gradient ----
             if trains:
-                self._on_side(lambda: self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w))
+                self._wgrad_conv(idx, node, aux, s_st, src, dy, c, h, w)
         elif node.kind == "blockdense":
             src = node.sources[0]
             s_st = self.storage_of(src)
@@ -1503,7 +1489,7 @@ class TowerPlan:
                     self._emit_gemm(self.bwd, tb, width, dy, c, 0, Ref(self.sess.params), cout, 1, self._ref(gst.buf),
                                     gst.ld, None, acc, f"dgrad:{node.branches[0].scope}+", allow_split=False)
             if trains:
-                self._on_side(lambda: self._wgrad_blockdense(idx, node, s_st, dy, c, cout))
+                self._wgrad_blockdense(idx, node, s_st, dy, c, cout)
         else:
             b = node.branches[0]
             rowbase = 0
@@ -1518,7 +1504,7 @@ class TowerPlan:
                                     gst.ld, None, acc, f"dgrad:{b.scope}", bnbwd=self._bnbwd_producer(idx, src, gst, 1))
                 rowbase += src.npix * src.c
             if trains:
-                self._on_side(lambda: self._wgrad_dense(idx, node, aux, dy, c))
+                self._wgrad_dense(idx, node, aux, dy, c)
 
     def _emit_post_bwd(self, node, aux, dz, y_ref, rows, c, dy, want_param):
         has_bn = isinstance(node, G.LinearNode) and node.has_bn
@@ -1631,38 +1617,6 @@ class TowerPlan:
             if sums is not None:
                 self._scratch(l3, 13, "sums", 2 * c)
             self.bwd.append(l3)
-
-    def _on_side(self, emit):
-        """Emit launches that only READ the layer's finished dY / X and WRITE parameter gradients on the side
-        stream: they run concurrently with the data-gradient chain that continues on the main stream.  Scratch
-        used there gets its own buffers (suffix _s1)."""
-        if not USE_SIDE_STREAM:
-            emit()
-            return
-        start = len(self.bwd)
-        emit()
-        new = self.bwd[start:]
-        if not new:
-            return
-        k = 1 + getattr(self, "_side_rr", 0) % SIDE_STREAMS
-        self._side_rr = getattr(self, "_side_rr", 0) + 1
-        suffix = f"_s{k}"
-        for l in new:
-            l.stream = k
-        for i, (launch, pos, name) in enumerate(self._pending_scratch):
-            if launch in new and not name.endswith(suffix):
-                self.scratch_sizes[name + suffix] = max(self.scratch_sizes.get(name + suffix, 1), self.scratch_sizes[name])
-                self._pending_scratch[i] = (launch, pos, name + suffix)
-        self.bwd[start:start] = [Launch("_fork", (k,), tag="fork")]
-        self._side_open = True
-        self._side_used = getattr(self, "_side_used", set()) | {k}
-
-    def _join_sides(self):
-        """The main stream waits for every side stream forked since the last join."""
-        used = tuple(sorted(getattr(self, "_side_used", {1})))
-        self._side_used = set()
-        self._side_open = False
-        return Launch("_join", used, tag="join")
 
     def _wgrad_splits(self, base_blocks, n_pairs):
         """Filter-gradient reduction = S_pix x S_row splits: the pixel-pair list is cut into S_pix contiguous chunks
@@ -1830,8 +1784,7 @@ class TowerPlan:
             for (wdt, _), (wk, r) in loc_groups.items():  # inside a locality group: heavy blocks first
                 r.sort(key=lambda t: -t[0])
                 per_width[wdt]["lists"].append((wk, [rec for _, rec in r]))
-        par_used = []
-        for width in sorted(per_width, reverse=False if WGRAD_PARALLEL else True):
+        for width in sorted(per_width, reverse=True):
             pw = per_width[width]
             segs, lists = pw["segs"], pw["lists"]
             lists.sort(key=lambda t: -t[0])
@@ -1853,16 +1806,7 @@ class TowerPlan:
                        tag=f"wgrad-merged/{'s' if width & GEMM_MULTI_SPLIT6 else ''}{width & 0xff}")
             l.meta = {"products": pw["tags"], "blocks": int(sum(len(r) for r in xcd_recs)),
                       "xcd_work": [int(w) for w in xcd_work]}
-            if WGRAD_PARALLEL and width != max(per_width):
-                # experiment (NOTES 4.E): the narrower launches as parallel branches of the step's graph, so that their ramp
-                # and drain overlap the 64-wide launch's
-                k = 1 + len(par_used)
-                par_used.append(k)
-                l.stream = k
-                self.bwd.append(Launch("_fork", (k,), tag="fork"))
             self.bwd.append(l)
-        if par_used:
-            self.bwd.append(Launch("_join", tuple(par_used), tag="join"))
         if entries:
             earr = np.array([(p, o, st, cnt, S, acc) for (p, o, st, cnt, S, acc) in entries], REDUCE_ENTRY_DTYPE)
             e_t = self.be.upload(earr)
@@ -2227,8 +2171,6 @@ class PhasePlan(TowerPlan):
                 self._bwd_node(idx, node)
             self._flush_wgrads()
             self._flush_slab_reduces()
-            if getattr(self, "_side_open", False):
-                self.bwd.append(self._join_sides())
             self._emit_regularisers()
             self._finish_loss_slots()
         self._finish_scratch()

@@ -21,8 +21,8 @@ class CompiledTower:
     def __init__(self, plan, backend):
         self.plan = plan
         self.be = backend
-        self.fwd = [backend.bind(l.name, l.args, l.stream) for l in plan.fwd]
-        self.bwd = [backend.bind(l.name, l.args, l.stream) for l in plan.bwd]
+        self.fwd = [backend.bind(l.name, l.args) for l in plan.fwd]
+        self.bwd = [backend.bind(l.name, l.args) for l in plan.bwd]
         self._graph_fwd = None
         self._graph_all = None
         self._segments = None  # graph replay callables of [fwd + bwd up to sync point 0], [.. sync point 1], ...

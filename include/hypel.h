@@ -595,10 +595,6 @@ int hypel_nce_loss(const float* g, int64_t ldg, const float* r, int64_t ldr, int
                    int32_t acc_dg, float* dr, int64_t lddr, int32_t acc_dr, float* ws, hypel_stream_t stream);
 
 /* ---- graph capture helpers (HIP graphs instead of a tracing compiler) ---------------------------------------- */
-/* fork: `side` waits for everything enqueued on `main` so far; join: `main` waits for `side`.  Work on the two
- * streams in between runs concurrently (inside a capture the dependencies become graph edges). */
-int hypel_stream_fork(hypel_stream_t main_stream, hypel_stream_t side_stream);
-int hypel_stream_join(hypel_stream_t main_stream, hypel_stream_t side_stream);
 int hypel_graph_begin_capture(hypel_stream_t stream);
 int hypel_graph_end_capture(hypel_stream_t stream, void** graph_exec_out);
 int hypel_graph_launch(void* graph_exec, hypel_stream_t stream);

@@ -103,8 +103,6 @@ class EmuBackend:
         pass
 
     def bind(self, name, args, stream=None):
-        if name in ("_fork", "_join"):
-            return lambda: None
         if name in COLLECTIVES:
             return bind_collective(name, args)
         fn = getattr(self, "k_" + name)

@@ -51,7 +51,7 @@ def test_signature_table_matches_header():
     special = {"hypel_crc32c", "hypel_version", "hypel_last_error", "hypel_device_info", "hypel_gan_generator_blocks",
                "hypel_dense_stack_blocks", "hypel_gan_generator_blocks_apps", "hypel_dense_stack_blocks_apps",
                "hypel_dense_stack_supported", "hypel_gan_generator_tap_supported",
-               "hypel_graph_begin_capture", "hypel_stream_fork", "hypel_stream_join",
+               "hypel_graph_begin_capture",
                "hypel_graph_end_capture", "hypel_graph_launch", "hypel_graph_destroy"}
     missing = set(decl) - bound - special
     assert not missing, f"header functions without a Python binding: {missing}"

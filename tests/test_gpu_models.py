@@ -426,7 +426,7 @@ def test_backend_objects_share_the_device_stream_pair(hip):
     created its own backend)."""
     from hypelcnn_amd.backend import HipBackend
     other = HipBackend()
-    assert other.stream is hip.stream and other.side_streams is hip.side_streams
+    assert other.stream is hip.stream
     assert torch.cuda.current_stream().cuda_stream == hip.stream.cuda_stream
     built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 5, 11, 4, SMALL_H, 6, 11)
     ct = U.run_train_step(built, x, onehot, masks)

@@ -28,7 +28,7 @@ def main():
     dg = [l for l in bwd if l.name.startswith("seg_gemm") and not l.name.startswith("seg_gemm_multi")]
     wg = [l for l in bwd if l.name.startswith("seg_gemm_multi")]
     print(f"elementwise {len(ew)} launches, dgrad {len(dg)}, wgrad-merged {len(wg)}")
-    main_s, side_s = be.stream, be.side_streams[0]
+    main_s, side_s = be.stream, torch.cuda.Stream(be.device)  # (the package itself runs on one stream since round 5)
 
     def run(lists, reps=30):
         """lists: [(launch list, stream index)] started together; returns mean wall us."""
