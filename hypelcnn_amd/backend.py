@@ -83,12 +83,9 @@ SIGNATURES = {
     "reduce_splits_pair_f32": [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I32, _I32],
     "seg_gemm_multi_f32": [_P, _I32, _I32, _I32, _P, _P, _I32],
     "copy_blocks_f32": [_P, _P, _I32, _I64],
-    "bn_act_chunks_fwd": [_P, _I64, _I64, _I32, _P, _I32, _I32, _F, _P, _I32, _F, _P, _I64, _P, _P, _P, _P, _F, _P, _I64],
-    "bn_act_chunks_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I32, _P, _I64, _P, _I32],
     "reduce_splits_wave_multi_f32": [_P, _P, _I32, _I64],
     "reduce_splits_multi_f32": [_P, _P, _I32],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
-    "bn_stats_f32": [_P, _I64, _I64, _I32, _I32, _P, _P, _F, _P, _P, _P, _P, _F],
     "bn_act_small_fwd": [_P, _I64, _I64, _I32, _F, _P, _I32, _F, _P, _I64, _P, _P, _P, _P, _F, _P, _I64],
     "bn_act_small_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _I32],
     "bn_finalize": [_P, _I32, _I32, _I64, _I32, _F, _P, _P, _P, _P, _F],
@@ -98,7 +95,6 @@ SIGNATURES = {
     "bn_act_fwd": [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64],
     "bn_act_bwd_reduce": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P],
     "act_bias_bwd_reduce": [_P, _I64, _P, _I64, _I64, _I32, _I32, _F, _P, _I64, _I32, _P, _P, _I64],
-    "bn_act_bwd_sums": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _I32, _P, _P, _P, _P, _I32],
     "bwd_reduce_finalize": [_P, _I32, _I32, _P, _P, _I32],
     "bn_act_bwd_apply": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _P, _I64],
     "bn_act_bwd_apply_global": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _I64],

@@ -7,9 +7,6 @@
 
 #include "common.h"
 
-#ifndef HYPEL_TAIL_ACQUIRE
-#define HYPEL_TAIL_ACQUIRE 1
-#endif
 
 namespace {
 
@@ -303,23 +300,6 @@ __global__ void reduce_splits_multi_kernel(const float* __restrict__ base,
 constexpr int STAT_V4_TY = 16;
 
 // Combine the chunk partials: mean = sum n_k mean_k / N, M2 = sum (M2_k + n_k (mean_k - mean)^2), both as fp64
-// MI355X has one L2 per XCD and they are not coherent with each other inside a kernel: a device-scope fence per
-// block (what __threadfence() costs: an L2 write-back) made these kernels 10x slower.  Instead the few values that
-// cross blocks -- the chunk partials and the ticket -- are written and read with agent-scope atomics (write-through /
-// L2-bypassing accesses), and each writer drains its stores (s_waitcnt) before its block takes a ticket.
-__device__ __forceinline__ void st_agent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COHERENT>
-__device__ __forceinline__ float ld_partial(const float* p) {
-#if HYPEL_TAIL_ACQUIRE
-    return *p;  // the finishing block invalidated its caches once (stripe_is_complete)
-#else
-    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-#endif
-}
-
 // sums with a FIXED association (16 strided lanes per channel, then an xor tree) -> deterministic, and ~20x
 // shorter than a serial Chan chain over ~200 chunks.  block = 16 channels x 16 lanes.
 __device__ __forceinline__ double lanes16_sum(double v, double* sh) {
@@ -338,7 +318,7 @@ __device__ __forceinline__ double lanes16_sum(double v, double* sh) {
 // The chunk partials are read in bursts of 16 per lane with clamped (always valid) addresses, so the loads of a
 // burst are all in flight together; a plain `for k` loop made this kernel a chain of ~2 x n_chunks/16 dependent
 // memory round trips (14 us for 256 chunks).
-template <bool COHERENT, bool M2OUT = false>  // M2OUT: `rstd` receives the merged sum of squared deviations instead
+template <bool M2OUT = false>  // M2OUT: `rstd` receives the merged sum of squared deviations instead
 __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks,
                                                  int chunk_rows, int64_t rows, int c, float eps,
                                                  float* __restrict__ mean, float* __restrict__ rstd,
@@ -354,7 +334,7 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
     // dependent load bursts): deviations are taken from the first chunk's mean instead, which every lane loads along
     // with its burst; sum n_k d_k and sum (M2_k + n_k d_k^2) then give mean and M2 without cancellation (fp64, and the
     // chunk means of one channel lie within a few batch standard deviations of each other).
-    const double shift = (double)ld_partial<COHERENT>(partial + colc);
+    const double shift = (double)*(partial + colc);
     // requested up front: behind the reductions' barriers these would be one more memory round trip
     const float mm0 = (!M2OUT && moving_mean) ? moving_mean[colc] : 0.0f;
     const float mv0 = (!M2OUT && moving_mean) ? moving_var[colc] : 0.0f;
@@ -364,8 +344,8 @@ __device__ __forceinline__ void bn_finalize_body(int blk16, const float* __restr
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int k = min(k0 + lane + 16 * j, n_chunks - 1);
-            m[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + colc);
-            q[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + colc);
+            m[j] = *(partial + (int64_t)k * 2 * c + colc);
+            q[j] = *(partial + (int64_t)k * 2 * c + c + colc);
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -405,7 +385,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                            float* __restrict__ moving_mean,
                                                            float* __restrict__ moving_var, float decay) {
     __shared__ double sh[64];
-    bn_finalize_body<false>(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, moving_mean,
+    bn_finalize_body<>(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, moving_mean,
                             moving_var, decay, sh);
 }
 
@@ -417,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_merge_partials_kernel(const float* __r
                                                                  int chunk_rows, int64_t rows, int c,
                                                                  float* __restrict__ out) {
     __shared__ double sh[64];
-    bn_finalize_body<false, true>(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, 0.0f, out, out + c, nullptr,
+    bn_finalize_body<true>(blockIdx.x, partial, n_chunks, chunk_rows, rows, c, 0.0f, out, out + c, nullptr,
                                   nullptr, 0.0f, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * c] = (float)rows;
 }
@@ -451,48 +431,8 @@ __global__ void bn_finalize_ranks_kernel(const float* __restrict__ gathered, int
     }
 }
 
-// Fused statistics: the LAST block of a 64-channel stripe to publish its partials (ticket counter, self-resetting so
-// that a HIP-graph replay finds it at zero again) runs the finaliser for that stripe.  Which block that is varies
-// from run to run, what it computes does not: the partials are combined in the same fixed order.
-struct BnFin {
-    int* counters;  // [ceil(c/64)], zero before the first launch; NULL = partials only
-    float eps;
-    float* mean;
-    float* rstd;
-    float* moving_mean;
-    float* moving_var;
-    float decay;
-};
-
-__device__ __forceinline__ bool stripe_is_complete(int* counters) {
-    __shared__ int last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(&counters[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t == (int)gridDim.x - 1);
-        if (last) __hip_atomic_store(&counters[blockIdx.y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-#if HYPEL_TAIL_ACQUIRE
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-    return last != 0;
-}
-
-__device__ __forceinline__ void bn_stats_tail(const BnFin& f, const float* partial, int chunk_rows, int64_t rows,
-                                              int c) {
-    __shared__ double shd[64];
-    if (f.counters == nullptr) return;
-    if (!stripe_is_complete(f.counters)) return;
-    for (int q = 0; q < STAT_TX / 16; ++q)
-        bn_finalize_body<true>(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, chunk_rows, rows, c, f.eps, f.mean,
-                         f.rstd, f.moving_mean, f.moving_var, f.decay, shd);
-}
-
 __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t rows,
-                                                                 int c, int chunk_rows, float* __restrict__ partial,
-                                                                 BnFin fin) {
+                                                                 int c, int chunk_rows, float* __restrict__ partial) {
     __shared__ float sh[2][STAT_TY][STAT_TX];
     const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
     const int col = blockIdx.y * STAT_TX + tx;
@@ -523,20 +463,14 @@ __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __r
         float m2 = tss - ts * mean_d;
         if (m2 < 0.0f) m2 = 0.0f;
         float* po = partial + (int64_t)blockIdx.x * 2 * c;
-        if (fin.counters) {
-            st_agent(po + col, shift + mean_d);
-            st_agent(po + c + col, m2);
-        } else {
-            po[col] = shift + mean_d;
-            po[c + col] = m2;
-        }
+        po[col] = shift + mean_d;
+        po[c + col] = m2;
     }
-    bn_stats_tail(fin, partial, chunk_rows, rows, c);
 }
 
 __global__ __launch_bounds__(256) void col_stats_partial_v4_kernel(const float* __restrict__ x, int64_t ld,
                                                                     int64_t rows, int c, int chunk_rows,
-                                                                    float* __restrict__ partial, BnFin fin) {
+                                                                    float* __restrict__ partial) {
     __shared__ float sh[2][STAT_V4_TY][STAT_TX];
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int col = blockIdx.y * STAT_TX + tq * 4;
@@ -570,16 +504,10 @@ __global__ __launch_bounds__(256) void col_stats_partial_v4_kernel(const float* 
             float m2 = tss - ts * mean_d;
             if (m2 < 0.0f) m2 = 0.0f;
             float* po = partial + (int64_t)blockIdx.x * 2 * c;
-            if (fin.counters) {
-                st_agent(po + cc, x[r0 * ld + cc] + mean_d);
-                st_agent(po + c + cc, m2);
-            } else {
-                po[cc] = x[r0 * ld + cc] + mean_d;
-                po[c + cc] = m2;
-            }
+            po[cc] = x[r0 * ld + cc] + mean_d;
+            po[c + cc] = m2;
         }
     }
-    bn_stats_tail(fin, partial, chunk_rows, rows, c);
 }
 
 __global__ void rstd_from_var_kernel(const float* __restrict__ var, int c, float eps, float* __restrict__ rstd) {
@@ -659,7 +587,6 @@ __device__ __forceinline__ void bwd_elem(const float* dz, int64_t lddz, const fl
 
 // float4 x 16 row lanes (see col_stats_partial_v4_kernel)
 
-template <bool COHERENT>
 __device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __restrict__ partial, int n_chunks, int c,
                                                   float* __restrict__ sums, float* __restrict__ dparam,
                                                   int accumulate, double* sh) {
@@ -674,8 +601,8 @@ __device__ __forceinline__ void bwd_finalize_body(int blk16, const float* __rest
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int k = min(k0 + lane + 16 * j, n_chunks - 1);
-            pa[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + colc);
-            pb[j] = ld_partial<COHERENT>(partial + (int64_t)k * 2 * c + c + colc);
+            pa[j] = *(partial + (int64_t)k * 2 * c + colc);
+            pb[j] = *(partial + (int64_t)k * 2 * c + c + colc);
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -697,23 +624,7 @@ __global__ __launch_bounds__(256) void bwd_reduce_finalize_kernel(const float* _
                                                                    int c, float* __restrict__ sums,
                                                                    float* __restrict__ dparam, int accumulate) {
     __shared__ double sh[64];
-    bwd_finalize_body<false>(blockIdx.x, partial, n_chunks, c, sums, dparam, accumulate, sh);
-}
-
-struct BwdFin {
-    int* counters;  // NULL = partials only
-    float* sums;
-    float* dparam;
-    int accumulate;
-};
-
-__device__ __forceinline__ void bwd_reduce_tail(const BwdFin& f, const float* partial, int c) {
-    __shared__ double shd[64];
-    if (f.counters == nullptr) return;
-    if (!stripe_is_complete(f.counters)) return;
-    for (int q = 0; q < STAT_TX / 16; ++q)
-        bwd_finalize_body<true>(blockIdx.y * (STAT_TX / 16) + q, partial, (int)gridDim.x, c, f.sums, f.dparam, f.accumulate,
-                          shd);
+    bwd_finalize_body(blockIdx.x, partial, n_chunks, c, sums, dparam, accumulate, sh);
 }
 
 // DY (layers WITHOUT batch norm only): the pass also writes dY = dZ * act'(y) (* mask) -- there the input gradient does
@@ -725,7 +636,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const float* dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
-    BwdFin fin, float* dy, int64_t lddy) {
+    float* dy, int64_t lddy) {
     __shared__ float sh[2][STAT_TY][STAT_TX];
     const int tx = threadIdx.x & (STAT_TX - 1), ty = threadIdx.x / STAT_TX;
     const int col = blockIdx.y * STAT_TX + tx;
@@ -753,15 +664,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
             t1 += sh[1][k][tx];
         }
         float* po = partial + (int64_t)blockIdx.x * 2 * c;
-        if (fin.counters) {
-            st_agent(po + col, t0);
-            st_agent(po + c + col, t1);
-        } else {
-            po[col] = t0;
-            po[c + col] = t1;
-        }
+        po[col] = t0;
+        po[c + col] = t1;
     }
-    bwd_reduce_tail(fin, partial, c);
 }
 
 template <bool DY>
@@ -769,7 +674,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
     const float* dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int64_t rows, int c,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act,
     float alpha, const float* __restrict__ mask, int64_t ldm, int chunk_rows, float* __restrict__ partial,
-    BwdFin fin, float* dy, int64_t lddy) {
+    float* dy, int64_t lddy) {
     __shared__ float sh[2][STAT_V4_TY][STAT_TX];
     const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int col = blockIdx.y * STAT_TX + tq * 4;
@@ -825,16 +730,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_v4_kernel(
                 t1 += sh[1][k][tx];
             }
             float* po = partial + (int64_t)blockIdx.x * 2 * c;
-            if (fin.counters) {
-                st_agent(po + cc, t0);
-                st_agent(po + c + cc, t1);
-            } else {
-                po[cc] = t0;
-                po[c + cc] = t1;
-            }
+            po[cc] = t0;
+            po[c + cc] = t1;
         }
     }
-    bwd_reduce_tail(fin, partial, c);
 }
 
 template <int VEC>
@@ -1334,132 +1233,6 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(const float* __restric
     }
 }
 
-// ------------------------------------------------------------------------------------- short matrices, row-parallel
-// Batch norm of a short matrix (rows = the batch: the fully-connected tail) WITHOUT a block that owns all rows of a
-// stripe (bn_act_small_*: 31 blocks for 980 channels, a 12-17 us latency chain) and WITHOUT a finaliser launch: the
-// statistics arrive as a handful of row-chunk partials -- from the GEMM epilogue (hypel_seg_gemm_stats_f32: one
-// (mean, M2) pair per 128-row tile) or from hypel_col_stats_partial / hypel_bn_act_bwd_reduce -- and EVERY block of the
-// apply kernel merges the partials of its own 32 columns itself (n_chunks <= 64: 8 for a batch of 1024), in chunk order,
-// fp64: identical values in every block; the blocks of the first row range also write mean / rstd / moving averages
-// (forward) or the parameter gradient (backward).  Block = 32 columns x 8 row lanes, 64 rows per block.
-constexpr int CHK_ROWS = 64;
-
-__global__ __launch_bounds__(256) void bn_act_chunks_fwd_kernel(
-    const float* __restrict__ y, int64_t ldy, int rows, int c, const float* __restrict__ partial, int n_chunks,
-    int chunk_rows, float eps, const float* __restrict__ beta, int act, float alpha, const float* __restrict__ mask,
-    int64_t ldm, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ moving_mean,
-    float* __restrict__ moving_var, float decay, float* __restrict__ z, int64_t ldz) {
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + tx;
-    if (col >= c) return;
-    const int r0 = blockIdx.y * CHK_ROWS + ty;
-    float yv[CHK_ROWS / 8], mk[CHK_ROWS / 8];
-#pragma unroll
-    for (int i = 0; i < CHK_ROWS / 8; ++i) {  // the tile's loads are in flight while the statistics are merged
-        const int r = r0 + 8 * i;
-        yv[i] = r < rows ? y[(int64_t)r * ldy + col] : 0.0f;
-        mk[i] = (mask && r < rows) ? mask[(int64_t)r * ldm + col] : 1.0f;
-    }
-    const double shift = (double)partial[col];
-    double s = 0.0, m2 = 0.0;
-    for (int k0 = 0; k0 < n_chunks; k0 += 8) {  // bursts of 16 independent loads (a dependent chain of n_chunks round
-        float m[8], q[8];                       // trips otherwise: the whole kernel is a few microseconds)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = min(k0 + j, n_chunks - 1);
-            m[j] = partial[(int64_t)k * 2 * c + col];
-            q[j] = partial[(int64_t)k * 2 * c + c + col];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
-            if (k < n_chunks) {
-                const int n_k = min(rows, (k + 1) * chunk_rows) - k * chunk_rows;
-                const double d = (double)m[j] - shift;
-                s += (double)n_k * d;
-                m2 += (double)q[j] + (double)n_k * d * d;
-            }
-        }
-    }
-    const double n_total = (double)rows;
-    const double mean_a = shift + s / n_total;
-    double m2_a = m2 - s * s / n_total;
-    if (m2_a < 0.0) m2_a = 0.0;
-    const double var = m2_a / n_total;
-    const float mu = (float)mean_a, rs = (float)(1.0 / sqrt(var + (double)eps));
-    const float be = beta[col];
-    if (blockIdx.y == 0 && ty == 0) {
-        mean[col] = mu;
-        rstd[col] = rs;
-        if (moving_mean) {
-            const double unbiased = n_total > 1.0 ? m2_a / (n_total - 1.0) : var;
-            moving_mean[col] = (float)((double)moving_mean[col] * decay + mean_a * (1.0 - (double)decay));
-            moving_var[col] = (float)((double)moving_var[col] * decay + unbiased * (1.0 - (double)decay));
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < CHK_ROWS / 8; ++i) {
-        const int r = r0 + 8 * i;
-        if (r < rows) {
-            float v = hypel_act(hypel_bn_pre(hypel_bn_xhat(yv[i], mu, rs), be), act, alpha);
-            if (mask) v *= mk[i];
-            z[(int64_t)r * ldz + col] = v;
-        }
-    }
-}
-
-// partial[k][0][col] = sum of dyh over row chunk k, partial[k][1][col] = sum of dyh * xhat (hypel_bn_act_bwd_reduce);
-// dy may alias dz.
-__global__ __launch_bounds__(256) void bn_act_chunks_bwd_kernel(
-    const float* dz, int64_t lddz, const float* __restrict__ y, int64_t ldy, int rows, int c,
-    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ beta, int act, float alpha,
-    const float* __restrict__ mask, int64_t ldm, const float* __restrict__ partial, int n_chunks, float* dy,
-    int64_t lddy, float* __restrict__ dparam, int accumulate) {
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + tx;
-    if (col >= c) return;
-    const int r0 = blockIdx.y * CHK_ROWS + ty;
-    float yv[CHK_ROWS / 8], gv[CHK_ROWS / 8];
-#pragma unroll
-    for (int i = 0; i < CHK_ROWS / 8; ++i) {
-        const int r = r0 + 8 * i;
-        yv[i] = r < rows ? y[(int64_t)r * ldy + col] : 0.0f;
-        float g = r < rows ? dz[(int64_t)r * lddz + col] : 0.0f;
-        if (mask && r < rows) g *= mask[(int64_t)r * ldm + col];
-        gv[i] = g;
-    }
-    double a0 = 0.0, a1 = 0.0;
-    for (int k0 = 0; k0 < n_chunks; k0 += 8) {
-        float p0[8], p1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = min(k0 + j, n_chunks - 1);
-            p0[j] = partial[(int64_t)k * 2 * c + col];
-            p1[j] = partial[(int64_t)k * 2 * c + c + col];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (k0 + j < n_chunks) {
-                a0 += (double)p0[j];
-                a1 += (double)p1[j];
-            }
-    }
-    const float s0 = (float)a0, s1 = (float)a1;
-    const float mu = mean[col], rs = rstd[col], be = beta[col];
-    const float dp0 = (dparam && accumulate && blockIdx.y == 0 && ty == 0) ? dparam[col] : 0.0f;
-    const float inv_m = 1.0f / (float)rows;
-#pragma unroll
-    for (int i = 0; i < CHK_ROWS / 8; ++i) {
-        const int r = r0 + 8 * i;
-        if (r < rows) {
-            const float xhat = hypel_bn_xhat(yv[i], mu, rs);
-            const float dyh = gv[i] * hypel_act_grad(hypel_bn_pre(xhat, be), act, alpha);
-            dy[(int64_t)r * lddy + col] = rs * (dyh - s0 * inv_m - xhat * (s1 * inv_m));
-        }
-    }
-    if (dparam && blockIdx.y == 0 && ty == 0) dparam[col] = dp0 + s0;
-}
-
 // ------------------------------------------------------------------------------------- metrics
 __global__ void argmax_confusion_kernel(const float* __restrict__ logits, int64_t ld, int64_t n, int c,
                                         const int32_t* __restrict__ labels, int32_t* __restrict__ pred,
@@ -1659,37 +1432,25 @@ extern "C" int hypel_reduce_splits_multi_f32(const float* base, const hypel_redu
 }
 
 static int launch_col_stats(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows, float* partial,
-                            const BnFin& fin, hypel_stream_t stream) {
+                            hypel_stream_t stream) {
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
     static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
     const bool v4 = v4_on && (c % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
     if (v4)
         hipLaunchKernelGGL(col_stats_partial_v4_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST,
-                           x, ld, rows, c, chunk_rows, partial, fin);
+                           x, ld, rows, c, chunk_rows, partial);
     else
         hipLaunchKernelGGL(col_stats_partial_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST, x,
-                           ld, rows, c, chunk_rows, partial, fin);
+                           ld, rows, c, chunk_rows, partial);
     return 0;
 }
 
 extern "C" int hypel_col_stats_partial(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows,
                                        float* partial, hypel_stream_t stream) {
     HYPEL_REQUIRE(x && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_col_stats_partial");
-    launch_col_stats(x, ld, rows, c, chunk_rows, partial, BnFin{nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f},
+    launch_col_stats(x, ld, rows, c, chunk_rows, partial,
                      stream);
     HYPEL_CHECK_LAUNCH("hypel_col_stats_partial");
-    return 0;
-}
-
-extern "C" int hypel_bn_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows,
-                                  float* partial, int32_t* counters, float eps, float* mean, float* rstd,
-                                  float* moving_mean, float* moving_var, float decay, hypel_stream_t stream) {
-    HYPEL_REQUIRE(x && partial && counters && mean && rstd && rows > 0 && c > 0 && chunk_rows > 0,
-                  "hypel_bn_stats_f32");
-    HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_stats_f32");
-    launch_col_stats(x, ld, rows, c, chunk_rows, partial, BnFin{counters, eps, mean, rstd, moving_mean, moving_var, decay},
-                     stream);
-    HYPEL_CHECK_LAUNCH("hypel_bn_stats_f32");
     return 0;
 }
 
@@ -1754,7 +1515,7 @@ extern "C" int hypel_bn_act_fwd(const float* y, int64_t ldy, int64_t rows, int32
 
 static int launch_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
                              const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
-                             const float* mask, int64_t ldm, int32_t chunk_rows, float* partial, const BwdFin& fin,
+                             const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
                              hypel_stream_t stream, float* dy = nullptr, int64_t lddy = 0) {
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
     static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
@@ -1764,7 +1525,7 @@ static int launch_bwd_reduce(const float* dz, int64_t lddz, const float* y, int6
     const dim3 grid(n_chunks, (c + STAT_TX - 1) / STAT_TX);
 #define HYPEL_BWD_REDUCE(K, D)                                                                                          \
     hipLaunchKernelGGL(K<D>, grid, dim3(256), 0, ST, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, \
-                       chunk_rows, partial, fin, dy, lddy)
+                       chunk_rows, partial, dy, lddy)
     if (v4) {
         if (dy) HYPEL_BWD_REDUCE(bn_act_bwd_reduce_v4_kernel, true);
         else HYPEL_BWD_REDUCE(bn_act_bwd_reduce_v4_kernel, false);
@@ -1782,21 +1543,8 @@ extern "C" int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const floa
                                        hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && y && partial && rows > 0 && c > 0 && chunk_rows > 0, "hypel_bn_act_bwd_reduce");
     launch_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
-                      BwdFin{nullptr, nullptr, nullptr, 0}, stream);
+                      stream);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_reduce");
-    return 0;
-}
-
-extern "C" int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
-                                     int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
-                                     float alpha, const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
-                                     int32_t* counters, float* sums, float* dparam, int32_t accumulate,
-                                     hypel_stream_t stream) {
-    HYPEL_REQUIRE(dz && y && partial && counters && sums && rows > 0 && c > 0 && chunk_rows > 0,
-                  "hypel_bn_act_bwd_sums");
-    launch_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows, partial,
-                      BwdFin{counters, sums, dparam, accumulate}, stream);
-    HYPEL_CHECK_LAUNCH("hypel_bn_act_bwd_sums");
     return 0;
 }
 
@@ -1806,7 +1554,7 @@ extern "C" int hypel_act_bias_bwd_reduce(const float* dz, int64_t lddz, const fl
                                          hypel_stream_t stream) {
     HYPEL_REQUIRE(dz && y && partial && dy && rows > 0 && c > 0 && chunk_rows > 0 && lddy >= c, "hypel_act_bias_bwd_reduce");
     launch_bwd_reduce(dz, lddz, y, ldy, rows, c, nullptr, nullptr, nullptr, act, alpha, mask, ldm, chunk_rows, partial,
-                      BwdFin{nullptr, nullptr, nullptr, 0}, stream, dy, lddy);
+                      stream, dy, lddy);
     HYPEL_CHECK_LAUNCH("hypel_act_bias_bwd_reduce");
     return 0;
 }
@@ -1851,38 +1599,6 @@ extern "C" int hypel_bn_act_small_bwd(const float* dz, int64_t lddz, const float
         hipLaunchKernelGGL(bn_act_small_bwd_kernel<false>, grid, dim3(1024), 0, ST, dz, (int)lddz, y, (int)ldy,
                            (int)rows, c, mean, rstd, beta, act, alpha, mask, (int)ldm, dy, (int)lddy, dparam, accumulate);
     HYPEL_CHECK_LAUNCH("hypel_bn_act_small_bwd");
-    return 0;
-}
-
-extern "C" int hypel_bn_act_chunks_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, const float* partial,
-                                       int32_t n_chunks, int32_t chunk_rows, float eps, const float* beta, int32_t act,
-                                       float alpha, const float* mask, int64_t ldm, float* mean, float* rstd,
-                                       float* moving_mean, float* moving_var, float decay, float* z, int64_t ldz,
-                                       hypel_stream_t stream) {
-    HYPEL_REQUIRE(y && partial && beta && mean && rstd && z && rows > 0 && c > 0, "hypel_bn_act_chunks_fwd");
-    HYPEL_REQUIRE(n_chunks > 0 && n_chunks <= 64 && chunk_rows > 0 && (int64_t)n_chunks * chunk_rows >= rows &&
-                      (int64_t)(n_chunks - 1) * chunk_rows < rows && rows < (1 << 24),
-                  "hypel_bn_act_chunks_fwd");
-    HYPEL_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "hypel_bn_act_chunks_fwd");
-    hipLaunchKernelGGL(bn_act_chunks_fwd_kernel, dim3((c + 31) / 32, (unsigned)((rows + CHK_ROWS - 1) / CHK_ROWS)), dim3(256),
-                       0, ST, y, ldy, (int)rows, c, partial, n_chunks, chunk_rows, eps, beta, act, alpha, mask, ldm, mean,
-                       rstd, moving_mean, moving_var, decay, z, ldz);
-    HYPEL_CHECK_LAUNCH("hypel_bn_act_chunks_fwd");
-    return 0;
-}
-
-extern "C" int hypel_bn_act_chunks_bwd(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows,
-                                       int32_t c, const float* mean, const float* rstd, const float* beta, int32_t act,
-                                       float alpha, const float* mask, int64_t ldm, const float* partial,
-                                       int32_t n_chunks, float* dy, int64_t lddy, float* dparam, int32_t accumulate,
-                                       hypel_stream_t stream) {
-    HYPEL_REQUIRE(dz && y && mean && rstd && beta && partial && dy && rows > 0 && rows < (1 << 24) && c > 0 &&
-                      n_chunks > 0 && n_chunks <= 64,
-                  "hypel_bn_act_chunks_bwd");
-    hipLaunchKernelGGL(bn_act_chunks_bwd_kernel, dim3((c + 31) / 32, (unsigned)((rows + CHK_ROWS - 1) / CHK_ROWS)), dim3(256),
-                       0, ST, dz, lddz, y, ldy, (int)rows, c, mean, rstd, beta, act, alpha, mask, ldm, partial, n_chunks, dy,
-                       lddy, dparam, accumulate);
-    HYPEL_CHECK_LAUNCH("hypel_bn_act_chunks_bwd");
     return 0;
 }
 

@@ -58,10 +58,6 @@ class Launch:
         self.meta = {}  # diagnostics (e.g. the products a merged filter-gradient launch contains)
 
 
-# Statistics kernels that finalise themselves (last block of a channel stripe, ticket counter): correct and tested,
-# but measured SLOWER on MI355X (8.65 vs 7.88 ms/step): every block pays the round trip of a device-scope atomic
-# through the cross-XCD coherence point, which costs more than the launches it saves.  Off by default.
-FUSED_STATS = os.environ.get("HYPEL_FUSED_STATS", "0") == "1"
 # layers without batch norm: the bias-gradient reduction also writes dY (no separate activation-backward launch)
 ACT_BIAS_BWD = os.environ.get("HYPEL_ACT_BIAS_BWD", "1") != "0"
 # bias + leaky-ReLU of a normaliser-less fully-connected layer in the product's epilogue (HYPEL_GEMM_ACT_*): no post-op launch
@@ -72,14 +68,6 @@ GEN_KEEP = os.environ.get("HYPEL_GEN_KEEP", "1") != "0"  # generator backward st
 TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
 SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
 SMALL_BN_ROWS = 1024  # hypel_bn_act_small_*: rows kept in registers (32 row lanes x 32 rows)
-# Short matrices (the fully-connected tail): row-parallel batch norm without a finaliser launch -- statistics as <= 64
-# row-chunk partials (from the GEMM epilogue where the layer is one unsplit product), merged by every block of the apply
-# launch itself (hypel_bn_act_chunks_*).  Built on the round-3 verdict's suggestion, parity-tested, measured SLOWER on
-# MI355X (NOTES 4.F: 6.557-6.570 vs 6.499-6.502 ms/step, three interleaved pairs): it trades eight 16 us one-block-per-stripe
-# launches for sixteen short ones, and a dependent launch costs ~5 us whatever it does.  Off by default.
-CHUNK_BN = os.environ.get("HYPEL_CHUNK_BN", "0") != "0"
-CHUNK_BN_ROWS = 128  # rows per statistics chunk = the GEMM's row tile (GEMM_BM)
-CHUNK_BN_MAX_ROWS = 4096
 FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
 # Filter gradients have no consumer before the optimiser: instead of one launch (+ one reduce) per layer they are
 # collected and go out as ONE hypel_seg_gemm_multi_f32 per tile width (+ ONE hypel_reduce_splits_multi_f32) at the end
@@ -304,8 +292,6 @@ class TowerPlan:
         dist_ = getattr(session, "dist", None)
         self.sync_bn = bool(sync_bn) and dist_ is not None and tower.is_training
         self.world = dist_[0] if dist_ is not None else 1
-        if self.sync_bn and FUSED_STATS:
-            raise RuntimeError("HYPEL_FUSED_STATS and synchronised batch norm exclude each other")
         self.sess = session
         self.be = session.backend
         self.training = tower.is_training
@@ -388,16 +374,6 @@ class TowerPlan:
             written = True
         self.grad_written[id(own)] = True
         return gst, 1 if written else 0
-
-    def _tickets(self, c):
-        """Zero-initialised int32 ticket counters of the fused statistics kernels (one per 64-channel stripe; the
-        finishing block resets its counter, so the buffer is shared by every launch of a stream)."""
-        import torch
-        n = (c + 63) // 64
-        cur = self.buffers.get("tickets")
-        if cur is None or cur.numel() < n:
-            self.buffers["tickets"] = self.be.zeros(max(n, 1024), torch.int32)
-        return Ref(self.buffers["tickets"])
 
     # ------------------------------------------------------------------ parameters
     def _p(self, var):
@@ -1028,11 +1004,6 @@ class TowerPlan:
                 tb = GemmTables()
                 segs = [(s_st.pix_off(p), b.w.offset + (rowbase + p * src.c) * c, src.c) for p in range(src.npix)]
                 tb.add_group(0, segs, nb)
-                # row-parallel batch norm of the tail: an unsplit single-source layer leaves its 128-row tile statistics
-                # from the accumulators (no statistics pass at all)
-                gemm_stats = (STATS_EPILOGUE and len(node.sources) == 1 and c > 16 and self._chunk_bn(node, nb)
-                              and self._split_k(tb, c, s_st.ld, 0, c, 0, c) is None)
-                aux["stats_in_gemm"] = gemm_stats
                 act_flag = 0
                 if len(node.sources) == 1 and self._split_k(tb, c, s_st.ld, 0, c, 0, c) is None:
                     act_flag = self._act_in_gemm(node, c)
@@ -1040,7 +1011,7 @@ class TowerPlan:
                 self._emit_gemm(self.fwd, tb, c, self._ref(s_st.buf), s_st.ld, 0, Ref(self.sess.params), c, 0,
                                 self._ref(ybuf), c, bias_ref if si == 0 else None, 1 if si > 0 else 0,
                                 f"fwd:{b.scope}",
-                                stats=((nb + GEMM_BM - 1) // GEMM_BM) * 2 * c if gemm_stats else None, flags=act_flag)
+                                flags=act_flag)
                 rowbase += src.npix * src.c
 
         rows = out.npix * nb
@@ -1048,18 +1019,7 @@ class TowerPlan:
         if node.has_bn:
             self._alloc(f"mean:{idx}", c)
             self._alloc(f"rstd:{idx}", c)
-            if self._chunk_bn(node, rows):
-                # short matrix: row-chunk statistics (from the GEMM epilogue, else one statistics launch), merged by the
-                # blocks of the apply launch themselves (_emit_post_fwd)
-                n_chunks = (rows + CHUNK_BN_ROWS - 1) // CHUNK_BN_ROWS
-                aux["chunk_bn"] = n_chunks
-                if not aux.get("stats_in_gemm"):
-                    l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, CHUNK_BN_ROWS, None),
-                                nbytes=4 * rows * c, tag="bn-stats")
-                    self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                    self.fwd.append(l1)
-                aux["mean"] = self._ref(f"mean:{idx}")
-            elif node.training and self._small_bn(node, rows):
+            if node.training and self._small_bn(node, rows):
                 # short matrix (rows = batch): statistics + finaliser + activation in ONE launch (_emit_post_fwd)
                 aux["small_bn"] = True
                 aux["mean"] = self._ref(f"mean:{idx}")
@@ -1071,20 +1031,11 @@ class TowerPlan:
             elif node.training:
                 chunk = stat_chunk_rows(rows)
                 n_chunks = (rows + chunk - 1) // chunk
-                mean_ref, rstd_ref = self._ref(f"mean:{idx}"), self._ref(f"rstd:{idx}")
-                if FUSED_STATS:  # one launch: the last block of a channel stripe finalises it (see FUSED_STATS)
-                    l1 = Launch("bn_stats_f32", (self._ref(ybuf), c, rows, c, chunk, None, self._tickets(c),
-                                                 float(node.bn_eps), mean_ref, rstd_ref, self._s(aux["mm"]),
-                                                 self._s(aux["mv"]), float(node.bn_decay)),
-                                nbytes=4 * rows * c, tag="bn-stats")
-                    self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                    self.fwd.append(l1)
-                else:
-                    l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, chunk, None),
-                                nbytes=4 * rows * c, tag="bn-stats")
-                    self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
-                    self.fwd.append(l1)
-                    self._emit_bn_finalize(idx, node, aux, n_chunks, chunk, rows, c)
+                l1 = Launch("col_stats_partial", (self._ref(ybuf), c, rows, c, chunk, None),
+                            nbytes=4 * rows * c, tag="bn-stats")
+                self._scratch(l1, 5, "scratch_partial", n_chunks * 2 * c)
+                self.fwd.append(l1)
+                self._emit_bn_finalize(idx, node, aux, n_chunks, chunk, rows, c)
                 aux["mean"] = self._ref(f"mean:{idx}")
             else:
                 self.fwd.append(Launch("rstd_from_var", (self._s(aux["mv"]), c, float(node.bn_eps),
@@ -1175,25 +1126,12 @@ class TowerPlan:
         return (SMALL_BN and rows <= SMALL_BN_ROWS and not node.residuals and node.has_post
                 and not (self.sync_bn and node.has_bn))
 
-    def _chunk_bn(self, node, rows):
-        return (CHUNK_BN and rows <= CHUNK_BN_MAX_ROWS and not node.residuals and node.has_post and node.has_bn
-                and node.training and not self.sync_bn and node.kind == "dense")
-
     def _emit_post_fwd(self, idx, node, y_ref, ldy, rows, c, aux, z_ref):
         has_bn = isinstance(node, G.LinearNode) and node.has_bn
         mask = self._mask_ref(idx, node, rows, c)
         aux["mask"] = mask
         (r1, ld1, i1), (r2, ld2, i2) = self._res_args(node)
         act = node.act
-        if aux.get("chunk_bn"):
-            n_chunks = aux["chunk_bn"]
-            l = Launch("bn_act_chunks_fwd", (
-                y_ref, ldy, rows, c, None, n_chunks, CHUNK_BN_ROWS, float(node.bn_eps), aux["beta_ref"],
-                act.code if act else 0, act.alpha if act else 0.0, mask, c, aux["mean"], aux["rstd"], self._s(aux["mm"]),
-                self._s(aux["mv"]), float(node.bn_decay), z_ref, c), nbytes=12 * rows * c, tag="post-fwd-chunks")
-            self._scratch(l, 4, "scratch_partial", n_chunks * 2 * c)
-            self.fwd.append(l)
-            return
         if aux.get("small_bn"):
             self.fwd.append(Launch("bn_act_small_fwd", (
                 y_ref, ldy, rows, c, float(node.bn_eps), aux["beta_ref"], act.code if act else 0,
@@ -1520,18 +1458,6 @@ class TowerPlan:
                 dparam = self._g(aux["beta"])
             elif node.has_bias:
                 dparam = self._g(aux["bias"])
-        if aux.get("chunk_bn") and has_bn and dy is not None:
-            pacc = self._param_acc(aux["beta"]) if dparam is not None else 0
-            n_chunks = aux["chunk_bn"]
-            l1 = Launch("bn_act_bwd_reduce", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
-                                              CHUNK_BN_ROWS, None), nbytes=8 * rows * c, tag="post-bwd-reduce-chunks")
-            self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
-            l2 = Launch("bn_act_chunks_bwd", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c, None,
-                                              n_chunks, dy, c, dparam, pacc), nbytes=12 * rows * c,
-                        tag="post-bwd-chunks")
-            self._scratch(l2, 13, "scratch_partial", n_chunks * 2 * c)
-            self.bwd += [l1, l2]
-            return
         if aux.get("small_bn") and has_bn and dy is not None:
             pacc = self._param_acc(aux["beta"]) if dparam is not None else 0
             self.bwd.append(Launch("bn_act_small_bwd", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
@@ -1552,13 +1478,6 @@ class TowerPlan:
                             tag="post-bwd-finalize")
                 self._scratch(l2, 3, "sums", 2 * c)
                 self.bwd.append(l2)
-            elif FUSED_STATS:
-                l1 = Launch("bn_act_bwd_sums", (dz, c, y_ref, c, rows, c, mean, rstd, beta, code, alpha, mask, c,
-                                                chunk, None, self._tickets(c), None, dparam, pacc),
-                            nbytes=8 * rows * c, tag="post-bwd-reduce")
-                self._scratch(l1, 14, "scratch_partial", n_chunks * 2 * c)
-                self._scratch(l1, 16, "sums", 2 * c)
-                self.bwd.append(l1)
             elif (ACT_BIAS_BWD and not has_bn and dy is not None and (code != 0 or mask is not None)
                   and not self.sync_bn):
                 # no batch norm: dY = dZ * act'(y) needs no column sum -- the bias-gradient reduction writes it too

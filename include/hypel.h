@@ -258,30 +258,6 @@ int hypel_bn_merge_partials(const float* partial, int32_t n_chunks, int32_t chun
                             float* out, hypel_stream_t stream);
 int hypel_bn_finalize_ranks(const float* gathered, int32_t world, int32_t c, float eps, float* mean, float* rstd,
                             float* moving_mean, float* moving_var, float decay, hypel_stream_t stream);
-/* hypel_col_stats_partial + hypel_bn_finalize in ONE launch: the last block of each 64-channel stripe to publish
- * its partials (ticket in counters[ceil(c/64)], int32, zero before the first call; the finishing block resets it,
- * so a HIP-graph replay needs no memset) merges that stripe's partials in the same fixed chunk order. */
-int hypel_bn_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows, float* partial,
-                       int32_t* counters, float eps, float* mean, float* rstd, float* moving_mean, float* moving_var,
-                       float decay, hypel_stream_t stream);
-/* Batch norm of a SHORT matrix (rows = the batch: the fully-connected tail, HYPELCNNModel.py:80-94) in one launch per
- * direction: a block owns a 32-channel stripe for all rows, so statistics + finaliser + normalise/activate/dropout
- * (forward) and both reductions + the gradient (backward; dy may alias dz) need no second kernel.  rows <= 1024.
- * Same definitions as hypel_col_stats_partial/hypel_bn_finalize/hypel_bn_act_fwd resp. the three backward calls. */
-/* The same batch norm of a short matrix, ROW-PARALLEL and without a finaliser launch (round 4): the statistics arrive as
- * at most 64 row-chunk partials -- `partial` in the format of hypel_col_stats_partial / the epilogue of
- * hypel_seg_gemm_stats_f32 (forward: chunk k = rows [k * chunk_rows, ...): mean, sum of squared deviations) resp. of
- * hypel_bn_act_bwd_reduce (backward: sum dyh, sum dyh * xhat) -- and every block of the apply launch merges the partials of
- * its own 32 columns (chunk order, fp64) before it normalises / differentiates its 64 rows; the blocks of the first row
- * range write mean / rstd / the moving averages (forward) resp. the parameter gradient (backward).  dy may alias dz. */
-int hypel_bn_act_chunks_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, const float* partial, int32_t n_chunks,
-                            int32_t chunk_rows, float eps, const float* beta, int32_t act, float alpha, const float* mask,
-                            int64_t ldm, float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
-                            float* z, int64_t ldz, hypel_stream_t stream);
-int hypel_bn_act_chunks_bwd(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
-                            const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
-                            const float* mask, int64_t ldm, const float* partial, int32_t n_chunks, float* dy, int64_t lddy,
-                            float* dparam, int32_t accumulate, hypel_stream_t stream);
 int hypel_bn_act_small_fwd(const float* y, int64_t ldy, int64_t rows, int32_t c, float eps, const float* beta,
                            int32_t act, float alpha, const float* mask, int64_t ldm, float* mean, float* rstd,
                            float* moving_mean, float* moving_var, float decay, float* z, int64_t ldz,
@@ -310,12 +286,6 @@ int hypel_bn_act_bwd_reduce(const float* dz, int64_t lddz, const float* y, int64
  * dparam (beta or bias gradient) = sums[0] (+= when accumulate). */
 int hypel_bwd_reduce_finalize(const float* partial, int32_t n_chunks, int32_t c, float* sums, float* dparam,
                               int32_t accumulate, hypel_stream_t stream);
-/* hypel_bn_act_bwd_reduce + hypel_bwd_reduce_finalize in one launch (same ticket scheme as hypel_bn_stats_f32). */
-int hypel_bn_act_bwd_sums(const float* dz, int64_t lddz, const float* y, int64_t ldy, int64_t rows, int32_t c,
-                          const float* mean, const float* rstd, const float* beta, int32_t act, float alpha,
-                          const float* mask, int64_t ldm, int32_t chunk_rows, float* partial, int32_t* counters,
-                          float* sums, float* dparam, int32_t accumulate, hypel_stream_t stream);
-
 /* hypel_bn_act_bwd_reduce for a layer WITHOUT batch norm (tf_slim.fully_connected / conv2d with biases:
  * shadow_data_models.py:95-146, DUALCNNModel.py:48-54,99-100) that ALSO writes dY = dZ * act'(y) (* mask): there dY
  * needs no column sum, so the pass that reduces the bias gradient delivers it and hypel_bn_act_bwd_apply (one more read

@@ -449,19 +449,6 @@ class EmuBackend:
             po[k, 0] = m
             po[k, 1] = ((blk - m) ** 2).sum(0)
 
-    def k_bn_stats_f32(self, x, ld, rows, c, chunk_rows, partial, counters, eps, mean, rstd, mm, mv, decay):
-        assert (_arr(counters, np.int32)[: (c + 63) // 64] == 0).all(), "ticket counters must be zero between launches"
-        self.k_col_stats_partial(x, ld, rows, c, chunk_rows, partial)
-        self.k_bn_finalize(partial, (rows + chunk_rows - 1) // chunk_rows, chunk_rows, rows, c, eps, mean, rstd, mm, mv,
-                           decay)
-
-    def k_bn_act_bwd_sums(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows,
-                          partial, counters, sums, dparam, accumulate):
-        assert (_arr(counters, np.int32)[: (c + 63) // 64] == 0).all()
-        self.k_bn_act_bwd_reduce(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, chunk_rows,
-                                 partial)
-        self.k_bwd_reduce_finalize(partial, (rows + chunk_rows - 1) // chunk_rows, c, sums, dparam, accumulate)
-
     def k_act_bias_bwd_reduce(self, dz, lddz, y, ldy, rows, c, act, alpha, mask, ldm, chunk_rows, partial, dy, lddy):
         dyh, _ = self._dyh(dz, lddz, y, ldy, rows, c, None, None, None, act, alpha, mask, ldm)
         self.k_bn_act_bwd_reduce(dz, lddz, y, ldy, rows, c, None, None, None, act, alpha, mask, ldm, chunk_rows, partial)
@@ -488,19 +475,6 @@ class EmuBackend:
             dp[:c] = (dp[:c] if accumulate else 0) + s0.astype(np.float32)
         g = _arr(rstd)[:c] * (dyh - s0 / rows - xhat * s1 / rows)
         _mat(dy, lddy, rows, c)[...] = g.astype(np.float32)
-
-    def k_bn_act_chunks_fwd(self, y, ldy, rows, c, partial, n_chunks, chunk_rows, eps, beta, act, alpha, mask, ldm, mean,
-                            rstd, mm, mv, decay, z, ldz):
-        assert 0 < n_chunks <= 64 and (n_chunks - 1) * chunk_rows < rows <= n_chunks * chunk_rows
-        self.k_bn_finalize(partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, mm, mv, decay)
-        self.k_bn_act_fwd(y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, None, 0, None, None, 0, None, z, ldz)
-
-    def k_bn_act_chunks_bwd(self, dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, partial, n_chunks,
-                            dy, lddy, dparam, accumulate):
-        assert 0 < n_chunks <= 64
-        sums = type(partial)(partial.t.new_zeros(2 * c))
-        self.k_bwd_reduce_finalize(partial, n_chunks, c, sums, dparam, accumulate)
-        self.k_bn_act_bwd_apply(dz, lddz, y, ldy, rows, c, mean, rstd, beta, act, alpha, mask, ldm, sums, dy, lddy)
 
     def k_bn_finalize(self, partial, n_chunks, chunk_rows, rows, c, eps, mean, rstd, mm, mv, decay):
         po = _arr(partial)[: n_chunks * 2 * c].reshape(n_chunks, 2, c).astype(np.float64)

@@ -539,41 +539,6 @@ def test_small_rows_bn_kernels(hip, rows, c, act, use_mask):
     assert (b.h["z"].cpu().numpy().reshape(rows, ld)[:, c:] == 0).all(), "pad columns untouched"
 
 
-@pytest.mark.parametrize("rows,c", [(50176 // 8, 480), (1000, 145), (333, 60), (64, 7105)])
-def test_fused_statistics_kernels_match_two_stage(hip, rows, c):
-    """hypel_bn_stats_f32 / hypel_bn_act_bwd_sums == partial kernel + finaliser, also on the second and third call
-    (the ticket counters must come back to zero by themselves)."""
-    rng = np.random.default_rng(rows + c)
-    b = Both(hip)
-    chunk = 64
-    nch = (rows + chunk - 1) // chunk
-    x = (rng.standard_normal((rows, c)) * 2 + rng.standard_normal(c)).astype(np.float32)
-    dz = rng.standard_normal((rows, c)).astype(np.float32)
-    b.arr("x", x)
-    b.arr("dz", dz)
-    b.arr("part", np.zeros(nch * 2 * c, np.float32))
-    b.arr("tick", np.zeros(256, np.int32))
-    for nm in ("mean", "rstd", "dbeta"):
-        b.arr(nm, np.zeros(c, np.float32))
-    b.arr("sums", np.zeros(2 * c, np.float32))
-    b.arr("beta", rng.standard_normal(c).astype(np.float32))
-    b.arr("mm", rng.standard_normal(c).astype(np.float32))
-    b.arr("mv", (rng.random(c) + 0.5).astype(np.float32))
-    for rep in range(3):
-        b.run("bn_stats_f32", "x", c, rows, c, chunk, "part", "tick", 1e-3, "mean", "rstd", "mm", "mv", 0.95)
-        for nm in ("mean", "rstd", "mm", "mv"):
-            b.check(nm, rtol=1e-5, atol=1e-6)
-        assert int(b.h["tick"].abs().sum()) == 0
-        b.run("bn_act_bwd_sums", "dz", c, "x", c, rows, c, "mean", "rstd", "beta", 1, 0.18, None, 0, chunk, "part", "tick",
-              "sums", "dbeta", rep > 0)
-        b.check("sums", rtol=2e-4, atol=2e-4)
-        b.check("dbeta", rtol=2e-4, atol=2e-4)
-        assert int(b.h["tick"].abs().sum()) == 0
-    x64 = x.astype(np.float64)
-    np.testing.assert_allclose(b.h["mean"].cpu().numpy(), x64.mean(0), rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(b.h["rstd"].cpu().numpy(), 1 / np.sqrt(x64.var(0) + 1e-3), rtol=1e-5)
-
-
 @pytest.mark.parametrize("cin,c,ld_pad", [(60, 120, 0), (240, 120, 0), (60, 120, 2), (240, 120, 4), (30, 120, 0),
                                            (120, 120, 0), (145, 120, 0), (62, 124, 1)])
 def test_post_op_forward_channel_maps(hip, cin, c, ld_pad):
@@ -1280,47 +1245,6 @@ def test_reduce_splits_wave_multi(hip):
     b.arr("e", np.array(ents, REDUCE_ENTRY_DTYPE))
     b.run("reduce_splits_wave_multi_f32", "buf", "e", len(ents), sum(e[3] for e in ents))
     b.check("buf", rtol=2e-5, atol=2e-6)
-
-
-@pytest.mark.parametrize("rows,c,act,use_mask,in_place", [(1024, 980, 1, True, True), (1024, 108, 0, False, False),
-                                                           (1024, 7105, 3, False, True), (300, 45, 1, False, False),
-                                                           (4096, 33, 2, True, True), (1, 5, 1, False, False)])
-def test_chunk_bn_kernels(hip, rows, c, act, use_mask, in_place):
-    """Row-parallel batch norm of a short matrix: 128-row chunk statistics (here from hypel_col_stats_partial; in the plan
-    from the GEMM epilogue where possible) merged by every block of the apply launch; backward from the chunk sums of
-    hypel_bn_act_bwd_reduce -- against the specification (finaliser + generic apply)."""
-    rng = np.random.default_rng(rows + c)
-    b = Both(hip)
-    ld = c + 3
-    n_chunks = (rows + 127) // 128
-    b.arr("y", (rng.standard_normal((rows, ld)) * 1.5 + rng.standard_normal(ld) * 2).astype(np.float32))
-    b.arr("dz", rng.standard_normal((rows, ld)).astype(np.float32))
-    b.arr("beta", rng.standard_normal(c).astype(np.float32))
-    b.arr("mask", (rng.random((rows, c)) < 0.7).astype(np.float32) / 0.7)
-    for nm in ("mean", "rstd"):
-        b.arr(nm, np.zeros(c, np.float32))
-    b.arr("mm", rng.standard_normal(c).astype(np.float32))
-    b.arr("mv", (rng.random(c) + 0.5).astype(np.float32))
-    b.arr("z", np.zeros(rows * ld, np.float32))
-    b.arr("dy", np.zeros(rows * ld, np.float32))
-    b.arr("dbeta", rng.standard_normal(c).astype(np.float32))
-    b.arr("part", np.zeros(n_chunks * 2 * c, np.float32))
-    m = "mask" if use_mask else None
-    b.run("col_stats_partial", "y", ld, rows, c, 128, "part")
-    b.run("bn_act_chunks_fwd", "y", ld, rows, c, "part", n_chunks, 128, 1e-3, "beta", act, 0.18, m, c, "mean", "rstd", "mm",
-          "mv", 0.95, "z", ld)
-    for nm in ("mean", "rstd", "mm", "mv"):
-        b.check(nm, rtol=2e-5, atol=2e-6)
-    b.check("z", rtol=1e-4, atol=1e-5)
-    assert (b.h["z"].cpu().numpy().reshape(rows, ld)[:, c:] == 0).all(), "pad columns untouched"
-    b.run("bn_act_bwd_reduce", "dz", ld, "y", ld, rows, c, "mean", "rstd", "beta", act, 0.18, m, c, 128, "part")
-    out = "dz" if in_place else "dy"
-    b.run("bn_act_chunks_bwd", "dz", ld, "y", ld, rows, c, "mean", "rstd", "beta", act, 0.18, m, c, "part", n_chunks, out, ld,
-          "dbeta", 1)
-    got = b.h[out].cpu().numpy().reshape(rows, ld)[:, :c]
-    ref = b.e[out].numpy().reshape(rows, ld)[:, :c]
-    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
-    b.check("dbeta", rtol=2e-4, atol=2e-4)
 
 
 @pytest.mark.parametrize("bands,n,kept", [(360, 200, True), (64, 2048, True), (144, 37, False), (16, 5, False)])

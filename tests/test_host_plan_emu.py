@@ -299,17 +299,3 @@ def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 
-def test_row_parallel_batch_norm_of_the_fc_tail_matches_oracle(monkeypatch):
-    """HYPEL_CHUNK_BN (off by default, NOTES 4.F): the fully-connected tail's batch norm from 128-row chunk statistics --
-    out of the GEMM epilogue for the unsplit layers -- merged by the blocks of the apply launch; no finaliser launches."""
-    from hypelcnn_amd import plan
-    monkeypatch.setattr(plan, "CHUNK_BN", True)
-    alg = dict(ALG_H, filter_count=96)
-    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 7, 9, 4, alg, 37, 41)
-    ct = U.run_train_step(built, x, onehot, masks)
-    names = [l.name for l in ct.plan.fwd + ct.plan.bwd]
-    assert names.count("bn_act_chunks_fwd") >= 6 and names.count("bn_act_chunks_fwd") == names.count("bn_act_chunks_bwd")
-    assert "bn_act_small_fwd" not in names
-    tags = [l.tag for l in ct.plan.fwd]
-    assert sum(1 for l in ct.plan.fwd if l.name == "seg_gemm_stats_f32" and l.tag.startswith("fwd:fc_")) >= 1, tags
-    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
