@@ -76,8 +76,6 @@ SIGNATURES = {
     "fill_f32": [_P, _I64, _F],
     "seg_gemm_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32],
     "seg_gemm_stats_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32, _P],
-    "seg_gemm_bnbwd_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P,
-                           _P, _I64, _P, _P, _P, _I32, _F, _P],
     "seg_gemm_res_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P],
     "reduce_splits_f32": [_P, _I64, _I32, _P, _I64, _I32, _P, _I32, _I64],
     "reduce_splits_pair_f32": [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I32, _I32],

@@ -23,19 +23,6 @@
 
 #include "common.h"
 
-// Batch-norm backward reduction riding in a data-gradient epilogue (see the kernel's epilogue): the layer whose
-// output gradient dZ this launch finishes.  partial == nullptr: off.
-struct BnBwdEpi {
-    const float* y;  // that layer's pre-normalisation output Y, row-aligned with C
-    int64_t ldy;
-    const float* mean;
-    const float* rstd;
-    const float* beta;
-    int act;
-    float alpha;
-    float* partial;  // [n_tiles][2][n]: per tile sum(dyh), sum(dyh * xhat)
-};
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -126,8 +113,6 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // array of hypel_mtile_t, one record per BLOCK, that carries the block's column tile, its product's n / lda / ldb /
 // ldc and accumulate flag; operand offsets (records and segments) are relative to the one base pointer passed as
 // A = B = C.
-// BNB: instantiate the batch-norm backward epilogue (16 more live registers at the end of the block: a separate
-// instantiation keeps the register allocation -- 6 waves per SIMD -- of every other launch).
 // PAIR (data gradients, !TA && TB): two consecutive segments of at most 16 reduction columns each share ONE k-tile
 // (columns 0-15 from the first, 16-31 from the second).  A data gradient through a convolution with 15 filters (the
 // narrowest HYPELCNN level, DUALCNN's last levels) otherwise stages, synchronises and walks a whole 32-column k-tile
@@ -140,8 +125,8 @@ static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, 
 // tf_slim.fully_connected (the GAN critics' and feature-discriminator layers, gan/shadow_data_models.py:95-149) is gone.
 // SPLIT: operands split three ways on their way into LDS (three bf16 planes per operand, reduction dimension
 // contiguous), six v_mfma_f32_32x32x16_bf16 per 32x32x16 step; prologue, segment walk and epilogues are shared.
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
-          bool PAIR = false, bool VARN = false, bool ACT = false, bool SPLIT = false>
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool PAIR = false,
+          bool VARN = false, bool ACT = false, bool SPLIT = false>
 __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         float* __restrict__ C, int64_t ldc, int n,
@@ -151,7 +136,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                                                         int n_ntiles, const float* __restrict__ bias,
                                                         int accumulate, const float* __restrict__ res, int64_t ldr,
                                                         const int32_t* __restrict__ res_start,
-                                                        float* __restrict__ stats, BnBwdEpi bnb) {
+                                                        float* __restrict__ stats) {
     constexpr int BM = WM * TM * 32;
     // NARROW with TN = 4 (forward only): 128x64 blocks whose waves own 32 rows x FOUR 16-column tiles -- the merged
     // form of a multi-kernel level with <= 16 filters per branch (groups of 15 / 30 / 45 / 60 output columns, see
@@ -161,8 +146,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     constexpr int NT = 64 * WM * WN;  // threads per block
     static_assert(WM * WN == 4 || (SPLIT && WM * WN == 8), "4 waves per block (split variants: 4 or 8)");
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
-    static_assert(!ACT || (!TA && !TB && !NARROW && !MULTI && !BNB && !PAIR && !VARN), "activation epilogue: plain forward only");
-    static_assert(!SPLIT || (!NARROW && !BNB && !PAIR && !VARN && !ACT && !(TA && TB)), "split variants: plain NN / NT / TN products");
+    static_assert(!ACT || (!TA && !TB && !NARROW && !MULTI && !PAIR && !VARN), "activation epilogue: plain forward only");
+    static_assert(!SPLIT || (!NARROW && !PAIR && !VARN && !ACT && !(TA && TB)), "split variants: plain NN / NT / TN products");
     [[maybe_unused]] int act_idx = 0;
     if constexpr (ACT) {
         act_idx = accumulate >> 16;
@@ -225,7 +210,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     struct { int64_t c_off; int seg_begin, seg_count, rows; } grp;
     struct { int64_t a_off0, b_off0; int k0; } tile;
     int m0, n0;
-    int tile_index = 0;  // position in the tile table (non-MULTI): the chunk index of the epilogue reductions
     if constexpr (MULTI) {
         if (lid >= n_tiles) return;
         const hypel_mtile_t rec = reinterpret_cast<const hypel_mtile_t*>(tiles_v)[lid];
@@ -244,7 +228,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         if (tile_id >= n_tiles) return;
         // one record per tile: the group's fields and its first segment travel with it (no tiles -> groups -> segs
         // chain in front of the first operand loads)
-        tile_index = tile_id;
         const hypel_tile_t t = reinterpret_cast<const hypel_tile_t*>(tiles_v)[tile_id];
         grp = {t.c_off, t.seg_begin, t.seg_count, t.rows};
         tile = {t.a_off0, t.b_off0, t.k0};
@@ -516,7 +499,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     // the gather passes (HYPEL_GEMM_HOIST_EPI=0: load them in the epilogue).
     [[maybe_unused]] int h_o0[TN], h_o1[TN];
     [[maybe_unused]] float h_bv[TN];
-    constexpr bool HOIST = HYPEL_GEMM_HOIST_EPI && !NARROW && !BNB && !TA && TM * TN == 1;  // wider tiles: 6 more live
+    constexpr bool HOIST = HYPEL_GEMM_HOIST_EPI && !NARROW && !TA && TM * TN == 1;  // wider tiles: 6 more live
     if constexpr (HOIST) {                                                                 // registers cost a wave per SIMD
         const int bias_c0 = bias ? (int)(grp.c_off % ldc) + n0 : 0;
 #pragma unroll
@@ -876,7 +859,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                             }
                         }
                     };
-                    constexpr bool PREFIX = VARN && TN == 2 && TM == 1 && !TA && !TB && !MULTI && !BNB && !PAIR;
+                    constexpr bool PREFIX = VARN && TN == 2 && TM == 1 && !TA && !TB && !MULTI && !PAIR;
                     if constexpr (PREFIX) {
                         if (tn_act >= 2) phase(std::integral_constant<int, 2>{});
                         else phase(std::integral_constant<int, 1>{});
@@ -1077,9 +1060,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         }
         }
     } else {
-        float bs0[TN], bs1[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bs0[j] = bs1[j] = 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1103,38 +1083,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                     }
                 }
                 const bool full_tile = rows_left >= (wm * TM + i) * 32 + 32;
-                if (BNB && bnb.partial && !(HYPEL_GEMM_BATCHED_EPILOGUE && full_tile)) {
-                    // The value just written IS the finished gradient dZ of the producing layer's output (this launch
-                    // is its last writer): feed the batch-norm / activation backward reduction of that layer from it
-                    // -- sum(dyh) and sum(dyh * xhat) per column, dyh = dZ * act'(pre) -- instead of a separate pass
-                    // over dZ and Y (hypel_bn_act_bwd_reduce).
-                    const int colabs = (int)(grp.c_off % ldc) + n0 + col;
-                    const float mu = bnb.mean[colabs], rs = bnb.rstd[colabs], be = bnb.beta[colabs];
-                    const float* yb = bnb.y + (grp.c_off / ldc + m0) * bnb.ldy + colabs;
-                    // all 16 loads of Y in flight before the first store (a load behind a store through another
-                    // pointer cannot be hoisted by the compiler: 16 serialised round trips otherwise)
-                    float yv[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                        yv[e] = row < rows_left ? yb[(int64_t)row * bnb.ldy] : 0.0f;
-                    }
-                    float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-                        const float v = put(row, col, acc[i][j][e], bv, o0, o1);
-                        if (row < rows_left) {
-                            const float xhat = hypel_bn_xhat(yv[e], mu, rs);
-                            const float dyh = v * hypel_act_grad(hypel_bn_pre(xhat, be), bnb.act, bnb.alpha);
-                            s0 += dyh;
-                            s1 += dyh * xhat;
-                        }
-                    }
-                    bs0[j] += s0;
-                    bs1[j] += s1;
-                } else if (HYPEL_GEMM_BATCHED_EPILOGUE &&
-                           (HYPEL_GEMM_BATCHED_EPILOGUE > 1 || accumulate || res || (BNB && bnb.partial)) && full_tile) {
+                if (HYPEL_GEMM_BATCHED_EPILOGUE && (HYPEL_GEMM_BATCHED_EPILOGUE > 1 || accumulate || res) && full_tile) {
                     // Read-modify-write epilogue of a FULL 32-row accumulator tile with every addend IN FLIGHT before the
                     // first store.  As `put` writes it, hipcc must keep each load behind the previous element's store
                     // (they may alias): 16 x (1 + gathered addends) dependent round trips per lane, 15-40 us of a
@@ -1147,28 +1096,6 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                     const int ldc4 = __builtin_amdgcn_readfirstlane((int)ldc * 4);
                     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, 0x7ffffff0, 0x00020000);
                     const int cvo = (row0 * (int)ldc + col) * 4;
-                    // batch-norm backward reduction of the producing layer (see the element-wise form above): its 16
-                    // values of Y and the column's (mean, rstd, beta) are requested FIRST, behind them the addends
-                    float yv[BNB ? 16 : 1], mu = 0.0f, rs = 0.0f, be = 0.0f;
-                    if constexpr (BNB) {
-                        if (bnb.partial) {
-                            const int colabs = (int)(grp.c_off % ldc) + n0 + col;
-                            mu = bnb.mean[colabs];
-                            rs = bnb.rstd[colabs];
-                            be = bnb.beta[colabs];
-                            const float* yb = bnb.y + (grp.c_off / ldc + m0) * bnb.ldy;
-                            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, 0x7ffffff0, 0x00020000);
-                            const int ldy4 = __builtin_amdgcn_readfirstlane((int)bnb.ldy * 4);
-                            const int yvo = (row0 * (int)bnb.ldy + colabs) * 4;
-                            int so = 0;
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                yv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo, so, 0));
-                                const int step = (e & 3) == 3 ? 5 * ldy4 : ldy4;
-                                asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
-                            }
-                        }
-                    }
                     float v[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e] + bv;
@@ -1208,51 +1135,12 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                         const int step = (e & 3) == 3 ? 5 * ldc4 : ldc4;
                         asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc");
                     }
-                    if constexpr (BNB) {
-                        if (bnb.partial) {
-                            float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) {  // rows ascending, as in the element-wise form
-                                const float xhat = hypel_bn_xhat(yv[e], mu, rs);
-                                const float dyh = v[e] * hypel_act_grad(hypel_bn_pre(xhat, be), bnb.act, bnb.alpha);
-                                s0 += dyh;
-                                s1 += dyh * xhat;
-                            }
-                            bs0[j] += s0;
-                            bs1[j] += s1;
-                        }
-                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         put((wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi, col, acc[i][j][e], bv, o0, o1);
                 }
             }
-        if (BNB && bnb.partial) {
-            float* red = lds;  // [WM][BN][2]
-            __syncthreads();   // every wave has left its last MFMA phase: the operand tiles are dead
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float t0 = bs0[j] + __shfl_xor(bs0[j], 32, 64);
-                const float t1 = bs1[j] + __shfl_xor(bs1[j], 32, 64);
-                if (lhi == 0) {
-                    const int cl = (wn * TN + j) * 32 + l31;
-                    red[(wm * BN + cl) * 2 + 0] = t0;
-                    red[(wm * BN + cl) * 2 + 1] = t1;
-                }
-            }
-            __syncthreads();
-            if (tid < BN && tid < cols_left) {
-                float t0 = 0.0f, t1 = 0.0f;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) {
-                    t0 += red[(w * BN + tid) * 2 + 0];
-                    t1 += red[(w * BN + tid) * 2 + 1];
-                }
-                bnb.partial[((int64_t)tile_index * 2 + 0) * n + n0 + tid] = t0;
-                bnb.partial[((int64_t)tile_index * 2 + 1) * n + n0 + tid] = t1;
-            }
-        }
     }
 }
 
@@ -1260,18 +1148,17 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, float *__restrict__ C,       \
         int64_t ldc, int n, const hypel_group_t *__restrict__ groups, const hypel_seg_t *__restrict__ segs,           \
         const void *__restrict__ tiles_v, int n_tiles, int n_ntiles, const float *__restrict__ bias, int accumulate, \
-        const float *__restrict__ res, int64_t ldr, const int32_t *__restrict__ res_start, float *__restrict__ stats, \
-        BnBwdEpi bnb
+        const float *__restrict__ res, int64_t ldr, const int32_t *__restrict__ res_start, float *__restrict__ stats
 #define HYPEL_GEMM_ARGS \
-    A, lda, B, ldb, C, ldc, n, groups, segs, tiles_v, n_tiles, n_ntiles, bias, accumulate, res, ldr, res_start, stats, bnb
+    A, lda, B, ldb, C, ldc, n, groups, segs, tiles_v, n_tiles, n_ntiles, bias, accumulate, res, ldr, res_start, stats
 #define HYPEL_GEMM_BOUNDS \
     __launch_bounds__(256, (TM * TN == 1 ? (TA ? HYPEL_OCC_BN32_TA : HYPEL_OCC_BN32)       \
                                          : (TM * TN == 3 ? (TB ? HYPEL_OCC_BN96 : 4) : (TA && TM * TN == 2 ? HYPEL_OCC_BN64_TA : 3))))
 
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool BNB = false,
-          bool PAIR = false, bool VARN = false, bool ACT = false>
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool NARROW = false, bool MULTI = false, bool PAIR = false,
+          bool VARN = false, bool ACT = false>
 __global__ HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PARAMS) {
-    seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, BNB, PAIR, VARN, ACT>(HYPEL_GEMM_ARGS);
+    seg_gemm_body<WM, WN, TM, TN, TA, TB, NARROW, MULTI, PAIR, VARN, ACT>(HYPEL_GEMM_ARGS);
 }
 
 // The same code under a cap of 96 scalar registers: 7 instead of 6 resident 128x32 blocks per CU (hipcc uses all 106
@@ -1282,7 +1169,7 @@ __global__ HYPEL_GEMM_BOUNDS void seg_gemm_kernel(HYPEL_GEMM_PARAMS) {
 // (round-2 A/B), and the attribute cannot depend on a template parameter: hence a second kernel symbol.
 template <int WM, int WN, int TM, int TN, bool TA, bool TB>
 __global__ __attribute__((amdgpu_num_sgpr(96))) HYPEL_GEMM_BOUNDS void seg_gemm_kernel_s96(HYPEL_GEMM_PARAMS) {
-    seg_gemm_body<WM, WN, TM, TN, TA, TB, false, false, false, false>(HYPEL_GEMM_ARGS);
+    seg_gemm_body<WM, WN, TM, TN, TA, TB>(HYPEL_GEMM_ARGS);
 }
 
 // Split-operand variants (HYPEL_GEMM_SPLIT6): 128x128 blocks of 512 threads (2 x 4 waves of 64x32; 72 KB of LDS: two
@@ -1292,7 +1179,7 @@ __global__ __attribute__((amdgpu_num_sgpr(96))) HYPEL_GEMM_BOUNDS void seg_gemm_
 // every 16-column k-tile and the split's VALU work better than two.
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool MULTI = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void seg_gemm_split_kernel(HYPEL_GEMM_PARAMS) {
-    seg_gemm_body<WM, WN, TM, TN, TA, TB, false, MULTI, false, false, false, false, true>(HYPEL_GEMM_ARGS);
+    seg_gemm_body<WM, WN, TM, TN, TA, TB, false, MULTI, false, false, false, true>(HYPEL_GEMM_ARGS);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -1302,22 +1189,9 @@ int launch_cfg_pair(const float* a, int64_t lda, const float* b, int64_t ldb, fl
                     hipStream_t st) {
     constexpr int BN = WN * TN * 32;
     const int n_nt = (n + BN - 1) / BN;
-    hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, false, true, false, false, false, true>), dim3(n_tiles * n_nt),
-                       dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate,
-                       res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
-    return 0;
-}
-
-template <int WM, int WN, int TM, int TN, bool NARROW = false, bool MULTI = false>
-int launch_cfg_bnb(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int n,
-                   const hypel_group_t* groups, const hypel_seg_t* segs, const void* tiles, int n_tiles,
-                   const float* bias, int accumulate, const float* res, int64_t ldr, const int32_t* res_start,
-                   hipStream_t st, BnBwdEpi bnb) {
-    constexpr int BN = WN * TN * 32;
-    const int n_nt = (n + BN - 1) / BN;
     hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, false, true, false, false, true>), dim3(n_tiles * n_nt),
                        dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate,
-                       res, ldr, res_start, (float*)nullptr, bnb);
+                       res, ldr, res_start, (float*)nullptr);
     return 0;
 }
 
@@ -1332,7 +1206,7 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
     if constexpr (NARROW && TN > 1) {  // forward products only (dispatch checks trans_a = trans_b = 0)
         hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, false, false, true, false>), dim3(grid), dim3(256), 0, st, a,
                            lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,
-                           res_start, stats, BnBwdEpi{});
+                           res_start, stats);
         return 0;
     } else {
     if constexpr (TM * TN == 1 && !NARROW && !MULTI) {
@@ -1340,18 +1214,18 @@ int launch_cfg(const float* a, int64_t lda, int ta, const float* b, int64_t ldb,
             if (tb)
                 hipLaunchKernelGGL((seg_gemm_kernel_s96<WM, WN, TM, TN, false, true>), dim3(grid), dim3(256), 0, st, a, lda,
                                    b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,
-                                   res_start, stats, BnBwdEpi{});
+                                   res_start, stats);
             else
                 hipLaunchKernelGGL((seg_gemm_kernel_s96<WM, WN, TM, TN, false, false>), dim3(grid), dim3(256), 0, st, a, lda,
                                    b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,
-                                   res_start, stats, BnBwdEpi{});
+                                   res_start, stats);
             return 0;
         }
     }
 #define HYPEL_GO(TA_, TB_)                                                                                         \
     hipLaunchKernelGGL((seg_gemm_kernel<WM, WN, TM, TN, TA_, TB_, NARROW, MULTI>), dim3(grid), dim3(256), 0, st, a,  \
                        lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr,     \
-                       res_start, stats, BnBwdEpi{})
+                       res_start, stats)
     if constexpr (MULTI) {  // filter gradients only: A transposed, B as stored
         HYPEL_GO(true, false);
     } else {
@@ -1373,8 +1247,7 @@ int launch_split(const float* a, int64_t lda, int ta, const float* b, int64_t ld
     const int grid = n_tiles * n_nt;
 #define HYPEL_GO(TA_, TB_)                                                                                           \
     hipLaunchKernelGGL((seg_gemm_split_kernel<WM, WN, TM, TN, TA_, TB_, MULTI>), dim3(grid), dim3(64 * WM * WN), 0, st, a, lda, b, \
-                       ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr, res_start, stats, \
-                       BnBwdEpi{})
+                       ldb, c, ldc, n, groups, segs, tiles, n_tiles, n_nt, bias, accumulate, res, ldr, res_start, stats)
     if constexpr (MULTI) {
         HYPEL_GO(true, false);
     } else {
@@ -1392,7 +1265,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
                              int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
                              const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles, const float* bias,
                              int32_t accumulate, const float* res, int64_t ldr, const int32_t* res_start,
-                             hypel_stream_t stream, float* stats = nullptr, BnBwdEpi bnb = BnBwdEpi{}) {
+                             hypel_stream_t stream, float* stats = nullptr) {
     HYPEL_REQUIRE(a && b && c && groups && segs && tiles, "hypel_seg_gemm_f32");
     HYPEL_REQUIRE(n > 0 && n_tiles >= 0, "hypel_seg_gemm_f32");
     HYPEL_REQUIRE(!(trans_a && trans_b), "hypel_seg_gemm_f32: A^T B^T products are not part of the path");
@@ -1414,7 +1287,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     const int act_idx = (accumulate >> 16) & 7;                     // HYPEL_GEMM_ACT_*: leaky-ReLU of (product + bias)
     accumulate &= 1;
     if (split6) {
-        HYPEL_REQUIRE(!pairs && !bnb.partial && !mfma16x4 && !act_idx && n > 16,
+        HYPEL_REQUIRE(!pairs && !mfma16x4 && !act_idx && n > 16,
                       "hypel_seg_gemm_f32: HYPEL_GEMM_SPLIT6 needs a plain product with n > 16");
         (void)var_n;  // tile records with their own column count are honoured by every variant (blocks beyond them exit)
         // hint: 1 = 128x32, 2 = 128x64, 3 = 128x128 blocks; 0 = by n
@@ -1431,7 +1304,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
         return 0;
     }
-    const bool plain_fwd = !trans_a && !trans_b && !pairs && !bnb.partial && !stats && !res;
+    const bool plain_fwd = !trans_a && !trans_b && !pairs && !stats && !res;
     if (act_idx) {
         HYPEL_REQUIRE(plain_fwd && !accumulate && !mfma16x4 && !var_n && act_idx <= 4,
                       "hypel_seg_gemm_f32: HYPEL_GEMM_ACT_* needs a plain forward product (no accumulate / shortcut / statistics)");
@@ -1439,13 +1312,13 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
         const int bn = narrow_a ? 32 : 64;
         const int n_nt = (n + bn - 1) / bn;
         if (narrow_a)
-            hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 1, false, false, false, false, false, false, false, true>),
+            hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 1, false, false, false, false, false, false, true>),
                                dim3(n_tiles * n_nt), dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles,
-                               n_nt, bias, act_idx << 16, res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
+                               n_nt, bias, act_idx << 16, res, ldr, res_start, (float*)nullptr);
         else
-            hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 2, false, false, false, false, false, false, false, true>),
+            hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 2, false, false, false, false, false, false, true>),
                                dim3(n_tiles * n_nt), dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles,
-                               n_nt, bias, act_idx << 16, res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
+                               n_nt, bias, act_idx << 16, res, ldr, res_start, (float*)nullptr);
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
         return 0;
     }
@@ -1457,16 +1330,16 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     }
     if (var_n && n > 32 && plain_fwd && hint != 1) {  // 128x64 blocks, one- and two-tile MFMA phases
         const int n_nt = (n + 63) / 64;
-        hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 2, false, false, false, false, false, false, true>),
+        hipLaunchKernelGGL((seg_gemm_kernel<4, 1, 1, 2, false, false, false, false, false, true>),
                            dim3(n_tiles * n_nt), dim3(256), 0, st, a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles,
-                           n_nt, bias, accumulate, res, ldr, res_start, (float*)nullptr, BnBwdEpi{});
+                           n_nt, bias, accumulate, res, ldr, res_start, (float*)nullptr);
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
         return 0;
     }
     // hint 3 = 128x96 blocks (three 32x32 accumulators per wave, 5 resident blocks per CU): N = 240 / 480 tile without
     // padding (5 x 96, 96 + 96 + 48) and a layer's 392 row tiles x 3 or 5 column tiles fit the resident capacity where
     // 392 x 4 / x 8 of the 64-wide tiling overflow it by 2 %.
-    if (hint == 3 && n > 64 && !bnb.partial) {
+    if (hint == 3 && n > 64) {
         launch_cfg<4, 1, 1, 3>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                accumulate, res, ldr, res_start, st, stats);
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
@@ -1475,7 +1348,7 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     if (hint == 3) hint = 2;
     const bool narrow = hint == 1 || (hint == 0 && (int64_t)n_tiles * ((n + 63) / 64) < 1000);
     if (pairs) {  // data gradients only: A as stored, B transposed; n > 16
-        HYPEL_REQUIRE(!trans_a && trans_b && n > 16 && !stats && !bnb.partial, "hypel_seg_gemm_f32: paired segments");
+        HYPEL_REQUIRE(!trans_a && trans_b && n > 16 && !stats, "hypel_seg_gemm_f32: paired segments");
         if (n <= 32 || narrow)
             launch_cfg_pair<4, 1, 1, 1>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
                                         ldr, res_start, st);
@@ -1483,17 +1356,6 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
             launch_cfg_pair<4, 1, 1, 2>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
                                         ldr, res_start, st);
         HYPEL_CHECK_LAUNCH("hypel_seg_gemm_f32");
-        return 0;
-    }
-    if (bnb.partial) {  // data gradients only: A as stored, B transposed
-        HYPEL_REQUIRE(!trans_a && trans_b, "hypel_seg_gemm_bnbwd_f32: data-gradient operand layout only");
-        if (n <= 32 || narrow)
-            launch_cfg_bnb<4, 1, 1, 1>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
-                                       ldr, res_start, st, bnb);
-        else
-            launch_cfg_bnb<4, 1, 1, 2>(a, lda, b, ldb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate, res,
-                                       ldr, res_start, st, bnb);
-        HYPEL_CHECK_LAUNCH("hypel_seg_gemm_bnbwd_f32");
         return 0;
     }
     // n <= 16 (the Cout = 15 level, fc_final): 128x16 blocks on the 16x16x4 MFMA (no reduction epilogues there)
@@ -1526,20 +1388,6 @@ extern "C" int hypel_seg_gemm_stats_f32(const float* a, int64_t lda, int32_t tra
     HYPEL_REQUIRE(stats_partial && (accumulate & 1) == 0, "hypel_seg_gemm_stats_f32");
     return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                              accumulate, nullptr, 0, nullptr, stream, stats_partial);
-}
-
-extern "C" int hypel_seg_gemm_bnbwd_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
-                                        int32_t trans_b, float* c, int64_t ldc, int32_t n,
-                                        const hypel_group_t* groups, const hypel_seg_t* segs, const hypel_tile_t* tiles,
-                                        int32_t n_tiles, const float* bias, int32_t accumulate, const float* res,
-                                        int64_t ldr, const int32_t* res_start, const float* y, int64_t ldy,
-                                        const float* mean, const float* rstd, const float* beta, int32_t act,
-                                        float alpha, float* partial, hypel_stream_t stream) {
-    HYPEL_REQUIRE(y && mean && rstd && beta && partial && ldy > 0 && n > 16, "hypel_seg_gemm_bnbwd_f32");
-    HYPEL_REQUIRE(res == nullptr || ldr > 0, "hypel_seg_gemm_bnbwd_f32");
-    return seg_gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
-                             accumulate, res, ldr, res_start, stream, nullptr,
-                             BnBwdEpi{y, ldy, mean, rstd, beta, act, alpha, partial});
 }
 
 extern "C" int hypel_seg_gemm_res_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,

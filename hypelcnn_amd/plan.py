@@ -76,12 +76,6 @@ MERGE_WGRAD = os.environ.get("HYPEL_MERGE_WGRAD", "1") != "0"
 # Batch-norm statistics of a 1x1 convolution's output in the GEMM epilogue (hypel_seg_gemm_stats_f32) instead of a
 # separate pass over Y (hypel_col_stats_partial)
 STATS_EPILOGUE = os.environ.get("HYPEL_STATS_EPILOGUE", "1") != "0"
-# First pass of the batch-norm backward (column sums of dyh and dyh * xhat) in the epilogue of the data-gradient GEMM
-# that finishes the layer's output gradient (hypel_seg_gemm_bnbwd_f32) instead of hypel_bn_act_bwd_reduce.  Correct
-# (emulation + GPU parity tests run it) but OFF by default: measured on MI355X (round 2, same-box A/B) the twelve
-# reduction passes it removes cost 0.21 ms at HBM speed, while the row-strided reads of Y at the end of every
-# data-gradient block cost the GEMMs 0.26 ms (step 7.12-7.14 vs 7.07-7.08 ms).
-BNBWD_EPILOGUE = os.environ.get("HYPEL_BNBWD_EPILOGUE", "0") != "0"
 
 
 class Storage:
@@ -162,18 +156,18 @@ GEMM_MFMA16X4 = 0x2000  # include/hypel.h HYPEL_GEMM_MFMA16X4: 128x64 blocks on 
 GEMM_VAR_N = 0x4000     # ... HYPEL_GEMM_VAR_N: tile records carry their group's column count
 # Merged multi-kernel levels (include/hypel.h): the nested branches of a level share one packed weight image
 # W_pack[offset][Cin][C]; per output pixel and ring of input offsets ONE product on the column range of the branches
-# that contain the ring.  HYPEL_MERGE_LEVELS: comma list of the passes that use it -- "fwd", "dgrad", "wgrad" -- or "0".
+# that contain the ring.  HYPEL_MERGE_LEVELS: comma list of the passes that use it -- "fwd", "dgrad" -- or "0".
 # Measured on MI355X (round 4, NOTES 4.A; per-launch and step-level A/B on one box): the merged FORWARD pays only for
 # levels with <= 16 filters per branch (128x64 blocks on the 16x16x4 MFMA instead of 128x16: 146 -> 128 us); with 30 / 60
 # filters a branch already fills a 32- / 64-column tile, the A stagings per FLOP do not change and the mixed-width launch
 # loses 50 - 60 % (380 -> 583 us, 430 -> 687 us).  The merged DATA GRADIENT (49 instead of 84 segments per pixel) gains
-# 2 - 7 % per launch.  The merged FILTER GRADIENT moves work between the three tile-width launches without shortening
-# their sum (1584 -> 1593 us): off.  Step: 6.51 -> 6.49 ms, i.e. neutral.
+# 2 - 7 % per launch.  The merged FILTER GRADIENT moved work between the three tile-width launches without shortening
+# their sum (1584 -> 1593 us): removed in round 5 (NOTES 4.A keeps the numbers).  Step: 6.51 -> 6.49 ms, i.e. neutral.
 MERGE_LEVELS = set(x for x in os.environ.get("HYPEL_MERGE_LEVELS", "fwd,dgrad").split(",") if x and x != "0")
 MERGE_LEVELS_MAX_COUT = int(os.environ.get("HYPEL_MERGE_LEVELS_MAX_COUT", "32"))
 # per pass: widest branch (filters) the pass is merged for, taps per merged forward tile, forward tile-width hint
 MERGE_PASS_MAX_COUT = {k: int(os.environ.get(f"HYPEL_MERGE_{k.upper()}_MAX_COUT", d))
-                       for k, d in (("fwd", "16"), ("dgrad", "1048576"), ("wgrad", "1048576"))}
+                       for k, d in (("fwd", "16"), ("dgrad", "1048576"))}
 # ... and for the split-operand kernels, whose cost is dominated by staging A: sharing one staged A tile between the
 # branches of a ring pays for wider branches too
 MERGE_FWD_MAX_COUT_SPLIT = int(os.environ.get("HYPEL_MERGE_FWD_MAX_COUT_SPLIT", "16"))
@@ -486,11 +480,11 @@ class TowerPlan:
         rem = n % 128
         return 2 if n <= 64 or 0 < rem <= 64 and n < 256 else 3
 
-    def _split6(self, tag, tables, n, ta, tb, flags, bnbwd, paired):
+    def _split6(self, tag, tables, n, ta, tb, flags, paired):
         """0 = fp32 MFMA kernel, else the tile-width hint of the split-operand kernel for this launch."""
         if tag in SPLIT_OVERRIDE:
             return SPLIT_OVERRIDE[tag]
-        if GEMM_SPLIT != 6 or n <= GEMM_SPLIT_MIN_N or (ta and tb) or (flags & ~GEMM_VAR_N) or bnbwd is not None or paired:
+        if GEMM_SPLIT != 6 or n <= GEMM_SPLIT_MIN_N or (ta and tb) or (flags & ~GEMM_VAR_N) or paired:
             return 0
         macs = sum(rows * sum(k for _, _, k in gs) * tables.n_of(gi, n) for gi, (_, gs, rows) in enumerate(tables.groups))
         if 2 * macs < GEMM_SPLIT_MIN_FLOPS:
@@ -498,13 +492,10 @@ class TowerPlan:
         return self._split6_width(n)
 
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
-                   allow_split=True, res=None, stats=None, bnbwd=None, pair=False, hint=None, flags=0):
+                   allow_split=True, res=None, stats=None, pair=False, hint=None, flags=0):
         """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32).
-        stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate).
-        bnbwd = producer node index whose batch-norm backward reduction rides in this data gradient's epilogue
-        (hypel_seg_gemm_bnbwd_f32); dropped (returns False) when the product is split along K."""
+        stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate)."""
         split = self._split_k(tables, n, lda, ta, ldb, tb, ldc) if allow_split and res is None else None
-        fused_bnbwd = False
         if split is not None:
             stab, S, c_min, count = split
             pos = len(lst)
@@ -516,14 +507,14 @@ class TowerPlan:
             self._scratch(l2, 0, "scratch_wgrad", S * count)
             lst.append(l2)
             return
-        pair = bool(pair and PAIR_SEGS and not ta and tb and n > 16 and bnbwd is None and stats is None)
+        pair = bool(pair and PAIR_SEGS and not ta and tb and n > 16 and stats is None)
         if hint is None:
             hint = self._tile_hint(tables, n, ta, tb, res is not None) if TILE_HINTS else 0
         if HINT_OVERRIDE and tag in HINT_OVERRIDE:  # per-launch A/B: HYPEL_HINT_OVERRIDE="fwd:conv_enc_2=1,dgrad:fc_0=2"
             hint = HINT_OVERRIDE[tag]
-        single_seg = bool(SINGLE_SEG_HINT and not ta and bnbwd is None and
+        single_seg = bool(SINGLE_SEG_HINT and not ta and
                           all(len(segs) == 1 for _, segs, _ in tables.groups))
-        sp6 = self._split6(tag, tables, n, ta, tb, flags, bnbwd,
+        sp6 = self._split6(tag, tables, n, ta, tb, flags,
                            pair and any(k <= 16 for _, gs, _ in tables.groups for _, _, k in gs))
         if sp6:
             pair, hint, single_seg = False, sp6, False
@@ -541,19 +532,7 @@ class TowerPlan:
         args = (a_ref, int(lda), int(ta), b_ref, int(ldb), int(tb), c_ref, int(ldc), int(n), Ref(g_t), Ref(s_t),
                 Ref(t_t), int(len(tarr)), bias_ref, int(accumulate) | (hint << 8))
         name = "seg_gemm_f32"
-        if bnbwd is not None:
-            paux = self.node_aux[bnbwd]
-            pnode = self.tower.nodes[bnbwd]
-            pname = f"bnbwd_partial:{bnbwd}"
-            self._alloc(pname, len(tarr) * 2 * int(n))
-            act = pnode.act
-            name = "seg_gemm_bnbwd_f32"
-            r = res if res is not None else (None, 0, None)
-            args = args + (r[0], int(r[1]), r[2], self._ref(paux["y"].buf), int(paux["y"].ld), paux["mean"], paux["rstd"],
-                           paux["beta_ref"], act.code if act else 0, float(act.alpha) if act else 0.0, self._ref(pname))
-            paux["bwd_partial"] = (pname, int(len(tarr)))
-            fused_bnbwd = True
-        elif res is not None:
+        if res is not None:
             name = "seg_gemm_res_f32"
             args = args + (res[0], int(res[1]), res[2])
         elif stats is not None:
@@ -564,7 +543,6 @@ class TowerPlan:
         if stats is not None:
             self._scratch(l, len(args) - 1, "scratch_partial", stats)
         lst.append(l)
-        return fused_bnbwd
 
     def _dp_sync_node(self):
         """Data-parallel overlap: [(node index, lo, hi)] -- walking backward, the nodes after which the weight gradients
@@ -637,38 +615,9 @@ class TowerPlan:
             return list(node.srcs)
         return [node.src]
 
-    def _index_consumers(self):
-        self._node_index = {id(n): i for i, n in enumerate(self.tower.nodes)}
-        self._first_consumer = {}
-        for i, n in enumerate(self.tower.nodes):
-            for t in self._inputs_of(n):
-                self._first_consumer.setdefault(id(t.owner), i)
-
-    def _bnbwd_producer(self, idx, src, gst, n_launches):
-        """Index of the layer whose batch-norm backward reduction can ride in the epilogue of the data gradient that
-        node `idx` is about to write into d(src): src is that layer's whole output, `idx` is its FIRST consumer in
-        forward order (= the last writer of the gradient in backward order), one launch writes it, plain storage."""
-        if not BNBWD_EPILOGUE or not self.training or n_launches != 1 or not hasattr(self, "_first_consumer"):
-            return None
-        own = src.owner
-        p = own.node
-        if p is None or not isinstance(p, G.LinearNode) or not (p.has_bn and p.has_post and p.training):
-            return None
-        if src.root is not None or self._first_consumer.get(id(own)) != idx:
-            return None
-        pidx = self._node_index[id(p)]
-        paux = self.node_aux.get(pidx, {})
-        if paux.get("small_bn") or paux.get("mask") is not None or "mean" not in paux:
-            return None
-        if not (gst.contiguous and gst.ch_off == 0 and gst.ld == src.c and src.c > 16):
-            return None
-        return pidx
-
-    # ------------------------------------------------------------------ build
     def _build(self):
         tw = self.tower
         nb = self.nb
-        self._index_consumers()
         # inputs: the loader hands over NHWC batches; keep a persistent staging tensor and convert
         for name, t in tw.inputs.items():
             if t.hw is None:
@@ -779,14 +728,7 @@ class TowerPlan:
                     offs += [(dy, dx, r) for dy in range(-r, r + 1) for dx in range(-r, r + 1) if max(abs(dy), abs(dx)) == r]
                 C = co * len(brs)
                 lay = dict(offs=offs, index={(dy, dx): d for d, (dy, dx, _) in enumerate(offs)}, rmax=rmax, first=first,
-                           col0=[f * co for f in first], co=co, C=C, cin=src.c, buf=f"wpack:{idx}",
-                           dense_off=[], dense_size=0)
-                pos = 0
-                for (_, _, r) in offs:  # dense image of the packed filter gradient: [d] -> [Cin x (C - col0[r])]
-                    lay["dense_off"].append(pos)
-                    pos += src.c * (C - lay["col0"][r])
-                lay["dense_size"] = pos
-                assert pos == sum(b.w.size for b in brs)
+                           col0=[f * co for f in first], co=co, C=C, cin=src.c, buf=f"wpack:{idx}")
                 if any(w_ in MERGE_LEVELS and co <= max(MERGE_PASS_MAX_COUT[w_], MERGE_FWD_MAX_COUT_SPLIT if GEMM_SPLIT == 6 else 0)
                        for w_ in ("fwd", "dgrad")):
                     # these passes read the packed image (the filter gradient does not)
@@ -796,7 +738,7 @@ class TowerPlan:
         return lay
 
     def _level_pass(self, idx, node, what):
-        """The level's packed layout if pass `what` ("fwd" / "dgrad" / "wgrad") uses the merged form, else None."""
+        """The level's packed layout if pass `what` ("fwd" / "dgrad") uses the merged form, else None."""
         lay = self._level_layout(idx, node)
         cap = MERGE_PASS_MAX_COUT[what]
         if what == "fwd" and GEMM_SPLIT == 6:
@@ -1404,8 +1346,7 @@ class TowerPlan:
                         tb.add_group(gst.pix_off(pin), segs, nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, w_ref, w_ld or cout, 1,
                                     self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}{mtag}",
-                                    res=fold_res, bnbwd=self._bnbwd_producer(idx, src, gst, len(by_cout)),
-                                    pair=cout <= 16)
+                                    res=fold_res, pair=cout <= 16)
                     fold_res = None
                     acc = 1
             # ---- filter gradient ----
@@ -1439,7 +1380,7 @@ class TowerPlan:
                     for p in range(src.npix):
                         tb.add_group(gst.pix_off(p), [(0, b.w.offset + (rowbase + p * src.c) * c, c)], nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, Ref(self.sess.params), c, 1, self._ref(gst.buf),
-                                    gst.ld, None, acc, f"dgrad:{b.scope}", bnbwd=self._bnbwd_producer(idx, src, gst, 1))
+                                    gst.ld, None, acc, f"dgrad:{b.scope}")
                 rowbase += src.npix * src.c
             if trains:
                 self._wgrad_dense(idx, node, aux, dy, c)
@@ -1471,14 +1412,7 @@ class TowerPlan:
             pacc = 0
             if dparam is not None:
                 pacc = self._param_acc(aux["beta"] if has_bn else aux["bias"])
-            if aux.get("bwd_partial") is not None and has_bn and mask is None:
-                # the data gradient that finished dZ already left sum(dyh), sum(dyh * xhat) per tile
-                pname, n_tiles = aux["bwd_partial"]
-                l2 = Launch("bwd_reduce_finalize", (self._ref(pname), n_tiles, c, None, dparam, pacc),
-                            tag="post-bwd-finalize")
-                self._scratch(l2, 3, "sums", 2 * c)
-                self.bwd.append(l2)
-            elif (ACT_BIAS_BWD and not has_bn and dy is not None and (code != 0 or mask is not None)
+            if (ACT_BIAS_BWD and not has_bn and dy is not None and (code != 0 or mask is not None)
                   and not self.sync_bn):
                 # no batch norm: dY = dZ * act'(y) needs no column sum -- the bias-gradient reduction writes it too
                 l1 = Launch("act_bias_bwd_reduce", (dz, c, y_ref, c, rows, c, code, alpha, mask, c, chunk, None, dy, c),
@@ -1569,7 +1503,7 @@ class TowerPlan:
         return out
 
     def _emit_wgrad(self, tables_by_split_builder, n_groups_blocks, max_segs, slab, w0_offset, n, a_ref, lda, b_ref, ldb,
-                    tag, acc=0, unpack=None):
+                    tag, acc=0):
         """tables_by_split_builder(S) -> GemmTables whose groups write to c_off = split*slab + local."""
         s_pix, s_row = self._wgrad_splits(n_groups_blocks, max_segs)
         S = s_pix * s_row
@@ -1581,9 +1515,8 @@ class TowerPlan:
                 self._flush_wgrads()
                 pend = self._pending_wgrads
             pend.append(dict(tb=tb, S=S, slab=int(slab), w0=int(w0_offset), n=int(n), a_ref=a_ref, lda=int(lda),
-                             b_ref=b_ref, ldb=int(ldb), tag=tag, acc=int(acc), unpack=unpack))
+                             b_ref=b_ref, ldb=int(ldb), tag=tag, acc=int(acc)))
             return
-        assert unpack is None, "merged-level filter gradients need the merged launch (HYPEL_MERGE_WGRAD)"
         if S == 1:
             self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None,
                             acc, tag, allow_split=False)
@@ -1628,55 +1561,36 @@ class TowerPlan:
         spos = 0
         grads0 = rel(Ref(self.sess.grads))
         entries = []
-        unpacks = []  # block copies packed gradient image -> TF-layout gradient slots (merged levels)
 
-        def col_tiles(n, merged, split6=0):
-            """[(n0, tile width)] of a product with n output columns.  Ordinary products: one width per product.  The
-            per-offset products of a merged level (n = 15 .. 240): 64-wide tiles while >= 48 columns remain, then 32, 16.
-            split6 = tile-width hint of the split-operand kernel (widths | GEMM_MULTI_SPLIT6: their own launches)."""
+        def col_tiles(n, split6=0):
+            """[(n0, tile width)] of a product with n output columns: one width per product.  split6 = tile-width hint of
+            the split-operand kernel (widths | GEMM_MULTI_SPLIT6: their own launches)."""
             if split6:
                 wdt = {1: 32, 2: 64, 3: 128}[split6]
                 return [(n0, wdt | GEMM_MULTI_SPLIT6) for n0 in range(0, n, wdt)]
-            if not merged:
-                wdt = 16 if n <= 16 else (32 if n <= 32 else 64)
-                return [(n0, wdt) for n0 in range(0, n, wdt)]
-            out, n0 = [], 0
-            while n0 < n:
-                rem = n - n0
-                wdt = 64 if rem >= 48 else (32 if rem > 16 else 16)
-                out.append((n0, wdt))
-                n0 += wdt
-            return out
+            wdt = 16 if n <= 16 else (32 if n <= 32 else 64)
+            return [(n0, wdt) for n0 in range(0, n, wdt)]
 
         per_width = {}  # width -> dict(segs, lists, macs, nbytes, tags)
         for e in pend:
             n = e["n"]
-            up = e.get("unpack")
-            if up is not None:
-                # the reduction target is the level's packed gradient image (dense per-offset blocks), scattered into the
-                # variables' gradient slots afterwards
-                self._alloc(up["buf"], e["slab"])
-                out_base = rel(self._ref(up["buf"]))
-                unpacks += [(out_base + so, grads0 + do, rows, cols, sld, dld, acc, 0)
-                            for (so, do, rows, cols, sld, dld, acc) in up["entries"]]
-            else:
-                out_base = grads0 + e["w0"]
+            out_base = grads0 + e["w0"]
             if e["S"] > 1:
                 c_base = rel(self._ref(sname, spos))
-                entries.append((c_base, out_base, e["slab"], e["slab"], e["S"], 0 if up is not None else e["acc"]))
+                entries.append((c_base, out_base, e["slab"], e["slab"], e["S"], e["acc"]))
                 spos += e["S"] * e["slab"]
                 flags = 0
             else:
                 c_base = out_base
-                flags = 0 if up is not None else e["acc"]
+                flags = e["acc"]
             a0, b0 = rel(e["a_ref"]), rel(e["b_ref"])
             tb = e["tb"]
-            sp6 = 0 if up is not None else self._split6(e["tag"], tb, n, 1, 0, 0, None, False)
+            sp6 = self._split6(e["tag"], tb, n, 1, 0, 0, False)
             first_width = None
             loc_groups = {}  # (width, locality key) -> [work, [(work, record)]]
             for gi, (c_off, gs, rows) in enumerate(tb.groups):
                 gn = tb.n_of(gi, n)
-                tiles = col_tiles(gn, up is not None, sp6)
+                tiles = col_tiles(gn, sp6)
                 ksum = sum(k for _, _, k in gs)
                 key = tb.keys[gi] if tb.keys[gi] is not None else 0
                 seg_begin = {}
@@ -1734,68 +1648,14 @@ class TowerPlan:
                        nbytes=4 * sum(cnt * (S + 1) for (_, _, _, cnt, S, _) in entries), tag="wgrad-reduce")
             l.meta = {"splits": [int(S) for (_, _, _, _, S, _) in entries]}
             self.bwd.append(l)
-        if unpacks:
-            from .backend import COPY_BLOCK_DTYPE
-            u_t = self.be.upload(np.array(unpacks, COPY_BLOCK_DTYPE))
-            self.tables.append(u_t)
-            self.bwd.append(Launch("copy_blocks_f32", (base, Ref(u_t), len(unpacks), max(u[2] * u[3] for u in unpacks)),
-                                   nbytes=8 * sum(u[2] * u[3] for u in unpacks), tag="level-unpack"))
-
     @staticmethod
     def _split_even(segs, S):
         """Partition a list into S contiguous chunks (some possibly empty)."""
         n = len(segs)
         return [segs[(n * s) // S:(n * (s + 1)) // S] for s in range(S)]
 
-    def _wgrad_level_merged(self, idx, node, lay, s_st, src, dy, c, h, w):
-        """Filter gradient of a merged level: per input offset d ONE product dW_pack[d] = sum_p X[p + d]^T dY[p][:, col0:]
-        with n = C - col0[ring] columns (15 .. 60 for the narrowest HYPELCNN level instead of 15 per (branch, tap)), written
-        into a dense packed image; hypel_copy_blocks_f32 scatters the [Cin x cout] slices into the HWIO gradient slots."""
-        nb = self.nb
-        C, cin, co = lay["C"], lay["cin"], lay["co"]
-        group_list = []  # (offset of the block in the dense image, [(a_off, b_off)] pixel pairs, columns)
-        for d, (ofy, ofx, r) in enumerate(lay["offs"]):
-            col0 = lay["col0"][r]
-            pairs = [(s_st.pix_off((oy + ofy) * w + ox + ofx), (oy * w + ox) * nb * c + col0)
-                     for oy in range(h) for ox in range(w) if 0 <= oy + ofy < h and 0 <= ox + ofx < w]
-            if pairs:
-                group_list.append((lay["dense_off"][d], pairs, C - col0))
-        slab = lay["dense_size"]
-        blocks = sum(((cin + GEMM_BM - 1) // GEMM_BM) * ((n_d + 63) // 64) for _, _, n_d in group_list)
-        max_segs = max(len(prs) for _, prs, _ in group_list)
-
-        def build(S, group_list=group_list, slab=slab, rows=cin, lda=s_st.ld, ldb=c, npairs=max_segs):
-            tb = GemmTables()
-            for si, (p0, p1, r0, r1) in enumerate(self._split_ranges(S[0], S[1], npairs)):
-                for (loc, pairs, n_d) in group_list:
-                    q0, q1 = len(pairs) * p0 // npairs, len(pairs) * p1 // npairs
-                    segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs[q0:q1]] if r1 > r0 else []
-                    tb.add_group(si * slab + loc, segs, rows, key=si, n=n_d)
-            return tb
-
-        ents = []
-        for bi, b in enumerate(node.branches):
-            acc = self._param_acc(b.w)
-            pb = (b.k - 1) // 2
-            for i in range(b.k):
-                for j in range(b.k):
-                    d = lay["index"][(i - pb, j - pb)]
-                    r = lay["offs"][d][2]
-                    n_d = C - lay["col0"][r]
-                    dst = b.w.offset + (i * b.k + j) * cin * co
-                    ents.append((lay["dense_off"][d] + (bi - lay["first"][r]) * co, dst, cin, co, n_d, co, acc))
-        self._emit_wgrad(build, blocks, max_segs, slab, 0, C, self._ref(s_st.buf), s_st.ld, dy, c,
-                         f"wgrad:{node.branches[0].scope}/merged", acc=0,
-                         unpack=dict(buf=f"dwpack:{idx}", entries=ents))
-
     def _wgrad_conv(self, idx, node, aux, s_st, src, dy, c, h, w):
         nb = self.nb
-        lay = self._level_pass(idx, node, "wgrad") if MERGE_WGRAD else None
-        # (every offset of the largest kernel must meet at least one pixel pair, or its block of the packed image would
-        # never be written: (k - 1) / 2 <= min(h, w) - 1)
-        if lay is not None and max(b.k for b in node.branches) <= 2 * min(h, w) - 1:
-            self._wgrad_level_merged(idx, node, lay, s_st, src, dy, c, h, w)
-            return
         choff = 0
         w_base = aux["w0"].offset
         by_cout = {}

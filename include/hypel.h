@@ -145,21 +145,6 @@ int hypel_seg_gemm_stats_f32(const float* a, int64_t lda, int32_t trans_a, const
                              const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles, const float* bias,
                              int32_t accumulate, float* stats_partial, hypel_stream_t stream);
 
-/* Data gradient (optionally with the folded shortcut gradient of hypel_seg_gemm_res_f32: res NULL = none) that ALSO
- * performs the first pass of the batch-norm / activation backward of the layer whose output gradient dZ it finishes
- * (tf.gradients through tf_slim.batch_norm + leaky_relu, nnmodel/HYPELCNNModel.py:40-45): C is dZ of that layer
- * (this launch must be its last writer), `y` its pre-normalisation output (row-aligned with C, leading dimension
- * ldy), mean / rstd / beta its batch statistics and offset, indexed by the absolute output column.  For every tile t
- * of the tile table: partial[(2t) * n + col] = sum over the tile's rows of dyh, partial[(2t+1) * n + col] = sum of
- * dyh * xhat, dyh = dZ * act'(xhat + beta), xhat = (y - mean) * rstd -- the chunk format hypel_bwd_reduce_finalize
- * sums (n_chunks = n_tiles), i.e. what hypel_bn_act_bwd_reduce computes in a separate pass over dZ and Y.  n > 16. */
-int hypel_seg_gemm_bnbwd_f32(const float* a, int64_t lda, int32_t trans_a, const float* b, int64_t ldb,
-                             int32_t trans_b, float* c, int64_t ldc, int32_t n, const hypel_group_t* groups,
-                             const hypel_seg_t* segs, const hypel_tile_t* tiles, int32_t n_tiles, const float* bias,
-                             int32_t accumulate, const float* res, int64_t ldr, const int32_t* res_start,
-                             const float* y, int64_t ldy, const float* mean, const float* rstd, const float* beta,
-                             int32_t act, float alpha, float* partial, hypel_stream_t stream);
-
 /* hypel_seg_gemm_f32 with the shortcut gradient folded into the epilogue.  For `net = f(conv(net)) + scale_in_to_out(
  * net)` (nnmodel/HYPELCNNModel.py:160-163,176-183) the gradient of `net` is conv-data-gradient + transpose of the
  * channel map applied to dZ; instead of a separate gather pass plus a read-modify-write of the result, output

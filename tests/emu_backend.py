@@ -219,29 +219,6 @@ class EmuBackend:
                     rm = np.lib.stride_tricks.as_strided(R[r0 * ldr + o0:], (rows, o1 - o0), (ldr * 4, 4))
                     cm[:, col] += rm.astype(np.float64).sum(1).astype(np.float32)
 
-    def k_seg_gemm_bnbwd_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate,
-                             res, ldr, res_start, y, ldy, mean, rstd, beta, act, alpha, partial):
-        """The data gradient (with or without the folded shortcut gradient), then per tile of the tile table the
-        batch-norm backward sums of the layer whose output gradient C now is: sum(dyh), sum(dyh * xhat)."""
-        if res is None:
-            self.k_seg_gemm_f32(a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate)
-        else:
-            self.k_seg_gemm_res_f32(a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate,
-                                    res, ldr, res_start)
-        C, Y = _arr(c), _arr(y)
-        t = tiles.t.numpy()[tiles.off:].view(TILE_DTYPE)[:n_tiles]
-        po = _arr(partial)[: n_tiles * 2 * n].reshape(n_tiles, 2, n)
-        for ti, tt in enumerate(t):
-            co, m0, rows = int(tt["c_off"]), int(tt["m0"]), int(tt["rows"])
-            mr = min(128, rows - m0)
-            col0, row0 = co % ldc, co // ldc + m0
-            dz = np.lib.stride_tricks.as_strided(C[co + m0 * ldc:], (mr, n), (ldc * 4, 4)).astype(np.float64)
-            yv = np.lib.stride_tricks.as_strided(Y[row0 * ldy + col0:], (mr, n), (ldy * 4, 4)).astype(np.float64)
-            xhat = (yv - _arr(mean)[col0:col0 + n]) * _arr(rstd)[col0:col0 + n]
-            dyh = dz * _act_grad(xhat + _arr(beta)[col0:col0 + n], act, alpha)
-            po[ti, 0] = dyh.sum(0)
-            po[ti, 1] = (dyh * xhat).sum(0)
-
     def k_seg_gemm_stats_f32(self, a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate,
                              stats):
         """The product, then per 128-row tile of its single group the (mean, sum of squared deviations) of every

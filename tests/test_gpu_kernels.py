@@ -328,52 +328,6 @@ def test_seg_gemm_split6_error_vs_fp32_chain(hip):
         print("  rows=%5d K=%5d n=%5d ta=%d tb=%d  split %.2e  fp32 %.2e" % r)
 
 
-@pytest.mark.parametrize("cin,cout,mapped,acc,act,hint", [(120, 240, True, 0, 1, 1), (240, 120, True, 1, 1, 2),
-                                                           (60, 60, False, 0, 0, 0), (145, 480, True, 0, 3, 2),
-                                                           (33, 48, None, 1, 1, 1)])
-def test_seg_gemm_bnbwd_epilogue(hip, cin, cout, mapped, acc, act, hint):
-    """Data gradient whose epilogue also reduces the batch-norm backward sums of the layer that produced its output
-    tensor: with / without the folded shortcut gradient (mapped None = no shortcut), accumulate, several groups with
-    ragged rows, both tile widths -- dX and the per-tile partials against the specification."""
-    rng = np.random.default_rng(cin * 3 + cout)
-    nb, P = 150, 3
-    rows = P * nb
-    dy = rng.standard_normal((rows, cout)).astype(np.float32)
-    dz = rng.standard_normal((rows, cout)).astype(np.float32)
-    w = rng.standard_normal((cin, cout)).astype(np.float32)
-    dx = rng.standard_normal((rows, cin)).astype(np.float32)
-    yprev = rng.standard_normal((rows, cin)).astype(np.float32)
-    mean = rng.standard_normal(cin).astype(np.float32) * 0.1
-    rstd = (0.5 + rng.random(cin)).astype(np.float32)
-    beta = rng.standard_normal(cin).astype(np.float32) * 0.1
-    sc = cin / cout
-    idx = (np.arange(cout) // (cout // cin) if cout % cin == 0 else
-           np.minimum(np.round(np.arange(cout) * sc), cin - 1).astype(int))
-    start = np.searchsorted(idx, np.arange(cin + 1), side="left").astype(np.int32)
-    b = Both(hip)
-    groups = [(p * nb * cin, [(p * nb * cout, 0, cout)], nb) for p in range(P)]
-    garr, sarr, tarr, _ = _tables(b, groups).finalize(cin)
-    n_tiles = len(tarr)
-    for nm, arr in (("dy", dy), ("dz", dz), ("w", w), ("dx", dx), ("g", garr), ("s", sarr), ("t", tarr),
-                    ("start", start), ("y", yprev), ("mean", mean), ("rstd", rstd), ("beta", beta),
-                    ("part", np.zeros(n_tiles * 2 * cin, np.float32))):
-        b.arr(nm, arr)
-    res = (None, 0, None) if mapped is None else ("dz", cout, "start" if mapped else None)
-    b.run("seg_gemm_bnbwd_f32", "dy", cout, 0, "w", cout, 1, "dx", cin, cin, "g", "s", "t", n_tiles, None,
-          acc | (hint << 8), res[0], res[1], res[2], "y", cin, "mean", "rstd", "beta", act, 0.18, "part")
-    b.check("dx", rtol=2e-4, atol=2e-5)
-    b.check("part", rtol=1e-3, atol=3e-4)
-    # and against the plain definition (sum over ALL tiles = the column sums hypel_bn_act_bwd_reduce would produce)
-    got = b.h["part"].cpu().numpy().reshape(n_tiles, 2, cin).sum(0)
-    dzf = b.h["dx"].cpu().numpy().reshape(rows, cin).astype(np.float64)
-    xhat = (yprev.astype(np.float64) - mean) * rstd
-    pre = xhat + beta
-    slope = {0: np.ones_like(pre), 1: np.where(pre > 0, 1.0, 0.18), 3: (1 / (1 + np.exp(-pre))) * (1 - 1 / (1 + np.exp(-pre)))}[act]
-    dyh = dzf * slope
-    np.testing.assert_allclose(got[0], dyh.sum(0), rtol=2e-3, atol=2e-3)
-    np.testing.assert_allclose(got[1], (dyh * xhat).sum(0), rtol=2e-3, atol=2e-3)
-
-
 @pytest.mark.parametrize("cin,cout,hint,with_res,acc", [(120, 15, 2, True, 0), (120, 15, 1, False, 1), (60, 7, 0, False, 0),
                                                           (33, 16, 2, True, 1), (240, 9, 1, False, 0)])
 def test_seg_gemm_paired_short_segments(hip, cin, cout, hint, with_res, acc):

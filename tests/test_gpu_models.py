@@ -344,20 +344,20 @@ def test_grss2013_hypelcnn_batch1024_vs_oracle(hip):
 
 @pytest.mark.parametrize("nb", [64, 1024])
 def test_grss2013_hypelcnn_every_level_pass_merged_vs_oracle(hip, monkeypatch, nb):
-    """The merged form of the multi-kernel levels forced for ALL three levels and ALL three passes (forward on 128x64
-    blocks with per-tile column counts -- 16x16x4 MFMA for the 15-filter level --, merged data-gradient segments, packed
-    filter gradients + scatter launch) at the benchmark's shapes, against the float64 oracle."""
+    """The merged form of the multi-kernel levels forced for ALL three levels, forward and data gradient (forward on
+    blocks with per-tile column counts -- 16x16x4 MFMA for the 15-filter level, the split-operand kernels for the wide
+    ones --, merged data-gradient segments) at the benchmark's shapes, against the float64 oracle."""
     from hypelcnn_amd import plan
-    monkeypatch.setattr(plan, "MERGE_LEVELS", {"fwd", "dgrad", "wgrad"})
+    monkeypatch.setattr(plan, "MERGE_LEVELS", {"fwd", "dgrad"})
     monkeypatch.setattr(plan, "MERGE_LEVELS_MAX_COUT", 1 << 20)
-    monkeypatch.setattr(plan, "MERGE_PASS_MAX_COUT", {"fwd": 1 << 20, "dgrad": 1 << 20, "wgrad": 1 << 20})
+    monkeypatch.setattr(plan, "MERGE_PASS_MAX_COUT", {"fwd": 1 << 20, "dgrad": 1 << 20})
     alg = _alg("alg_param_hypelcnn.json")
     built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 7, 145, 15, alg, nb, 78)
     ct = U.run_train_step(built, x, onehot, masks)
     tags = _tags(ct)
     assert sum(1 for t in tags if t.startswith("fwd:") and t.endswith("/merged")) == 3, sorted(set(tags))
     assert sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 3
-    assert "level-unpack" in tags and "level-pack" in tags
+    assert "level-pack" in tags
     ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 15, alg,
                                      tol_logit=1e-3, tol_grad=5e-4)
     got = ct.value(built.y_conv).cpu().numpy()

@@ -245,40 +245,12 @@ def test_filter_gradients_go_out_as_merged_launches(monkeypatch):
     torch.testing.assert_close(sess2.grads, g_merged, rtol=1e-5, atol=1e-7)
 
 
-def test_bn_backward_reduction_rides_in_the_data_gradient_epilogue(monkeypatch):
-    """Every batch-normed convolution's first backward pass (column sums of dyh, dyh * xhat) is produced by the data
-    gradient that finishes its output gradient: no stand-alone reduction launch is left for them, and the step equals
-    the oracle; switching the fusion off gives the same gradients through the separate pass."""
-    from hypelcnn_amd import plan
-    monkeypatch.setattr(plan, "BNBWD_EPILOGUE", True)  # an option (measured slower on MI355X, see plan.py)
-    alg = dict(ALG_H, filter_count=96)
-    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 7, 9, 4, alg, 5, 31)
-    ct = U.run_train_step(built, x, onehot, masks)
-    names = [l.name for l in ct.plan.bwd]
-    assert "seg_gemm_bnbwd_f32" in names
-    n_conv_bn = sum(1 for n in built.train_tower.nodes if getattr(n, "kind", "") == "conv" and n.has_bn)
-    # (layers with <= 16 channels keep the separate pass: the 16-wide GEMM variant has no reduction epilogue)
-    assert names.count("seg_gemm_bnbwd_f32") >= n_conv_bn - 3
-    # (the fully-connected tail's row-parallel batch norm has a reduction launch of its own: tag post-bwd-reduce-chunks)
-    assert sum(1 for l in ct.plan.bwd if l.name == "bn_act_bwd_reduce" and l.tag == "post-bwd-reduce") <= 3
-    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
-    g_fused = sess.grads.clone()
-    monkeypatch.setattr(plan, "BNBWD_EPILOGUE", False)
-    built2, sess2, _, _, _, _ = _case("HYPELCNNModel", 7, 9, 4, alg, 5, 31)
-    ct2 = U.run_train_step(built2, x, onehot, masks)
-    assert "seg_gemm_bnbwd_f32" not in [l.name for l in ct2.plan.bwd]
-    import torch
-    torch.testing.assert_close(sess2.grads, g_fused, rtol=1e-5, atol=1e-7)
-
-
-@pytest.mark.parametrize("passes,patch,fc", [("fwd", 7, 48), ("fwd,dgrad,wgrad", 7, 48), ("fwd,dgrad,wgrad", 5, 96),
-                                             ("wgrad", 7, 48), ("dgrad", 5, 48)])
+@pytest.mark.parametrize("passes,patch,fc", [("fwd", 7, 48), ("fwd,dgrad", 7, 48), ("fwd,dgrad", 5, 96), ("dgrad", 5, 48)])
 def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
     """Merged multi-kernel levels (include/hypel.h, HYPEL_GEMM_VAR_N): the nested branches of a level share one packed
     weight image; per output pixel and ring ONE product on the column range of the branches that contain the ring
-    (forward), merged reduction segments (data gradient), per-offset products into a packed gradient image that one
-    block-copy launch scatters back into the TF-layout gradient slots (filter gradient).  Forced at a tiny batch, every
-    pass alone and together, incl. channel parts, against the float64 oracle."""
+    (forward), merged reduction segments (data gradient).  Forced at a tiny batch, every pass alone and together, incl.
+    channel parts, against the float64 oracle."""
     from hypelcnn_amd import plan
     monkeypatch.setattr(plan, "TAP_SPLIT_MIN_BATCH", 1)
     monkeypatch.setattr(plan, "MAX_TAPS_PER_TILE", 5)
@@ -292,10 +264,8 @@ def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
     tags = _tags(ct)
     names = [l.name for l in ct.plan.fwd + ct.plan.bwd]
     for what in passes.split(","):
-        assert any(t.startswith(what + ":") and t.endswith("/merged") for t in tags) or \
-            (what == "wgrad" and "level-unpack" in tags), (what, tags)
-    assert ("level-pack" in tags) == bool(set(passes.split(",")) & {"fwd", "dgrad"})
-    assert ("copy_blocks_f32" in names) == ("level-pack" in tags or "level-unpack" in tags)
+        assert any(t.startswith(what + ":") and t.endswith("/merged") for t in tags), (what, tags)
+    assert "level-pack" in tags and "copy_blocks_f32" in names
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 
