@@ -71,12 +71,7 @@ extern "C" uint32_t hypel_crc32c(uint32_t crc, const void* data, uint64_t n) {
 }
 
 extern "C" int hypel_graph_begin_capture(hypel_stream_t stream) {
-    // HYPEL_CAPTURE_MODE=relaxed|global: experiments (default thread-local)
-    static const char* mode_env = getenv("HYPEL_CAPTURE_MODE");
-    hipStreamCaptureMode mode = hipStreamCaptureModeThreadLocal;
-    if (mode_env && mode_env[0] == 'r') mode = hipStreamCaptureModeRelaxed;
-    if (mode_env && mode_env[0] == 'g') mode = hipStreamCaptureModeGlobal;
-    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, mode);
+    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) {
         hypel_set_error("hypel_graph_begin_capture: %s", hipGetErrorString(e));
         return -2;

@@ -26,7 +26,7 @@ static inline EwShape ew_shape(int64_t rows, int cvec) {
     const int ty = 256 >> l;
     int64_t g = (rows + ty - 1) / ty;
     if (g < 1) g = 1;
-    static const int cap = getenv("HYPEL_EW_MAX_BLOCKS") ? atoi(getenv("HYPEL_EW_MAX_BLOCKS")) : 8192;
+    constexpr int cap = 8192;
     if (g > cap) g = cap;
     return EwShape{l, (int)g};
 }
@@ -1327,7 +1327,7 @@ extern "C" int hypel_fill_f32(float* dst, int64_t count, float value, hypel_stre
 }
 
 static int red_max_blocks() {
-    static const int v = getenv("HYPEL_RED_MAX_BLOCKS") ? atoi(getenv("HYPEL_RED_MAX_BLOCKS")) : 8192;
+    constexpr int v = 8192;
     return v;
 }
 
@@ -1340,7 +1340,7 @@ extern "C" int hypel_reduce_splits_f32(const float* partial, int64_t stride, int
     if (n_splits >= 32 && count <= 65536)
         hipLaunchKernelGGL(reduce_splits_wave_kernel, dim3(hypel_grid_1d(count * 64, 256)), dim3(256), 0, ST, partial,
                            stride, n_splits, out, count, accumulate, bias, n, ldc);
-    else if (!(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0) && (count % 4 == 0) &&
+    else if ((count % 4 == 0) &&
              (stride % 4 == 0) && aligned16(partial) && aligned16(out) &&
              ((ldc <= 0 && (!bias || n % 4 == 0)) || (ldc > 0 && ldc % 4 == 0 && n % 4 == 0)))
         hipLaunchKernelGGL(reduce_splits_v4_kernel, dim3(hypel_grid_1d(count / 4, 256, red_max_blocks())), dim3(256), 0, ST,
@@ -1425,7 +1425,7 @@ extern "C" int hypel_reduce_splits_multi_f32(const float* base, const hypel_redu
     if (n_entries == 0) return 0;
     // blocks per entry: the big entries (FC weights: 3 M elements x 2-3 slabs) want many, the many-slab entries of the
     // 1x1 convolutions few; 768 measured best on the H13 step (192: +35 us, 1536: +8, 3072: +20; HYPEL_RED_GX)
-    static const int gx = getenv("HYPEL_RED_GX") ? atoi(getenv("HYPEL_RED_GX")) : 768;
+    constexpr int gx = 768;
     hipLaunchKernelGGL(reduce_splits_multi_kernel, dim3(gx, n_entries), dim3(256), 0, ST, base, entries);
     HYPEL_CHECK_LAUNCH("hypel_reduce_splits_multi_f32");
     return 0;
@@ -1434,7 +1434,7 @@ extern "C" int hypel_reduce_splits_multi_f32(const float* base, const hypel_redu
 static int launch_col_stats(const float* x, int64_t ld, int64_t rows, int32_t c, int32_t chunk_rows, float* partial,
                             hypel_stream_t stream) {
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
-    static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
+    constexpr bool v4_on = true;
     const bool v4 = v4_on && (c % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
     if (v4)
         hipLaunchKernelGGL(col_stats_partial_v4_kernel, dim3(n_chunks, (c + STAT_TX - 1) / STAT_TX), dim3(256), 0, ST,
@@ -1518,7 +1518,7 @@ static int launch_bwd_reduce(const float* dz, int64_t lddz, const float* y, int6
                              const float* mask, int64_t ldm, int32_t chunk_rows, float* partial,
                              hypel_stream_t stream, float* dy = nullptr, int64_t lddy = 0) {
     const int n_chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
-    static const bool v4_on = !(getenv("HYPEL_STAT_V4") && atoi(getenv("HYPEL_STAT_V4")) == 0);
+    constexpr bool v4_on = true;
     const bool v4 = v4_on && (c % 4 == 0) && (lddz % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dz & 15) == 0) &&
                     (((uintptr_t)y & 15) == 0) && (!mask || ((ldm % 4 == 0) && (((uintptr_t)mask & 15) == 0))) &&
                     (!dy || ((lddy % 4 == 0) && (((uintptr_t)dy & 15) == 0)));

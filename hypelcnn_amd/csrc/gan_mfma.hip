@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 bool hypel_gm_supported(int bands) {
     // HYPEL_GAN_MFMA_MIN: smallest band count that runs here.  Default 16: also the narrow Gulfport stacks (B = 64:
     // CycleGAN step 0.922 -> 0.887 ms, generator launches 31 -> 26 us) -- gan.hip's kernels keep B < 16 and B > 384
-    static const int min_bands = getenv("HYPEL_GAN_MFMA_MIN") ? atoi(getenv("HYPEL_GAN_MFMA_MIN")) : 16;
+    constexpr int min_bands = 16;
     return bands >= min_bands && bands >= 16 && bands <= GM_MAX_BANDS && gm_bwd_lds(bands) <= 160 * 1024;
 }
 

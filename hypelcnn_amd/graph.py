@@ -397,7 +397,7 @@ def _defaults(kwargs):
     return out
 
 
-MERGE_PATCH_MLPS = os.environ.get("HYPEL_MERGE_PATCH_MLPS", "1") != "0"
+MERGE_PATCH_MLPS = True
 _UNSET = object()
 batch_norm = "batch_norm"  # normalizer_fn marker (tf_slim.batch_norm: center=True, scale=False, eps=1e-3)
 
@@ -664,7 +664,7 @@ def _merge_patch_mlps(embeddings):
     return out, len(chains), prev_cout
 
 
-DENSE_STACK = os.environ.get("HYPEL_DENSE_STACK", "1") != "0"
+DENSE_STACK = True
 DENSE_STACK_MAX_WIDTH = 128  # hypel.h: hypel_dense_stack_supported
 
 

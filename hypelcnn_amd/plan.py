@@ -21,8 +21,8 @@ import numpy as np
 from . import graph as G
 from .backend import GEMM_BM, GROUP_DTYPE, MTILE_DTYPE, REDUCE_ENTRY_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
 
-STAT_CHUNK_ROWS = int(os.environ.get("HYPEL_STAT_CHUNK_ROWS", "256"))  # upper bound; see stat_chunk_rows()
-STAT_BLOCKS = int(os.environ.get("HYPEL_STAT_BLOCKS", "256"))            # blocks per 64-column stripe aimed at
+STAT_CHUNK_ROWS = 256  # upper bound; see stat_chunk_rows()
+STAT_BLOCKS = 256            # blocks per 64-column stripe aimed at
 
 
 def stat_chunk_rows(rows):
@@ -32,16 +32,16 @@ def stat_chunk_rows(rows):
     c = max(16, min(STAT_CHUNK_ROWS, c))
     return (c + 3) // 4 * 4
 WGRAD_ROW_CHUNK = 512
-TARGET_BLOCKS = int(os.environ.get("HYPEL_WGRAD_TARGET_BLOCKS", "1536"))  # blocks a filter-gradient product is split towards
-WGRAD_MAX_SPLITS = int(os.environ.get("HYPEL_WGRAD_MAX_SPLITS", "64"))
-WGRAD_MIN_SPLITS = int(os.environ.get("HYPEL_WGRAD_MIN_SPLITS", "0"))  # 0 = one split per 64 batch rows once a launch fills the device unsplit
-SPLIT_BIASED = os.environ.get("HYPEL_SPLIT_BIASED", "1") != "0"  # tap / channel-part splitting also for biased convs
-DGRAD_MAX_SEGS = int(os.environ.get("HYPEL_DGRAD_MAX_SEGS", "18"))  # segments per data-gradient tile (0 = never split)
-MAX_TAPS_PER_TILE = int(os.environ.get("HYPEL_MAX_TAPS", "9"))  # taps per forward tile of a multi-kernel level
-L2_CHUNK_BYTES = int(float(os.environ.get("HYPEL_L2_CHUNK_MB", "3.5")) * (1 << 20))  # X working set an XCD's L2 keeps
-FWD_HINT_R2 = os.environ.get("HYPEL_FWD_HINT_R2", "1") != "0"  # round-2 forward tile-width rule (incl. 128x96 tiles)
-SPLITK_BELOW = int(os.environ.get("HYPEL_SPLITK_BELOW", "400"))    # FC-shaped products with fewer 128x64 blocks are cut along K
-SPLITK_TARGET = int(os.environ.get("HYPEL_SPLITK_TARGET", "768"))  # ... into slices that give about this many blocks
+TARGET_BLOCKS = 1536  # blocks a filter-gradient product is split towards
+WGRAD_MAX_SPLITS = 64
+WGRAD_MIN_SPLITS = 0  # 0 = one split per 64 batch rows once a launch fills the device unsplit
+SPLIT_BIASED = True  # tap / channel-part splitting also for biased convs
+DGRAD_MAX_SEGS = 18  # segments per data-gradient tile (0 = never split)
+MAX_TAPS_PER_TILE = 9  # taps per forward tile of a multi-kernel level
+L2_CHUNK_BYTES = int(3.5 * (1 << 20))  # X working set an XCD's L2 keeps
+FWD_HINT_R2 = True  # round-2 forward tile-width rule (incl. 128x96 tiles)
+SPLITK_BELOW = 400    # FC-shaped products with fewer 128x64 blocks are cut along K
+SPLITK_TARGET = 768  # ... into slices that give about this many blocks
 TAP_SPLIT_MIN_BATCH = 64  # below this a pixel block has too few rows for splitting to pay
 
 
@@ -59,23 +59,23 @@ class Launch:
 
 
 # layers without batch norm: the bias-gradient reduction also writes dY (no separate activation-backward launch)
-ACT_BIAS_BWD = os.environ.get("HYPEL_ACT_BIAS_BWD", "1") != "0"
+ACT_BIAS_BWD = True
 # bias + leaky-ReLU of a normaliser-less fully-connected layer in the product's epilogue (HYPEL_GEMM_ACT_*): no post-op launch
-ACT_IN_GEMM = os.environ.get("HYPEL_ACT_IN_GEMM", "1") != "0"
+ACT_IN_GEMM = True
 # GAN loss terms and regularisers leave weighted partials in slots; one finaliser launch per train op sums them
-LOSS_SLOTS = os.environ.get("HYPEL_LOSS_SLOTS", "1") != "0"
-GEN_KEEP = os.environ.get("HYPEL_GEN_KEEP", "1") != "0"  # generator backward starts from the forward pass's kept activations
-TILE_HINTS = os.environ.get("HYPEL_TILE_HINTS", "1") != "0"
-SMALL_BN = os.environ.get("HYPEL_SMALL_BN", "1") != "0"
+LOSS_SLOTS = True
+GEN_KEEP = True  # generator backward starts from the forward pass's kept activations
+TILE_HINTS = True
+SMALL_BN = True
 SMALL_BN_ROWS = 1024  # hypel_bn_act_small_*: rows kept in registers (32 row lanes x 32 rows)
-FOLD_RESIDUAL_GRAD = os.environ.get("HYPEL_FOLD_RES", "1") != "0"
+FOLD_RESIDUAL_GRAD = True
 # Filter gradients have no consumer before the optimiser: instead of one launch (+ one reduce) per layer they are
 # collected and go out as ONE hypel_seg_gemm_multi_f32 per tile width (+ ONE hypel_reduce_splits_multi_f32) at the end
 # of the backward pass (and at every data-parallel sync point).  A step's twenty ~25 us launch ramps/drains become three.
-MERGE_WGRAD = os.environ.get("HYPEL_MERGE_WGRAD", "1") != "0"
+MERGE_WGRAD = True
 # Batch-norm statistics of a 1x1 convolution's output in the GEMM epilogue (hypel_seg_gemm_stats_f32) instead of a
 # separate pass over Y (hypel_col_stats_partial)
-STATS_EPILOGUE = os.environ.get("HYPEL_STATS_EPILOGUE", "1") != "0"
+STATS_EPILOGUE = True
 
 
 class Storage:
@@ -119,9 +119,9 @@ def valid_taps(h, w, k, oy, ox):
 
 
 SEG_PAIR_FLAG = 0x40000000  # include/hypel.h: HYPEL_SEG_PAIR_FLAG
-LOSS_TAIL = os.environ.get("HYPEL_LOSS_TAIL", "1") != "0"  # xent / MSE sums, non-finite flag, step counter: one finaliser
+LOSS_TAIL = True  # xent / MSE sums, non-finite flag, step counter: one finaliser
 MSE_PARTIALS = 1024  # include/hypel.h HYPEL_MSE_PARTIALS
-DP_SYNC_WORK = float(os.environ.get("HYPEL_DP_SYNC_WORK", "0.5"))  # share of the filter-gradient work before the sync point
+DP_SYNC_WORK = 0.5  # share of the filter-gradient work before the sync point
 # Gradient buckets of the data-parallel exchange: two by default (one sync point: >= 60 % of the bytes leave under the
 # second half of the backward pass).  More buckets are available for large models -- one sync point per DP_BUCKET_BYTES
 # once the weight gradients exceed DP_TWO_BUCKET_BYTES -- but every extra sync point flushes the merged filter-gradient
@@ -130,11 +130,11 @@ DP_SYNC_WORK = float(os.environ.get("HYPEL_DP_SYNC_WORK", "0.5"))  # share of th
 # of ring all-reduce.  Hence off by default (HYPEL_DP_TWO_BUCKET_MB=256 switches the byte rule on).
 DP_TWO_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_TWO_BUCKET_MB", "1048576")) * (1 << 20))
 DP_BUCKET_BYTES = int(float(os.environ.get("HYPEL_DP_BUCKET_MB", "256")) * (1 << 20))
-DP_MAX_BUCKETS = int(os.environ.get("HYPEL_DP_MAX_BUCKETS", "8"))
+DP_MAX_BUCKETS = 8
 HINT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_HINT_OVERRIDE", "").split(",") if kv)}
 RESIDENT_BLOCKS_64 = 6 * 256  # 128x64 (and multi-segment 128x32) blocks the device holds at once
 GEMM_SINGLE_SEG = 0x800  # include/hypel.h HYPEL_GEMM_SINGLE_SEG
-SINGLE_SEG_HINT = os.environ.get("HYPEL_SINGLE_SEG_HINT", "1") != "0"
+SINGLE_SEG_HINT = True
 GEMM_PAIRED_SEGS = 0x400    # ... HYPEL_GEMM_PAIRED_SEGS (bit of `accumulate`)
 GEMM_BK = 32  # reduction columns per k-tile of the kernel
 # fp32 products on the bf16 matrix cores with three-way split operands and six partial products (include/hypel.h
@@ -149,9 +149,9 @@ GEMM_SPLIT_WIDTH = int(_gs[1]) if len(_gs) > 1 else 0
 GEMM_SPLIT_MIN_FLOPS = float(os.environ.get("HYPEL_GEMM_SPLIT_MIN_GFLOP", "2")) * 1e9
 # narrow products stage a whole 128-row A tile per 32 output columns: the split costs more than the matrix rate returns
 # (H13 level 1, 30 filters per branch: 382 -> 397 us forward, 103 -> 95 TFLOP/s filter gradient; per-launch A/B, round 5)
-GEMM_SPLIT_MIN_N = int(os.environ.get("HYPEL_GEMM_SPLIT_MIN_N", "32"))
+GEMM_SPLIT_MIN_N = 32
 SPLIT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_SPLIT_OVERRIDE", "").split(",") if kv)}
-PAIR_SEGS = os.environ.get("HYPEL_PAIR_SEGS", "1") != "0"  # short data-gradient segments (k <= 16) share k-tiles
+PAIR_SEGS = True  # short data-gradient segments (k <= 16) share k-tiles
 GEMM_MFMA16X4 = 0x2000  # include/hypel.h HYPEL_GEMM_MFMA16X4: 128x64 blocks on the 16x16x4 MFMA (merged level, <= 16 filters)
 GEMM_VAR_N = 0x4000     # ... HYPEL_GEMM_VAR_N: tile records carry their group's column count
 # Merged multi-kernel levels (include/hypel.h): the nested branches of a level share one packed weight image
@@ -164,15 +164,14 @@ GEMM_VAR_N = 0x4000     # ... HYPEL_GEMM_VAR_N: tile records carry their group's
 # 2 - 7 % per launch.  The merged FILTER GRADIENT moved work between the three tile-width launches without shortening
 # their sum (1584 -> 1593 us): removed in round 5 (NOTES 4.A keeps the numbers).  Step: 6.51 -> 6.49 ms, i.e. neutral.
 MERGE_LEVELS = set(x for x in os.environ.get("HYPEL_MERGE_LEVELS", "fwd,dgrad").split(",") if x and x != "0")
-MERGE_LEVELS_MAX_COUT = int(os.environ.get("HYPEL_MERGE_LEVELS_MAX_COUT", "32"))
+MERGE_LEVELS_MAX_COUT = 32
 # per pass: widest branch (filters) the pass is merged for, taps per merged forward tile, forward tile-width hint
-MERGE_PASS_MAX_COUT = {k: int(os.environ.get(f"HYPEL_MERGE_{k.upper()}_MAX_COUT", d))
-                       for k, d in (("fwd", "16"), ("dgrad", "1048576"))}
+MERGE_PASS_MAX_COUT = {"fwd": 16, "dgrad": 1 << 20}
 # ... and for the split-operand kernels, whose cost is dominated by staging A: sharing one staged A tile between the
 # branches of a ring pays for wider branches too
-MERGE_FWD_MAX_COUT_SPLIT = int(os.environ.get("HYPEL_MERGE_FWD_MAX_COUT_SPLIT", "16"))
-MERGE_MAX_TAPS = int(os.environ.get("HYPEL_MERGE_MAX_TAPS", "0"))  # 0 = MAX_TAPS_PER_TILE
-MERGE_FWD_HINT = int(os.environ.get("HYPEL_MERGE_FWD_HINT", "2"))
+MERGE_FWD_MAX_COUT_SPLIT = 16
+MERGE_MAX_TAPS = 0  # 0 = MAX_TAPS_PER_TILE
+MERGE_FWD_HINT = 2
 
 
 class GemmTables:
@@ -1801,19 +1800,19 @@ def gen_kernel_sizes(bands):
 # Same-weight applications of one phase as ONE application on the row-concatenated batch (no GAN network has batch
 # statistics, so D([real; fake]), enc([G(x); x; y; G(y)]), G([x; y]) and the feature-discriminator layers on 4N rows are
 # exact; cut_wrapper.py:301-339): fewer, longer launches, >= 2 resident blocks per CU for the generator kernels.
-BATCH_APPS = os.environ.get("HYPEL_GAN_BATCH_APPS", "1") != "0"
-BATCH_APPS_MAX = int(os.environ.get("HYPEL_GAN_BATCH_APPS_MAX", "8"))
+BATCH_APPS = True
+BATCH_APPS_MAX = 8
 # the per-block gradient slabs of every fused generator / dense-stack application of a train op in ONE reduction launch
-SLAB_REDUCE_MULTI = os.environ.get("HYPEL_SLAB_REDUCE_MULTI", "1") != "0"
+SLAB_REDUCE_MULTI = True
 # An encoder-only generator application on a tensor that the FULL generator of the same train op (same variables) also
 # consumes is that application's n_4 (cut_wrapper.py:301-339: gen(x) and gen(x, only_encoder), gen(y) and gen(y, only_encoder)):
 # the full launch writes it too (hypel_gan_generator_fwd_tap) and its backward takes the gradient that reached it
 # (hypel_gan_generator_bwd_tap) -- the encoder-only launches of those tensors disappear.
-GEN_TAP = os.environ.get("HYPEL_GAN_GEN_TAP", "1") != "0"
+GEN_TAP = True
 # Two same-shaped networks with DIFFERENT variables (CycleGAN's G_x2y / G_y2x and D_x / D_y, cycle_gan_wrapper.py:82-124) whose
 # applications can run side by side share one launch: each takes its own share of the blocks (hypel_*_apps).  At the
 # Gulfport sizes every one of those applications is a latency chain on a fraction of the chip.
-BATCH_HETERO = os.environ.get("HYPEL_GAN_BATCH_HETERO", "1") != "0"
+BATCH_HETERO = True
 
 
 class PhasePlan(TowerPlan):
