@@ -14,7 +14,8 @@ import torch
 
 from . import graph as G
 from .backend import Ref, note_collective
-from .plan import PhasePlan, TowerPlan
+from .plan import TowerPlan
+from .plan_gan import PhasePlan
 
 
 class CompiledTower:

@@ -99,12 +99,12 @@ def _phase_launches(ops, sess, n):
 
 @pytest.mark.parametrize("kind,bands", [("cut_x2y", 24), ("cycle_gan", 16), ("dcl_gan", 16)])
 def test_same_weight_applications_run_as_one_row_concatenated_application(monkeypatch, kind, bands):
-    """Round 4 (plan.PhasePlan._schedule_units): the same-weight applications of a train op -- G([x; y]), enc on the four
+    """Round 4 (plan_gan.PhasePlan._schedule_units): the same-weight applications of a train op -- G([x; y]), enc on the four
     inputs of CUT, D([real; fake]), the feature-discriminator layers, the feature stack with per-application norms -- run
     as ONE application on the row-concatenated batch, and every per-block gradient slab of the op is summed by one launch.
     Fewer launches, same losses and gradients as the oracle; the unbatched form stays available and agrees too.
     CycleGAN's G_xy(G_yx(y)) next to G_xy(x) must NOT be grouped (the unit graph would be cyclic)."""
-    from hypelcnn_amd import plan
+    from hypelcnn_amd import plan_gan
     n = 6
     cfg = OG.GanConfig(kind, bands, patches=4 if bands == 16 else 6, max_steps=20)
     params = U.fp32(OG.init_gan_params(kind, bands, np.random.default_rng(2), patches=cfg.patches, dtype=np.float64,
@@ -112,8 +112,8 @@ def test_same_weight_applications_run_as_one_row_concatenated_application(monkey
     x, y = _data(n, bands, 4)
     counts = {}
     for batched in (True, False):
-        monkeypatch.setattr(plan, "BATCH_APPS", batched)
-        monkeypatch.setattr(plan, "SLAB_REDUCE_MULTI", batched)
+        monkeypatch.setattr(plan_gan, "BATCH_APPS", batched)
+        monkeypatch.setattr(plan_gan, "SLAB_REDUCE_MULTI", batched)
         wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
         sess = ops.ctx.session()
         U.inject(sess, params)
@@ -145,13 +145,13 @@ def test_same_weight_applications_run_as_one_row_concatenated_application(monkey
 def test_two_variable_sets_in_one_launch_can_be_switched_off(monkeypatch):
     """HYPEL_GAN_BATCH_HETERO=0: CycleGAN's generators and critics run one launch per variable set again; both forms give
     the oracle's phase gradients (the default form is covered by test_phase_gradients_match_oracle)."""
-    from hypelcnn_amd import plan
+    from hypelcnn_amd import plan_gan
     n, bands = 6, 16
     cfg = OG.GanConfig("cycle_gan", bands, patches=4, max_steps=20)
     params = U.fp32(OG.init_gan_params("cycle_gan", bands, np.random.default_rng(2), patches=4, dtype=np.float64,
                                        zero_generator=False))
     x, y = _data(n, bands, 4)
-    monkeypatch.setattr(plan, "BATCH_HETERO", False)
+    monkeypatch.setattr(plan_gan, "BATCH_HETERO", False)
     wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
     sess = ops.ctx.session()
     U.inject(sess, params)
