@@ -543,10 +543,22 @@ class PhasePlan(TowerPlan):
         def rel(ref):
             return (ref.ptr() - base.ptr()) // 4
 
+        # Two entries of one launch must not write the same output (include/hypel.h): a BN-less layer applied twice as
+        # separate units (no row-concatenated batch) leaves two chunk-sum entries for ONE bias gradient, acc = 0 then 1.
+        # Entry k of an output goes to round k; every round is its own launch, in order.
         ents, total = [], 0
+        later, seen = [], {}
         for part_ref, out_ref, stride, count, n_splits, acc in bias_entries:  # chunk sums [chunk][2][c]: plane 0 = sum(dY)
-            ents.append((rel(part_ref), rel(out_ref), stride, count, n_splits, acc))
-            total += count
+            e = (rel(part_ref), rel(out_ref), stride, count, n_splits, acc)
+            r = seen.get(e[1], 0)
+            seen[e[1]] = r + 1
+            if r == 0:
+                ents.append(e)
+                total += count
+            else:
+                while len(later) < r:
+                    later.append([])
+                later[r - 1].append(e)
         for k, st in enumerate(sets.values()):
             fid = self.__dict__.setdefault("_slab_bufs", 0)
             self._slab_bufs = fid + 1
@@ -574,6 +586,11 @@ class PhasePlan(TowerPlan):
         e_t = self.be.upload(np.array(ents, REDUCE_ENTRY_DTYPE))
         self.tables.append(e_t)
         self.bwd.append(Launch("reduce_splits_wave_multi_f32", (base, Ref(e_t), len(ents), total), tag="slab-reduce"))
+        for rnd in later:
+            e_t = self.be.upload(np.array(rnd, REDUCE_ENTRY_DTYPE))
+            self.tables.append(e_t)
+            self.bwd.append(Launch("reduce_splits_wave_multi_f32", (base, Ref(e_t), len(rnd), sum(e[3] for e in rnd)),
+                                   tag="slab-reduce"))
 
     @staticmethod
     def _rel(var0, var1):

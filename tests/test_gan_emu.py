@@ -142,6 +142,25 @@ def test_same_weight_applications_run_as_one_row_concatenated_application(monkey
         assert sum(l == "reduce_splits_wave_multi_f32" for v in counts[True].values() for l in v) == 2
 
 
+@pytest.mark.parametrize("kind,bands", [("cut_x2y", 24), ("cut_x2y", 144), ("cycle_gan", 144)])
+def test_unbatched_applications_with_the_one_launch_slab_reduction(monkeypatch, kind, bands):
+    """BATCH_APPS off, SLAB_REDUCE_MULTI on (round-4 advisor finding): a BN-less layer applied twice as separate units leaves
+    two chunk-sum entries for ONE bias gradient; they must not share a reduction launch (the emulation asserts that no two
+    entries of a launch write the same output) -- the second entry goes to a second launch, and the gradients stay the
+    oracle's."""
+    from hypelcnn_amd import plan_gan
+    monkeypatch.setattr(plan_gan, "BATCH_APPS", False)
+    monkeypatch.setattr(plan_gan, "SLAB_REDUCE_MULTI", True)
+    n = 6
+    cfg = OG.GanConfig(kind, bands, patches=6, max_steps=20)
+    params = U.fp32(OG.init_gan_params(kind, bands, np.random.default_rng(2), patches=cfg.patches, dtype=np.float64,
+                                       zero_generator=False))
+    x, y = _data(n, bands, 4)
+    wrapper, model, loss, ops = U.build(cfg, n, EmuBackend())
+    U.inject(ops.ctx.session(), params)
+    U.check_phase_gradients(cfg, ops, params, x, y, tol=5e-5)
+
+
 def test_two_variable_sets_in_one_launch_can_be_switched_off(monkeypatch):
     """HYPEL_GAN_BATCH_HETERO=0: CycleGAN's generators and critics run one launch per variable set again; both forms give
     the oracle's phase gradients (the default form is covered by test_phase_gradients_match_oracle)."""
