@@ -22,6 +22,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# fp32-equivalent peak of the split-operand kernels: six v_mfma_f32_32x32x16_bf16 per fp32 multiply-add step against the
+# dense bf16 peak of the same guide (~2.5 PFLOP/s; AMD's 5 PF headline includes 2:1 sparsity and is never used here)
+PEAK_SPLIT6_TFLOPS = 2500.0 / 6
 MAC_FWD_PER_PATCH = 78579058  # SURVEY.md Appendix B.1 (exact taps, training graph)
 
 
@@ -70,6 +73,11 @@ def measure_gemm_events(ct, sess, lr, steps):
         total_ms += sum(a.elapsed_time(b) for a, b, _ in evs)
         n_launch += len(evs)
         total_flops += sum(fl for _, _, fl in evs)
+    def is_split(l):  # include/hypel.h: HYPEL_GEMM_SPLIT6 in `accumulate` / HYPEL_GEMM_MULTI_SPLIT6 in tile_width
+        return bool(l.args[3] & 0x100) if l.name == "seg_gemm_multi_f32" else bool(l.args[14] & 0x8000)
+    gl = [l for l, _ in launches if l.name.startswith("seg_gemm")]
+    measure_gemm_events.split_flop_share = sum(l.flops for l in gl if is_split(l)) / max(1, sum(l.flops for l in gl))
+    measure_gemm_events.split_launches = sum(1 for l in gl if is_split(l))
     return total_ms, total_flops, n_launch
 
 
@@ -91,26 +99,33 @@ def _cpu_numpy_oracle(alg, nb, seconds_budget):
     return nb * n / (time.perf_counter() - t0), n
 
 
-def _cpu_torch_oracle(alg, nb, seconds_budget):
+def _cpu_torch_oracle(alg, nb, seconds_budget, workload="hypelcnn", max_steps=200):
     """oracle/torch_ref.py: the same graph as a torch-CPU (oneDNN/MKL) autograd composition + torch Adam with the
     TF1 epsilon placement folded into lr_t -- the closest stand-in for the reference's TF-CPU path."""
     from oracle import models as OM, torch_ref as TR
+    _, _, patch, chans, classes, _, _ = CLASSIFIER_WORKLOADS[workload]
     rng = np.random.default_rng(1234)
-    params = OM.hypelcnn_init_params(7, 145, 15, alg, rng, np.float32)
+    if workload == "hypelcnn":
+        params = OM.hypelcnn_init_params(patch, chans, classes, alg, rng, np.float32)
+    else:
+        params = OM.xavier_init_params(OM.dualcnn_layer_table(patch, chans, classes, alg), rng, np.float32)
     P = {k: torch.tensor(v, requires_grad=not k.endswith(("moving_mean", "moving_variance")))
          for k, v in params.items()}
     train = [v for v in P.values() if v.requires_grad]
     m = [torch.zeros_like(v) for v in train]
     vv = [torch.zeros_like(v) for v in train]
-    x = torch.tensor(rng.random((nb, 7, 7, 145), dtype=np.float32))
-    onehot = torch.tensor(np.eye(15, dtype=np.float32)[rng.integers(0, 15, nb)])
-    keep = alg["drop_out_ratio"] if "drop_out_ratio" in alg else 0.5
+    x = torch.tensor(rng.random((nb, patch, patch, chans), dtype=np.float32))
+    onehot = torch.tensor(np.eye(classes, dtype=np.float32)[rng.integers(0, classes, nb)])
     step = [0]
 
     def one():
-        out = TR.hypelcnn(P, x, 15, alg, True, masks=None)
-        logits, img = out[0], out[1]
-        loss = TR.hypelcnn_loss(logits, img, x, onehot).mean()
+        if workload == "hypelcnn":
+            out = TR.hypelcnn(P, x, classes, alg, True, masks=None)
+            loss = TR.hypelcnn_loss(out[0], out[1], x, onehot).mean()
+        else:
+            logits = TR.dualcnn(P, x, classes, alg, True, masks=None)
+            logits = logits[0] if isinstance(logits, tuple) else logits
+            loss = -(onehot * torch.log_softmax(logits, 1)).sum(1).mean()
         grads = torch.autograd.grad(loss, train)
         step[0] += 1
         t = step[0]
@@ -129,39 +144,67 @@ def _cpu_torch_oracle(alg, nb, seconds_budget):
     while True:
         one()
         n += 1
-        if time.perf_counter() - t0 > seconds_budget or n >= 200:
+        if time.perf_counter() - t0 > seconds_budget or n >= max_steps:
             break
     return nb * n / (time.perf_counter() - t0), n
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """The identical train step restated on the host cores, on a bounded sample: batch 64 (BASELINE configs[0]
-    shape) repeated for ~seconds_budget per restatement.  Two restatements are timed and the FASTER
-    one is reported: the numpy oracle (oracle/train.py) and the torch-CPU composition (oracle/torch_ref.py)."""
-    alg = json.load(open(os.path.join(ROOT, "hypelcnn_amd", "nnmodel", "modelconfigs", "alg_param_hypelcnn.json")))
-    nb = 64
-    res = {}
-    res["numpy"] = _cpu_numpy_oracle(alg, nb, seconds_budget)
-    torch_threads = None
+def _thread_sweep(fn, counts):
+    """fn() under each torch thread count: (best result, its thread count, {threads: value})."""
+    default_threads = torch.get_num_threads()
+    best, best_nt, table = (0.0, 0), None, {}
+    for nt in counts:
+        torch.set_num_threads(nt)
+        r = fn()
+        table[nt] = round(r[0], 1)
+        if r[0] > best[0]:
+            best, best_nt = r, nt
+    torch.set_num_threads(default_threads)
+    return best, best_nt, table
+
+
+def cpu_baseline(seconds_budget=12.0, workload="hypelcnn"):
+    """The identical train step restated on the host cores, on bounded samples (SURVEY 8d asks for both shapes):
+    batch 64 (BASELINE configs[0], the reference's own CPU-runnable case) and the benchmark's batch (configs[1]: 1024).
+    Restatements: the numpy oracle (oracle/train.py, batch 64 only) and the torch-CPU composition (oracle/torch_ref.py)
+    under a sweep of thread counts up to the host's logical cores; the FASTEST figure is `value`, `cores` the threads
+    that produced it.  DUALCNN: the torch-CPU composition at batch 16."""
+    cfg = CLASSIFIER_WORKLOADS[workload][1]
+    alg = json.load(open(os.path.join(ROOT, "hypelcnn_amd", "nnmodel", "modelconfigs", cfg)))
+    cores = os.cpu_count() or 8
+    counts = sorted({min(16, cores), min(64, cores), cores})
+    if workload == "dualcnn":
+        try:
+            best, nt, table = _thread_sweep(lambda: _cpu_torch_oracle(alg, 16, seconds_budget / len(counts), "dualcnn", 50), counts)
+        except Exception as e:
+            print(f"bench.py: torch-CPU baseline failed: {e!r}", file=sys.stderr)
+            return None
+        return {"value": best[0], "unit": "patches/s", "cores": nt, "kind": "port",
+                "sample": f"{best[1]} train steps of batch 16 (11x11x49, fp32) with the torch-CPU (oneDNN) composition of the "
+                          f"reference graph (oracle/torch_ref.py); thread sweep {table} patches/s; host has {cores} logical "
+                          f"cores; not a TensorFlow number"}
+    res = {"numpy": _cpu_numpy_oracle(alg, 64, seconds_budget / 2)}
+    torch_threads, t64, t1024, nt1024 = None, {}, {}, None
+    b1024 = (0.0, 0)
     try:
-        # small 7x7 convolutions do not scale to hundreds of threads: time a few pool sizes, keep the fastest
-        res["torch_cpu"] = (0.0, 0)
-        default_threads = torch.get_num_threads()
-        for nt in sorted({min(16, default_threads), min(64, default_threads)}):
-            torch.set_num_threads(nt)
-            r = _cpu_torch_oracle(alg, nb, seconds_budget / 2)
-            if r[0] > res["torch_cpu"][0]:
-                res["torch_cpu"], torch_threads = r, nt
-        torch.set_num_threads(default_threads)
+        res["torch_cpu"], torch_threads, t64 = _thread_sweep(
+            lambda: _cpu_torch_oracle(alg, 64, seconds_budget / (2 * len(counts))), counts)
+        b1024, nt1024, t1024 = _thread_sweep(lambda: _cpu_torch_oracle(alg, 1024, seconds_budget / len(counts), max_steps=8), counts)
     except Exception as e:  # the torch leg is optional evidence; never fail the bench line on it
         print(f"bench.py: torch-CPU baseline failed: {e!r}", file=sys.stderr)
+        res.setdefault("torch_cpu", (0.0, 0))
     best = max(res, key=lambda k: res[k][0])
-    return {"value": res[best][0], "unit": "patches/s", "cores": torch_threads if best == "torch_cpu"
-            else os.cpu_count(), "kind": "port",
-            "sample": f"{res[best][1]} train steps of batch 64 (7x7x145, fp32) with the {best} restatement of the "
-                      f"reference graph; numpy/OpenBLAS oracle {res['numpy'][0]:.1f} patches/s, torch-CPU (oneDNN) "
-                      f"composition {res['torch_cpu'][0]:.1f} patches/s; host has {os.cpu_count()} logical cores; "
-                      f"not a TensorFlow number"}
+    value, used = res[best][0], (torch_threads if best == "torch_cpu" else cores)
+    shape = "batch 64"
+    if b1024[0] > value:
+        value, used, shape, best = b1024[0], nt1024, "batch 1024", "torch_cpu"
+    return {"value": value, "unit": "patches/s", "cores": used, "kind": "port",
+            "batch_64": {"numpy_oracle": round(res["numpy"][0], 1), "torch_cpu_by_threads": t64},
+            "batch_1024": {"torch_cpu_by_threads": t1024},
+            "sample": f"fastest of: {res['numpy'][1]} train steps of batch 64 (7x7x145, fp32) with the numpy/OpenBLAS oracle; "
+                      f"the torch-CPU (oneDNN) composition at batch 64 and at batch 1024 (<= 8 steps) under "
+                      f"{counts} threads -- reported: {best} at {shape} with {used} threads; host has {cores} logical "
+                      f"cores; not a TensorFlow number"}
 
 
 def baseline_metric():
@@ -287,7 +330,7 @@ def gan_cpu_baseline(kind, bands, seconds_budget=12.0):
                       f"logical cores); not a TensorFlow number"}
 
 
-TRAFFIC_SUMMARIES = ("r4_hbm_traffic.json", "r4_hbm_traffic_dualcnn.json", "r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
+TRAFFIC_SUMMARIES = ("r5_hbm_traffic.json", "r5_hbm_traffic_dualcnn.json", "r4_hbm_traffic.json", "r4_hbm_traffic_dualcnn.json", "r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
 
 
 def pmc_traffic(workload, nb, launches_per_step):
@@ -315,7 +358,7 @@ def pmc_mfma_busy(workload):
     (tools/pmc_sq_per_launch.py: SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; its own rocprofv3 run).  Returns
     ({"busy": ..., "useful": ...} or None, source label)."""
     import re
-    name = f"r4_mfma_busy_per_launch_{workload}.txt"
+    name = f"r5_mfma_busy_per_launch_{workload}.txt"
     try:
         last = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     except OSError:
@@ -555,9 +598,23 @@ def main():
         ms, flops, n_launch = measure_gemm_events(ct, sess, lr, ev_steps)
         achieved = flops / (ms * 1e-3) / 1e12
         traffic, traffic_source = pmc_traffic(args.workload, nb, n_launch // ev_steps)
-        roof = {"bound": "mfma", "kernel": "hypel_seg_gemm_f32 / hypel_seg_gemm_multi_f32 (fp32 MFMA: v_mfma_f32_32x32x2, "
-                                           "16x16x4 for n <= 16)", "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+        share = measure_gemm_events.split_flop_share
+        split_on = share > 0
+        # The launches of a step run on two matrix pipes: the split-operand kernels (six bf16 MFMAs per fp32 step) and, for
+        # narrow / small / n <= 16 products, the fp32 MFMA kernels.  `peak` is the peak of the kernels that do the bulk of the
+        # FLOP (the split kernels' fp32-equivalent 2.5 PF / 6 when they are on); `frac_vs_fp32_mfma` prices the same
+        # achieved rate against the fp32 matrix peak, the yardstick of rounds 1-4.
+        peak = PEAK_SPLIT6_TFLOPS if split_on else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma",
+                "kernel": ("hypel_seg_gemm_f32 / hypel_seg_gemm_multi_f32 with HYPEL_GEMM_SPLIT6 (3 x bf16 split operands, "
+                           "six v_mfma_f32_32x32x16_bf16 per step, fp32 accumulate) for %.0f %% of the FLOP; the rest on the "
+                           "fp32 MFMA kernels (v_mfma_f32_32x32x2, 16x16x4 for n <= 16)" % (100 * share)) if split_on else
+                          "hypel_seg_gemm_f32 / hypel_seg_gemm_multi_f32 (fp32 MFMA: v_mfma_f32_32x32x2, 16x16x4 for n <= 16)",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "peak_note": "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products" if split_on
+                             else "fp32 MFMA peak",
+                "frac_vs_fp32_mfma": achieved / PEAK_F32_MFMA_TFLOPS, "peak_fp32_mfma": PEAK_F32_MFMA_TFLOPS,
+                "split6_flop_share": share, "split6_launches_per_step": measure_gemm_events.split_launches,
                 "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": n_launch // ev_steps,
                 "avg_launch_us": ms * 1e3 / n_launch,
                 "gemm_ms_per_step": ms / ev_steps,
@@ -565,10 +622,11 @@ def main():
                 "algorithmic_bytes_per_launch": measure_gemm_events.bytes_per_launch,
                 "kernel_launches_per_step": len(ct.serial_launches()) + 1}  # every launch of the step + the optimiser
         busy, busy_source = pmc_mfma_busy(args.workload)
-        if busy is not None:  # share of SIMD-cycles with the matrix pipe executing / executing exact-tap work (PMC)
-            roof["mfma_busy_pmc"], roof["mfma_useful_pmc"], roof["mfma_busy_source"] = busy["busy"], busy["useful"], busy_source
-        if world == 1 and not args.no_cpu_baseline and args.workload == "hypelcnn":
-            cpu = cpu_baseline()
+        if busy is not None:
+            # NOT measured by this run: the matrix-pipe busy share of the committed SQ-counter pass of the same command
+            roof["committed_profiles"] = {"mfma_busy_pmc": busy["busy"], "mfma_useful_pmc": busy["useful"], "source": busy_source}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(workload=args.workload)
     if rank == 0 and not classifier:
         step_ms_mean = dt / args.steps * 1e3
         gen_ms, gen_flops, n_gen, n_launch = measure_gan_events(gan_ops, nb, bands, max(2, min(5, args.steps)))
@@ -591,13 +649,15 @@ def main():
             # cfg4 (B = 64): 12 k multiply-adds per sample and generator pass -- neither HBM nor the matrix cores bound
             # the step, its kernel boundaries do.  HBM line for the record (algorithmic bytes: x and y read once,
             # SURVEY 8d), and the launch floor = launches x the guide's per-boundary cost against the measured step.
+            # the step is a chain of dependent launches: the bound that means something is the sum of the per-launch floors
+            # (guide: 1.45-1.9 us per dependent kernel boundary), not HBM (x and y once = 1 MB against 8 TB/s: 0.06 %)
             alg_bytes = 2 * 4 * bands * nb
-            achieved = alg_bytes / (dt / args.steps) / 1e9
-            roof = {"bound": "hbm", "kernel": "gan phases (fused generator / discriminator GEMMs / losses)",
-                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                    "note": "launch-latency bound: whole-step rate, not a single kernel; see launch_floor",
+            roof = {"bound": "launch-latency chain", "kernel": "gan phases (fused generator / dense-stack / loss launches)",
+                    "achieved": launch_floor_ms, "peak": step_ms_mean, "unit": "ms (sum of per-launch floors vs measured step)",
+                    "frac": launch_floor_ms / step_ms_mean, "traffic": None,
+                    "note": "frac = launches x boundary cost / step: what share of the step the dependent-launch floor explains",
                     "launches_per_step": n_launch, "boundary_us": boundary_us, "launch_floor_ms": launch_floor_ms,
-                    "launch_floor_frac": launch_floor_ms / step_ms_mean,
+                    "hbm_gbps_for_the_record": alg_bytes / (dt / args.steps) / 1e9,
                     "generator_launches_per_step": n_gen, "generator_ms_per_step": gen_ms}
         if world == 1 and not args.no_cpu_baseline:
             cpu = gan_cpu_baseline(kind, bands)
@@ -625,6 +685,7 @@ def main():
                 cfg_d["batch_norm"] = "synchronised (global batch)" if args.sync_bn else "per rank"
             if mac:
                 cfg_d["mfma_ceiling_patches_per_s_per_gpu"] = PEAK_F32_MFMA_TFLOPS * 1e12 / (6 * mac)
+                cfg_d["split6_ceiling_patches_per_s_per_gpu"] = PEAK_SPLIT6_TFLOPS * 1e12 / (6 * mac)
             unit = "patches/s"
         else:
             metric = f"spectral pairs/sec, full {kind} train step (all sequential train ops + Adam)"
@@ -639,7 +700,9 @@ def main():
                "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": median_ms,
                "ms_per_step_p10_p90": [step_ms[len(step_ms) // 10], step_ms[(9 * len(step_ms)) // 10]],
                "prewarm_steps": n_prewarm, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic", "config": cfg_d, "roofline": roof, "cpu_baseline": cpu}
+               "dtype": ("f32 (3 x bf16 split operands, 6 partial products, fp32 accumulate)"
+                         if classifier and roof and roof.get("split6_flop_share") else "f32"),
+               "data": "synthetic", "config": cfg_d, "roofline": roof, "cpu_baseline": cpu}
         if pipeline is not None:
             out["with_input_pipeline"] = pipeline
         out["commit"], note = commit_label()

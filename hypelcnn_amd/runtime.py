@@ -30,10 +30,8 @@ class CompiledTower:
         self.sync_points = list(getattr(plan, "sync_points", []))
 
     def serial_launches(self):
-        """The same step with every launch on the main stream (no fork/join): per-kernel timing needs kernels that
-        do not overlap."""
-        return [(l, self.be.bind(l.name, l.args, 0)) for l in self.plan.fwd + self.plan.bwd
-                if not l.name.startswith("_")]
+        """Every launch of the step, bound one by one (eager replay for per-kernel timing)."""
+        return [(l, self.be.bind(l.name, l.args, 0)) for l in self.plan.fwd + self.plan.bwd]
 
     # ---- inputs / outputs ----
     def input(self, name):
@@ -50,7 +48,10 @@ class CompiledTower:
         while len(items) >= 2:
             (n0, t0), (n1, t1) = items[0], items[1]
             d0, d1 = self.plan.buffers["in:" + n0], self.plan.buffers["in:" + n1]
-            ok = all(t.dtype == d.dtype == torch.float32 and t.device == d.device and t.is_contiguous() and
+            def same_dev(a, b):  # torch.device("cuda") != torch.device("cuda:0"): compare type and resolved index
+                return a.type == b.type and (a.index if a.index is not None else torch.cuda.current_device() if a.type == "cuda" else 0) == \
+                    (b.index if b.index is not None else torch.cuda.current_device() if b.type == "cuda" else 0)
+            ok = all(t.dtype == d.dtype == torch.float32 and same_dev(t.device, d.device) and t.is_contiguous() and
                      t.numel() == d.numel() for t, d in ((t0, d0), (t1, d1)))
             if not ok:
                 break
