@@ -369,12 +369,16 @@ class TowerPlan:
         rem = n % 128
         return 2 if n <= 64 or 0 < rem <= 64 and n < 256 else 3
 
-    def _split6(self, tag, tables, n, ta, tb, flags, paired):
-        """0 = fp32 MFMA kernel, else the tile-width hint of the split-operand kernel for this launch."""
+    def _split6(self, tag, tables, n, ta, tb, flags, paired, in_multi=False):
+        """0 = fp32 MFMA kernel, else the tile-width hint of the split-operand kernel for this launch.  in_multi: a product
+        of the merged filter-gradient launch -- it shares its launch with the other products of its width class, so its
+        own size does not matter (left on the fp32 kernels, the few small ones formed a 102 us launch of 4.4 GFLOP)."""
         if tag in SPLIT_OVERRIDE:
             return SPLIT_OVERRIDE[tag]
         if GEMM_SPLIT != 6 or n <= GEMM_SPLIT_MIN_N or (ta and tb) or (flags & ~GEMM_VAR_N) or paired:
             return 0
+        if in_multi:
+            return self._split6_width(n)
         macs = sum(rows * sum(k for _, _, k in gs) * tables.n_of(gi, n) for gi, (_, gs, rows) in enumerate(tables.groups))
         if 2 * macs < GEMM_SPLIT_MIN_FLOPS:
             return 0
@@ -1474,7 +1478,7 @@ class TowerPlan:
                 flags = e["acc"]
             a0, b0 = rel(e["a_ref"]), rel(e["b_ref"])
             tb = e["tb"]
-            sp6 = self._split6(e["tag"], tb, n, 1, 0, 0, False)
+            sp6 = self._split6(e["tag"], tb, n, 1, 0, 0, False, in_multi=True)
             first_width = None
             loc_groups = {}  # (width, locality key) -> [work, [(work, record)]]
             for gi, (c_off, gs, rows) in enumerate(tb.groups):

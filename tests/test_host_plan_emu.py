@@ -226,7 +226,7 @@ def test_filter_gradients_go_out_as_merged_launches(monkeypatch):
     ct = U.run_train_step(built, x, onehot, masks)
     names = [l.name for l in ct.plan.bwd]
     n_multi = names.count("seg_gemm_multi_f32")
-    assert 1 <= n_multi <= 3 and names.count("reduce_splits_multi_f32") == 1
+    assert 1 <= n_multi <= 4 and names.count("reduce_splits_multi_f32") == 1  # (split 128 / 64, fp32 32 / 16)
     assert not any(l.tag.startswith("wgrad:") for l in ct.plan.bwd), "a filter gradient was launched on its own"
     merged = [l for l in ct.plan.bwd if l.name == "seg_gemm_multi_f32"]
     n_layers = sum(1 for n in built.train_tower.nodes if hasattr(n, "branches"))
