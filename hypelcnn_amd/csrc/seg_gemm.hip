@@ -568,103 +568,91 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             have = ls < s_end;
             nseg = segs[min(ls + 1, s_end - 1)];
         };
-        // The split of a k-tile is scheduled PAIR by pair (two k-adjacent elements -> one word per plane): a thread's share of
-        // a tile is SP_PA pairs of A and SP_PB of B; pair p lives in chunk p / (pairs per chunk) (a quad of a k-contiguous
-        // operand = 2 pairs, a KR-run of a k-strided one = KR / 2), and a chunk's three plane words go to LDS buffer `buf`
-        // (plane q of element (x, k) at q * PLANE + x * 48 + 2 k bytes) as soon as its last pair is split.
-        constexpr int SP_CPA = !TA ? 2 : SA_KR / 2, SP_CPB = TB ? 2 : SB_KR / 2;  // pairs per chunk
-        constexpr int SP_PA = (!TA ? SA_N : SA_U) * SP_CPA, SP_PB = (TB ? SB_N : SB_U) * SP_CPB;
-        constexpr int SP_NP = SP_PA + SP_PB;
-        // a chunk leaves for LDS in granules of at most two pairs (8 bytes per plane): no more than two pairs' packed words
-        // are ever live (slots P & 1)
-        unsigned wh[2], wm_[2], wl[2];
-        auto pair_in = [&](const Raw& r, auto p_c, auto ragged_c, float& x0, float& x1) {
-            constexpr int P = decltype(p_c)::value;
-            constexpr bool RAGGED = decltype(ragged_c)::value;
-            constexpr bool IS_A = P < SP_PA;
-            constexpr int Q = IS_A ? P : P - SP_PA;
-            constexpr bool QUAD = IS_A ? !TA : TB;
-            if constexpr (QUAD) {
-                const f32x4& v = IS_A ? r.qa[Q / 2] : r.qb[Q / 2];
-                x0 = v[2 * (Q % 2)];
-                x1 = v[2 * (Q % 2) + 1];
-                if constexpr (RAGGED) {  // the tile ends inside a quad: what follows its end are the row's next columns
-                    const int k0 = (tid % SP_QPR) * 4 + 2 * (Q % 2);
-                    x0 = k0 < r.kv ? x0 : 0.0f;
-                    x1 = k0 + 1 < r.kv ? x1 : 0.0f;
-                }
+        // chunk c of an operand's raw registers (a quad of a k-contiguous operand, a KR-run of a k-strided one) -> split
+        // -> the three planes of LDS buffer `buf`: plane p of element (x, k) at p * PLANE + x * 80 + 2 k bytes
+        constexpr int SP_NCA = !TA ? SA_N : SA_U, SP_NCB = TB ? SB_N : SB_U;
+        auto chunk_q = [&](f32x4 v, int kv, float* img, int plane, int i, auto rows_c) {
+            constexpr int ROWS = decltype(rows_c)::value;
+            if (ROWS < SP_RP && tid / SP_QPR >= ROWS) return;  // (an operand with fewer rows than one pass of the block covers)
+            if (kv & 3) {  // the tile ends inside a quad: the elements behind its end are the row's next columns, not zeros
+                asm volatile("" ::: "memory");  // (keeps this a rare uniform branch: if-converted it is 4 selects per quad)
+                const int q4 = (tid % SP_QPR) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = q4 + e < kv ? v[e] : 0.0f;
+            }
+            const unsigned h0 = hypel_cvt_pk_bf16(v[0], v[1]), h1 = hypel_cvt_pk_bf16(v[2], v[3]);
+            float r0 = v[0] - __builtin_bit_cast(float, h0 << 16), r1 = v[1] - __builtin_bit_cast(float, h0 & 0xffff0000u);
+            float r2 = v[2] - __builtin_bit_cast(float, h1 << 16), r3 = v[3] - __builtin_bit_cast(float, h1 & 0xffff0000u);
+            const unsigned m0_ = hypel_cvt_pk_bf16(r0, r1), m1_ = hypel_cvt_pk_bf16(r2, r3);
+            r0 -= __builtin_bit_cast(float, m0_ << 16);
+            r1 -= __builtin_bit_cast(float, m0_ & 0xffff0000u);
+            r2 -= __builtin_bit_cast(float, m1_ << 16);
+            r3 -= __builtin_bit_cast(float, m1_ & 0xffff0000u);
+            float* o = img + (tid / SP_QPR + SP_RP * i) * SP_PITCH + 2 * (tid % SP_QPR);
+            *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(o + plane) = u32x2{m0_, m1_};
+            *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{hypel_cvt_pk_bf16(r0, r1), hypel_cvt_pk_bf16(r2, r3)};
+        };
+        auto chunk_s = [&](const auto& v, float* img, int plane, int u, auto xw_c, auto kr_c, auto u_c) {
+            constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
+            int x, kg;
+            if constexpr (XW >= 64) {
+                const int unit = wave * U + u;
+                x = (unit % (XW / 64)) * 64 + lane;
+                kg = unit / (XW / 64);
             } else {
-                constexpr int CP = IS_A ? SP_CPA : SP_CPB;
-                if constexpr (IS_A) { x0 = r.sa[Q / CP][2 * (Q % CP)]; x1 = r.sa[Q / CP][2 * (Q % CP) + 1]; }
-                else { x0 = r.sb[Q / CP][2 * (Q % CP)]; x1 = r.sb[Q / CP][2 * (Q % CP) + 1]; }
+                x = tid & 31;
+                kg = tid >> 5;
+            }
+            unsigned h[KR / 2], m[KR / 2], l[KR / 2];
+#pragma unroll
+            for (int e = 0; e < KR / 2; ++e) {
+                h[e] = hypel_cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+                float r0 = v[2 * e] - __builtin_bit_cast(float, h[e] << 16);
+                float r1 = v[2 * e + 1] - __builtin_bit_cast(float, h[e] & 0xffff0000u);
+                m[e] = hypel_cvt_pk_bf16(r0, r1);
+                r0 -= __builtin_bit_cast(float, m[e] << 16);
+                r1 -= __builtin_bit_cast(float, m[e] & 0xffff0000u);
+                l[e] = hypel_cvt_pk_bf16(r0, r1);
+            }
+            if constexpr (KR == 8) {
+                float* o = img + x * SP_PITCH + 4 * kg;
+                *reinterpret_cast<u32x4*>(o) = u32x4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<u32x4*>(o + plane) = u32x4{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<u32x4*>(o + 2 * plane) = u32x4{l[0], l[1], l[2], l[3]};
+            } else if constexpr (KR == 2) {
+                unsigned* o = reinterpret_cast<unsigned*>(img + x * SP_PITCH + kg);
+                o[0] = h[0];
+                o[plane] = m[0];
+                o[2 * plane] = l[0];
+            } else {
+                float* o = img + x * SP_PITCH + 2 * kg;
+                *reinterpret_cast<u32x2*>(o) = u32x2{h[0], h[1]};
+                *reinterpret_cast<u32x2*>(o + plane) = u32x2{m[0], m[1]};
+                *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l[0], l[1]};
             }
         };
-        auto store_granule = [&](auto p_last_c, int buf) {  // pairs P - 1, P (or P alone) of their chunk -> LDS
-            constexpr int P = decltype(p_last_c)::value;
-            constexpr bool IS_A = P < SP_PA;
-            constexpr int Q = IS_A ? P : P - SP_PA;
-            constexpr bool QUAD = IS_A ? !TA : TB;
-            constexpr int CP = IS_A ? SP_CPA : SP_CPB, ROWS = IS_A ? BM : BN, plane = IS_A ? SP_PLANE_A : SP_PLANE_B;
-            constexpr int C = Q / CP, QC = Q % CP;  // chunk index, position of pair P inside it
-            float* img = (IS_A ? As : Bs) + buf * SP_BUF;
-            if constexpr (QUAD) {
-                if (ROWS < SP_RP && tid / SP_QPR >= ROWS) return;  // (an operand with fewer rows than one pass covers)
-                float* o = img + (tid / SP_QPR + SP_RP * C) * SP_PITCH + 2 * (tid % SP_QPR);
-                *reinterpret_cast<u32x2*>(o) = u32x2{wh[0], wh[1]};
-                *reinterpret_cast<u32x2*>(o + plane) = u32x2{wm_[0], wm_[1]};
-                *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{wl[0], wl[1]};
-            } else {
-                constexpr int XW = ROWS, KR = 2 * CP, U = IS_A ? SA_U : SB_U;
-                int x, kg;
-                if constexpr (XW >= 64) {
-                    const int unit = wave * U + C;
-                    x = (unit % (XW / 64)) * 64 + lane;
-                    kg = unit / (XW / 64);
-                } else {
-                    x = tid & 31;
-                    kg = tid >> 5;
-                }
-                if constexpr (CP >= 2) {  // words of k = KR kg + 2 (QC - 1) .. + 3
-                    float* o = img + x * SP_PITCH + (KR / 2) * kg + (QC - 1);
-                    *reinterpret_cast<u32x2*>(o) = u32x2{wh[0], wh[1]};
-                    *reinterpret_cast<u32x2*>(o + plane) = u32x2{wm_[0], wm_[1]};
-                    *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{wl[0], wl[1]};
-                } else {
-                    unsigned* o = reinterpret_cast<unsigned*>(img + x * SP_PITCH + kg);
-                    o[0] = wh[0];
-                    o[plane] = wm_[0];
-                    o[2 * plane] = wl[0];
-                }
-            }
+        auto chunk_a = [&](const Raw& r, int c, int buf) {
+            if constexpr (!TA) chunk_q(r.qa[c], r.kv, As + buf * SP_BUF, SP_PLANE_A, c, std::integral_constant<int, BM>{});
+            else chunk_s(r.sa[c], As + buf * SP_BUF, SP_PLANE_A, c, std::integral_constant<int, BM>{},
+                         std::integral_constant<int, SA_KR>{}, std::integral_constant<int, SA_U>{});
         };
-        auto split_pairs = [&](const Raw& r, auto lo_c, auto hi_c, auto ragged_c, int buf) {  // pairs [LO, HI) of r
-            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-            hypel_for_range<LO>([&](auto p_c) {
-                constexpr int P = decltype(p_c)::value;
-                float x0, x1;
-                pair_in(r, p_c, ragged_c, x0, x1);
-                constexpr int CP = P < SP_PA ? SP_CPA : SP_CPB, Q = P < SP_PA ? P : P - SP_PA;
-                constexpr int S = CP >= 2 ? (Q % CP) & 1 : 0;  // slot of this pair's words
-                wh[S] = hypel_cvt_pk_bf16(x0, x1);
-                float r0 = x0 - __builtin_bit_cast(float, wh[S] << 16), r1 = x1 - __builtin_bit_cast(float, wh[S] & 0xffff0000u);
-                wm_[S] = hypel_cvt_pk_bf16(r0, r1);
-                r0 -= __builtin_bit_cast(float, wm_[S] << 16);
-                r1 -= __builtin_bit_cast(float, wm_[S] & 0xffff0000u);
-                wl[S] = hypel_cvt_pk_bf16(r0, r1);
-                if constexpr (CP < 2 || S == 1) store_granule(p_c, buf);
-            }, std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{});
+        auto chunk_b = [&](const Raw& r, int c, int buf) {
+            if constexpr (TB) chunk_q(r.qb[c], r.kv, Bs + buf * SP_BUF, SP_PLANE_B, c, std::integral_constant<int, BN>{});
+            else chunk_s(r.sb[c], Bs + buf * SP_BUF, SP_PLANE_B, c, std::integral_constant<int, BN>{},
+                         std::integral_constant<int, SB_KR>{}, std::integral_constant<int, SB_U>{});
         };
         // One 32x32x16 step per k-tile: lane half h supplies k = 8 h .. 8 h + 7 of its row (column) from each plane with one
-        // ds_read_b128; six products per accumulator tile, smallest first.  WITH: the pairs of the next tile (raw set
-        // P + 1) are split and stored in between, spread over the first five groups of MFMAs (the sixth covers the tail of
-        // the last pair's latency chain).
+        // ds_read_b128; six products per accumulator tile, smallest first.  WITH: the chunks of the next tile (raw set
+        // P + 1) are split and stored in between, spread over the six groups of MFMAs
         const int sa_rd = (wm * TM * 32 + l31) * SP_PITCH + 4 * lhi;
         const int sb_rd = (wn * TN * 32 + l31) * SP_PITCH + 4 * lhi;
-        auto phase = [&](auto p_c, auto with_c, auto mfma_c, auto ragged_c) {
+        auto phase = [&](auto p_c, auto with_c, auto mfma_c) {
             constexpr int P = decltype(p_c)::value, CUR = P & 1;
             constexpr bool WITH = decltype(with_c)::value, MF = decltype(mfma_c)::value;
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int NC = SP_NCA + SP_NCB;
             const Raw& rs = raw_of(std::integral_constant<int, P + 1>{});
             bf16x8 a[TM][3], b[TN][3];
             if constexpr (MF) {
@@ -689,33 +677,26 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[Gi]], b[j][PB[Gi]], acc[i][j], 0, 0, 0);
                 }
-                if constexpr (WITH && Gi < 5)
-                    split_pairs(rs, std::integral_constant<int, Gi * SP_NP / 5>{}, std::integral_constant<int, (Gi + 1) * SP_NP / 5>{},
-                                ragged_c, CUR ^ 1);
+                if constexpr (WITH) {
+#pragma unroll
+                    for (int c = Gi * NC / 6; c < (Gi + 1) * NC / 6; ++c) {
+                        if (c < SP_NCA) chunk_a(rs, c, CUR ^ 1);
+                        else chunk_b(rs, c - SP_NCA, CUR ^ 1);
+                    }
+                }
             }, std::make_integer_sequence<int, 6>{});
         };
         // pipeline stage P (= t mod 4) of a tile that HAS a successor: fetch tile t + 4 into the set tile t left, run the
         // phase, one barrier (tile t is done with, tile t + 1 is complete in the other buffer)
         auto stage_of = [&](auto p_c) {
             constexpr int P = decltype(p_c)::value;
-            const bool ragged = ((!TA || TB) && (raw_of(std::integral_constant<int, P + 1>{}).kv & 3)) != 0;
             fetch(raw_of(std::integral_constant<int, P>{}));
-            if (ragged) {
-                // rare (the last k-tile of a segment whose k is not a multiple of 4): split with the column masks first,
-                // then the plain phase -- as a variant of the overlapped phase it cost every launch 50 - 60 spilled registers
-                split_pairs(raw_of(std::integral_constant<int, P + 1>{}), std::integral_constant<int, 0>{},
-                            std::integral_constant<int, SP_NP>{}, std::true_type{}, (P & 1) ^ 1);
-                if (any_act) {
-                    __builtin_amdgcn_s_setprio(1);
-                    phase(p_c, std::false_type{}, std::true_type{}, std::false_type{});
-                    __builtin_amdgcn_s_setprio(0);
-                }
-            } else if (any_act) {
+            if (any_act) {
                 __builtin_amdgcn_s_setprio(1);
-                phase(p_c, std::true_type{}, std::true_type{}, std::false_type{});
+                phase(p_c, std::true_type{}, std::true_type{});
                 __builtin_amdgcn_s_setprio(0);
             } else {
-                phase(p_c, std::true_type{}, std::false_type{}, std::false_type{});
+                phase(p_c, std::true_type{}, std::false_type{});
             }
             __syncthreads();
         };
@@ -724,7 +705,10 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             fetch(raw1);
             fetch(raw2);
             fetch(raw3);
-            split_pairs(raw0, std::integral_constant<int, 0>{}, std::integral_constant<int, SP_NP>{}, std::true_type{}, 0);
+#pragma unroll
+            for (int c = 0; c < SP_NCA; ++c) chunk_a(raw0, c, 0);
+#pragma unroll
+            for (int c = 0; c < SP_NCB; ++c) chunk_b(raw0, c, 0);
             __syncthreads();
             int t = 0;
             while (true) {
@@ -740,8 +724,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             }
             if (any_act) {  // the last tile: nothing left to split
                 __builtin_amdgcn_s_setprio(1);
-                if (t & 1) phase(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{}, std::false_type{});
-                else phase(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, std::false_type{});
+                if (t & 1) phase(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
+                else phase(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
                 __builtin_amdgcn_s_setprio(0);
             }
         }
