@@ -161,6 +161,14 @@ MERGE_MAX_TAPS = 0  # 0 = MAX_TAPS_PER_TILE
 MERGE_FWD_HINT = 2
 
 
+# Same-box A/B of the planner's constants without editing the file: HYPEL_PLAN_SET="GEMM_SPLIT_MIN_N=64,TARGET_BLOCKS=768"
+# (integers / floats; names must exist in this module).  Not read by any test or benchmark default.
+for _kv in filter(None, os.environ.get("HYPEL_PLAN_SET", "").split(",")):
+    _k, _v = _kv.split("=")
+    assert _k in globals(), _k
+    globals()[_k] = type(globals()[_k])(float(_v)) if not isinstance(globals()[_k], bool) else bool(int(_v))
+
+
 class TowerPlan:
     """Buffers + launch lists of one tower at one batch size."""
 
