@@ -43,21 +43,17 @@ __device__ __forceinline__ unsigned hypel_cvt_pk_bf16(float a, float b) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// two floats -> their (hi, mid, lo) bf16 parts, element 0 in the low half of each word: 11 VALU operations per pair.
-// Measured and dropped (round-5 notes): the residual as one v_dot2c_f32_bf16 per element with the constants (-1, 0) /
-// (0, -1) -- 7 operations per pair, but the instruction runs below the full VALU rate on gfx950 (171 vs 160 us on the
-// M = 50 176, K = n = 480 product) and does not return the exact residual; as one v_pk_add_f32 per pair -- hipcc pays
-// for the register pairing with more moves than it saves.
-__device__ __forceinline__ void hypel_residual2(float& x0, float& x1, unsigned part) {
-    x0 -= __builtin_bit_cast(float, part << 16);
-    x1 -= __builtin_bit_cast(float, part & 0xffff0000u);
-}
+// two floats -> their (hi, mid, lo) bf16 parts, element 0 in the low half of each word
 __device__ __forceinline__ void hypel_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = hypel_cvt_pk_bf16(x0, x1);
-    hypel_residual2(x0, x1, h);
-    m = hypel_cvt_pk_bf16(x0, x1);
-    hypel_residual2(x0, x1, m);
-    l = hypel_cvt_pk_bf16(x0, x1);
+    bf16x2 p = {(__bf16)x0, (__bf16)x1};
+    h = __builtin_bit_cast(unsigned, p);
+    float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    p = bf16x2{(__bf16)r0, (__bf16)r1};
+    m = __builtin_bit_cast(unsigned, p);
+    r0 -= __builtin_bit_cast(float, m << 16);
+    r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+    p = bf16x2{(__bf16)r0, (__bf16)r1};
+    l = __builtin_bit_cast(unsigned, p);
 }
 
 namespace {
@@ -423,9 +419,11 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     // Operand with its reduction dimension contiguous: [rows][16 k] as 16-byte quads (dword-aligned addresses suffice for
     // buffer_load_dwordx4; each dword is range-checked on its own).  A k-tile that ends inside a quad (segment k not a
     // multiple of 4) reads the row's next columns with it: split_quad() masks them.
-    [[maybe_unused]] auto stage_q = [&](const float* base, int64_t ld, int span, int k_valid, auto& regs, auto count_c) {
+    [[maybe_unused]] auto stage_q = [&](const float* base, int64_t ld, int rows_valid, int k_valid, auto& regs, auto count_c) {
         constexpr int COUNT = decltype(count_c)::value;
         const int ld4 = __builtin_amdgcn_readfirstlane((int)ld * 4);
+        const int span = __builtin_amdgcn_readfirstlane(
+            rows_valid > 0 && k_valid > 0 ? ((rows_valid - 1) * (int)ld + k_valid) * 4 : 0);
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
         const int q4 = (tid % SP_QPR) * 4;
         const int voff = q4 < k_valid ? ((tid / SP_QPR) * (int)ld + q4) * 4 : 0x7fffffff;
@@ -440,10 +438,12 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     // Operand with its reduction dimension strided: [16 k][XW x], dword loads along x (fully coalesced), a thread keeps KR
     // consecutive k of one x.  XW >= 64: unit = wave * U + u -> x = (unit % (XW / 64)) * 64 + lane, k = KR * (unit /
     // (XW / 64)) + r; XW = 32 (256 threads): x = tid & 31, k = 2 * (tid >> 5) + r
-    [[maybe_unused]] auto stage_s = [&](const float* base, int64_t ld, int span, int x_valid, auto& regs, auto xw_c,
+    [[maybe_unused]] auto stage_s = [&](const float* base, int64_t ld, int k_valid, int x_valid, auto& regs, auto xw_c,
                                         auto kr_c, auto u_c) {
         constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
         const int ld4 = __builtin_amdgcn_readfirstlane((int)ld * 4);
+        const int span = __builtin_amdgcn_readfirstlane(
+            k_valid > 0 && x_valid > 0 ? ((k_valid - 1) * (int)ld + x_valid) * 4 : 0);
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -542,67 +542,31 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         const int m_left = min(BM, rows_left), n_left = min(BN, cols_left);
         // cursor of the load stream: (seg, lk) = the next k-tile, nseg = the record behind seg (always requested one fetch
         // ahead, clamped at the group's last); have = the stream has not ended.  No branches (see stage_q).
-        // The operand addresses of the next k-tile are kept as two running 64-bit scalars (a_cur, b_cur): + one tile's
-        // distance per fetch, or the next segment's start when the segment ends -- ~30 scalar instructions less per
-        // k-tile than rebuilding base + offset + k * ld (the scalar port issues one instruction per SIMD and 4 cycles;
-        // at ~95 per wave and k-tile it was as busy as the matrix pipe).
         hypel_seg_t nseg = segs[min(ls + 1, s_end - 1)];
         int n_fetched = 0;  // real k-tiles requested so far: tile t + 1 exists iff t + 1 < n_fetched
-        const uint64_t a_base0 = (uint64_t)(A + (!TA ? (int64_t)m0 * lda : (int64_t)m0));
-        const uint64_t b_base0 = (uint64_t)(B + (TB ? (int64_t)n0 * ldb : (int64_t)n0));
-        const uint64_t a_step = !TA ? (uint64_t)(4 * SP_BK) : (uint64_t)lda * (4 * SP_BK);
-        const uint64_t b_step = TB ? (uint64_t)(4 * SP_BK) : (uint64_t)ldb * (4 * SP_BK);
-        uint64_t a_cur = a_base0 + (uint64_t)seg.a_off * 4, b_cur = b_base0 + (uint64_t)seg.b_off * 4;
-        int seg_k = seg.k;
-        // descriptor spans (bytes up to the end of the last valid row) of a k-tile with kl valid reduction columns
-        auto span_q = [&](int rows_valid, int64_t ld, int kl) {
-            return __builtin_amdgcn_readfirstlane(rows_valid > 0 && kl > 0 ? ((rows_valid - 1) * (int)ld + kl) * 4 : 0);
-        };
-        auto span_s = [&](int x_valid, int64_t ld, int kl) {
-            return __builtin_amdgcn_readfirstlane(x_valid > 0 && kl > 0 ? ((kl - 1) * (int)ld + x_valid) * 4 : 0);
-        };
-        const int span_a_full = !TA ? span_q(m_left, lda, SP_BK) : span_s(m_left, lda, SP_BK);
-        const int span_b_full = TB ? span_q(n_left, ldb, SP_BK) : span_s(n_left, ldb, SP_BK);
         auto fetch = [&](Raw& r) {
-            // what this fetch loads, and the cursor behind it -- ONE uniform branch of scalar work, the loads follow the
-            // join (a branch that contains loads makes hipcc's s_waitcnt insertion drain the whole prefetch ring)
-            const uint64_t a_ptr = a_cur, b_ptr = b_cur;
-            int k_left, span_a, span_b;
-            if (have && seg_k - lk > SP_BK) {  // a whole tile that is not its segment's last: constants, the cursor steps
-                k_left = SP_BK;
-                span_a = span_a_full;
-                span_b = span_b_full;
-                n_fetched += 1;
-                lk += SP_BK;
-                a_cur += a_step;
-                b_cur += b_step;
-            } else {
-                k_left = have ? min(SP_BK, seg_k - lk) : 0;  // 0: every load of this fetch is out of range
-                span_a = !TA ? span_q(m_left, lda, k_left) : span_s(m_left, lda, k_left);
-                span_b = TB ? span_q(n_left, ldb, k_left) : span_s(n_left, ldb, k_left);
-                n_fetched += have ? 1 : 0;
-                lk += SP_BK;
-                const bool adv = have && lk >= seg_k;
-                const uint64_t a_nxt = a_base0 + (uint64_t)nseg.a_off * 4, b_nxt = b_base0 + (uint64_t)nseg.b_off * 4;
-                a_cur = adv ? a_nxt : a_cur + a_step;
-                b_cur = adv ? b_nxt : b_cur + b_step;
-                seg_k = adv ? nseg.k : seg_k;
-                lk = adv ? 0 : lk;
-                ls += adv ? 1 : 0;
-                have = ls < s_end;
-                nseg = segs[min(ls + 1, s_end - 1)];
-            }
+            const int k_left = have ? min(SP_BK, seg.k - lk) : 0;  // 0: every load of this fetch is out of range
             r.kv = k_left;
             if constexpr (!TA)
-                stage_q(reinterpret_cast<const float*>(a_ptr), lda, span_a, k_left, r.qa, std::integral_constant<int, SA_N>{});
+                stage_q(A + seg.a_off + (int64_t)m0 * lda + lk, lda, m_left, k_left, r.qa, std::integral_constant<int, SA_N>{});
             else
-                stage_s(reinterpret_cast<const float*>(a_ptr), lda, span_a, m_left, r.sa, std::integral_constant<int, BM>{},
+                stage_s(A + seg.a_off + (int64_t)lk * lda + m0, lda, k_left, m_left, r.sa, std::integral_constant<int, BM>{},
                         std::integral_constant<int, SA_KR>{}, std::integral_constant<int, SA_U>{});
             if constexpr (TB)
-                stage_q(reinterpret_cast<const float*>(b_ptr), ldb, span_b, k_left, r.qb, std::integral_constant<int, SB_N>{});
+                stage_q(B + seg.b_off + (int64_t)n0 * ldb + lk, ldb, n_left, k_left, r.qb, std::integral_constant<int, SB_N>{});
             else
-                stage_s(reinterpret_cast<const float*>(b_ptr), ldb, span_b, n_left, r.sb, std::integral_constant<int, BN>{},
+                stage_s(B + seg.b_off + (int64_t)lk * ldb + n0, ldb, k_left, n_left, r.sb, std::integral_constant<int, BN>{},
                         std::integral_constant<int, SB_KR>{}, std::integral_constant<int, SB_U>{});
+            n_fetched += have ? 1 : 0;
+            lk += SP_BK;
+            const bool adv = have && lk >= seg.k;
+            ls += adv ? 1 : 0;
+            lk = adv ? 0 : lk;
+            seg.a_off = adv ? nseg.a_off : seg.a_off;
+            seg.b_off = adv ? nseg.b_off : seg.b_off;
+            seg.k = adv ? nseg.k : seg.k;
+            have = ls < s_end;
+            nseg = segs[min(ls + 1, s_end - 1)];
         };
         // chunk c of an operand's raw registers (a quad of a k-contiguous operand, a KR-run of a k-strided one) -> split
         // -> the three planes of LDS buffer `buf`: plane p of element (x, k) at p * PLANE + x * 80 + 2 k bytes
@@ -616,13 +580,18 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = q4 + e < kv ? v[e] : 0.0f;
             }
-            unsigned h0, h1, m0_, m1_, l0, l1;
-            hypel_split2(v[0], v[1], h0, m0_, l0);
-            hypel_split2(v[2], v[3], h1, m1_, l1);
+            const unsigned h0 = hypel_cvt_pk_bf16(v[0], v[1]), h1 = hypel_cvt_pk_bf16(v[2], v[3]);
+            float r0 = v[0] - __builtin_bit_cast(float, h0 << 16), r1 = v[1] - __builtin_bit_cast(float, h0 & 0xffff0000u);
+            float r2 = v[2] - __builtin_bit_cast(float, h1 << 16), r3 = v[3] - __builtin_bit_cast(float, h1 & 0xffff0000u);
+            const unsigned m0_ = hypel_cvt_pk_bf16(r0, r1), m1_ = hypel_cvt_pk_bf16(r2, r3);
+            r0 -= __builtin_bit_cast(float, m0_ << 16);
+            r1 -= __builtin_bit_cast(float, m0_ & 0xffff0000u);
+            r2 -= __builtin_bit_cast(float, m1_ << 16);
+            r3 -= __builtin_bit_cast(float, m1_ & 0xffff0000u);
             float* o = img + (tid / SP_QPR + SP_RP * i) * SP_PITCH + 2 * (tid % SP_QPR);
             *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(o + plane) = u32x2{m0_, m1_};
-            *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l0, l1};
+            *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{hypel_cvt_pk_bf16(r0, r1), hypel_cvt_pk_bf16(r2, r3)};
         };
         auto chunk_s = [&](const auto& v, float* img, int plane, int u, auto xw_c, auto kr_c, auto u_c) {
             constexpr int XW = decltype(xw_c)::value, KR = decltype(kr_c)::value, U = decltype(u_c)::value;
@@ -637,7 +606,15 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
             }
             unsigned h[KR / 2], m[KR / 2], l[KR / 2];
 #pragma unroll
-            for (int e = 0; e < KR / 2; ++e) hypel_split2(v[2 * e], v[2 * e + 1], h[e], m[e], l[e]);
+            for (int e = 0; e < KR / 2; ++e) {
+                h[e] = hypel_cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+                float r0 = v[2 * e] - __builtin_bit_cast(float, h[e] << 16);
+                float r1 = v[2 * e + 1] - __builtin_bit_cast(float, h[e] & 0xffff0000u);
+                m[e] = hypel_cvt_pk_bf16(r0, r1);
+                r0 -= __builtin_bit_cast(float, m[e] << 16);
+                r1 -= __builtin_bit_cast(float, m[e] & 0xffff0000u);
+                l[e] = hypel_cvt_pk_bf16(r0, r1);
+            }
             if constexpr (KR == 8) {
                 float* o = img + x * SP_PITCH + 4 * kg;
                 *reinterpret_cast<u32x4*>(o) = u32x4{h[0], h[1], h[2], h[3]};

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--layout", default="nn")
     ap.add_argument("--variants", default="0,1,2,3")  # 0 = fp32 kernel (library heuristic), 1/2/3 = split widths
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--clk", action="store_true", help="library built with -DHYPEL_GEMM_CLK=1: the shader clock each block ran at")
     args = ap.parse_args()
     be = HipBackend()
     m, k, n = args.m, args.k, args.n
@@ -45,7 +46,9 @@ def main():
     lda, ldb = a.shape[1], b.shape[1]
     for v in [int(x) for x in args.variants.split(",")]:
         flags = 0 if v == 0 else (0x8000 | (v << 8))
-        f = be.bind("seg_gemm_f32", (Ref(a), lda, ta, Ref(b), ldb, tb, Ref(c), n, n, Ref(gt), Ref(st), Ref(tt), len(t), None, flags))
+        dbg = torch.zeros(1 << 17, dtype=torch.int64, device="cuda") if args.clk else None
+        f = be.bind("seg_gemm_f32", (Ref(a), lda, ta, Ref(b), ldb, tb, Ref(c), n, n, Ref(gt), Ref(st), Ref(tt), len(t),
+                                     Ref(dbg.view(torch.float32)) if args.clk else None, flags))
         f()
         torch.cuda.synchronize()
         ts = []
@@ -57,6 +60,13 @@ def main():
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         med = float(np.median(ts))
+        if args.clk:
+            d = dbg.cpu().numpy().reshape(-1, 2)
+            d = d[d[:, 1] > 0]
+            ghz = d[:, 0] / (d[:, 1] * 10.0)  # shader cycles per ns (the wall counter ticks at 100 MHz)
+            print(f"    blocks {len(d)}: shader clock over each block's k loop  median {np.median(ghz):.3f} GHz  "
+                  f"p10 {np.percentile(ghz, 10):.3f}  p90 {np.percentile(ghz, 90):.3f};  block life median "
+                  f"{np.median(d[:, 1]) / 100:.1f} us  max {d[:, 1].max() / 100:.1f} us")
         print(f"layout {args.layout} M={m} K={k} n={n} variant {v}: med {med:8.1f} us  min {min(ts):8.1f} us  "
               f"{2 * macs / med / 1e6:6.1f} TF/s")
 
