@@ -20,8 +20,8 @@ class Built:
     pass
 
 
-def build(model_name, patch, channels, classes, alg, backend, with_eval=True):
-    model = cno.get_model_from_name(model_name)
+def build(model_name, patch, channels, classes, alg, backend, with_eval=True, model=None):
+    model = model or cno.get_model_from_name(model_name)
     template = cno.Template("nn_core", model.create_tensor_graph, class_count=classes)
     ctx = cno.GraphContext(template, backend)
     ctx.external_masks = True

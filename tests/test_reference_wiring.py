@@ -12,6 +12,7 @@ residual channel maps.  NOT the operator semantics -- the stand-in evaluates wit
 unpinned at the TensorFlow boundary)."""
 import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -19,6 +20,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, GOLD)
 
 from graph_dump import dump_output, dump_store, dump_tower  # noqa: E402
@@ -232,3 +234,52 @@ print("ok")
     # a fresh interpreter: the stand-in installs a meta-path finder and shims numpy attributes
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ the facade, end to end
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference checkout exists in the build container only")
+@pytest.mark.parametrize("model_name,patch,ch,classes,alg,nb", [
+    ("HYPELCNNModel", 5, 11, 4, {"drop_out_ratio": 0.7, "filter_count": 48, "learning_rate": 3e-4,
+                                 "learning_rate_decay_factor": 0.96, "learning_rate_decay_step": 350, "lrelu_alpha": 0.18,
+                                 "optimizer": "AdamOptimizer", "bn_decay": 0.95, "l2regularizer_scale": 1e-5,
+                                 "spectral_hierarchy_level": 3, "spatial_hierarchy_level": 3, "degradation_coeff": 3,
+                                 "use_residual": True, "batch_size": 6}, 6),
+    ("DUALCNNModel", 5, 7, 3, {"drop_out_ratio": 0.7, "lrelu_alpha": 0.18, "filter_count": 32, "hs_lidar_diff": 1,
+                               "optimizer": "AdamOptimizer", "learning_rate": 3e-4, "learning_rate_decay_factor": 0.96,
+                               "learning_rate_decay_step": 350}, 4),
+    ("CONCNNModel", 5, 9, 3, {"drop_out_ratio": 0.5, "filter_count": 6, "optimizer": ["MomentumOptimizer", 0.9],
+                              "learning_rate": 1e-3, "learning_rate_decay_factor": 0.01,
+                              "learning_rate_decay_step": 33333}, 4),
+])
+def test_reference_plugin_file_trains_through_the_facade(model_name, patch, ch, classes, alg, nb):
+    """`hypelcnn_amd.tf_facade.reference_model`: the reference's UNCHANGED plugin file in the place of the product's plugin
+    -- optimize_nn, planning, one training step on the kernel emulation -- gives the product plugin's numbers bit for bit
+    (the two record the same Tower) and the oracle's to the usual tolerance.  Runs in a subprocess: the facade's finder
+    and the reference's `common` / `nnmodel` packages must not leak into this test process."""
+    code = """
+import sys, json
+import numpy as np
+sys.path.insert(0, %r)
+from hypelcnn_amd import tf_facade
+from tests import parity_util as U
+from tests.emu_backend import EmuBackend
+model_name, patch, ch, classes, alg, nb = json.loads(%r)
+def run(model):
+    rng = np.random.default_rng(3)
+    built = U.build(model_name, patch, ch, classes, alg, EmuBackend(), model=model)
+    sess = built.ctx.session()
+    params = U.make_params(model_name, patch, ch, classes, alg, rng)
+    U.inject(sess, params)
+    x = rng.random((nb, patch, patch, ch)).astype(np.float32)
+    onehot = np.eye(classes, dtype=np.float32)[rng.integers(0, classes, nb)]
+    masks = U.make_masks(built, nb, rng)
+    ct = U.run_train_step(built, x, onehot, masks)
+    ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, model_name, classes, alg, tol_logit=2e-5, tol_grad=2e-4)
+    return np.concatenate([np.asarray(sess.get_gradient("nn_core/" + k), np.float32).ravel() for k in sorted(params)])
+a = run(None)
+b = run(tf_facade.reference_model(model_name, "/root/reference"))
+assert a.shape == b.shape and np.array_equal(a, b), float(np.abs(a - b).max())
+print("FACADE_OK", a.size)
+""" % (ROOT, json.dumps([model_name, patch, ch, classes, alg, nb]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert "FACADE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
