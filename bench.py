@@ -614,7 +614,8 @@ def main():
                            "fp32 MFMA kernels (v_mfma_f32_32x32x2, 16x16x4 for n <= 16)" % (100 * share)) if split_on else
                           "hypel_seg_gemm_f32 / hypel_seg_gemm_multi_f32 (fp32 MFMA: v_mfma_f32_32x32x2, 16x16x4 for n <= 16)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "peak_note": "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products" if split_on
+                "peak_note": ("fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s (at 2.4 GHz) / 6 partial products; the split kernels "
+                              "run against the 1.4 kW power cap at 1.4-1.8 GHz (profiles/r5_exp_split_ablation.txt)") if split_on
                              else "fp32 MFMA peak",
                 "frac_vs_fp32_mfma": achieved / PEAK_F32_MFMA_TFLOPS, "peak_fp32_mfma": PEAK_F32_MFMA_TFLOPS,
                 "split6_flop_share": share, "split6_launches_per_step": measure_gemm_events.split_launches,

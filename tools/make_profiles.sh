@@ -17,7 +17,7 @@ ROOT=$(pwd)
 for WL in $WLS; do
   case $WL in
     hypelcnn) STEPS=100; TSTEPS=20; KNOWN=$((1024*49*145*4)); NB=1024;;
-    dualcnn)  STEPS=20;  TSTEPS=4;  KNOWN=$((512*121*49*4));  NB=512;;
+    dualcnn)  STEPS=30;  TSTEPS=4;  KNOWN=$((512*121*49*4));  NB=512;;
     *)        STEPS=100; TSTEPS=30; KNOWN=0; NB=0;;
   esac
   EXTRA=""; [ $WL = hypelcnn ] || EXTRA="--workload $WL"
