@@ -269,7 +269,14 @@ class HipBackend:
         return torch.empty(int(n), dtype=dtype, device=self.device)
 
     def zeros(self, n, dtype=torch.float32):
-        return torch.zeros(int(n), dtype=dtype, device=self.device)
+        t = torch.empty(int(n), dtype=dtype, device=self.device)
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0:
+            return t
+        if nbytes % 4:  # (byte tables of odd length: not on any step path)
+            return t.zero_()
+        self.call("fill_f32", Ref(t.view(torch.uint8).view(torch.float32)), nbytes // 4, 0.0)  # hypel_fill, not a torch kernel
+        return t
 
     def upload(self, array):
         """numpy array (any dtype, incl. structured tables) -> flat device tensor."""

@@ -428,7 +428,9 @@ class Session:
         if not self._guard_free:  # ring full: the oldest copy is several steps old, its event long since signalled
             self._guard_fold(self._guard_q.pop(0))
         host, ev = self._guard_free.pop()
-        host.copy_(self.grads[self.n_train:self.n_train + 1], non_blocking=True)
+        # the library's own copy kernel stores the flag straight into the pinned (device-mapped) slot: no runtime blit
+        # kernel (__amd_rocclr_copyBuffer) in the step
+        self.backend.call("copy_pair_f32", Ref(host), Ref(self.grads, self.n_train), 1, Ref(host), Ref(self.grads, self.n_train), 0)
         ev.record()
         self._guard_q.append((self.global_step, host, ev))
 

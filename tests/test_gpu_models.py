@@ -465,3 +465,25 @@ def test_concnn_shipped_config_vs_oracle(hip):
         OT.momentum_tf1_step(exp_o, g, np.zeros_like(exp_o), lr0, mu)
         assert np.abs(gotp - exp_o).max() <= lr0 * 1e-4 * max(np.abs(g).max(), 1e-6) + 2e-7 * max(1.0, np.abs(exp).max()), k
     print(f"\nCONCNN (384-channel LRN, batch {nb}): logits {err:.2e}, worst grad {worst}")
+
+
+@pytest.mark.gpu
+def test_nonfinite_loss_flag_reaches_the_host_through_the_pinned_slot(hip):
+    """The GPU twin of tests/test_host_plan_emu.py::test_nonfinite_loss_is_flagged_on_the_device_and_the_update_refused
+    (NanTensorHook, monitored_session_runner.py:151): the flag behind the gradient buffer travels to the host through the
+    library's own copy kernel writing into a pinned, device-mapped slot (no runtime blit in the step); a NaN input must
+    refuse the update on the device and be reported with its step number."""
+    import torch
+    built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 5, 11, 4, SMALL_H, 6, 3)
+    for _ in range(6):  # more steps than the ring has slots: slots are recycled
+        U.run_train_step(built, x, onehot, masks)
+        sess.adam_step(1e-3)
+    assert sess.nonfinite_step(sync=True) is None
+    p1, m1 = sess.params.clone(), sess.slot_m.clone()
+    bad = x.copy()
+    bad[0, 0, 0, 0] = np.nan
+    U.run_train_step(built, bad, onehot, masks)
+    sess.adam_step(1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(sess.params, p1) and torch.equal(sess.slot_m, m1), "a non-finite step must not update anything"
+    assert sess.nonfinite_step(sync=True) == 7
