@@ -32,6 +32,9 @@ namespace {
 #ifndef DS_DIAG
 #define DS_DIAG 0  // timing diagnostics (results wrong): 1 = no weight staging, 2 = no layer products, 3 = no zero fill
 #endif
+#ifndef DS_REGW
+#define DS_REGW 1  // forward of stacks with every width <= 64: weights in registers (0: the LDS-staged kernel for every shape)
+#endif
 constexpr int DS_ROWS = 16;
 constexpr int DS_THREADS = 256;
 constexpr int DS_WAVES = 4;
@@ -202,6 +205,91 @@ __global__ __launch_bounds__(DS_THREADS) void dense_stack_fwd_kernel(const float
     }
 }
 
+// Forward, widths <= 64 (the Gulfport critic 64-64-64-32, the feature-discriminator slices): every layer has at most four 16-column
+// tiles -- one per wave -- and at most 16 k-steps, so a lane's share of ALL layers' weights is <= 4 x 16 fragments.  They are
+// requested straight from global memory (L2: every block reads the same 40 KB) into registers at kernel entry, all layers at once,
+// under the input tile's DMA; no weight image in LDS, no margin zeroing, none of the 160 dword LDS-DMA instructions and their drain in
+// front of the first barrier (round-4 diagnostic DS_DIAG=1: 4.3 us of the forward launch's 11.2).  Same k-step order as
+// ds_layer_fwd, i.e. the same fmaf chain.
+constexpr int DS_RW = 64;             // widest layer of the register-weight path
+constexpr int DS_RK = DS_RW / 4;      // k-steps of its widest layer
+__global__ __launch_bounds__(DS_THREADS) void dense_stack_fwd_regw_kernel(const float* __restrict__ x, int64_t ldx, int64_t n,
+                                                                          DsShape sh, const float* __restrict__ w,
+                                                                          const float* __restrict__ b, float* __restrict__ out,
+                                                                          int64_t ldo, DsApps apps) {
+    extern __shared__ __attribute__((aligned(16))) float ds_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bpa = gridDim.x / apps.n_apps, app = blockIdx.x / bpa, blk = blockIdx.x - app * bpa;
+    w += app * apps.w_stride;
+    b += app * apps.b_stride;
+    x += (int64_t)app * n * ldx;
+    out += (int64_t)app * n * ldo;
+    const int r = lane & 15, kq = lane >> 4;
+    const int col = 16 * wave + r;  // this lane's output column in every layer
+    const int img = DS_ROWS * sh.pa;
+    float* X = ds_lds;
+    float* P0 = ds_lds + img;
+    float* P1 = ds_lds + 2 * img;
+    // this lane's weight fragments of every layer: wf[l][s] = W_l[4 s + kq][col] (0 outside the matrix), and its bias
+    float wf[DS_MAXL][DS_RK], bv[DS_MAXL];
+#pragma unroll
+    for (int l = 0; l < DS_MAXL; ++l) {
+        const int cin = l < sh.n_layers ? sh.width[l] : 0, cout = l < sh.n_layers ? sh.width[l + 1] : 0;
+        const float* wl = w + sh.woff[l];
+#pragma unroll
+        for (int s = 0; s < DS_RK; ++s) {
+            const int k = 4 * s + kq;
+            wf[l][s] = (k < cin && col < cout) ? wl[k * cout + col] : 0.0f;
+        }
+        bv[l] = col < cout ? b[sh.boff[l] + col] : 0.0f;
+    }
+    ds_zero(ds_lds, 3 * img, tid);
+    __syncthreads();
+    const int64_t tiles = (n + DS_ROWS - 1) / DS_ROWS;
+    for (int64_t t = blk; t < tiles; t += bpa) {
+        const int64_t r0 = t * DS_ROWS;
+        const int rows_valid = (int)min((int64_t)DS_ROWS, n - r0);
+        ds_load_rows(X, sh.pa, sh.width[0], x + r0 * ldx, ldx, rows_valid, tid, lane, wave);
+        __syncthreads();
+        const float* src = X;
+        float* dst = P0;
+#pragma unroll
+        for (int l = 0; l < DS_MAXL; ++l) {
+            if (l < sh.n_layers) {
+                const int cin = sh.width[l], cout = sh.width[l + 1];
+                const int ksteps = (cin + 3) >> 2;
+                if (16 * wave < cout) {  // wave-uniform: this wave owns a column tile of the layer
+                    const float* ap = src + r * sh.pa + kq;
+                    float a[DS_RK];
+#pragma unroll
+                    for (int s = 0; s < DS_RK; ++s) a[s] = s < ksteps ? ap[4 * s] : 0.0f;
+                    ds_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int s = 0; s < DS_RK; ++s)
+                        if (s < ksteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wf[l][s], acc, 0, 0, 0);
+                    if (col < cout) {
+                        float* o = l == sh.n_layers - 1 ? out + r0 * ldo : nullptr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = 4 * kq + e;
+                            const float v = ds_act(acc[e] + bv[l], sh.act[l], sh.alpha);
+                            dst[row * sh.pa + col] = v;
+                            if (o != nullptr && row < rows_valid) o[(int64_t)row * ldo + col] = v;
+                        }
+                    }
+                }
+                if (tid < DS_ROWS * 4) {  // columns [cout, next multiple of 4) of dst must read as zero for the next layer's k loop
+                    const int c = cout + (tid & 3);
+                    if (c < ((cout + 3) & ~3)) dst[(tid >> 2) * sh.pa + c] = 0.0f;
+                }
+                __syncthreads();
+                src = dst;
+                dst = dst == P0 ? P1 : P0;
+            }
+        }
+    }
+}
+
 // Backward.  LDS: A_0..A_L (L + 1 images), the output-gradient tile, two gradient images, every layer's weights + biases.
 __global__ __launch_bounds__(DS_THREADS) void dense_stack_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dout, int64_t lddo, int64_t n, DsShape sh,
@@ -368,6 +456,16 @@ bool ds_shape(int n_layers, const int32_t* widths, int32_t act_mask, float alpha
     return true;
 }
 
+// The register-weight forward pays a fixed price (4 x 16 predicated fragment loads, a 16-step predicated product loop) and saves the
+// weight image's staging, so it is chosen by the size of that image -- same-box A/B, round 5 (tools/exp/dense_regw_ab.sh):
+// 64-64-64-32 (10 240 floats) 11.3 -> 8.8 us, 64-64 (4 096) 5.9 -> 6.5, 16-16-16-8 (640) 6.2 -> 8.1.
+constexpr int DS_REGW_MIN_WEIGHTS = 8192;
+bool ds_regw(const DsShape& sh) {
+    for (int l = 0; l <= sh.n_layers; ++l)
+        if (sh.width[l] > DS_RW) return false;
+    return sh.woff[sh.n_layers] >= DS_REGW_MIN_WEIGHTS;
+}
+size_t ds_fwd_regw_lds(const DsShape& sh) { return (size_t)(3 * DS_ROWS * sh.pa) * sizeof(float); }
 size_t ds_fwd_lds(const DsShape& sh) {
     return (size_t)(3 * DS_ROWS * sh.pa + sh.wlds[sh.n_layers] + sh.boff[sh.n_layers]) * sizeof(float);
 }
@@ -407,6 +505,12 @@ extern "C" int hypel_dense_stack_fwd(const float* x, int64_t ldx, int64_t n, int
     const int32_t widths[DS_MAXL + 1] = {w0, w1, w2, w3, w4};
     DsShape sh;
     HYPEL_REQUIRE(x && w && b && out && n > 0 && ds_shape(n_layers, widths, act_mask, alpha, sh), "hypel_dense_stack_fwd");
+    if (DS_REGW && ds_regw(sh)) {
+        hipLaunchKernelGGL(dense_stack_fwd_regw_kernel, dim3(hypel_dense_stack_blocks(n)), dim3(DS_THREADS), ds_fwd_regw_lds(sh), ST,
+                           x, ldx, n, sh, w, b, out, ldo, DsApps{1, 0, 0, 0, 0});
+        HYPEL_CHECK_LAUNCH("hypel_dense_stack_fwd");
+        return 0;
+    }
     const size_t lds = ds_fwd_lds(sh);
     HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_dense_stack_fwd");
     (void)hipFuncSetAttribute((const void*)dense_stack_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -424,6 +528,12 @@ extern "C" int hypel_dense_stack_fwd_apps(const float* x, int64_t ldx, int64_t n
     DsShape sh;
     HYPEL_REQUIRE(x && w && b && out && n > 0 && n_apps >= 1 && n_apps <= 16 && ds_shape(n_layers, widths, act_mask, alpha, sh),
                   "hypel_dense_stack_fwd_apps");
+    if (DS_REGW && ds_regw(sh)) {
+        hipLaunchKernelGGL(dense_stack_fwd_regw_kernel, dim3(hypel_dense_stack_blocks_apps(n, n_apps)), dim3(DS_THREADS),
+                           ds_fwd_regw_lds(sh), ST, x, ldx, n, sh, w, b, out, ldo, DsApps{n_apps, w_stride, b_stride, 0, 0});
+        HYPEL_CHECK_LAUNCH("hypel_dense_stack_fwd_apps");
+        return 0;
+    }
     const size_t lds = ds_fwd_lds(sh);
     HYPEL_REQUIRE(lds <= 160 * 1024, "hypel_dense_stack_fwd_apps");
     (void)hipFuncSetAttribute((const void*)dense_stack_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
