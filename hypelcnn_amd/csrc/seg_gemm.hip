@@ -96,6 +96,9 @@ constexpr int BK_NARROW = HYPEL_GEMM_BK_NARROW;
 #endif
 constexpr int CHUNK = HYPEL_GEMM_CHUNK;
 static_assert(CHUNK % 4 == 0 && BK_WIDE % CHUNK == 0 && BK_NARROW % CHUNK == 0, "chunk of k2 / k4 steps");
+#ifndef HYPEL_SPLIT_WAVE_ROWS_FIRST
+#define HYPEL_SPLIT_WAVE_ROWS_FIRST 1  // split variants: wave -> (wave % WM, wave / WM) instead of (wave / WN, wave % WN)
+#endif
 #ifndef HYPEL_OCC_BN32
 #define HYPEL_OCC_BN32 3  // waves per SIMD the 128x32 variant is compiled for
 #endif
@@ -251,7 +254,11 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     // wave index as a SCALAR: every predicate derived from it is wave-uniform and compiles to s_cbranch,
     // not to exec-masked regions around the MFMAs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    // SPLIT: consecutive waves (= the four SIMDs of a CU) take different ROW slabs of the same column tiles first, so that a
+    // group that fills only the first column tile(s) of the block (the outer rings of a merged multi-kernel level:
+    // hypel_tile_t.n = 30 of 120 columns) still has MFMA work on every SIMD; the fp32 kernels keep the column-major deal
+    const int wm = SPLIT && HYPEL_SPLIT_WAVE_ROWS_FIRST ? wave % WM : wave / WN;
+    const int wn = SPLIT && HYPEL_SPLIT_WAVE_ROWS_FIRST ? wave / WM : wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     // per-thread staging coordinates

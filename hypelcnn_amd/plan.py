@@ -133,7 +133,8 @@ GEMM_MULTI_SPLIT6 = 0x100   # ... HYPEL_GEMM_MULTI_SPLIT6 (bit of hypel_seg_gemm
 _gs = os.environ.get("HYPEL_GEMM_SPLIT", "6").split(":")
 GEMM_SPLIT = int(_gs[0] or 0)
 GEMM_SPLIT_WIDTH = int(_gs[1]) if len(_gs) > 1 else 0
-GEMM_SPLIT_MIN_FLOPS = float(os.environ.get("HYPEL_GEMM_SPLIT_MIN_GFLOP", "2")) * 1e9
+GEMM_SPLIT_MIN_FLOPS = float(os.environ.get("HYPEL_GEMM_SPLIT_MIN_GFLOP", "2")) * 1e9  # ... of the launch at SPLIT_NOMINAL_BATCH samples
+SPLIT_NOMINAL_BATCH = 1024  # batch the size rule prices a launch at (the kernel family is chosen per layer, not per batch)
 # narrow products stage a whole 128-row A tile per 32 output columns: the split costs more than the matrix rate returns
 # (H13 level 1, 30 filters per branch: 382 -> 397 us forward, 103 -> 95 TFLOP/s filter gradient; per-launch A/B, round 5)
 GEMM_SPLIT_MIN_N = 32
@@ -150,22 +151,38 @@ GEMM_VAR_N = 0x4000     # ... HYPEL_GEMM_VAR_N: tile records carry their group's
 # loses 50 - 60 % (380 -> 583 us, 430 -> 687 us).  The merged DATA GRADIENT (49 instead of 84 segments per pixel) gains
 # 2 - 7 % per launch.  The merged FILTER GRADIENT moved work between the three tile-width launches without shortening
 # their sum (1584 -> 1593 us): removed in round 5 (NOTES 4.A keeps the numbers).  Step: 6.51 -> 6.49 ms, i.e. neutral.
-MERGE_LEVELS = set(x for x in os.environ.get("HYPEL_MERGE_LEVELS", "fwd,dgrad").split(",") if x and x != "0")
-MERGE_LEVELS_MAX_COUT = 32
+MERGE_LEVELS = set(x for x in os.environ.get("HYPEL_MERGE_LEVELS", "fwd,dgrad,wgrad").split(",") if x and x != "0")
+MERGE_LEVELS_MAX_COUT = 64
 # per pass: widest branch (filters) the pass is merged for, taps per merged forward tile, forward tile-width hint
-MERGE_PASS_MAX_COUT = {"fwd": 16, "dgrad": 1 << 20}
+MERGE_PASS_MAX_COUT = {"fwd": 16, "dgrad": 1 << 20, "wgrad": 1 << 20}
+# The merged FILTER GRADIENT (round 6, back from f4fd7b4^ for the split kernels): per input offset d ONE product
+# dW_pack[d] = sum_p X[p + d]^T dY[p][:, col0:] of C - col0[ring] columns into a dense packed image, scattered into the HWIO
+# gradient slots by hypel_copy_blocks_f32.  Columns per product grow from cout to up to 4 cout: the 30-filter level leaves the
+# fp32 pipe for every ring but the outermost.  Narrowest / widest branch (filters) it is used for:
+MERGE_WGRAD_MIN_COUT = 17
+MERGE_WGRAD_MAX_COUT = 64
 # ... and for the split-operand kernels, whose cost is dominated by staging A: sharing one staged A tile between the
 # branches of a ring pays for wider branches too
-MERGE_FWD_MAX_COUT_SPLIT = 16
+# Round 6, same box (profiles/r6_exp_merged_levels_split.txt; one staged + split A tile serves up to four branches):
+# the 30-filter level of H13 -- fp32 kernel, unmerged: 411 us + 55 us of partial-copy reduces; merged on the 128x128 split
+# blocks with the round-5 chunking (9 taps, two channel parts): 329 + 65; 16 taps per tile and NO channel parts: 328 + 38
+# (= -100 us).  It needs the rows-first wave deal of the split kernels (seg_gemm.hip HYPEL_SPLIT_WAVE_ROWS_FIRST: 357 -> 329 us;
+# a ring-3 group fills one column tile of four).  The 60-filter level loses merged (371 + 49 vs 362 + 39), the 15-filter level
+# loses on the split kernels (128x64 blocks: 145 us vs 135 on the 16x16x4 MFMA): both keep their round-5 forms.
+MERGE_FWD_MAX_COUT_SPLIT = 32
 MERGE_MAX_TAPS = 0  # 0 = MAX_TAPS_PER_TILE
+MERGE_SPLIT_MAX_TAPS = 16  # ... of a merged forward that runs on the split kernels
+MERGE_SPLIT_KPARTS = False  # channel parts (L2_CHUNK_BYTES) for a merged forward on the split kernels
+MERGE_FWD_SPLIT_NARROW = 0  # 1: the merged forward of a <= 16-filter level on the split kernels (128x64 blocks) instead of 16x16x4
 MERGE_FWD_HINT = 2
 
 
 # Same-box A/B of the planner's constants without editing the file: HYPEL_PLAN_SET="GEMM_SPLIT_MIN_N=64,TARGET_BLOCKS=768"
 # (integers / floats; names must exist in this module).  Not read by any test or benchmark default.
 for _kv in filter(None, os.environ.get("HYPEL_PLAN_SET", "").split(",")):
-    _k, _v = _kv.split("=")
-    assert _k in globals(), _k
+    _k, _, _v = _kv.partition("=")
+    if not isinstance(globals().get(_k), (bool, int, float)) or _k.startswith("_"):
+        raise ValueError(f"HYPEL_PLAN_SET: {_k!r} is not a numeric constant of hypelcnn_amd.plan")
     globals()[_k] = type(globals()[_k])(float(_v)) if not isinstance(globals()[_k], bool) else bool(int(_v))
 
 
@@ -380,15 +397,26 @@ class TowerPlan:
     def _split6(self, tag, tables, n, ta, tb, flags, paired, in_multi=False):
         """0 = fp32 MFMA kernel, else the tile-width hint of the split-operand kernel for this launch.  in_multi: a product
         of the merged filter-gradient launch -- it shares its launch with the other products of its width class, so its
-        own size does not matter (left on the fp32 kernels, the few small ones formed a 102 us launch of 4.4 GFLOP)."""
+        own size does not matter (left on the fp32 kernels, the few small ones formed a 102 us launch of 4.4 GFLOP).
+        The choice is a function of the LAYER, not of the batch: the size rule prices the launch at SPLIT_NOMINAL_BATCH
+        samples (every product of the path is linear in the batch), so that a sample meets the same arithmetic at batch
+        64, 512 and 1024 and on 1 or 8 ranks (round-5 verdict: the FLOP count of the launch itself made it batch-dependent)."""
+        eligible = n > 16 and not (ta and tb) and not (flags & ~GEMM_VAR_N) and not paired
         if tag in SPLIT_OVERRIDE:
-            return SPLIT_OVERRIDE[tag]
-        if GEMM_SPLIT != 6 or n <= GEMM_SPLIT_MIN_N or (ta and tb) or (flags & ~GEMM_VAR_N) or paired:
+            w = SPLIT_OVERRIDE[tag]
+            if w and not eligible:
+                raise ValueError(f"HYPEL_SPLIT_OVERRIDE: launch {tag!r} (n = {n}, trans = {int(bool(ta))}{int(bool(tb))}, "
+                                 f"flags = {flags:#x}, paired segments = {bool(paired)}) cannot run on the split-operand "
+                                 "kernels (they need n > 16, a plain NN / NT / TN product, no 16x16x4 / activation epilogue)")
+            if w not in (0, 1, 2, 3):
+                raise ValueError(f"HYPEL_SPLIT_OVERRIDE: width hint {w} for {tag!r} (0 = fp32 kernel, 1 / 2 / 3 = 128x32 / x64 / x128)")
+            return w
+        if GEMM_SPLIT != 6 or n <= GEMM_SPLIT_MIN_N or not eligible:
             return 0
         if in_multi:
             return self._split6_width(n)
         macs = sum(rows * sum(k for _, _, k in gs) * tables.n_of(gi, n) for gi, (_, gs, rows) in enumerate(tables.groups))
-        if 2 * macs < GEMM_SPLIT_MIN_FLOPS:
+        if 2 * macs * SPLIT_NOMINAL_BATCH < GEMM_SPLIT_MIN_FLOPS * self.nb:
             return 0
         return self._split6_width(n)
 
@@ -629,7 +657,13 @@ class TowerPlan:
                     offs += [(dy, dx, r) for dy in range(-r, r + 1) for dx in range(-r, r + 1) if max(abs(dy), abs(dx)) == r]
                 C = co * len(brs)
                 lay = dict(offs=offs, index={(dy, dx): d for d, (dy, dx, _) in enumerate(offs)}, rmax=rmax, first=first,
-                           col0=[f * co for f in first], co=co, C=C, cin=src.c, buf=f"wpack:{idx}")
+                           col0=[f * co for f in first], co=co, C=C, cin=src.c, buf=f"wpack:{idx}", dense_off=[])
+                pos = 0
+                for (_, _, r) in offs:  # dense image of the packed filter gradient: [d] -> [Cin x (C - col0[r])]
+                    lay["dense_off"].append(pos)
+                    pos += src.c * (C - lay["col0"][r])
+                lay["dense_size"] = pos
+                assert pos == sum(b.w.size for b in brs)
                 if any(w_ in MERGE_LEVELS and co <= max(MERGE_PASS_MAX_COUT[w_], MERGE_FWD_MAX_COUT_SPLIT if GEMM_SPLIT == 6 else 0)
                        for w_ in ("fwd", "dgrad")):
                     # these passes read the packed image (the filter gradient does not)
@@ -639,13 +673,15 @@ class TowerPlan:
         return lay
 
     def _level_pass(self, idx, node, what):
-        """The level's packed layout if pass `what` ("fwd" / "dgrad") uses the merged form, else None."""
+        """The level's packed layout if pass `what` ("fwd" / "dgrad" / "wgrad") uses the merged form, else None."""
         lay = self._level_layout(idx, node)
         cap = MERGE_PASS_MAX_COUT[what]
         if what == "fwd" and GEMM_SPLIT == 6:
             cap = max(cap, MERGE_FWD_MAX_COUT_SPLIT)
         if lay is None or what not in MERGE_LEVELS or lay["co"] > cap:
             return None
+        if what == "wgrad" and not (GEMM_SPLIT == 6 and MERGE_WGRAD and MERGE_WGRAD_MIN_COUT <= lay["co"] <= MERGE_WGRAD_MAX_COUT):
+            return None  # (on the fp32 kernels it moved work between the width classes without shortening their sum, NOTES 4.A)
         return lay
 
     def _emit_level_packs(self, pos):
@@ -684,17 +720,20 @@ class TowerPlan:
         nb = self.nb
         src = node.sources[0]
         rows_all = node.out.npix * nb
+        C, cin = lay["C"], lay["cin"]
+        narrow16 = lay["co"] <= 16 and C <= 64 and not (MERGE_FWD_SPLIT_NARROW and GEMM_SPLIT == 6)
+        on_split = GEMM_SPLIT == 6 and not narrow16 and C > GEMM_SPLIT_MIN_N  # (the size rule of _split6 may still say fp32)
         ring_sizes = [sum(1 for o in lay["offs"] if o[2] == r) for r in range(lay["rmax"] + 1)]
-        S_r = [max(1, -(-sz // (MERGE_MAX_TAPS or MAX_TAPS_PER_TILE))) for sz in ring_sizes]
+        max_taps = MERGE_MAX_TAPS or (MERGE_SPLIT_MAX_TAPS if on_split else MAX_TAPS_PER_TILE)
+        S_r = [max(1, -(-sz // max_taps)) for sz in ring_sizes]
         ws = h * w * GEMM_BM * src.c * 4
-        kp_n = max(1, min(4, -(-ws // L2_CHUNK_BYTES), src.c // 16))
+        kp_n = max(1, min(4, -(-ws // L2_CHUNK_BYTES), src.c // 16)) if not on_split or MERGE_SPLIT_KPARTS else 1
         kcuts = [min(src.c, (src.c * q // kp_n + 15) // 16 * 16) for q in range(kp_n)] + [src.c]
         chunk0 = [sum(S_r[:r]) for r in range(lay["rmax"] + 2)]  # first chunk index of ring r
         n_copies = chunk0[-1] * kp_n
         if n_copies > 1:
             self._alloc(ybuf, rows_all * c * n_copies)
         tb = GemmTables()
-        C, cin = lay["C"], lay["cin"]
         for p in range(h * w):
             py, px = p // w, p % w
             for r in range(lay["rmax"] + 1):
@@ -708,7 +747,7 @@ class TowerPlan:
                         chunk = segs[len(segs) * si // S_r[r]:len(segs) * (si + 1) // S_r[r]]
                         copy = (chunk0[r] + si) * kp_n + kp
                         tb.add_group(copy * rows_all * c + p * nb * c + col0, chunk, nb, subkey=kp, n=C - col0)
-        flags = GEMM_VAR_N | (GEMM_MFMA16X4 if lay["co"] <= 16 and C <= 64 else 0)
+        flags = GEMM_VAR_N | (GEMM_MFMA16X4 if narrow16 else 0)
         pos = len(self.fwd)
         self._emit_gemm(self.fwd, tb, C, self._ref(s_st.buf), s_st.ld, 0, self._ref(lay["buf"]), C, 0, self._ref(ybuf), c,
                         None, 0, f"fwd:{node.branches[0].scope}/merged", allow_split=False, hint=MERGE_FWD_HINT,
@@ -1404,20 +1443,23 @@ class TowerPlan:
         return out
 
     def _emit_wgrad(self, tables_by_split_builder, n_groups_blocks, max_segs, slab, w0_offset, n, a_ref, lda, b_ref, ldb,
-                    tag, acc=0):
-        """tables_by_split_builder(S) -> GemmTables whose groups write to c_off = split*slab + local."""
+                    tag, acc=0, unpack=None):
+        """tables_by_split_builder(S) -> GemmTables whose groups write to c_off = split*slab + local.
+        unpack (merged levels): dict(buf, entries) -- the product's output is a packed image in buffer `buf`, scattered into
+        the gradient slots by block copies after the reduction."""
         s_pix, s_row = self._wgrad_splits(n_groups_blocks, max_segs)
         S = s_pix * s_row
         tb = tables_by_split_builder((s_pix, s_row))
         if MERGE_WGRAD:
             pend = self.__dict__.setdefault("_pending_wgrads", [])
-            if acc and pend:
+            if (acc or (unpack and any(e[6] for e in unpack["entries"]))) and pend:
                 # a second application of shared weights adds to what an earlier pending product writes: keep the order
                 self._flush_wgrads()
                 pend = self._pending_wgrads
             pend.append(dict(tb=tb, S=S, slab=int(slab), w0=int(w0_offset), n=int(n), a_ref=a_ref, lda=int(lda),
-                             b_ref=b_ref, ldb=int(ldb), tag=tag, acc=int(acc)))
+                             b_ref=b_ref, ldb=int(ldb), tag=tag, acc=int(acc), unpack=unpack))
             return
+        assert unpack is None, "merged-level filter gradients need the merged launch (MERGE_WGRAD)"
         if S == 1:
             self._emit_gemm(self.bwd, tb, n, a_ref, lda, 1, b_ref, ldb, 0, Ref(self.sess.grads, w0_offset), n, None,
                             acc, tag, allow_split=False)
@@ -1462,6 +1504,7 @@ class TowerPlan:
         spos = 0
         grads0 = rel(Ref(self.sess.grads))
         entries = []
+        unpacks = []  # block copies packed gradient image -> TF-layout gradient slots (merged levels)
 
         def col_tiles(n, split6=0):
             """[(n0, tile width)] of a product with n output columns: one width per product.  split6 = tile-width hint of
@@ -1475,15 +1518,24 @@ class TowerPlan:
         per_width = {}  # width -> dict(segs, lists, macs, nbytes, tags)
         for e in pend:
             n = e["n"]
-            out_base = grads0 + e["w0"]
+            up = e.get("unpack")
+            if up is not None:
+                # the reduction target is the level's packed gradient image (dense per-offset blocks), scattered into the
+                # variables' gradient slots afterwards
+                self._alloc(up["buf"], e["slab"])
+                out_base = rel(self._ref(up["buf"]))
+                unpacks += [(out_base + so, grads0 + do, rows, cols, sld, dld, acc, 0)
+                            for (so, do, rows, cols, sld, dld, acc) in up["entries"]]
+            else:
+                out_base = grads0 + e["w0"]
             if e["S"] > 1:
                 c_base = rel(self._ref(sname, spos))
-                entries.append((c_base, out_base, e["slab"], e["slab"], e["S"], e["acc"]))
+                entries.append((c_base, out_base, e["slab"], e["slab"], e["S"], 0 if up is not None else e["acc"]))
                 spos += e["S"] * e["slab"]
                 flags = 0
             else:
                 c_base = out_base
-                flags = e["acc"]
+                flags = 0 if up is not None else e["acc"]
             a0, b0 = rel(e["a_ref"]), rel(e["b_ref"])
             tb = e["tb"]
             sp6 = self._split6(e["tag"], tb, n, 1, 0, 0, False, in_multi=True)
@@ -1491,7 +1543,9 @@ class TowerPlan:
             loc_groups = {}  # (width, locality key) -> [work, [(work, record)]]
             for gi, (c_off, gs, rows) in enumerate(tb.groups):
                 gn = tb.n_of(gi, n)
-                tiles = col_tiles(gn, sp6)
+                # a merged level's per-offset products differ in their column count: each takes the width class of ITS n
+                sp_g = sp6 if gn == n else (self._split6_width(gn) if sp6 and gn > GEMM_SPLIT_MIN_N else 0)
+                tiles = col_tiles(gn, sp_g)
                 ksum = sum(k for _, _, k in gs)
                 key = tb.keys[gi] if tb.keys[gi] is not None else 0
                 seg_begin = {}
@@ -1549,14 +1603,66 @@ class TowerPlan:
                        nbytes=4 * sum(cnt * (S + 1) for (_, _, _, cnt, S, _) in entries), tag="wgrad-reduce")
             l.meta = {"splits": [int(S) for (_, _, _, _, S, _) in entries]}
             self.bwd.append(l)
+        if unpacks:
+            from .backend import COPY_BLOCK_DTYPE
+            u_t = self.be.upload(np.array(unpacks, COPY_BLOCK_DTYPE))
+            self.tables.append(u_t)
+            self.bwd.append(Launch("copy_blocks_f32", (base, Ref(u_t), len(unpacks), max(u[2] * u[3] for u in unpacks)),
+                                   nbytes=8 * sum(u[2] * u[3] for u in unpacks), tag="level-unpack"))
     @staticmethod
     def _split_even(segs, S):
         """Partition a list into S contiguous chunks (some possibly empty)."""
         n = len(segs)
         return [segs[(n * s) // S:(n * (s + 1)) // S] for s in range(S)]
 
+    def _wgrad_level_merged(self, idx, node, lay, s_st, src, dy, c, h, w):
+        """Filter gradient of a merged level: per input offset d ONE product dW_pack[d] = sum_p X[p + d]^T dY[p][:, col0:]
+        with n = C - col0[ring] columns (30 .. 120 for the 30-filter HYPELCNN level instead of 30 per (branch, tap)), written
+        into a dense packed image; hypel_copy_blocks_f32 scatters the [Cin x cout] slices into the HWIO gradient slots."""
+        nb = self.nb
+        C, cin, co = lay["C"], lay["cin"], lay["co"]
+        group_list = []  # (offset of the block in the dense image, [(a_off, b_off)] pixel pairs, columns)
+        for d, (ofy, ofx, r) in enumerate(lay["offs"]):
+            col0 = lay["col0"][r]
+            pairs = [(s_st.pix_off((oy + ofy) * w + ox + ofx), (oy * w + ox) * nb * c + col0)
+                     for oy in range(h) for ox in range(w) if 0 <= oy + ofy < h and 0 <= ox + ofx < w]
+            group_list.append((lay["dense_off"][d], pairs, C - col0))
+        slab = lay["dense_size"]
+        blocks = sum(((cin + GEMM_BM - 1) // GEMM_BM) * ((n_d + 63) // 64) for _, _, n_d in group_list)
+        max_segs = max(len(prs) for _, prs, _ in group_list)
+
+        def build(S, group_list=group_list, slab=slab, rows=cin, lda=s_st.ld, ldb=c, npairs=max_segs):
+            tb = GemmTables()
+            for si, (p0, p1, r0, r1) in enumerate(self._split_ranges(S[0], S[1], npairs)):
+                for (loc, pairs, n_d) in group_list:
+                    q0, q1 = len(pairs) * p0 // npairs, len(pairs) * p1 // npairs
+                    segs = [(a + r0 * lda, b_ + r0 * ldb, r1 - r0) for (a, b_) in pairs[q0:q1]] if r1 > r0 else []
+                    tb.add_group(si * slab + loc, segs, rows, key=si, n=n_d)
+            return tb
+
+        ents = []
+        for bi, b in enumerate(node.branches):
+            acc = self._param_acc(b.w)
+            pb = (b.k - 1) // 2
+            for i in range(b.k):
+                for j in range(b.k):
+                    d = lay["index"][(i - pb, j - pb)]
+                    r = lay["offs"][d][2]
+                    n_d = C - lay["col0"][r]
+                    dst = b.w.offset + (i * b.k + j) * cin * co
+                    ents.append((lay["dense_off"][d] + (bi - lay["first"][r]) * co, dst, cin, co, n_d, co, acc))
+        self._emit_wgrad(build, blocks, max_segs, slab, 0, C, self._ref(s_st.buf), s_st.ld, dy, c,
+                         f"wgrad:{node.branches[0].scope}/merged", acc=0,
+                         unpack=dict(buf=f"dwpack:{idx}", entries=ents))
+
     def _wgrad_conv(self, idx, node, aux, s_st, src, dy, c, h, w):
         nb = self.nb
+        lay = self._level_pass(idx, node, "wgrad")
+        # (every offset of the largest kernel must meet at least one pixel pair, or its block of the packed image would
+        # never be written: (k - 1) / 2 <= min(h, w) - 1)
+        if lay is not None and max(b.k for b in node.branches) <= 2 * min(h, w) - 1:
+            self._wgrad_level_merged(idx, node, lay, s_st, src, dy, c, h, w)
+            return
         choff = 0
         w_base = aux["w0"].offset
         by_cout = {}

@@ -331,10 +331,19 @@ def test_grss2013_hypelcnn_batch1024_vs_oracle(hip):
     ct = U.run_train_step(built, x, onehot, masks)
     tags = _tags(ct)
     assert "tap-split-reduce" in tags and "wgrad-reduce" in tags and "splitk-reduce" in tags
-    # the default plan runs the narrowest level's forward and the data gradients of the levels with <= 32 filters per
-    # branch in the merged form
-    assert "level-pack" in tags and sum(1 for t in tags if t.startswith("fwd:") and t.endswith("/merged")) == 1 and \
-        sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 2, sorted(set(tags))
+    # the default plan (round 6): merged forward of the 30- and 15-filter levels, merged data gradients of all three levels,
+    # merged filter gradients of the 60- and 30-filter levels (packed image + scatter)
+    assert "level-pack" in tags and sum(1 for t in tags if t.startswith("fwd:") and t.endswith("/merged")) == 2 and \
+        sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 3, sorted(set(tags))
+    launches = ct.plan.fwd + ct.plan.bwd
+    merged_products = [p for l in launches if l.name == "seg_gemm_multi_f32" for p in l.meta["products"] if p.endswith("/merged")]
+    assert len(merged_products) >= 2 and "level-unpack" in tags, merged_products
+    # ... and it is the split-operand plan that is held to the oracle here: the heavy launches of every pass carry the flag
+    split = [l.tag for l in launches if l.name.startswith("seg_gemm") and
+             (l.args[3] & 0x100 if l.name == "seg_gemm_multi_f32" else l.args[14] & 0x8000)]
+    for must in ("fwd:conv_dec_0", "fwd:connector_0_conv1x1", "fwd:connector_1_conv1x1/merged", "dgrad:conv_dec_0",
+                 "dgrad:connector_0_conv1x1/merged", "dgrad:connector_1_conv1x1/merged", "wgrad-merged/s128", "wgrad-merged/s64"):
+        assert must in split, (must, split)
     ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 15, alg,
                                      tol_logit=1e-3, tol_grad=5e-4)
     got = ct.value(built.y_conv).cpu().numpy()

@@ -245,7 +245,8 @@ def test_filter_gradients_go_out_as_merged_launches(monkeypatch):
     torch.testing.assert_close(sess2.grads, g_merged, rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("passes,patch,fc", [("fwd", 7, 48), ("fwd,dgrad", 7, 48), ("fwd,dgrad", 5, 96), ("dgrad", 5, 48)])
+@pytest.mark.parametrize("passes,patch,fc", [("fwd", 7, 48), ("fwd,dgrad", 7, 48), ("fwd,dgrad", 5, 96), ("dgrad", 5, 48),
+                                             ("wgrad", 7, 96), ("fwd,dgrad,wgrad", 5, 480), ("fwd,dgrad,wgrad", 7, 48)])
 def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
     """Merged multi-kernel levels (include/hypel.h, HYPEL_GEMM_VAR_N): the nested branches of a level share one packed
     weight image; per output pixel and ring ONE product on the column range of the branches that contain the ring
@@ -256,6 +257,9 @@ def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
     monkeypatch.setattr(plan, "MAX_TAPS_PER_TILE", 5)
     monkeypatch.setattr(plan, "MERGE_LEVELS", set(passes.split(",")))
     monkeypatch.setattr(plan, "MERGE_LEVELS_MAX_COUT", 1 << 20)
+    monkeypatch.setattr(plan, "MERGE_WGRAD_MIN_COUT", 1)
+    monkeypatch.setattr(plan, "MERGE_WGRAD_MAX_COUT", 1 << 20)
+    monkeypatch.setattr(plan, "MERGE_SPLIT_KPARTS", True)
     if patch == 5:
         monkeypatch.setattr(plan, "L2_CHUNK_BYTES", 4096)  # channel parts in the merged forward
     alg = dict(ALG_H, filter_count=fc)
@@ -264,8 +268,12 @@ def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
     tags = _tags(ct)
     names = [l.name for l in ct.plan.fwd + ct.plan.bwd]
     for what in passes.split(","):
+        if what == "wgrad":  # the packed filter gradients travel in the merged multi-product launches + one scatter
+            prods = [p_ for l in ct.plan.bwd if l.name == "seg_gemm_multi_f32" for p_ in l.meta["products"]]
+            assert any(p_.endswith("/merged") for p_ in prods) and "level-unpack" in tags, (prods, tags)
+            continue
         assert any(t.startswith(what + ":") and t.endswith("/merged") for t in tags), (what, tags)
-    assert "level-pack" in tags and "copy_blocks_f32" in names
+    assert ("level-pack" in tags or passes == "wgrad") and "copy_blocks_f32" in names
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--filter", type=str, default="")
+    ap.add_argument("--with-reduce", action="store_true", help="also time the reduce_splits launches (partial copies of a level)")
     ap.add_argument("--workload", type=str, default="hypelcnn", choices=list(bench.CLASSIFIER_WORKLOADS))
     ap.add_argument("--timeline", action="store_true",
                     help="HYPEL_LIB_PATH build with -DHYPEL_GEMM_CLK=2: blocks inside their k loop over each launch "
@@ -37,7 +38,11 @@ def main():
     ct.set_input("labels", torch.nn.functional.one_hot(torch.randint(0, classes, (nb,)), classes).float().cuda())
     ct.forward_backward()  # fill every buffer with realistic data
     torch.cuda.synchronize()
-    items = [(l, f) for l, f in ct.serial_launches() if l.name.startswith("seg_gemm") and args.filter in l.tag]
+    items = [(l, f) for l, f in ct.serial_launches()
+             if (l.name.startswith("seg_gemm") and args.filter in l.tag) or (args.with_reduce and l.name.startswith("reduce_splits"))]
+    for i, (l, _) in enumerate(items):  # reduce launches share their tags: make them unique
+        if not l.name.startswith("seg_gemm"):
+            l.tag = f"{l.tag}#{i}"
     times = {l.tag: [] for l, _ in items}
     for r in range(args.rounds):
         for l, f in items:
@@ -76,6 +81,9 @@ def main():
         tot += med
         if med > 10:
             a = l.args
+            if not l.name.startswith("seg_gemm"):
+                print(f"{l.tag:34s} {'':7s}     med {med:8.1f} us  min {t.min():8.1f} us")
+                continue
             shape = f"  n={a[8]} tiles={a[12]} ta={a[2]} tb={a[5]}" if len(a) > 12 else f"  blocks={a[6]}"
             print(f"{l.tag:34s} {l.flops / 1e9:7.2f} GF  med {med:8.1f} us  min {t.min():8.1f} us  {l.flops / med / 1e6:6.1f} TF/s"
                   + shape + ("  SPLIT6" if (len(a) > 12 and a[14] & 0x8000) or (len(a) <= 12 and a[3] & 0x100) else ""))
