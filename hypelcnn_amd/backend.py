@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("HYPEL_LIB_PATH") or os.path.join(_HERE, "csrc", "libh
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 GEMM_BM = 128
-ABI_VERSION = 5  # include/hypel.h HYPEL_ABI_VERSION: a library built from other headers is refused at load time
+ABI_VERSION = 6  # include/hypel.h HYPEL_ABI_VERSION: a library built from other headers is refused at load time
 
 SEG_DTYPE = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("k", "<i4"), ("reserved", "<i4")])
 GROUP_DTYPE = np.dtype([("c_off", "<i8"), ("seg_begin", "<i4"), ("seg_count", "<i4"), ("rows", "<i4"),
@@ -39,7 +39,8 @@ REDUCE_ENTRY_DTYPE = np.dtype([("partial_off", "<i8"), ("out_off", "<i8"), ("str
                                ("n_splits", "<i4"), ("flags", "<i4")])
 TILE_DTYPE = np.dtype([("group", "<i4"), ("m0", "<i4"), ("rows", "<i4"), ("seg_begin", "<i4"), ("seg_count", "<i4"),
                        ("k0", "<i4"), ("c_off", "<i8"), ("a_off0", "<i8"), ("b_off0", "<i8"),
-                       ("reserved", "<i4"), ("n", "<i4")])
+                       ("flags", "<i4"), ("n", "<i4")])
+TILE_PLAIN = 1  # include/hypel.h HYPEL_TILE_PLAIN: K-slice partial (no bias / accumulate / shortcut gather)
 COPY_BLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("src_ld", "<i4"),
                              ("dst_ld", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
 

@@ -240,6 +240,11 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         tile = {t.a_off0, t.b_off0, t.k0};
         m0 = t.m0;
         if (t.n > 0) n = t.n;  // this tile's group has its own column count (merged multi-kernel levels)
+        if (t.flags & HYPEL_TILE_PLAIN) {  // K-slice partial: the plain sum into its own region (block-uniform)
+            bias = nullptr;
+            res = nullptr;
+            accumulate &= ~1;
+        }
     }
     const int rows_left = grp.rows - m0;  // valid rows in this tile (may exceed BM)
     if (rows_left <= 0) return;           // empty record (padding of an XCD's share of the table)

@@ -29,12 +29,16 @@ class GemmTables:
         self.keys = []  # optional locality key per group (tiles are ordered key-major)
         self.subkeys = []  # secondary locality key (phase inside a row chunk)
         self.ns = []  # per-group column count (0 = the launch's n): the ring groups of a merged multi-kernel level
+        self.flags = []  # per-group hypel_tile_t.flags (TILE_PLAIN: a K-slice partial)
+        self.tail = []   # per-group: dealt to the END of the XCDs' work lists (the K-slices of a launch, see finalize)
 
-    def add_group(self, c_off, segs, rows, key=None, subkey=0, n=0):
+    def add_group(self, c_off, segs, rows, key=None, subkey=0, n=0, flags=0, tail=False):
         self.groups.append((int(c_off), segs, int(rows)))
         self.keys.append(key)
         self.subkeys.append(subkey)
         self.ns.append(int(n))
+        self.flags.append(int(flags))
+        self.tail.append(bool(tail))
 
     def n_of(self, gi, n):
         return self.ns[gi] or n
@@ -78,9 +82,33 @@ class GemmTables:
             c_off, gs, rows = self.groups[g]
             sb, sc = int(garr[g]["seg_begin"]), len(gs)
             a0, b0, k0 = segs[sb][:3] if sc else (0, 0, 0)  # incl. the pair flag
-            return (g, m0, rows, sb, sc, k0, c_off, a0, b0, 0, self.ns[g])
+            return (g, m0, rows, sb, sc, k0, c_off, a0, b0, self.flags[g], self.ns[g])
 
-        recs = [record(g, m0) for (_, g, m0, _) in tiles]
+        if any(self.tail):
+            # K-slices (plan.py::_kslice): the kernel's XCD remap hands XCD x the x-th EIGHTH of the record array, in order.
+            # The ordinary tiles keep their order and are cut into eight contiguous shares; the slices -- the small pieces
+            # that are to fill the end of the launch -- are dealt heaviest first onto the XCD with the least work and go
+            # to the END of its share; shares are padded with empty records (rows = 0: the block exits) to one length.
+            main = [t for t in tiles if not self.tail[t[1]]]
+            extra = sorted((t for t in tiles if self.tail[t[1]]), key=lambda t: -t[0])
+            q, r = divmod(len(main), 8)
+            shares, pos = [], 0
+            for x in range(8):
+                cnt = q + (1 if x < r else 0)
+                shares.append(main[pos:pos + cnt])
+                pos += cnt
+            work = [sum(t[0] for t in sh) for sh in shares]
+            for t in extra:
+                x = min(range(8), key=lambda i: (work[i], i))
+                shares[x].append(t)
+                work[x] += t[0]
+            L = max(len(sh) for sh in shares)
+            empty = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+            recs = []
+            for sh in shares:
+                recs += [record(g, m0) for (_, g, m0, _) in sh] + [empty] * (L - len(sh))
+        else:
+            recs = [record(g, m0) for (_, g, m0, _) in tiles]
         sarr = np.array(segs, SEG_DTYPE) if segs else np.zeros(1, SEG_DTYPE)
         tarr = np.array(recs, TILE_DTYPE) if recs else np.zeros(0, TILE_DTYPE)
         return garr, sarr, tarr, macs

@@ -140,6 +140,22 @@ SPLIT_NOMINAL_BATCH = 1024  # batch the size rule prices a launch at (the kernel
 GEMM_SPLIT_MIN_N = 32
 SPLIT_OVERRIDE = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HYPEL_SPLIT_OVERRIDE", "").split(",") if kv)}
 PAIR_SEGS = True  # short data-gradient segments (k <= 16) share k-tiles
+# K-slice records for the split-operand kernels (include/hypel.h HYPEL_TILE_PLAIN; round-5 verdict item 1).  The 128-wide
+# split blocks have 512 resident slots (two per CU), a third of what the fp32 kernels had: a data gradient of 392 x 4 = 1 568
+# equal blocks runs 3.06 rounds and pays for 4, and the 392 blocks of a multi-kernel level's data gradient are all resident
+# at once and the launch lasts as long as its heaviest tile (the centre pixel sums 1.57x the mean).  The planner SIMULATES the
+# launch -- list scheduling of the blocks in table order on 64 slots per XCD -- for a few slicings (every tile above a K
+# threshold cut into equal slices; the tiles of each XCD's last, partly filled round cut into s slices) and takes the best
+# one if it beats the unsliced launch by KSLICE_MIN_GAIN.  Slices >= 1 write plain partials to scratch, one
+# hypel_reduce_splits_multi_f32 adds them in slice order.
+KSLICE = True
+KSLICE_MIN_GAIN = 0.10
+KSLICE_OVERHEAD_K = 24   # fixed cost of a block in reduction columns (prologue, pipeline fill, epilogue)
+KSLICE_MIN_K = 48        # shortest slice (reduction columns)
+KSLICE_MAX_SLICES = 16
+KSLICE_FRAC_MIN = 0.25   # smallest threshold (fraction of the launch's heaviest tile) above which tiles are sliced
+KSLICE_REDUCE_COST_K = 55  # the reduce launch behind a sliced launch (~6 us), in reduction columns of a 128 x 128 block
+KSLICE_SLOTS = {1: 768, 2: 512, 3: 512}  # resident blocks of the split kernels by tile-width hint (3 / 2 / 2 per CU)
 GEMM_MFMA16X4 = 0x2000  # include/hypel.h HYPEL_GEMM_MFMA16X4: 128x64 blocks on the 16x16x4 MFMA (merged level, <= 16 filters)
 GEMM_VAR_N = 0x4000     # ... HYPEL_GEMM_VAR_N: tile records carry their group's column count
 # Merged multi-kernel levels (include/hypel.h): the nested branches of a level share one packed weight image
@@ -158,8 +174,10 @@ MERGE_PASS_MAX_COUT = {"fwd": 16, "dgrad": 1 << 20, "wgrad": 1 << 20}
 # The merged FILTER GRADIENT (round 6, back from f4fd7b4^ for the split kernels): per input offset d ONE product
 # dW_pack[d] = sum_p X[p + d]^T dY[p][:, col0:] of C - col0[ring] columns into a dense packed image, scattered into the HWIO
 # gradient slots by hypel_copy_blocks_f32.  Columns per product grow from cout to up to 4 cout: the 30-filter level leaves the
-# fp32 pipe for every ring but the outermost.  Narrowest / widest branch (filters) it is used for:
-MERGE_WGRAD_MIN_COUT = 17
+# fp32 pipe for every ring but the outermost.  Same box (profiles/r6_exp_merged_wgrad.txt), sum of the four filter-gradient
+# launches of the H13 step: unmerged 1 324 us; levels of 60 + 30 filters merged 1 227; all three levels 1 187 (+ ~8 us for the
+# scatter); step 5.62 -> 5.53 ms with the first form.  Narrowest / widest branch (filters) it is used for:
+MERGE_WGRAD_MIN_COUT = 1
 MERGE_WGRAD_MAX_COUT = 64
 # ... and for the split-operand kernels, whose cost is dominated by staging A: sharing one staged A tile between the
 # branches of a ring pays for wider branches too
@@ -420,10 +438,137 @@ class TowerPlan:
             return 0
         return self._split6_width(n)
 
+    @staticmethod
+    def _kslice_makespan(shares, extra, slots):
+        """Simulated duration of a launch: shares = eight lists of block costs in dispatch order, extra = block costs dealt
+        heaviest first to the end of the least loaded share (GemmTables.finalize does the same); every XCD runs its list on
+        slots / 8 block slots, next block to the slot that frees first."""
+        import heapq
+        shares = [list(sh) for sh in shares]
+        work = [sum(sh) for sh in shares]
+        for c in sorted(extra, reverse=True):
+            x = min(range(8), key=lambda i: (work[i], i))
+            shares[x].append(c)
+            work[x] += c
+        per = max(1, slots // 8)
+        worst = 0.0
+        for sh in shares:
+            free = [0.0] * per
+            for c in sh:
+                t = heapq.heappop(free)
+                heapq.heappush(free, t + c)
+            worst = max(worst, max(free))
+        return worst
+
+    def _kslice(self, tables, n, ta, tb, lda, ldb, width_hint):
+        """Choose K-slices for a launch on the split kernels (see KSLICE above).  Returns None (leave the launch alone) or
+        {group index: number of slices}."""
+        groups = tables.groups
+        bn = {1: 32, 2: 64, 3: 128}[width_hint]
+        slots = KSLICE_SLOTS[width_hint]
+        ct = (n + bn - 1) // bn
+        ov = KSLICE_OVERHEAD_K
+        # tile records in dispatch order (GemmTables.finalize: key-major, heavy first), one entry per record
+        order = []
+        for gi, (c_off, gs, rows) in enumerate(groups):
+            ksum = sum(k for _, _, k in gs)
+            for m0 in range(0, rows, GEMM_BM):
+                key = (tables.keys[gi] if tables.keys[gi] is not None else m0 // GEMM_BM, tables.subkeys[gi])
+                order.append((key, -ksum * min(GEMM_BM, rows - m0), gi, ksum))
+        order.sort(key=lambda t: (t[0], t[1]))
+
+        def shares_of(recs):
+            q, r = divmod(len(recs), 8)
+            out, pos = [], 0
+            for x in range(8):
+                cnt = q + (1 if x < r else 0)
+                out.append(recs[pos:pos + cnt])
+                pos += cnt
+            return out
+
+        def evaluate(slices):  # slices: {gi: s}
+            main = [t for t in order if slices.get(t[2], 1) == 1]
+            extra, pieces = [], 0
+            for t in order:
+                s_ = slices.get(t[2], 1)
+                if s_ > 1:
+                    extra += [t[3] / s_ + ov] * (s_ * ct)
+                    pieces += (s_ - 1) * ct
+            sh = [[t[3] + ov for t in share for _ in range(ct)] for share in shares_of(main)]
+            # + what the partials cost: a 128 x bn partial is written, read back and added into the output (4 passes of
+            # 512 bn bytes at ~4 TB/s; one reduction column of a 128 x 128 block is ~0.11 us), + the reduce launch (~6 us)
+            traffic = pieces * (4 * 512 * bn / 4e12) / (0.11e-6 * bn / 128)
+            return self._kslice_makespan(sh, extra, slots) + (traffic + KSLICE_REDUCE_COST_K if pieces else 0)
+
+        base = evaluate({})
+        kmax = max(t[3] for t in order)
+        cands = []
+        for f in (0.75, 0.6, 0.5, 0.4, 0.33, 0.25):  # every tile above a threshold, in equal slices
+            if f < KSLICE_FRAC_MIN:
+                continue
+            T = max(kmax * f, KSLICE_MIN_K)
+            sl = {}
+            for gi, (c_off, gs, rows) in enumerate(groups):
+                ksum = sum(k for _, _, k in gs)
+                s_ = min(KSLICE_MAX_SLICES, -(-ksum // int(T)), max(1, ksum // KSLICE_MIN_K))
+                if s_ > 1:
+                    sl[gi] = s_
+            if sl:
+                cands.append(sl)
+        per = max(1, slots // 8)
+        single_tile_groups = all(rows <= GEMM_BM for _, _, rows in groups)
+        for s_ in (2, 3, 4, 6, 8, 12, 16):  # the tiles of each XCD's last, partly filled round
+            sl = {}
+            for share in shares_of(order):
+                tail_blocks = (len(share) * ct) % per
+                if tail_blocks == 0 or tail_blocks * s_ > per + per // 4:
+                    continue
+                for t in share[len(share) - (-(-tail_blocks // ct)):]:
+                    if t[3] // s_ >= KSLICE_MIN_K:
+                        sl[t[2]] = s_
+            if sl and single_tile_groups:  # (a group = one tile record there: slicing a group slices exactly that tile)
+                cands.append(sl)
+        best, best_t = None, base
+        for sl in cands:
+            t = evaluate(sl)
+            if t < best_t:
+                best, best_t = sl, t
+        if best is None or best_t > base * (1.0 - KSLICE_MIN_GAIN):
+            return None
+        return best
+
+    @staticmethod
+    def _group_per_tile(tables, lda, ldc):
+        """The same launch with one group per 128-row tile record (A not transposed: rows of A = rows of C)."""
+        out = GemmTables()
+        for gi, (c_off, gs, rows) in enumerate(tables.groups):
+            for m0 in range(0, rows, GEMM_BM):
+                key = tables.keys[gi] if tables.keys[gi] is not None else m0 // GEMM_BM
+                out.add_group(c_off + m0 * int(ldc), [(a + m0 * int(lda), b, k) for (a, b, k) in gs], min(GEMM_BM, rows - m0),
+                              key=key, subkey=tables.subkeys[gi])
+        return out
+
+    @staticmethod
+    def _cut_segments(gs, s_, a_ks, b_ks):
+        """Cut a segment list into s_ slices of (nearly) equal reduction length, at multiples of 16 columns inside a
+        segment; a_ks / b_ks = element distance of one reduction column in A / B."""
+        ktot = sum(k for _, _, k in gs)
+        cuts = [min(ktot, (ktot * i // s_ + 15) // 16 * 16) for i in range(s_)] + [ktot]
+        parts = [[] for _ in range(s_)]
+        base = 0
+        for (a_off, b_off, k) in gs:
+            for i in range(s_):
+                lo, hi = max(cuts[i], base), min(cuts[i + 1], base + k)
+                if hi > lo:
+                    parts[i].append((a_off + (lo - base) * a_ks, b_off + (lo - base) * b_ks, hi - lo))
+            base += k
+        return parts
+
     def _emit_gemm(self, lst, tables, n, a_ref, lda, ta, b_ref, ldb, tb, c_ref, ldc, bias_ref, accumulate, tag,
-                   allow_split=True, res=None, stats=None, pair=False, hint=None, flags=0):
+                   allow_split=True, res=None, stats=None, pair=False, hint=None, flags=0, kslice=False):
         """res = (ref, ld, start_ref or None): fold a shortcut gradient into the epilogue (hypel_seg_gemm_res_f32).
-        stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate)."""
+        stats = floats of the per-tile statistics scratch: hypel_seg_gemm_stats_f32 (single group, no accumulate).
+        kslice: the launch may be balanced with K-slice records (dense output, ldc = n)."""
         split = self._split_k(tables, n, lda, ta, ldb, tb, ldc) if allow_split and res is None else None
         if split is not None:
             stab, S, c_min, count = split
@@ -448,6 +593,14 @@ class TowerPlan:
         if sp6:
             pair, hint, single_seg = False, sp6, False
             accumulate = int(accumulate) | GEMM_SPLIT6
+        reduce_after = None
+        if (sp6 and kslice and KSLICE and stats is None and not flags and int(ldc) == int(n) and not (ta and tb)
+                and tables.groups and not any(tables.ns)):
+            # (one group per 128-row tile record first: a 1x1 convolution's data gradient is ONE group of 50 176 rows)
+            per_tile = tables if ta or all(rows <= GEMM_BM for _, _, rows in tables.groups) else self._group_per_tile(tables, lda, ldc)
+            slices = self._kslice(per_tile, n, ta, tb, lda, ldb, sp6)
+            if slices:
+                tables, reduce_after = self._apply_kslices(per_tile, slices, n, lda, ta, ldb, tb, c_ref, ldc, tag)
         garr, sarr, tarr, macs = tables.finalize(n, pair=pair)
         if len(tarr) == 0:
             return
@@ -472,6 +625,49 @@ class TowerPlan:
         if stats is not None:
             self._scratch(l, len(args) - 1, "scratch_partial", stats)
         lst.append(l)
+        if reduce_after is not None:
+            l.meta["kslices"] = reduce_after.meta["kslices"]
+            lst.append(reduce_after)
+
+    def _apply_kslices(self, tables, slices, n, lda, ta, ldb, tb, c_ref, ldc, tag):
+        """The tables with the chosen groups cut into K-slices + the launch that adds the partials to the output."""
+        from .backend import TILE_PLAIN
+        a_ks = int(lda) if ta else 1
+        b_ks = 1 if tb else int(ldb)
+        kid = self.__dict__.setdefault("_kslice_bufs", 0)
+        self._kslice_bufs = kid + 1
+        need = sum((s_ - 1) * tables.groups[gi][2] * int(ldc) for gi, s_ in slices.items())
+        sname = f"kslice:{kid}"
+        self._alloc(sname, need)
+        base = Ref(self.sess.params)
+
+        def rel(ref, to):
+            d = ref.ptr() - to.ptr()
+            assert d % 4 == 0
+            return d // 4
+
+        scratch_from_c = rel(self._ref(sname), c_ref)
+        out = GemmTables()
+        entries, spos = [], 0
+        for gi, (c_off, gs, rows) in enumerate(tables.groups):
+            s_ = slices.get(gi, 1)
+            if s_ == 1:
+                out.add_group(c_off, gs, rows, key=tables.keys[gi], subkey=tables.subkeys[gi])
+                continue
+            parts = self._cut_segments(gs, s_, a_ks, b_ks)
+            region = rows * int(ldc)
+            out.add_group(c_off, parts[0], rows, key=tables.keys[gi], subkey=tables.subkeys[gi], tail=True)
+            for i in range(1, s_):
+                out.add_group(scratch_from_c + spos + (i - 1) * region, parts[i], rows, flags=TILE_PLAIN, tail=True)
+            entries.append((rel(self._ref(sname, spos), base), rel(c_ref, base) + c_off, region, region, s_ - 1, 1))
+            spos += (s_ - 1) * region
+        earr = np.array(entries, REDUCE_ENTRY_DTYPE)
+        e_t = self.be.upload(earr)
+        self.tables.append(e_t)
+        red = Launch("reduce_splits_multi_f32", (base, Ref(e_t), int(len(earr))),
+                     nbytes=4 * sum(cnt * (S + 2) for (_, _, _, cnt, S, _) in entries), tag="kslice-reduce")
+        red.meta = {"kslices": {"tiles": len(entries), "slices": int(sum(slices.values())), "of": tag}}
+        return out, red
 
     def _dp_sync_node(self):
         """Data-parallel overlap: [(node index, lo, hi)] -- walking backward, the nodes after which the weight gradients
@@ -1286,7 +1482,7 @@ class TowerPlan:
                         tb.add_group(gst.pix_off(pin), segs, nb)
                     self._emit_gemm(self.bwd, tb, src.c, dy, c, 0, w_ref, w_ld or cout, 1,
                                     self._ref(gst.buf), gst.ld, None, acc, f"dgrad:{items[0][0].scope}{mtag}",
-                                    res=fold_res, pair=cout <= 16)
+                                    res=fold_res, pair=cout <= 16, kslice=True)
                     fold_res = None
                     acc = 1
             # ---- filter gradient ----

@@ -6,7 +6,10 @@ where the real packages are absent) with the few dozen functions the plugin file
 convolution1d / dropout / flatten / batch_norm / l2_regularizer / arg_scope`, `tf.concat / split / gather / repeat / squeeze /
 expand_dims / nn.local_response_normalization / math.l2_normalize`, the initialisers, tensors with `get_shape()[i].value`, `+`
 and slicing -- each forwarding to the ENGINE in force.  `GraphEngine` is the product's engine: every call lands in
-`hypelcnn_amd.graph` (conv2d, fully_connected, arg_scope semantics, batch norm, dropout, ChanMap, crops, LRN).
+`hypelcnn_amd.graph` (conv2d, fully_connected, arg_scope semantics, batch norm, dropout, ChanMap, crops, LRN, and the
+`tf.nn.softmax_cross_entropy_with_logits` / `tf.reshape` / `tf.square` / `tf.reduce_mean` calls of `get_loss_func`).
+The hijack is scoped: `installed(checkout)` is a context manager, `reference_model` enters it only while the reference's
+code is imported or executed, and only names that no installed package serves are stubbed.
 
     from hypelcnn_amd import tf_facade
     model = tf_facade.reference_model("HYPELCNNModel", "/path/to/hypelcnn")     # the reference checkout, unchanged
@@ -25,7 +28,7 @@ import types
 
 import numpy as np
 
-STUB_ROOTS = ("tensorflow", "tf_slim", "tifffile", "tqdm", "tensorflow_gan", "numba", "sklearn")
+STUB_ROOTS = ("tensorflow", "tf_slim", "tensorflow_gan", "tifffile", "tqdm", "numba", "sklearn", "optuna", "matplotlib")  # only those that are ABSENT get stubbed
 
 
 # ------------------------------------------------------------------------------------------------ permissive fallback
@@ -127,8 +130,47 @@ class GraphEngine:
         def __getitem__(self, sl):
             return self.eng.slice(self, sl)
 
+        def __sub__(self, other):  # image_output - reshape(image_original, [-1, F])  (HYPELCNNModel.py:108)
+            if not isinstance(other, GraphEngine.Reshaped):
+                raise RuntimeError("tensor subtraction is only the reconstruction error's on this path")
+            return GraphEngine.Diff(self, other)
+
+    class Reshaped:
+        """tf.reshape(patch tensor, [-1, H * W * C]) -- the flattened original of the reconstruction loss."""
+
+        def __init__(self, t):
+            self.t = t
+
+    class Diff:
+        def __init__(self, a, b):
+            self.a, self.b = a, b
+
+    class Squared:
+        def __init__(self, d):
+            self.d = d
+
     def wrap(self, sym):
         return GraphEngine.T(self, sym)
+
+    # -- the classifier plugins' loss (get_loss_func): the product's loss expressions
+    def softmax_xent(self, labels, logits):
+        return self.G.softmax_cross_entropy_with_logits(labels=labels, logits=logits.sym)
+
+    def loss_reshape(self, tensor, shape):
+        feats = tensor.sym.npix * tensor.sym.c
+        if len(shape) != 2 or _int(shape[0]) != -1 or _int(shape[1]) != feats:
+            raise RuntimeError(f"tf.reshape to {shape}: only the flattening [-1, {feats}] of the reconstruction loss is on the path")
+        return GraphEngine.Reshaped(tensor)
+
+    def loss_square(self, x):
+        if not isinstance(x, GraphEngine.Diff):
+            raise RuntimeError("tf.square is only the reconstruction error's on this path")
+        return GraphEngine.Squared(x)
+
+    def loss_reduce_mean(self, x):
+        if not isinstance(x, GraphEngine.Squared):
+            raise RuntimeError("tf.reduce_mean is only the reconstruction error's on this path")
+        return self.G.mean_squared_reconstruction(x.d.a.sym, x.d.b.t.sym)
 
     def _act(self, opts):
         G = self.G
@@ -362,9 +404,52 @@ def l2_normalize(x, **kw):
     return ENGINE[0].l2_normalize(x)
 
 
+# The four tf.* calls of the classifier plugins' get_loss_func (nnmodel/HYPELCNNModel.py:101-112, DUALCNNModel.py:87-89,
+# CONCNNModel.py:66-68): softmax cross entropy per sample, + the scalar mean of squares of (image_output -
+# reshape(image_original, [-1, F])) broadcast onto every sample.  Served through the engine like the layers.
+def loss_softmax_xent(labels=None, logits=None, **kw):
+    return ENGINE[0].softmax_xent(labels, logits)
+
+
+def loss_reshape(tensor, shape, **kw):
+    return ENGINE[0].loss_reshape(tensor, shape)
+
+
+def loss_square(x, **kw):
+    return ENGINE[0].loss_square(x)
+
+
+def loss_reduce_mean(input_tensor=None, axis=None, **kw):
+    assert axis is None
+    return ENGINE[0].loss_reduce_mean(input_tensor)
+
+
+def _absent(roots):
+    """The names among `roots` that no real installed package serves (checked with our finder out of the way)."""
+    import importlib.util
+    out = []
+    for r in roots:
+        if r in sys.modules and not isinstance(sys.modules[r], _Anything):
+            continue
+        try:
+            spec = importlib.util.find_spec(r)
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or isinstance(spec.loader, _Finder):
+            out.append(r)
+    return tuple(out)
+
+
 class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Serves the root packages in `roots` (and everything below them).  EXTRA_SETUP: callables(module) that test
+    infrastructure may add to give more stub modules a functional surface (tests/golden/tfgan_standin.py)."""
+    EXTRA_SETUP = []
+
+    def __init__(self, roots):
+        self.roots = tuple(roots)
+
     def find_spec(self, name, path, target=None):
-        if name.split(".")[0] in STUB_ROOTS:
+        if name.split(".")[0] in self.roots:
             return importlib.machinery.ModuleSpec(name, self, is_package=True)
         return None
 
@@ -380,8 +465,10 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             module.concat, module.split, module.gather, module.repeat = concat, split, gather, repeat
             module.sigmoid, module.squeeze, module.expand_dims = sigmoid, squeeze, expand_dims
             module.transpose = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("NCHW is not on the path"))
+            module.reshape, module.square, module.reduce_mean = loss_reshape, loss_square, loss_reduce_mean
         elif n == "tensorflow.nn":
             module.local_response_normalization = local_response_normalization
+            module.softmax_cross_entropy_with_logits = loss_softmax_xent
         elif n == "tensorflow.math":
             module.l2_normalize = l2_normalize
         elif n in ("tensorflow.initializers", "tensorflow.compat.v1.initializers"):
@@ -389,6 +476,8 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             module.zeros = zeros_initializer
         elif n == "tensorflow.compat.v1":
             module.name_scope = _Ctx
+        elif n == "tensorflow.compat.v1.losses":
+            module.add_loss = lambda *a, **k: None  # the classifier's train op differentiates the returned loss only
         elif n == "tensorflow.python.ops.gen_nn_ops":
             module.leaky_relu = leaky_relu
         elif n == "tensorflow.python.keras.activations":
@@ -402,38 +491,102 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             module.conv2d_transpose = conv2d_transpose
         elif n == "numba":
             module.jit = lambda *a, **k: (lambda f: f)
+        for fn in _Finder.EXTRA_SETUP:
+            fn(module)
 
 
-_INSTALLED = [False]
+_TF_SUBMODULES = ("nn", "math", "initializers", "compat", "compat.v1", "compat.v1.initializers", "compat.v1.losses", "python",
+                  "python.ops", "python.ops.gen_nn_ops", "python.keras", "python.keras.activations",
+                  "python.ops.initializers_ns")
+
+
+class installed:
+    """Context manager around IMPORTING and EXECUTING the reference's files: inside it `tensorflow`, `tf_slim` and the other
+    imports of the reference that no installed package serves resolve to this module's facade, the reference checkout is
+    importable, and `np.int` exists (the reference's own shim for numpy >= 1.24, common/common_nn_ops.py:21).  On exit
+    everything is undone -- the finder leaves sys.meta_path, the checkout leaves sys.path, the stub modules AND the modules
+    imported from the checkout (`common`, `nnmodel`, `gan`, ...) leave sys.modules (they are kept inside this object and come
+    back on the next entry), modules they had shadowed are restored.  A process that builds a model through
+    `reference_model()` can therefore go on importing sklearn / tqdm / its own `common` package as if nothing had happened
+    (round-5 advisor finding: the hijack used to be permanent and stubbed installed packages)."""
+
+    def __init__(self, reference_root=None):
+        if reference_root is not None and not os.path.isdir(reference_root):
+            raise RuntimeError(f"no reference checkout at {reference_root}")
+        self.root = None if reference_root is None else os.path.abspath(reference_root)
+        self.modules = {}     # ours: stub modules + modules loaded from the checkout
+        self.finder = None
+        self.depth = 0
+
+    def _ours(self, m):
+        if isinstance(m, _Anything):
+            return True
+        f = getattr(m, "__file__", None) or ""
+        if self.root is not None and f and os.path.abspath(f).startswith(self.root + os.sep):
+            return True
+        # namespace packages of the checkout (directories without __init__.py) carry only __path__
+        paths = [os.path.abspath(q) for q in list(getattr(m, "__path__", []) or [])] if f == "" else []
+        return self.root is not None and any(q.startswith(self.root) for q in paths)
+
+    def __enter__(self):
+        self.depth += 1
+        if self.depth > 1:
+            return self
+        import importlib
+        if self.finder is None:
+            self.finder = _Finder(_absent(STUB_ROOTS))
+        self.shadowed = {k: sys.modules.pop(k) for k in list(self.modules) if k in sys.modules}
+        sys.modules.update(self.modules)
+        sys.meta_path.insert(0, self.finder)
+        self.path_added = self.root is not None and self.root not in sys.path
+        if self.path_added:
+            sys.path.insert(0, self.root)
+        self.np_int_added = not hasattr(np, "int")
+        if self.np_int_added:
+            np.int = int
+        if "tensorflow" in self.finder.roots and "tensorflow" not in self.modules:
+            # submodules are pre-imported so that `tf.nn.x` / `tf.compat.v1.y` resolve to the functional pieces
+            tf = importlib.import_module("tensorflow")
+            for sub in _TF_SUBMODULES:
+                m = importlib.import_module("tensorflow." + sub)
+                parent = tf
+                parts = sub.split(".")
+                for q in parts[:-1]:
+                    parent = getattr(parent, q)
+                setattr(parent, parts[-1], m)
+            for r in ("tf_slim", "numba"):
+                if r in self.finder.roots:
+                    importlib.import_module(r)
+        return self
+
+    def __exit__(self, *exc):
+        self.depth -= 1
+        if self.depth > 0:
+            return False
+        for k, m in list(sys.modules.items()):
+            if m is not None and self._ours(m):
+                self.modules[k] = sys.modules.pop(k)
+        sys.modules.update(self.shadowed)
+        self.shadowed = {}
+        if self.finder in sys.meta_path:
+            sys.meta_path.remove(self.finder)
+        if self.path_added and self.root in sys.path:
+            sys.path.remove(self.root)
+        if self.np_int_added and hasattr(np, "int"):
+            del np.int
+        return False
+
+
+_PERMANENT = []
 
 
 def install(reference_root=None):
-    """Serve tensorflow / tf_slim (and the other absent imports of the reference) from this module; put the reference
-    checkout on sys.path when given.  Submodules are pre-imported so that `tf.nn.x` / `tf.compat.v1.y` resolve to the
-    functional pieces."""
-    if reference_root is not None:
-        if not os.path.isdir(reference_root):
-            raise RuntimeError(f"no reference checkout at {reference_root}")
-        if reference_root not in sys.path:
-            sys.path.insert(0, reference_root)
-    if _INSTALLED[0]:
-        return
-    sys.meta_path.insert(0, _Finder())
-    import importlib
-    tf = importlib.import_module("tensorflow")
-    for sub in ("nn", "math", "initializers", "compat", "compat.v1", "compat.v1.initializers", "python",
-                "python.ops", "python.ops.gen_nn_ops", "python.keras", "python.keras.activations",
-                "python.ops.initializers_ns"):
-        m = importlib.import_module("tensorflow." + sub)
-        parent = tf
-        parts = sub.split(".")
-        for p in parts[:-1]:
-            parent = getattr(parent, p)
-        setattr(parent, parts[-1], m)
-    importlib.import_module("tf_slim")
-    importlib.import_module("numba")
-    np.int = int  # the reference's own shim (common/common_nn_ops.py:21) for numpy >= 1.24
-    _INSTALLED[0] = True
+    """Process-wide, never undone: for the fixture generators and subprocess tests under tests/golden (a fresh interpreter
+    per run).  Product code uses `installed(...)` / `reference_model(...)`, which clean up after themselves."""
+    ctx = installed(reference_root)
+    ctx.__enter__()
+    _PERMANENT.append(ctx)
+    return ctx
 
 
 class use_engine:
@@ -451,37 +604,44 @@ class use_engine:
 
 
 class ReferenceModel:
-    """The NNModel contract (`nnmodel/NNModel.py`) served by the REFERENCE's plugin file: `create_tensor_graph` executes the
-    reference's text through the facade into the Tower its input tensor belongs to; `get_loss_func` is the product plugin's
-    (the reference's builds its loss from `tf.nn` / `tf.losses` calls, which are not part of the facade)."""
+    """The NNModel contract (`nnmodel/NNModel.py`) served by the REFERENCE's plugin file, whole: `create_tensor_graph` executes
+    the reference's text through the facade into the Tower its input tensor belongs to, and `get_loss_func` executes the
+    reference's own (`nnmodel/HYPELCNNModel.py:101-112`, `DUALCNNModel.py:87-89`, `CONCNNModel.py:66-68`: its `tf.nn` /
+    `tf.reshape` / `tf.square` / `tf.reduce_mean` calls land on the product's loss expressions).  The import hijack lives only
+    while the reference's code is being imported or executed (`installed`)."""
 
     def __init__(self, model_name, reference_root):
-        install(reference_root)
         import importlib
         from .common import common_nn_ops as P
-        mod = importlib.import_module("nnmodel." + model_name)
-        if not getattr(mod, "__file__", "").startswith(os.path.abspath(reference_root)):
-            raise RuntimeError(f"nnmodel.{model_name} resolved to {getattr(mod, '__file__', None)}, not to the reference checkout")
-        self.reference = getattr(mod, model_name)()
-        self.product = P.get_model_from_name(model_name)
+        self._ctx = installed(reference_root)
+        with self._ctx:
+            mod = importlib.import_module("nnmodel." + model_name)
+            if not os.path.abspath(getattr(mod, "__file__", "") or "").startswith(os.path.abspath(reference_root) + os.sep):
+                raise RuntimeError(f"nnmodel.{model_name} resolved to {getattr(mod, '__file__', None)}, not to the reference checkout")
+            self.reference = getattr(mod, model_name)()
+            self.ref_ops = importlib.import_module("common.common_nn_ops")  # the reference's own value objects
+        self.product_ops = P
         self.name = model_name
 
     def create_tensor_graph(self, model_input_params, class_count, algorithm_params):
-        from .common import common_nn_ops as P
-        import importlib
-        ref_ops = importlib.import_module("common.common_nn_ops")  # the reference's own value objects
         x = model_input_params.x
         eng = GraphEngine(x.tower)
-        with use_engine(eng):
+        with self._ctx, use_engine(eng):
             out = self.reference.create_tensor_graph(
-                ref_ops.ModelInputParams(x=eng.wrap(x), y=None, device_id=model_input_params.device_id,
-                                         is_training=model_input_params.is_training), class_count, algorithm_params)
+                self.ref_ops.ModelInputParams(x=eng.wrap(x), y=None, device_id=model_input_params.device_id,
+                                              is_training=model_input_params.is_training), class_count, algorithm_params)
         sym = lambda t: None if t is None else t.sym  # noqa: E731
-        return P.ModelOutputTensors(y_conv=out.y_conv.sym, image_output=sym(getattr(out, "image_output", None)),
-                                    image_original=sym(getattr(out, "image_original", None)), histogram_tensors=[])
+        return self.product_ops.ModelOutputTensors(
+            y_conv=out.y_conv.sym, image_output=sym(getattr(out, "image_output", None)),
+            image_original=sym(getattr(out, "image_original", None)), histogram_tensors=[])
 
-    def get_loss_func(self, *a, **k):
-        return self.product.get_loss_func(*a, **k)
+    def get_loss_func(self, tensor_output, label):
+        eng = GraphEngine(tensor_output.y_conv.tower)
+        wrap = lambda t: None if t is None else eng.wrap(t)  # noqa: E731
+        with self._ctx, use_engine(eng):
+            out = self.ref_ops.ModelOutputTensors(y_conv=wrap(tensor_output.y_conv), image_output=wrap(tensor_output.image_output),
+                                                  image_original=wrap(tensor_output.image_original), histogram_tensors=[])
+            return self.reference.get_loss_func(out, label)
 
 
 def reference_model(model_name, reference_root):

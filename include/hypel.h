@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* hypel_stream_t; /* hipStream_t */
 
-#define HYPEL_ABI_VERSION 5  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
+#define HYPEL_ABI_VERSION 6  /* bump whenever a prototype, a struct layout or the meaning of a flag changes */
 
 /* activation codes (leaky_relu: HYPELCNNModel.py:39, DUALCNNModel.py:18, shadow_data_models.py:53;
  * relu: tf_slim default, CONCNNModel.py; sigmoid: HYPELCNNModel.py:93; tanh: shadow_data_models.py:86) */
@@ -75,9 +75,17 @@ typedef struct {
     int32_t group; int32_t m0;                         /* output rows [m0, min(m0 + 128, rows)) of groups[group] */
     int32_t rows; int32_t seg_begin; int32_t seg_count; /* copies of groups[group] */
     int32_t k0; int64_t c_off; int64_t a_off0; int64_t b_off0; /* c_off copy; segs[seg_begin] copy (0 if none) */
-    int32_t reserved; int32_t n;                       /* n > 0: THIS tile's group has n output columns (<= the launch's n) */
+    int32_t flags; int32_t n;                          /* HYPEL_TILE_*; n > 0: THIS tile's group has n output columns (<= the launch's n) */
 } hypel_tile_t;
 #define HYPEL_GEMM_BM 128
+/* K-slice records (round 6; tail splitting for the 512-slot split-operand kernels): the segment list of a heavy output tile
+ * -- or of the last, partly filled round of a launch -- is cut into slices that run as blocks of their own.  Slice 0 is an
+ * ordinary record of the launch (bias, accumulate, shortcut gather apply to it); the other slices carry HYPEL_TILE_PLAIN:
+ * their block writes its partial sum to its own c_off (a scratch region, addressed relative to `c` like every c_off)
+ * and IGNORES the launch's bias / accumulate bit / shortcut operands.  The caller adds the partials to the output in a
+ * fixed order afterwards (hypel_reduce_splits_multi_f32, accumulate flag set): deterministic, no atomics.  Not valid in
+ * hypel_seg_gemm_stats_f32 launches and with HYPEL_GEMM_ACT_* (their epilogues need the whole sum). */
+#define HYPEL_TILE_PLAIN 1
 /* Short segments (data gradients through convolutions with <= 16 filters: K = 15 in the narrowest HYPELCNN level):
  * a segment whose `k` has HYPEL_SEG_PAIR_FLAG set (real k = k & ~flag, <= 16) shares ONE 32-column k-tile with the
  * NEXT segment of its group (k <= 16, flag clear); the tile record's k0 copy carries the flag too.  Launches whose

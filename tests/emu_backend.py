@@ -209,7 +209,8 @@ class EmuBackend:
         g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
         t = tiles.t.numpy()[tiles.off:].view(TILE_DTYPE)[:n_tiles]
         st = None if res_start is None else _arr(res_start, np.int32)[: n + 1]
-        for gi in sorted({int(tt["group"]) for tt in t}):
+        plain = {int(tt["group"]) for tt in t if int(tt["rows"]) and int(tt["flags"]) & 1}  # HYPEL_TILE_PLAIN: no gather
+        for gi in sorted({int(tt["group"]) for tt in t if int(tt["rows"])} - plain):
             rows, co = int(g[gi]["rows"]), int(g[gi]["c_off"])
             cm = np.lib.stride_tricks.as_strided(C[co:], (rows, n), (ldc * 4, 4))
             r0 = co // ldc
@@ -227,6 +228,7 @@ class EmuBackend:
         self.k_seg_gemm_f32(a, lda, ta, b, ldb, tb, c, ldc, n, groups, segs, tiles, n_tiles, bias, accumulate)
         g = groups.t.numpy()[groups.off:].view(GROUP_DTYPE)
         t = tiles.t.numpy()[tiles.off:].view(TILE_DTYPE)[:n_tiles]
+        assert not any(int(tt["flags"]) for tt in t), "HYPEL_TILE_PLAIN records are not valid in a statistics launch"
         gis = {int(tt["group"]) for tt in t}
         assert len(gis) == 1, "statistics epilogue: single-group launches only"
         grp = g[gis.pop()]
@@ -244,10 +246,15 @@ class EmuBackend:
         seen = {}
         any_split = False
         group_n = {}  # hypel_tile_t.n: a group's own column count (merged levels); every tile of a group agrees
+        group_plain = {}  # hypel_tile_t.flags & HYPEL_TILE_PLAIN: K-slice partial (no bias / accumulate / activation)
         for tt in t:
             if int(tt["rows"]) != 0:
                 gn = int(tt["n"])
                 assert 0 <= gn <= n and group_n.setdefault(int(tt["group"]), gn) == gn, "per-tile n"
+                pl = int(tt["flags"]) & 1
+                assert int(tt["flags"]) in (0, 1) and group_plain.setdefault(int(tt["group"]), pl) == pl, "per-tile flags"
+        if any(group_plain.values()):
+            assert not ((accumulate_raw >> 16) & 7), "HYPEL_TILE_PLAIN records are not valid with HYPEL_GEMM_ACT_*"
         if any(group_n.values()):
             assert accumulate_raw & 0x4000, "tile records with their own n need HYPEL_GEMM_VAR_N"
         if accumulate_raw & 0x2000:
@@ -304,8 +311,10 @@ class EmuBackend:
                     bm = np.lib.stride_tricks.as_strided(B[bo:], (k, n), (ldb * 4, 4))
                 acc += am.astype(np.float64) @ bm.astype(np.float64)
             co = int(grp["c_off"])
-            cm = np.lib.stride_tricks.as_strided(C[co:], (rows, n), (ldc * 4, 4))
-            if bv is not None:
+            # (c_off may point into another allocation: the K-slice partials live in a scratch buffer)
+            cm = np.lib.stride_tricks.as_strided(_at(c, co, (rows - 1) * ldc + n), (rows, n), (ldc * 4, 4))
+            plain = bool(group_plain.get(gi))
+            if bv is not None and not plain:
                 col0 = co % ldc
                 acc += bv[col0:col0 + n]
             act_idx = (accumulate_raw >> 16) & 7  # HYPEL_GEMM_ACT_*: leaky-ReLU of (product + bias)
@@ -314,7 +323,7 @@ class EmuBackend:
                     not (accumulate_raw & 0x6000), "HYPEL_GEMM_ACT_*: plain forward products only"
                 alpha = np.float32([0.0, 0.1, 0.18, 0.2, 0.01][act_idx]).astype(np.float64)
                 acc = np.where(acc > 0, acc, alpha * acc)
-            if accumulate:
+            if accumulate and not plain:
                 cm += acc.astype(np.float32)
             else:
                 cm[...] = acc.astype(np.float32)

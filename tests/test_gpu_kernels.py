@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from hypelcnn_amd.backend import GROUP_DTYPE, SEG_DTYPE, TILE_DTYPE, Ref
-from hypelcnn_amd.plan import GemmTables
+from hypelcnn_amd.plan import GemmTables, TowerPlan
 from tests import emu_backend
 from tests.emu_backend import EmuBackend
 
@@ -1444,3 +1444,58 @@ def test_loss_terms_slots(hip):
         b.run("loss_finalize_slots", "slots", 4, "loss", acc)
     b.check("arena", rtol=1e-5, atol=1e-6)
     b.check("loss", rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("split,hint,with_res,acc", [(True, 3, True, 1), (True, 2, False, 0), (True, 1, True, 0),
+                                                     (False, 2, True, 1), (False, 1, False, 1)])
+def test_seg_gemm_kslice_plain_records(hip, split, hint, with_res, acc):
+    """K-slice records (HYPEL_TILE_PLAIN): a data gradient over 5 pixels whose heavy tiles are cut into slices -- slice 0 keeps
+    the launch's accumulate bit / bias-less shortcut gather, the other slices write plain partials into a scratch region
+    addressed relative to C, tail records dealt to the end of the eight XCD shares with empty padding records; then
+    hypel_reduce_splits_multi_f32 adds the partials.  Against the emulation, and the sum against the unsliced launch."""
+    rng = np.random.default_rng(5 + hint)
+    nb, P, cin, cout = 200, 5, 120, 60
+    rows = P * nb
+    dy = (rng.standard_normal((rows, cout)) * 0.5).astype(np.float32)
+    dz = rng.standard_normal((rows, cin)).astype(np.float32)
+    w = (rng.standard_normal((9, cin, cout)) * 0.5).astype(np.float32)
+    dx0 = rng.standard_normal((rows, cin)).astype(np.float32)
+    nseg = [9, 4, 6, 9, 2]
+    base_groups = [(p * nb * cin, [(((p + s) % P) * nb * cout, s * cin * cout, cout) for s in range(nseg[p])], nb)
+                   for p in range(P)]
+    region = nb * cin
+    scratch0 = rows * cin  # the partials live behind the output in the same test buffer
+    tb = GemmTables()
+    entries, spos = [], 0
+    for p, (c_off, gs, r) in enumerate(base_groups):
+        s_ = 3 if len(gs) == 9 else (2 if len(gs) == 6 else 1)
+        if s_ == 1:
+            tb.add_group(c_off, gs, r)
+            continue
+        parts = TowerPlan._cut_segments(gs, s_, 1, 1)
+        tb.add_group(c_off, parts[0], r, tail=True)
+        for i in range(1, s_):
+            tb.add_group(scratch0 + spos + (i - 1) * region, parts[i], r, flags=1, tail=True)
+        entries.append((scratch0 + spos, c_off, region, region, s_ - 1, 1))
+        spos += (s_ - 1) * region
+    garr, sarr, tarr, _ = tb.finalize(cin)
+    assert len(tarr) % 8 == 0 and (tarr["flags"] & 1).sum() == 2 * 2 * 2 + 1 * 2  # two row tiles per pixel
+    g0, s0, t0, _ = _tables(None, base_groups).finalize(cin)
+    flags = (SPLIT6 if split else 0) | (hint << 8) | acc
+    from hypelcnn_amd.backend import REDUCE_ENTRY_DTYPE
+    b = Both(hip)
+    buf = np.concatenate([dx0.ravel(), np.full(spos, 7.0, np.float32)])  # (the partials must not depend on what is there)
+    for nm, arr in (("dy", dy), ("dz", dz), ("w", w), ("y", buf), ("yref", dx0.ravel().copy()), ("g", garr), ("s", sarr),
+                    ("t", tarr), ("g0", g0), ("s0", s0), ("t0", t0), ("e", np.array(entries, REDUCE_ENTRY_DTYPE))):
+        b.arr(nm, arr)
+    if with_res:
+        b.run("seg_gemm_res_f32", "dy", cout, 0, "w", cout, 1, "y", cin, cin, "g", "s", "t", len(tarr), None, flags, "dz", cin, None)
+        b.run("seg_gemm_res_f32", "dy", cout, 0, "w", cout, 1, "yref", cin, cin, "g0", "s0", "t0", len(t0), None, flags, "dz", cin, None)
+    else:
+        b.run("seg_gemm_f32", "dy", cout, 0, "w", cout, 1, "y", cin, cin, "g", "s", "t", len(tarr), None, flags)
+        b.run("seg_gemm_f32", "dy", cout, 0, "w", cout, 1, "yref", cin, cin, "g0", "s0", "t0", len(t0), None, flags)
+    b.run("reduce_splits_multi_f32", "y", "e", len(entries))
+    b.check("y", rtol=2e-4, atol=2e-5)
+    got = b.h["y"].cpu().numpy()[:rows * cin]
+    want = b.h["yref"].cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * float(np.abs(want).max()))

@@ -331,13 +331,13 @@ def test_grss2013_hypelcnn_batch1024_vs_oracle(hip):
     ct = U.run_train_step(built, x, onehot, masks)
     tags = _tags(ct)
     assert "tap-split-reduce" in tags and "wgrad-reduce" in tags and "splitk-reduce" in tags
-    # the default plan (round 6): merged forward of the 30- and 15-filter levels, merged data gradients of all three levels,
-    # merged filter gradients of the 60- and 30-filter levels (packed image + scatter)
+    # the default plan (round 6): merged forward of the 30- and 15-filter levels, merged data gradients and merged filter
+    # gradients (packed image + scatter) of all three levels
     assert "level-pack" in tags and sum(1 for t in tags if t.startswith("fwd:") and t.endswith("/merged")) == 2 and \
         sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 3, sorted(set(tags))
     launches = ct.plan.fwd + ct.plan.bwd
     merged_products = [p for l in launches if l.name == "seg_gemm_multi_f32" for p in l.meta["products"] if p.endswith("/merged")]
-    assert len(merged_products) >= 2 and "level-unpack" in tags, merged_products
+    assert len(set(merged_products)) == 3 and "level-unpack" in tags, merged_products
     # ... and it is the split-operand plan that is held to the oracle here: the heavy launches of every pass carry the flag
     split = [l.tag for l in launches if l.name.startswith("seg_gemm") and
              (l.args[3] & 0x100 if l.name == "seg_gemm_multi_f32" else l.args[14] & 0x8000)]
@@ -353,20 +353,25 @@ def test_grss2013_hypelcnn_batch1024_vs_oracle(hip):
 
 @pytest.mark.parametrize("nb", [64, 1024])
 def test_grss2013_hypelcnn_every_level_pass_merged_vs_oracle(hip, monkeypatch, nb):
-    """The merged form of the multi-kernel levels forced for ALL three levels, forward and data gradient (forward on
-    blocks with per-tile column counts -- 16x16x4 MFMA for the 15-filter level, the split-operand kernels for the wide
-    ones --, merged data-gradient segments) at the benchmark's shapes, against the float64 oracle."""
+    """The merged form of the multi-kernel levels forced for ALL three levels and all three passes (forward on blocks with
+    per-tile column counts -- 16x16x4 MFMA for the 15-filter level, the split-operand kernels for the wide ones --, merged
+    data-gradient segments, per-offset filter gradients into a packed image + scatter) at the benchmark's shapes, against the
+    float64 oracle."""
     from hypelcnn_amd import plan
-    monkeypatch.setattr(plan, "MERGE_LEVELS", {"fwd", "dgrad"})
+    monkeypatch.setattr(plan, "MERGE_LEVELS", {"fwd", "dgrad", "wgrad"})
     monkeypatch.setattr(plan, "MERGE_LEVELS_MAX_COUT", 1 << 20)
-    monkeypatch.setattr(plan, "MERGE_PASS_MAX_COUT", {"fwd": 1 << 20, "dgrad": 1 << 20})
+    monkeypatch.setattr(plan, "MERGE_PASS_MAX_COUT", {"fwd": 1 << 20, "dgrad": 1 << 20, "wgrad": 1 << 20})
+    monkeypatch.setattr(plan, "MERGE_WGRAD_MIN_COUT", 1)
+    monkeypatch.setattr(plan, "MERGE_WGRAD_MAX_COUT", 1 << 20)
     alg = _alg("alg_param_hypelcnn.json")
     built, sess, params, x, onehot, masks = _case(hip, "HYPELCNNModel", 7, 145, 15, alg, nb, 78)
     ct = U.run_train_step(built, x, onehot, masks)
     tags = _tags(ct)
     assert sum(1 for t in tags if t.startswith("fwd:") and t.endswith("/merged")) == 3, sorted(set(tags))
     assert sum(1 for t in tags if t.startswith("dgrad:") and t.endswith("/merged")) == 3
-    assert "level-pack" in tags
+    assert "level-pack" in tags and "level-unpack" in tags
+    merged_products = {p for l in ct.plan.bwd if l.name == "seg_gemm_multi_f32" for p in l.meta["products"] if p.endswith("/merged")}
+    assert len(merged_products) == 3, merged_products  # the packed filter gradients of all three levels
     ref, err, worst = U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 15, alg,
                                      tol_logit=1e-3, tol_grad=5e-4)
     got = ct.value(built.y_conv).cpu().numpy()

@@ -277,3 +277,32 @@ def test_merged_levels_match_oracle(monkeypatch, passes, patch, fc):
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 
+
+
+@pytest.mark.parametrize("frac_min", [0.25, 0.75])
+def test_kslice_records_match_oracle(monkeypatch, frac_min):
+    """K-slice records (include/hypel.h HYPEL_TILE_PLAIN) forced onto the data gradients of a toy HYPELCNN: heavy tiles of the
+    multi-kernel levels cut into slices and the tail tiles of the 1x1 stack's launches, slice 0 with the folded shortcut
+    gather / accumulate bit, the others as plain partials in scratch, one reduce launch adding them in slice order; the
+    whole step still equals the oracle."""
+    from hypelcnn_amd import plan
+    monkeypatch.setattr(plan, "GEMM_SPLIT", 6)
+    monkeypatch.setattr(plan, "GEMM_SPLIT_MIN_FLOPS", 0.0)
+    monkeypatch.setattr(plan, "KSLICE_MIN_GAIN", -10.0)   # take the best candidate whatever it is worth here
+    monkeypatch.setattr(plan, "KSLICE_MIN_K", 4)
+    monkeypatch.setattr(plan, "KSLICE_OVERHEAD_K", 1)
+    monkeypatch.setattr(plan, "KSLICE_REDUCE_COST_K", 0)
+    monkeypatch.setattr(plan, "KSLICE_FRAC_MIN", frac_min)
+    monkeypatch.setattr(plan, "KSLICE_SLOTS", {1: 8, 2: 8, 3: 8})
+    alg = dict(ALG_H, filter_count=400)
+    built, sess, params, x, onehot, masks = _case("HYPELCNNModel", 5, 40, 4, alg, 150, 31)
+    ct = U.run_train_step(built, x, onehot, masks)
+    tags = _tags(ct)
+    sliced = [l for l in ct.plan.bwd if l.meta.get("kslices") and l.name.startswith("seg_gemm")]
+    assert "kslice-reduce" in tags and sliced, tags
+    assert any(l.name == "seg_gemm_res_f32" for l in sliced), "no sliced launch with a folded shortcut gradient"
+    from hypelcnn_amd.backend import TILE_DTYPE
+    for l in sliced:  # every sliced launch carries plain records and padding to eight equal shares
+        t = l.args[11].t.numpy()[l.args[11].off:].view(TILE_DTYPE)[:l.args[12]]
+        assert (t["flags"] & 1).any() and len(t) % 8 == 0
+    U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)

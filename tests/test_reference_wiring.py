@@ -283,3 +283,47 @@ print("FACADE_OK", a.size)
 """ % (ROOT, json.dumps([model_name, patch, ch, classes, alg, nb]))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert "FACADE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference checkout exists in the build container only")
+def test_facade_hijack_is_scoped_and_leaves_the_process_clean():
+    """Round-5 advisor finding: `reference_model()` used to leave a permissive stub finder at sys.meta_path[0], the checkout on
+    sys.path and stub `sklearn` / `tqdm` modules behind.  Now: after building a model (and its loss, through the REFERENCE's
+    own get_loss_func) nothing of it is left in the import system, installed packages import as themselves, and the product's
+    data split (which imports sklearn lazily) works in the same process."""
+    code = """
+import sys, importlib
+sys.path.insert(0, %r)
+before_path, before_meta = list(sys.path), list(sys.meta_path)
+from hypelcnn_amd import tf_facade, graph as G
+from hypelcnn_amd.common import common_nn_ops as P
+m = tf_facade.reference_model("HYPELCNNModel", "/root/reference")
+alg = {"drop_out_ratio": 0.7, "filter_count": 48, "lrelu_alpha": 0.18, "bn_decay": 0.95, "l2regularizer_scale": 1e-5,
+       "spectral_hierarchy_level": 3, "spatial_hierarchy_level": 3, "degradation_coeff": 3, "use_residual": True}
+tower = G.Tower(G.VariableStore("nn_core"), True)
+x = tower.placeholder("x", (5, 5), 11)
+out = m.create_tensor_graph(P.ModelInputParams(x=x, y=None, device_id="/gpu:0", is_training=True), 4, alg)
+labels = tower.placeholder("labels", None, 4)
+loss = m.get_loss_func(out, labels)                      # the reference's own text (HYPELCNNModel.py:101-112)
+ref = P.get_model_from_name("HYPELCNNModel").get_loss_func(out, labels)
+assert type(loss) is type(ref) is G.PerSampleXent and loss.extra_mse is not None and ref.extra_mse is not None
+assert loss.logits is ref.logits and loss.labels is ref.labels
+assert loss.extra_mse.a is ref.extra_mse.a and [s for s in loss.extra_mse.b.sources] == [s for s in ref.extra_mse.b.sources]
+clean = lambda: sys.path == before_path and not any(isinstance(f, tf_facade._Finder) for f in sys.meta_path)
+assert clean(), "finder / checkout left behind"
+for name in ("tensorflow", "tf_slim", "common", "nnmodel", "common.common_nn_ops"):
+    assert name not in sys.modules, name
+assert not hasattr(__import__("numpy"), "int")
+import sklearn.model_selection, tqdm
+assert "site-packages" in sklearn.__file__ or "dist-packages" in sklearn.__file__
+import numpy as np
+pts = np.stack([np.arange(40), np.arange(40), np.arange(40) %% 2], axis=1)
+tr, va = P.shuffle_training_data_using_ratio(pts, 0.25)     # the product's data split imports sklearn lazily: the REAL one
+assert len(tr) == 10 and len(va) == 30
+m.create_tensor_graph(P.ModelInputParams(x=G.Tower(G.VariableStore("nn_core"), False).placeholder("x", (5, 5), 11), y=None,
+                                         device_id="/gpu:0", is_training=False), 4, alg)   # and the model still works afterwards
+assert clean()
+print("SCOPED_OK")
+""" % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert "SCOPED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
