@@ -333,7 +333,57 @@ def gan_cpu_baseline(kind, bands, seconds_budget=12.0):
                       f"logical cores); not a TensorFlow number"}
 
 
-TRAFFIC_SUMMARIES = ("r5_hbm_traffic.json", "r5_hbm_traffic_dualcnn.json", "r4_hbm_traffic.json", "r4_hbm_traffic_dualcnn.json", "r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
+class ClockSampler:
+    """Shader clock (and socket power) of this rank's GPU while the timed steps run, read from sysfs every few milliseconds by
+    a host thread (amdgpu: pp_dpm_sclk marks the current level with '*', hwmon power1_average is in microwatts) -- the
+    driver-visible record behind `roofline.peak_note`: the split kernels run against the power cap, i.e. below the 2.4 GHz
+    the peak assumes.  Values are None where the files do not exist."""
+
+    def __init__(self, index=0, period=0.004):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self.sclk = cards[min(index, len(cards) - 1)] if cards else None
+        dev = os.path.dirname(self.sclk) if self.sclk else None
+        pw = sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_average"))) if dev else []
+        self.power = pw[0] if pw else None
+        self.period, self.mhz, self.watts, self._stop, self._t = period, [], [], False, None
+
+    def _run(self):
+        import re
+        while not self._stop:
+            try:
+                m = re.search(r"(\d+)\s*[Mm][Hh]z\s*\*", open(self.sclk).read())
+                if m:
+                    self.mhz.append(int(m.group(1)))
+                if self.power:
+                    self.watts.append(int(open(self.power).read()) / 1e6)
+            except (OSError, ValueError):
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.sclk:
+            import threading
+            self._t = threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        mean = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
+        ghz = mean(self.mhz)
+        return {"sustained_clock_ghz": None if ghz is None else ghz / 1e3,
+                "sustained_clock_min_max_ghz": [min(self.mhz) / 1e3, max(self.mhz) / 1e3] if self.mhz else None,
+                "sustained_power_w": mean(self.watts), "clock_samples": len(self.mhz),
+                "clock_source": "sysfs pp_dpm_sclk / hwmon power1_average sampled every 4 ms over the timed steps"}
+
+
+TRAFFIC_SUMMARIES = ("r6_hbm_traffic.json", "r6_hbm_traffic_dualcnn.json", "r5_hbm_traffic.json", "r5_hbm_traffic_dualcnn.json", "r4_hbm_traffic.json", "r4_hbm_traffic_dualcnn.json", "r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
 
 
 def pmc_traffic(workload, nb, launches_per_step):
@@ -361,10 +411,15 @@ def pmc_mfma_busy(workload):
     (tools/pmc_sq_per_launch.py: SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE; its own rocprofv3 run).  Returns
     ({"busy": ..., "useful": ...} or None, source label)."""
     import re
-    name = f"r5_mfma_busy_per_launch_{workload}.txt"
-    try:
-        last = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
-    except OSError:
+    last = None
+    for tag in ("r6", "r5"):
+        name = f"{tag}_mfma_busy_per_launch_{workload}.txt"
+        try:
+            last = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
+            break
+        except OSError:
+            continue
+    if last is None:
         return None, None
     m = re.search(r"mfma busy ([0-9.]+) % .* useful ([0-9.]+) %", last)
     if not m:
@@ -526,12 +581,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    clock = ClockSampler(int(os.environ.get("LOCAL_RANK", "0")))
     t0 = time.perf_counter()
     evs[0].record()
-    for i in range(args.steps):
-        one_step()
-        evs[i + 1].record()
-    torch.cuda.synchronize()
+    with clock:
+        for i in range(args.steps):
+            one_step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
     if use_dist:
         note_collective()
         dist.barrier()
@@ -615,7 +672,8 @@ def main():
                           "hypel_seg_gemm_f32 / hypel_seg_gemm_multi_f32 (fp32 MFMA: v_mfma_f32_32x32x2, 16x16x4 for n <= 16)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_note": ("fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s (at 2.4 GHz) / 6 partial products; the split kernels "
-                              "run against the 1.4 kW power cap at 1.4-1.8 GHz (profiles/r5_exp_split_ablation.txt)") if split_on
+                              "run against the 1.4 kW power cap at 1.4-1.8 GHz inside a launch (profiles/r5_exp_split_ablation.txt; "
+                              "sustained_clock_ghz = this run's average over the whole timed step loop)") if split_on
                              else "fp32 MFMA peak",
                 "frac_vs_fp32_mfma": achieved / PEAK_F32_MFMA_TFLOPS, "peak_fp32_mfma": PEAK_F32_MFMA_TFLOPS,
                 "split6_flop_share": share, "split6_launches_per_step": measure_gemm_events.split_launches,
@@ -625,6 +683,7 @@ def main():
                 "algorithmic_gflop_per_step": flops / ev_steps / 1e9,
                 "algorithmic_bytes_per_launch": measure_gemm_events.bytes_per_launch,
                 "kernel_launches_per_step": len(ct.serial_launches()) + 1}  # every launch of the step + the optimiser
+        roof.update(clock.summary())
         busy, busy_source = pmc_mfma_busy(args.workload)
         if busy is not None:
             # NOT measured by this run: the matrix-pipe busy share of the committed SQ-counter pass of the same command

@@ -84,6 +84,7 @@ SIGNATURES = {
     "copy_blocks_f32": [_P, _P, _I32, _I64],
     "reduce_splits_wave_multi_f32": [_P, _P, _I32, _I64],
     "reduce_splits_multi_f32": [_P, _P, _I32],
+    "reduce_splits_multi_sized_f32": [_P, _P, _I32, _I64],
     "col_stats_partial": [_P, _I64, _I64, _I32, _I32, _P],
     "bn_act_small_fwd": [_P, _I64, _I64, _I32, _F, _P, _I32, _F, _P, _I64, _P, _P, _P, _P, _F, _P, _I64],
     "bn_act_small_bwd": [_P, _I64, _P, _I64, _I64, _I32, _P, _P, _P, _I32, _F, _P, _I64, _P, _I64, _P, _I32],

@@ -332,7 +332,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
 
     float ra[SPLIT ? 1 : A_PER_THREAD], rb[SPLIT ? 1 : B_PER_THREAD];
     // SPLIT staging.  An operand stored with its reduction dimension contiguous ([x][k]: A of a forward / data gradient,
-    // B = W^T of a data gradient) is fetched as 16-byte quads: thread -> quad tid & 7 of rows (tid >> 3) + 32 i; one stored
+    // B = W^T of a data gradient) is fetched as 16-byte quads: thread -> quad tid % SP_QPR (= tid & 3) of rows tid / SP_QPR + SP_RP i; one stored
     // with k strided ([k][x]: both operands of a filter gradient, the weights of a forward product) by dword loads along
     // x, a thread keeping KR consecutive k of ONE x -- the transpose happens in the registers.  Either way a thread ends
     // up with PAIRS of k-adjacent elements: SP_NPA + SP_NPB pairs per k-tile.
@@ -558,7 +558,9 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
         // distance per fetch, or the next segment's start when the segment ends -- ~30 scalar instructions less per
         // k-tile than rebuilding base + offset + k * ld (the scalar port issues one instruction per SIMD and 4 cycles;
         // at ~95 per wave and k-tile it was as busy as the matrix pipe).
-        hypel_seg_t nseg = segs[min(ls + 1, s_end - 1)];
+        // (a group without segments -- a filter-gradient split with no reduction rows still owns its slab -- has s_end ==
+        // seg_begin: the clamp must not step in front of the table)
+        hypel_seg_t nseg = segs[max(grp.seg_begin, min(ls + 1, s_end - 1))];
         int n_fetched = 0;  // real k-tiles requested so far: tile t + 1 exists iff t + 1 < n_fetched
         const uint64_t a_base0 = (uint64_t)(A + (!TA ? (int64_t)m0 * lda : (int64_t)m0));
         const uint64_t b_base0 = (uint64_t)(B + (TB ? (int64_t)n0 * ldb : (int64_t)n0));
@@ -602,7 +604,7 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
                 lk = adv ? 0 : lk;
                 ls += adv ? 1 : 0;
                 have = ls < s_end;
-                nseg = segs[min(ls + 1, s_end - 1)];
+                nseg = segs[max(grp.seg_begin, min(ls + 1, s_end - 1))];
             }
             r.kv = k_left;
             if constexpr (!TA)
@@ -1324,9 +1326,13 @@ static int seg_gemm_dispatch(const float* a, int64_t lda, int32_t trans_a, const
     if (split6) {
         HYPEL_REQUIRE(!pairs && !mfma16x4 && !act_idx && n > 16,
                       "hypel_seg_gemm_f32: HYPEL_GEMM_SPLIT6 needs a plain product with n > 16");
-        (void)var_n;  // tile records with their own column count are honoured by every variant (blocks beyond them exit)
         // hint: 1 = 128x32, 2 = 128x64, 3 = 128x128 blocks; 0 = by n
         const int w = hint == 1 || n <= 32 ? 32 : (hint == 2 || n <= 64 ? 64 : (hint == 3 || n > 96 ? 128 : 64));
+        // tile records with their own column count are honoured by every variant (blocks beyond them exit).  A variant of
+        // its own for the forward VAR_N launches -- eight waves of 32 x 64 in a 4 x 2 deal, one active wave on EVERY SIMD for
+        // a one-tile group -- was built and measured SLOWER than the rows-first 2 x 4 deal of 64 x 32 wave tiles (round 6:
+        // 349 vs 328 us on the 30-filter level, profiles/r6_exp_varn_kernel.txt); removed.
+        (void)var_n;
         if (w == 32)
             launch_split<4, 1, 1, 1>(a, lda, trans_a, b, ldb, trans_b, c, ldc, n, groups, segs, tiles, n_tiles, bias,
                                      accumulate, res, ldr, res_start, st, stats);

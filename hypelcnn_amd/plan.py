@@ -134,7 +134,8 @@ _gs = os.environ.get("HYPEL_GEMM_SPLIT", "6").split(":")
 GEMM_SPLIT = int(_gs[0] or 0)
 GEMM_SPLIT_WIDTH = int(_gs[1]) if len(_gs) > 1 else 0
 GEMM_SPLIT_MIN_FLOPS = float(os.environ.get("HYPEL_GEMM_SPLIT_MIN_GFLOP", "2")) * 1e9  # ... of the launch at SPLIT_NOMINAL_BATCH samples
-SPLIT_NOMINAL_BATCH = 1024  # batch the size rule prices a launch at (the kernel family is chosen per layer, not per batch)
+SPLIT_NOMINAL_BATCH = 1024  # batch the size rule prices a classifier launch at (the kernel family is chosen per layer, not per batch)
+SPLIT_NOMINAL_BATCH_GAN = 4096  # ... and a GAN train op's (PhasePlan: the pair batch of BASELINE's CUT configuration)
 # narrow products stage a whole 128-row A tile per 32 output columns: the split costs more than the matrix rate returns
 # (H13 level 1, 30 filters per branch: 382 -> 397 us forward, 103 -> 95 TFLOP/s filter gradient; per-launch A/B, round 5)
 GEMM_SPLIT_MIN_N = 32
@@ -153,7 +154,10 @@ KSLICE_MIN_GAIN = 0.10
 KSLICE_OVERHEAD_K = 24   # fixed cost of a block in reduction columns (prologue, pipeline fill, epilogue)
 KSLICE_MIN_K = 48        # shortest slice (reduction columns)
 KSLICE_MAX_SLICES = 16
-KSLICE_FRAC_MIN = 0.25   # smallest threshold (fraction of the launch's heaviest tile) above which tiles are sliced
+KSLICE_FRAC_MIN = 0.7    # smallest threshold (fraction of the launch's heaviest tile) above which tiles are sliced.  Same box
+#                          (profiles/r6_exp_kslice.txt), the 60-filter level's data gradient, 392 tiles: unsliced 319 us; threshold
+#                          0.7 (496 records) 279 us; 0.5 (688: a second round) 299; 0.25 (960) 267 -- but with three times the
+#                          partial traffic; the simulation, which knows nothing of two blocks sharing a CU, prefers 0.25
 KSLICE_REDUCE_COST_K = 55  # the reduce launch behind a sliced launch (~6 us), in reduction columns of a 128 x 128 block
 KSLICE_SLOTS = {1: 768, 2: 512, 3: 512}  # resident blocks of the split kernels by tile-width hint (3 / 2 / 2 per CU)
 GEMM_MFMA16X4 = 0x2000  # include/hypel.h HYPEL_GEMM_MFMA16X4: 128x64 blocks on the 16x16x4 MFMA (merged level, <= 16 filters)
@@ -401,6 +405,9 @@ class TowerPlan:
             return 1
         return 1 if blocks64 < 768 else 2
 
+    def nominal_batch(self):
+        return SPLIT_NOMINAL_BATCH
+
     @staticmethod
     def _split6_width(n):
         """Tile-width hint of a split-operand launch by its column count: 128x128 blocks unless the last column tile
@@ -434,7 +441,7 @@ class TowerPlan:
         if in_multi:
             return self._split6_width(n)
         macs = sum(rows * sum(k for _, _, k in gs) * tables.n_of(gi, n) for gi, (_, gs, rows) in enumerate(tables.groups))
-        if 2 * macs * SPLIT_NOMINAL_BATCH < GEMM_SPLIT_MIN_FLOPS * self.nb:
+        if 2 * macs * self.nominal_batch() < GEMM_SPLIT_MIN_FLOPS * self.nb:
             return 0
         return self._split6_width(n)
 
@@ -495,9 +502,9 @@ class TowerPlan:
                     extra += [t[3] / s_ + ov] * (s_ * ct)
                     pieces += (s_ - 1) * ct
             sh = [[t[3] + ov for t in share for _ in range(ct)] for share in shares_of(main)]
-            # + what the partials cost: a 128 x bn partial is written, read back and added into the output (4 passes of
+            # + what the partials cost: a 128 x bn partial is written, read back and added into the output (~3 passes of
             # 512 bn bytes at ~4 TB/s; one reduction column of a 128 x 128 block is ~0.11 us), + the reduce launch (~6 us)
-            traffic = pieces * (4 * 512 * bn / 4e12) / (0.11e-6 * bn / 128)
+            traffic = pieces * (3 * 512 * bn / 4e12) / (0.11e-6 * bn / 128)
             return self._kslice_makespan(sh, extra, slots) + (traffic + KSLICE_REDUCE_COST_K if pieces else 0)
 
         base = evaluate({})
@@ -664,7 +671,7 @@ class TowerPlan:
         earr = np.array(entries, REDUCE_ENTRY_DTYPE)
         e_t = self.be.upload(earr)
         self.tables.append(e_t)
-        red = Launch("reduce_splits_multi_f32", (base, Ref(e_t), int(len(earr))),
+        red = Launch("reduce_splits_multi_sized_f32", (base, Ref(e_t), int(len(earr)), int(max(e[3] for e in entries))),
                      nbytes=4 * sum(cnt * (S + 2) for (_, _, _, cnt, S, _) in entries), tag="kslice-reduce")
         red.meta = {"kslices": {"tiles": len(entries), "slices": int(sum(slices.values())), "of": tag}}
         return out, red

@@ -38,6 +38,10 @@ class PhasePlan(TowerPlan):
     terms depend on, differentiated w.r.t. the variable groups the phase trains.  `outputs` (no loss terms) gives a
     forward-only plan, e.g. "generate fresh fake data for the tensor pool"."""
 
+    def nominal_batch(self):
+        from . import plan as _P
+        return _P.SPLIT_NOMINAL_BATCH_GAN
+
     def __init__(self, tower, nb, session, terms=(), train_groups=(), outputs=(), seed=1234):
         self.terms = list(terms)
         self.train_groups = set(train_groups)

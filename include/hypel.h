@@ -129,7 +129,21 @@ typedef struct {
  * both on every launch shape of the benchmark step) but not bit-identical to it.  Plain products only (no paired
  * segments, MFMA16X4, ACT; HYPEL_GEMM_VAR_N is fine), n > 16, not trans_a = trans_b = 1.  With this flag the tile-width hint reads
  * 1 = 128x32, 2 = 128x64, 3 = 128x128 blocks.  hypel_seg_gemm_multi_f32: OR HYPEL_GEMM_MULTI_SPLIT6 into tile_width
- * (32, 64 or 128 then). */
+ * (32, 64 or 128 then).
+ * Limits of the claim (tests/test_gpu_kernels.py::test_seg_gemm_split6_hard_operands, ..._nonfinite_and_extreme_operands):
+ *  - non-finite operands: an Inf splits into hi = Inf, mid = Inf - Inf = NaN, so a product the fp32 chain evaluates to
+ *    +-Inf comes out NaN here (a NaN operand gives NaN on both paths).  Non-finite stays non-finite -- the loss guard
+ *    (hypel_loss_guard, NanTensorHook's counterpart) fires either way -- but Inf is not distinguished from NaN;
+ *  - finite |x| >= 2^128 - 2^119 (above bf16's largest finite value, 3.3895e38: the top 0.4 % of fp32's last binade)
+ *    rounds hi to Inf and gives NaN where the fp32 chain would give a huge finite number or Inf;
+ *  - |x| < 2^-110: the lo (then the mid) part is a bf16 subnormal, which the matrix cores flush to zero -- the operand
+ *    keeps 16 (then 8) significand bits instead of 24; products of such operands are below fp32's own subnormal range
+ *    against any operand of ordinary magnitude;
+ *  - from 2^-110 up to bf16's maximum the result stays within a few 2^-24 of sum |a b| whatever the mix of signs and
+ *    magnitudes in a row: cancellation does not hurt (the partial products are exact), and where ONE product dominates a
+ *    row's sum (operands spanning tens of binades) its partial products enter the accumulator as three non-negligible
+ *    additions instead of the chain's one -- measured 1.5 x the fp32 chain's error there (7.3e-7 vs 4.7e-7 of sum |a b|),
+ *    bounded by 3 x. */
 #define HYPEL_GEMM_SPLIT6 0x8000
 #define HYPEL_GEMM_MULTI_SPLIT6 0x100
 
@@ -190,6 +204,10 @@ typedef struct {
 } hypel_reduce_entry_t;
 int hypel_reduce_splits_multi_f32(const float* base, const hypel_reduce_entry_t* entries, int32_t n_entries,
                                   hypel_stream_t stream);
+/* The same reduction when the caller knows max_count = the largest entry's count: the grid is sized for it (the K-slice
+ * partials of a GEMM launch, HYPEL_TILE_PLAIN: many entries of one 128-row tile each).  Same sums, same order. */
+int hypel_reduce_splits_multi_sized_f32(const float* base, const hypel_reduce_entry_t* entries, int32_t n_entries,
+                                        int64_t max_count, hypel_stream_t stream);
 
 /* The same table for reductions with MANY slabs and few outputs (the per-block gradient slabs that the fused
  * generator / dense-stack backward kernels of one GAN train op leave: all of them in one launch): one wavefront per

@@ -398,6 +398,11 @@ class EmuBackend:
             else:
                 o[...] = tot.astype(np.float32)
 
+    def k_reduce_splits_multi_sized_f32(self, base, entries, n_entries, max_count):
+        ents = entries.t.numpy()[entries.off:].view(REDUCE_ENTRY_DTYPE)[:n_entries]
+        assert all(int(e["count"]) <= max_count for e in ents), "max_count below an entry's count"
+        self.k_reduce_splits_multi_f32(base, entries, n_entries)
+
     def k_reduce_splits_wave_multi_f32(self, base, entries, n_entries, total_count):
         ents = entries.t.numpy()[entries.off:].view(REDUCE_ENTRY_DTYPE)[:n_entries]
         assert sum(int(e["count"]) for e in ents) == total_count

@@ -275,11 +275,36 @@ def test_seg_gemm_split6_filter_gradient_pixel_pairs(hip, cin, cout, nbr, hint):
     b.check("w", rtol=2e-4, atol=2e-5)
 
 
-def _gemm_errors(hip, rows, k, n, ta, tb_, hint, seed):
+def _hard_operands(kind, rng, rows, k, n):
+    """(A [rows, k], W [k, n]) float64 draws that stress the three-way split: see test_seg_gemm_split6_hard_operands."""
+    a, w = rng.standard_normal((rows, k)), rng.standard_normal((k, n)) * 0.3
+    if kind == "cancel":      # every product has a partner of opposite sign and almost equal size: sum a b << sum |a b|
+        half = k // 2
+        a[:, half:2 * half] = -a[:, :half] * (1.0 + rng.uniform(-1e-6, 1e-6, (rows, half)))
+        w[half:2 * half] = w[:half]
+    elif kind == "range":     # 2^-40 .. 2^40 inside every row and column
+        a *= np.exp2(rng.integers(-40, 41, (rows, k)))
+        w *= np.exp2(rng.integers(-40, 41, (k, n)))
+    elif kind == "tiny":      # 1e-30: the lo parts sit at bf16's last normal binades
+        a *= 1e-30
+    elif kind == "huge":      # 1e30 x 1e-3: sums near 1e29, far from ordinary training values
+        a *= 1e30
+        w *= 1e-3
+    elif kind == "mixed_sign_bits":  # mantissas of all ones / alternating bits: worst cases of the round-to-nearest split
+        bits = rng.choice(np.array([0x3fffffff, 0x3faaaaaa, 0x3f955555, 0x3f800001, 0x3f7fffff], np.uint32), (rows, k))
+        a = bits.view(np.float32).astype(np.float64) * rng.choice([-1.0, 1.0], (rows, k))
+    return a, w
+
+
+def _gemm_errors(hip, rows, k, n, ta, tb_, hint, seed, hard=None):
     """max |c - fp64| / sum |a b| (over sampled rows) of the split kernel and of the fp32 MFMA kernel on one product."""
     rng = np.random.default_rng(seed)
     a = (rng.standard_normal((k, rows) if ta else (rows, k)) * rng.uniform(0.1, 2.0)).astype(np.float32)
     w = (rng.standard_normal((n, k) if tb_ else (k, n)) * rng.uniform(0.01, 0.5)).astype(np.float32)
+    if hard is not None:
+        am_, wm_ = _hard_operands(hard, rng, rows, k, n)
+        a = np.ascontiguousarray((am_.T if ta else am_).astype(np.float32))
+        w = np.ascontiguousarray((wm_.T if tb_ else wm_).astype(np.float32))
     garr, sarr, tarr, _ = _tables(None, [(0, [(0, 0, k)], rows)]).finalize(n)
     h = {nm: hip.upload(np.ascontiguousarray(v)) for nm, v in (("a", a), ("w", w), ("g", garr), ("s", sarr), ("t", tarr))}
     sel = np.unique(np.concatenate([np.arange(min(rows, 8)), rng.integers(0, rows, 24), [rows - 1]]))
@@ -326,6 +351,59 @@ def test_seg_gemm_split6_error_vs_fp32_chain(hip):
     print("split6 error / fp32-MFMA error per shape:")
     for r in rows_out:
         print("  rows=%5d K=%5d n=%5d ta=%d tb=%d  split %.2e  fp32 %.2e" % r)
+
+
+@pytest.mark.parametrize("hard", ["cancel", "range", "tiny", "huge", "mixed_sign_bits"])
+def test_seg_gemm_split6_hard_operands(hip, hard):
+    """The error bound of HYPEL_GEMM_SPLIT6 on operands the Gaussian draws of the test above never produce (round-5 verdict):
+    rows whose products cancel to 1e-6 of their magnitude, 80 binades of dynamic range inside a row, operands at 1e-30 and at
+    1e30, mantissa patterns that sit on the rounding boundaries of the split.  Same measure (max |c - fp64| / sum |a b|), the
+    three operand layouts.  Bound: 1.25 x the fp32 MFMA chain + 1e-8 as on ordinary data -- except for "range", where ONE
+    product dominates a row's sum: its six partial products enter the accumulator as three non-negligible additions, each
+    rounded at the magnitude of the sum, where the fp32 chain rounds once (measured 1.5 x: 7.3e-7 vs 4.7e-7 of sum |a b| at
+    K = 480, 1.12e-6 vs 7.8e-7 at K = 2 048); the bound there is 3 x the chain's error and 2^-19 absolute -- the limit
+    include/hypel.h states."""
+    for i, (rows, k, n, ta, tb_, hint) in enumerate([(1024, 480, 480, 0, 0, 3), (1024, 240, 120, 0, 1, 2), (240, 2048, 480, 1, 0, 3),
+                                                     (512, 145, 60, 0, 0, 2)]):
+        e_split, e_f32 = _gemm_errors(hip, rows, k, n, ta, tb_, hint, 700 + i, hard=hard)
+        factor = 3.0 if hard == "range" else 1.25
+        assert np.isfinite(e_split) and e_split <= factor * e_f32 + 1e-8 and e_split < 2.0 ** -19, \
+            (hard, rows, k, n, ta, tb_, e_split, e_f32)
+        print(f"  {hard:16s} rows={rows:5d} K={k:5d} n={n:4d} ta={ta} tb={tb_}  split {e_split:.2e}  fp32 {e_f32:.2e}")
+
+
+def test_seg_gemm_split6_nonfinite_and_extreme_operands(hip):
+    """The written limits of HYPEL_GEMM_SPLIT6 (include/hypel.h): an Inf or a finite value above bf16's maximum in an operand
+    makes every output that meets it NON-FINITE (NaN where the fp32 chain says Inf or a huge number) and leaves all other
+    outputs exact to the usual bound; operands below 2^-110 lose their low parts gracefully (relative error of the affected
+    products <= 2^-15) instead of producing garbage."""
+    rng = np.random.default_rng(9)
+    rows, k, n = 256, 96, 64
+    a = rng.standard_normal((rows, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) * 0.3).astype(np.float32)
+    a[3, 5] = np.inf
+    a[7, 9] = np.float32(3.4e38)          # finite in fp32, above bf16's largest finite value
+    a[11, :] = (rng.standard_normal(k) * 1e-36).astype(np.float32)   # lo parts are bf16 subnormals
+    garr, sarr, tarr, _ = _tables(None, [(0, [(0, 0, k)], rows)]).finalize(n)
+    h = {nm: hip.upload(np.ascontiguousarray(v)) for nm, v in (("a", a), ("w", w), ("g", garr), ("s", sarr), ("t", tarr))}
+    outs = []
+    for flags in (SPLIT6 | (2 << 8), 0):
+        y = hip.zeros(rows * n)
+        hip.call("seg_gemm_f32", Ref(h["a"]), k, 0, Ref(h["w"]), n, 0, Ref(y), n, n, Ref(h["g"]), Ref(h["s"]), Ref(h["t"]),
+                 len(tarr), None, flags)
+        hip.synchronize()
+        outs.append(y.cpu().numpy().reshape(rows, n))
+    split, f32 = outs
+    assert not np.isfinite(split[3]).any() and not np.isfinite(f32[3]).any()       # Inf operand: NaN here, Inf there
+    assert not np.isfinite(split[7]).any()                                          # above bf16's range: non-finite
+    ok = np.ones(rows, bool)
+    ok[[3, 7, 11]] = False
+    ref = a[ok].astype(np.float64) @ w.astype(np.float64)
+    mag = np.abs(a[ok].astype(np.float64)) @ np.abs(w.astype(np.float64))
+    assert np.isfinite(split[ok]).all() and (np.abs(split[ok] - ref) / mag).max() < 1e-6
+    ref11 = a[11].astype(np.float64) @ w.astype(np.float64)
+    mag11 = np.abs(a[11].astype(np.float64)) @ np.abs(w.astype(np.float64))
+    assert np.isfinite(split[11]).all() and (np.abs(split[11] - ref11) / mag11).max() < 2.0 ** -15
 
 
 @pytest.mark.parametrize("cin,cout,hint,with_res,acc", [(120, 15, 2, True, 0), (120, 15, 1, False, 1), (60, 7, 0, False, 0),
@@ -1119,6 +1197,10 @@ def test_seg_gemm_single_segment_hint(hip, rows, k, n, tb_, kind):
     (20, 5, 90, 37, 0, "var_n"),        # DUALCNN-like: five rings
     (30, 4, 300, 240, 0, "none"),       # the flags are hints: the plain kernels give the same result
     (15, 4, 300, 120, 0, "none"),
+    # the same launches on the split-operand kernels: 128-wide blocks = the 4 x 2 / 32x64 variant with one- and two-tile
+    # MFMA phases per wave (round 6), 64-wide blocks = the ordinary split kernel
+    (30, 4, 300, 240, 0, "split128"), (30, 4, 129, 50, 1, "split128"), (60, 4, 200, 120, 0, "split128"),
+    (20, 5, 90, 37, 1, "split128"), (30, 4, 1024, 240, 0, "split128"), (15, 4, 300, 120, 0, "split64"),
 ])
 def test_seg_gemm_per_tile_column_counts(hip, co, branches, rows, cin, acc, flags_kind):
     """Merged multi-kernel levels (hypel_tile_t.n): the groups of ONE launch write column ranges [r * co, C) of different
@@ -1144,7 +1226,8 @@ def test_seg_gemm_per_tile_column_counts(hip, co, branches, rows, cin, acc, flag
     b = Both(hip)
     for nm, arr in (("x", x), ("w", wp), ("y", y0), ("g", garr), ("s", sarr), ("t", tarr)):
         b.arr(nm, arr)
-    flags = {"mfma16x4": GEMM_VAR_N | GEMM_MFMA16X4, "var_n": GEMM_VAR_N | (2 << 8), "none": GEMM_VAR_N}[flags_kind]
+    flags = {"mfma16x4": GEMM_VAR_N | GEMM_MFMA16X4, "var_n": GEMM_VAR_N | (2 << 8), "none": GEMM_VAR_N,
+             "split128": GEMM_VAR_N | SPLIT6 | (3 << 8), "split64": GEMM_VAR_N | SPLIT6 | (2 << 8)}[flags_kind]
     b.run("seg_gemm_f32", "x", cin, 0, "w", C, 0, "y", C, C, "g", "s", "t", len(tarr), None, acc | flags)
     b.check("y", rtol=3e-4, atol=3e-5)
     got = b.h["y"].cpu().numpy().reshape(ncopy, rows, C)
@@ -1494,7 +1577,7 @@ def test_seg_gemm_kslice_plain_records(hip, split, hint, with_res, acc):
     else:
         b.run("seg_gemm_f32", "dy", cout, 0, "w", cout, 1, "y", cin, cin, "g", "s", "t", len(tarr), None, flags)
         b.run("seg_gemm_f32", "dy", cout, 0, "w", cout, 1, "yref", cin, cin, "g0", "s0", "t0", len(t0), None, flags)
-    b.run("reduce_splits_multi_f32", "y", "e", len(entries))
+    b.run("reduce_splits_multi_sized_f32", "y", "e", len(entries), region)
     b.check("y", rtol=2e-4, atol=2e-5)
     got = b.h["y"].cpu().numpy()[:rows * cin]
     want = b.h["yref"].cpu().numpy()

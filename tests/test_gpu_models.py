@@ -284,11 +284,10 @@ def test_grss2018_dualcnn_large_batches_equal_oracle_checked_chunks(hip, dual_fu
     and configs[2] run at): DUALCNN has no batch statistics, so the step on nb patches must equal the 64-patch steps
     (the first of which the previous test pins to the oracle) -- logits row for row, gradient = mean of the chunk
     gradients -- up to fp32 summation order.  The comparison needs the SAME arithmetic per sample at every batch size (a
-    forward value that differs by one rounding can take the other leaky-ReLU branch): the choice between the fp32 MFMA and
-    the split-operand kernels depends on a launch's FLOP count, i.e. on the batch, so the threshold is taken out here
-    (every eligible launch on the split kernels at 64, 128 and 512 alike; the fp32 kernels are what the previous test runs)."""
-    from hypelcnn_amd import plan
-    monkeypatch.setattr(plan, "GEMM_SPLIT_MIN_FLOPS", 0.0)
+    forward value that differs by one rounding can take the other leaky-ReLU branch): since round 6 the planner chooses
+    between the fp32 MFMA and the split-operand kernels per LAYER (a launch is priced at a nominal batch,
+    plan.SPLIT_NOMINAL_BATCH), so the default plan is used as it is at 64, 128 and 512 (round 5 had to take the
+    batch-dependent FLOP threshold out here)."""
     alg = dual_full[0]
     built, sess, params, x, onehot, masks = _case(hip, "DUALCNNModel", 11, 49, 20, alg, 512, 2018)
     g_sum, logit_parts, loss_sum = None, [], 0.0
