@@ -155,6 +155,9 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     static_assert(BM == HYPEL_GEMM_BM, "tile table is built for BM = 128");
     static_assert(!ACT || (!TA && !TB && !NARROW && !MULTI && !PAIR && !VARN), "activation epilogue: plain forward only");
     static_assert(!SPLIT || (!NARROW && !PAIR && !VARN && !ACT && !(TA && TB)), "split variants: plain NN / NT / TN products");
+#if HYPEL_GEMM_CLK
+    const float* const clk_dbg = bias;  // (the debug buffer travels in `bias`; K-slice records null the bias itself below)
+#endif
     [[maybe_unused]] int act_idx = 0;
     if constexpr (ACT) {
         act_idx = accumulate >> 16;
@@ -930,8 +933,8 @@ __device__ __forceinline__ void seg_gemm_body(const float* __restrict__ A, int64
     }
 
 #if HYPEL_GEMM_CLK
-    if (tid == 0 && bias) {
-        long long* dbg = (long long*)bias + 2 * (size_t)blockIdx.x;
+    if (tid == 0 && clk_dbg) {
+        long long* dbg = (long long*)clk_dbg + 2 * (size_t)blockIdx.x;
 #if HYPEL_GEMM_CLK == 2  // absolute 100 MHz times of the block's start and end: occupancy timeline of a launch
         dbg[0] = wall0;
         dbg[1] = wall_clock64();

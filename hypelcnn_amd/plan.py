@@ -844,7 +844,9 @@ class TowerPlan:
             return cache[idx]
         lay = None
         brs = node.branches
-        if (MERGE_LEVELS and node.kind == "conv" and len(brs) >= 2 and not node.has_bias
+        # (a biased level -- DUALCNN -- keeps its unmerged forward: the bias rides in the GEMM epilogue / the tap-split
+        # reduce; its data and filter gradients do not see the bias at all)
+        if (MERGE_LEVELS and node.kind == "conv" and len(brs) >= 2
                 and self.nb >= TAP_SPLIT_MIN_BATCH and len(node.sources) == 1):
             ks = [b.k for b in brs]
             co = brs[0].cout
@@ -860,7 +862,8 @@ class TowerPlan:
                     offs += [(dy, dx, r) for dy in range(-r, r + 1) for dx in range(-r, r + 1) if max(abs(dy), abs(dx)) == r]
                 C = co * len(brs)
                 lay = dict(offs=offs, index={(dy, dx): d for d, (dy, dx, _) in enumerate(offs)}, rmax=rmax, first=first,
-                           col0=[f * co for f in first], co=co, C=C, cin=src.c, buf=f"wpack:{idx}", dense_off=[])
+                           col0=[f * co for f in first], co=co, C=C, cin=src.c, buf=f"wpack:{idx}", dense_off=[],
+                           has_bias=node.has_bias)
                 pos = 0
                 for (_, _, r) in offs:  # dense image of the packed filter gradient: [d] -> [Cin x (C - col0[r])]
                     lay["dense_off"].append(pos)
@@ -868,7 +871,7 @@ class TowerPlan:
                 lay["dense_size"] = pos
                 assert pos == sum(b.w.size for b in brs)
                 if any(w_ in MERGE_LEVELS and co <= max(MERGE_PASS_MAX_COUT[w_], MERGE_FWD_MAX_COUT_SPLIT if GEMM_SPLIT == 6 else 0)
-                       for w_ in ("fwd", "dgrad")):
+                       and not (w_ == "fwd" and node.has_bias) for w_ in ("fwd", "dgrad")):
                     # these passes read the packed image (the filter gradient does not)
                     lay["packed"] = True
                     self._alloc(lay["buf"], len(offs) * src.c * C)
@@ -881,7 +884,7 @@ class TowerPlan:
         cap = MERGE_PASS_MAX_COUT[what]
         if what == "fwd" and GEMM_SPLIT == 6:
             cap = max(cap, MERGE_FWD_MAX_COUT_SPLIT)
-        if lay is None or what not in MERGE_LEVELS or lay["co"] > cap:
+        if lay is None or what not in MERGE_LEVELS or lay["co"] > cap or (what == "fwd" and lay["has_bias"]):
             return None
         if what == "wgrad" and not (GEMM_SPLIT == 6 and MERGE_WGRAD and MERGE_WGRAD_MIN_COUT <= lay["co"] <= MERGE_WGRAD_MAX_COUT):
             return None  # (on the fp32 kernels it moved work between the width classes without shortening their sum, NOTES 4.A)

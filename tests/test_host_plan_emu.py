@@ -151,16 +151,26 @@ def test_split6_plan_matches_oracle(monkeypatch):
     U.compare_step(built, ct, params, x, onehot, masks, "HYPELCNNModel", 4, alg, tol_logit=2e-5, tol_grad=2e-4)
 
 
-def test_dgrad_segment_split_matches_oracle(monkeypatch):
+@pytest.mark.parametrize("merged", [False, True])
+def test_dgrad_segment_split_matches_oracle(monkeypatch, merged):
     """Data gradient of an unfolded multi-kernel level: the per-pixel segment list is cut into chunks that write
-    partial copies of dX, summed by one reduce (DUALCNN levels; HYPELCNN levels fold their shortcut instead)."""
+    partial copies of dX, summed by one reduce (DUALCNN levels; HYPELCNN levels fold their shortcut instead).  merged
+    (round 6): a BIASED level's data and filter gradients may take the merged per-offset form too (the bias only concerns
+    the forward pass, which stays unmerged): merged segments over the packed weight image, cut into the same chunks."""
     from hypelcnn_amd import plan
     monkeypatch.setattr(plan, "TAP_SPLIT_MIN_BATCH", 1)
     monkeypatch.setattr(plan, "DGRAD_MAX_SEGS", 5)
+    if not merged:
+        monkeypatch.setattr(plan, "MERGE_LEVELS", set())
     built, sess, params, x, onehot, masks = _case("DUALCNNModel", 5, 7, 3, ALG_D, 4, 37)
     ct = U.run_train_step(built, x, onehot, masks)
     tags = _tags(ct)
-    assert "dgrad-split-reduce" in tags and any(t.startswith("dgrad:") and t.endswith("/split") for t in tags)
+    want = "/split/merged" if merged else "/split"
+    assert "dgrad-split-reduce" in tags and any(t.startswith("dgrad:") and t.endswith(want) for t in tags), tags
+    assert ("level-pack" in tags) == merged and not any(t.startswith("fwd:") and t.endswith("/merged") for t in tags)
+    if merged:
+        prods = [p_ for l in ct.plan.bwd if l.name == "seg_gemm_multi_f32" for p_ in l.meta["products"]]
+        assert any(p_.endswith("/merged") for p_ in prods) and "level-unpack" in tags
     U.compare_step(built, ct, params, x, onehot, masks, "DUALCNNModel", 3, ALG_D, tol_logit=2e-5, tol_grad=2e-4)
 
 
