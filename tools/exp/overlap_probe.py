@@ -28,11 +28,15 @@ def main():
     dg = [l for l in bwd if l.name.startswith("seg_gemm") and not l.name.startswith("seg_gemm_multi")]
     wg = [l for l in bwd if l.name.startswith("seg_gemm_multi")]
     print(f"elementwise {len(ew)} launches, dgrad {len(dg)}, wgrad-merged {len(wg)}")
-    main_s, side_s = be.stream, torch.cuda.Stream(be.device)  # (the package itself runs on one stream since round 5)
+    # (the package itself runs on one stream since round 5.)  SIDE_PRIO: priority of the side stream (0 = normal; the main
+    # stream is the backend's, normal priority); MAIN_HI=1: run the main list on a high-priority stream of its own instead
+    main_s = torch.cuda.Stream(be.device, priority=-1) if os.environ.get("MAIN_HI") == "1" else be.stream
+    side_s = torch.cuda.Stream(be.device, priority=int(os.environ.get("SIDE_PRIO", "0")))
+    handles = [main_s.cuda_stream, side_s.cuda_stream]
 
     def run(lists, reps=30):
         """lists: [(launch list, stream index)] started together; returns mean wall us."""
-        bound = [[be.bind(l.name, l.args, si) for l in ls] for ls, si in lists]
+        bound = [[be.bind(l.name, l.args, handles[si]) for l in ls] for ls, si in lists]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tot = 0.0
         for r in range(reps + 3):
