@@ -263,3 +263,61 @@ print("ok")
 """ % (ROOT, GOLD, GOLD, GOLD)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# ------------------------------------------------------------------------------------------------ the facade, end to end
+def _canonical_phases(loss, ops, c):
+    out = []
+    by_name = {v.name: v for v in loss.tower.store.order}
+    for phase in loss.phases:
+        pool_of = {name: _label(t, {}) for name, t in (phase.pool or [])}
+        terms = {}
+        for t in phase.terms:
+            d = {"kind": t.kind, "a": _label(t.a, pool_of), "b": None if t.b is None else _label(t.b, pool_of),
+                 "target": t.target if t.kind == "mean_sq" else None, "tau": t.tau if t.kind == "nce" else None}
+            terms[_term_key(d)] = round(t.weight, 12)
+        groups = sorted(g if isinstance(g, str) else g.name for g in phase.train_groups)
+        out.append({"name": phase.name, "terms": terms, "groups": groups, "lr": [ops.lrs[phase.lr_key](s) for s in c["lr_steps"]],
+                    "pool": sorted(pool_of.items())})
+    return out, sorted((n, list(v.shape), round(v.l2_scale, 12)) for n, v in by_name.items())
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference checkout exists in the build container only")
+@pytest.mark.parametrize("case", CASES)
+def test_reference_wrapper_files_build_the_products_phases(case):
+    """`hypelcnn_amd.tfgan_facade.reference_wrapper`: the reference's UNCHANGED gan/wrapper_registry.py + gan/wrappers/*.py in
+    the place of the product's wrapper -- define_model -> define_loss -> define_train_ops through the tensorflow_gan facade
+    onto the product's graph -- give the product wrapper's phases (names, terms with operands by provenance, weights, trained
+    groups, LR schedule, tensor-pool feeds, variables with shapes and regulariser scales), the oracle's numbers on the kernel
+    emulation, and leave nothing behind in the import system."""
+    from hypelcnn_amd import tfgan_facade
+    from hypelcnn_amd.gan.wrappers import gan_common as C
+    from tests import gan_util as U
+    from tests.emu_backend import EmuBackend
+    c = FIX[case]
+    f = c["flags"]
+    before_path = list(sys.path)
+    wrapper = tfgan_facade.reference_wrapper(c["gan_type"], "/root/reference", SimpleNamespace(**f))
+    wrapper.backend = EmuBackend()
+    tower, x, y = C.new_gan_tower(c["bands"])
+    model = wrapper.define_model(x, y)
+    loss_ref = wrapper.define_loss(model)
+    ops = wrapper.define_train_ops(model, loss_ref, max_number_of_steps=c["max_steps"], generator_lr=f["generator_lr"],
+                                   discriminator_lr=f["discriminator_lr"], gen_discriminator_lr=f["gen_discriminator_lr"])
+    ops.capture_graphs = False
+    assert sys.path == before_path and not any(isinstance(m, tfgan_facade.F._Finder) for m in sys.meta_path)
+    assert not any(n in sys.modules for n in ("tensorflow", "tensorflow_gan", "tf_slim", "gan.wrapper_registry", "gan"))
+    _, _, loss_p, ops_p = _build_product(case, EmuBackend())
+    got, vars_got = _canonical_phases(ops.loss, ops, c)
+    want, vars_want = _canonical_phases(loss_p, ops_p, c)
+    assert vars_got == vars_want
+    assert got == want, (case, [(g["name"], w["name"]) for g, w in zip(got, want) if g != w])
+    assert ops.use_pool == ops_p.use_pool
+    # ... and the numbers: every phase's loss and gradients against the oracle, through planner + kernel emulation
+    cfg = _cfg(case)
+    params = U.fp32(_arrays(case, "param/"))
+    xv = ARR[f"{case}/x"].astype(np.float32).astype(np.float64)
+    yv = ARR[f"{case}/y"].astype(np.float32).astype(np.float64)
+    sess = ops.ctx.session()
+    U.inject(sess, params)
+    assert U.check_phase_gradients(cfg, ops, params, xv, yv, tol=5e-5) < 5e-5
