@@ -242,4 +242,20 @@ class OracleEngine:
     def l2_normalize(self, x):
         return self.new(self.O.l2_normalize_global(x.var), "l2_normalize", [x])
 
+    # -- the tf.* calls of get_loss_func / optimize_nn (nnmodel/HYPELCNNModel.py:101-112, common/common_nn_ops.py:208-240)
+    def softmax_xent(self, labels, logits):
+        lab = labels.var.v if isinstance(labels, OracleEngine.T) else np.asarray(labels, np.float64)
+        return self.new(self.O.softmax_xent(logits.var, lab), "softmax_cross_entropy_with_logits", [logits])
+
+    def loss_reshape(self, tensor, shape):
+        shp = tuple(_int(s) for s in shape)
+        return self.new(self.O.reshape(tensor.var, (tensor.var.v.shape[0],) + shp[1:] if shp[0] == -1 else shp), "reshape",
+                        [tensor], target=[int(s) for s in shp])
+
+    def loss_square(self, x):
+        return self.new(self.O.square(x.var), "square", [x])
+
+    def loss_reduce_mean(self, x):
+        return self.new(self.O.reduce_mean(x.var), "reduce_mean", [x])
+
 
