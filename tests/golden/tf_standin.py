@@ -210,6 +210,23 @@ class OracleEngine:
     def slice(self, x, sl):
         if not isinstance(sl, tuple):
             sl = (sl,)
+        if any(s is None or isinstance(s, (int, np.integer)) for s in sl):
+            # integer indices / numpy.newaxis (gan_common.py:293 `input_tensor[:, i, j]`, gan_utilities.py:35
+            # `input_data[:, :, -1, numpy.newaxis]`): a range of one, then a reshape
+            core = [s for s in sl if s is not None]
+            core = core + [slice(None)] * (x.var.v.ndim - len(core))
+            rng_sl = tuple(slice(int(s) % d, int(s) % d + 1) if isinstance(s, (int, np.integer)) else s
+                           for s, d in zip(core, x.var.v.shape))
+            cut = self.slice(x, rng_sl)
+            shape, di = [], 0
+            for s in list(sl) + [slice(None)] * (x.var.v.ndim - len([q for q in sl if q is not None])):
+                if s is None:
+                    shape.append(1)
+                    continue
+                if not isinstance(s, (int, np.integer)):
+                    shape.append(cut.var.v.shape[di])
+                di += 1
+            return self.reshape(cut, tuple(shape), "index")
         sl = tuple(sl) + (slice(None),) * (x.var.v.ndim - len(sl))
         norm = []
         for s, dim in zip(sl, x.var.v.shape):

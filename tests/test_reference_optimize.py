@@ -167,3 +167,50 @@ print("ok")
 """ % (ROOT, GOLD)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference checkout exists in the build container only")
+def test_generator_as_augmenter_equals_the_executed_reference():
+    """`gan/gan_utilities.py:30-43` (create_gan_struct) + `gan/wrappers/gan_common.py:282-304`
+    (create_inference_for_matrix_input) + the reference's CycleGANInferenceWrapper and generator, executed in float64 on a
+    [P, P, B + 1] patch -- P * P generator copies under Model/ModelX2Y|ModelY2X/Generator, the LiDAR channel passed through --
+    against the product's GeneratorAugmenter (ONE fused launch over all pixel spectra) on the kernel emulation, with the
+    variables the reference's run created, for the shadowing and the de-shadowing direction."""
+    code = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import tfgan_standin as W
+W.install()
+import importlib, torch
+util = importlib.import_module("gan.gan_utilities")
+registry = importlib.import_module("gan.wrapper_registry")
+P, B = 3, 16
+rng = np.random.default_rng(11)
+patch = rng.random((P, P, B + 1))
+ref_wrapper = registry.get_infer_wrapper_dict()["cycle_gan"]
+holder = util.create_gan_struct(ref_wrapper, "", "")
+eng = W.WiringEngine(rng=np.random.default_rng(12))
+outs = {}
+with W.S.use_engine(eng):
+    t = eng.placeholder(patch, "patch")
+    outs[True] = holder.shadow_op(t).var.v
+    outs[False] = holder.deshadow_op(t).var.v
+assert sorted({n.rsplit("/", 2)[0] for n in eng.variables}) == ["Model/ModelX2Y/Generator", "Model/ModelY2X/Generator"]
+assert len(eng.variables) == 28   # 2 x 7 layers x (weights, biases): P * P applications SHARE them
+from hypelcnn_amd.gan.gan_utilities import GeneratorAugmenter
+from hypelcnn_amd.gan.wrapper_registry import get_infer_wrapper_dict
+from tests.emu_backend import EmuBackend
+for is_shadow in (True, False):
+    aug = GeneratorAugmenter(get_infer_wrapper_dict()["cycle_gan"], is_shadow, B, EmuBackend())
+    aug.load({k: np.asarray(v, np.float32) for k, v in eng.params.items()})
+    got = aug(torch.as_tensor(patch[None].astype(np.float32))).numpy()[0]
+    want = outs[is_shadow]
+    assert got.shape == want.shape == (P, P, B + 1)
+    assert np.array_equal(got[..., -1], patch[..., -1].astype(np.float32)), "LiDAR channel must pass through"
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max()), (is_shadow, np.abs(got - want).max())
+assert np.abs(outs[True] - outs[False]).max() > 1e-3   # two different generators
+print("ok")
+""" % (ROOT, GOLD)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
