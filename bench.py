@@ -339,14 +339,41 @@ class ClockSampler:
     driver-visible record behind `roofline.peak_note`: the split kernels run against the power cap, i.e. below the 2.4 GHz
     the peak assumes.  Values are None where the files do not exist."""
 
+    @staticmethod
+    def _pci_address(index):
+        """PCI address ("0000:75:00.0") of HIP device `index` of this process -- the node's OTHER GPUs (other tenants' work) are
+        visible in sysfs too, and card numbers do not follow HIP's device order."""
+        try:
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            for lib in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+                try:
+                    hip = ctypes.CDLL(lib)
+                    break
+                except OSError:
+                    hip = None
+            if hip is not None and hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                return buf.value.decode().lower()
+        except Exception:  # noqa: BLE001 -- a diagnostic field, never a reason to fail the bench
+            pass
+        return None
+
     def __init__(self, index=0, period=0.004):
         import glob
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        self.sclk = cards[min(index, len(cards) - 1)] if cards else None
-        dev = os.path.dirname(self.sclk) if self.sclk else None
-        pw = sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_average"))) if dev else []
+        devs = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        addr = self._pci_address(index)
+        mine = [d for d in devs if addr and os.path.basename(os.path.realpath(d)).lower() == addr]
+        self.matched_by = "pci address" if mine else ("only card" if len(devs) == 1 else "not identified")
+        dev = mine[0] if mine else (devs[0] if len(devs) == 1 else None)  # never guess among several GPUs
+        self.sclk = os.path.join(dev, "pp_dpm_sclk") if dev and os.path.exists(os.path.join(dev, "pp_dpm_sclk")) else None
+        pw = (sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_average"))) or
+              sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_input")))) if dev else []
         self.power = pw[0] if pw else None
-        self.period, self.mhz, self.watts, self._stop, self._t = period, [], [], False, None
+        # hwmon freq1_input = the current shader clock in Hz; boxes of this pool whose level table is pinned at its top entry
+        # (a constant 2 400 MHz from pp_dpm_sclk whatever runs) still move here
+        fq = sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/freq1_input"))) if dev else []
+        self.freq = fq[0] if fq else None
+        self.period, self.mhz, self.watts, self.hz, self._stop, self._t = period, [], [], [], False, None
 
     def _run(self):
         import re
@@ -357,6 +384,8 @@ class ClockSampler:
                     self.mhz.append(int(m.group(1)))
                 if self.power:
                     self.watts.append(int(open(self.power).read()) / 1e6)
+                if self.freq:
+                    self.hz.append(int(open(self.freq).read()))
             except (OSError, ValueError):
                 pass
             time.sleep(self.period)
@@ -377,10 +406,13 @@ class ClockSampler:
     def summary(self):
         mean = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
         ghz = mean(self.mhz)
+        hw = mean(self.hz)
         return {"sustained_clock_ghz": None if ghz is None else ghz / 1e3,
+                "sustained_clock_hwmon_ghz": None if hw is None else hw / 1e9,
                 "sustained_clock_min_max_ghz": [min(self.mhz) / 1e3, max(self.mhz) / 1e3] if self.mhz else None,
                 "sustained_power_w": mean(self.watts), "clock_samples": len(self.mhz),
-                "clock_source": "sysfs pp_dpm_sclk / hwmon power1_average sampled every 4 ms over the timed steps"}
+                "clock_source": "sysfs pp_dpm_sclk (current level) / hwmon freq1_input / hwmon power1_average|input of this rank's GPU "
+                                f"({self.matched_by}), sampled every 4 ms over the timed steps"}
 
 
 TRAFFIC_SUMMARIES = ("r6_hbm_traffic.json", "r6_hbm_traffic_dualcnn.json", "r5_hbm_traffic.json", "r5_hbm_traffic_dualcnn.json", "r4_hbm_traffic.json", "r4_hbm_traffic_dualcnn.json", "r3_hbm_traffic.json", "r3_hbm_traffic_dualcnn.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json")
