@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS tools/exp/bnsum_epilogue.patch applied (git apply; the form was measured neutral and is not in the tree) and the library rebuilt
 # batch-norm backward sums in the data gradient's epilogue: kernel + model parity, then the step A/B on the same box
 o=gpurun_out/r6_exp14; mkdir -p $o
 timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "bnsum or res_epilogue or kslice" 2>&1 | tail -5 | tee $o/tests_kernels.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS tools/exp/bnsum_epilogue.patch applied (git apply; the form was measured neutral and is not in the tree) and the library rebuilt
 # the two forms of the BSUM epilogue (y tile requested before / after the tile's stores) against the plan without it, one box
 o=gpurun_out/r6_exp15; mkdir -p $o
 for pass in 1 2 3; do for cfg in "off" "early" "late"; do

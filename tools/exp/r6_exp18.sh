@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS the experiment constant of tools/exp/merged_fwd_tile_order.patch (two lines of plan.py, not in the tree: the order lost)
 # tile order of the merged forward inside a row chunk (L2 reuse of the packed weights / the chunk's pixel blocks): per launch and step
 for pass in 1 2; do for o in 0 1 2; do
   echo "== order $o pass $pass"
