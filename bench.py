@@ -352,8 +352,10 @@ class ClockSampler:
                     break
                 except OSError:
                     hip = None
-            if hip is not None and hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
-                return buf.value.decode().lower()
+            if hip is not None:
+                if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                    return buf.value.decode().lower()
+                hip.hipGetLastError()  # a failed query must not stay behind as the runtime's sticky error
         except Exception:  # noqa: BLE001 -- a diagnostic field, never a reason to fail the bench
             pass
         return None
@@ -633,7 +635,7 @@ def main():
     # Shader clock / power of this rank's GPU: sampled over an UNTIMED replay of the same steps behind the timed region, never
     # inside it -- a host thread that reads sysfs (every read is a query to the GPU's power firmware) every 4 ms cost the
     # launch-bound CycleGAN step 15 %, CUT 1.3 % and the headline 0.6 % when it ran under the timer (round 6, NOTES 6.L).
-    clock = ClockSampler(int(os.environ.get("LOCAL_RANK", "0")))
+    clock = ClockSampler(torch.cuda.current_device())  # (the device this rank actually runs on, not LOCAL_RANK: ranks may share one)
     if classifier and not use_dist:
         n_clock = max(3, min(200, int(0.5 / max(dt / args.steps, 1e-6)) + 1))
         with clock:

@@ -74,3 +74,16 @@ for wl in "$WLS".split():
         print(wl, "missing:", e)
 PY
 ls -la $OUT
+# every bench line of the set must be one valid JSON line: a failed leg (e.g. the 2-rank self-launch rehearsal) must not pass unseen
+python - <<PY | tee $OUT/validity.txt
+import glob, json
+bad = 0
+for f in sorted(glob.glob("$OUT/bench_*.json") + glob.glob("$OUT/dp_selftest_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print("ok     ", f, d.get("n_gpus"), round(d["ms_per_step"], 4))
+    except Exception as e:
+        bad += 1
+        print("INVALID", f, repr(e)[:80])
+print("PROFILE SET", "COMPLETE" if not bad else "HAS %d INVALID BENCH LINES" % bad)
+PY
