@@ -342,23 +342,14 @@ class ClockSampler:
     @staticmethod
     def _pci_address(index):
         """PCI address ("0000:75:00.0") of HIP device `index` of this process -- the node's OTHER GPUs (other tenants' work) are
-        visible in sysfs too, and card numbers do not follow HIP's device order."""
+        visible in sysfs too, and card numbers do not follow HIP's device order.  From torch's device properties: no second
+        handle on the HIP runtime, no failed query that stays behind as its sticky error."""
         try:
-            import ctypes
-            buf = ctypes.create_string_buffer(64)
-            for lib in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
-                try:
-                    hip = ctypes.CDLL(lib)
-                    break
-                except OSError:
-                    hip = None
-            if hip is not None:
-                if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
-                    return buf.value.decode().lower()
-                hip.hipGetLastError()  # a failed query must not stay behind as the runtime's sticky error
+            import torch
+            p = torch.cuda.get_device_properties(int(index))
+            return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
         except Exception:  # noqa: BLE001 -- a diagnostic field, never a reason to fail the bench
-            pass
-        return None
+            return None
 
     def __init__(self, index=0, period=0.004):
         import glob
